@@ -1,0 +1,71 @@
+"""Build the HIP engine library in-tree: ``cutter_vad_amd/libvad_engine.so`` (gfx950 only).
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container; the
+resulting .so travels to the GPU box with the repo snapshot.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from typing import List
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libvad_engine.so")
+ARCH = "gfx950"
+
+HIP_SOURCES = ["silero_v5.hip"]
+CPP_SOURCES = ["engine.cpp", "pack_weights.cpp"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the engine has no non-HIP build")
+
+
+def sources() -> List[str]:
+    out = [os.path.join(CSRC, s) for s in HIP_SOURCES + CPP_SOURCES]
+    out += [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    out.append(os.path.join(os.path.dirname(HERE), "include", "vad_engine.h"))
+    return out
+
+
+def up_to_date() -> bool:
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    return all(os.path.getmtime(s) <= t for s in sources())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and up_to_date():
+        return LIB
+    cc = _hipcc()
+    objs = []
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    common = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+    for s in HIP_SOURCES:
+        o = os.path.join(bdir, s + ".o")
+        cmd = [cc, f"--offload-arch={ARCH}", *common, "-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            cmd.append("-Rpass-analysis=kernel-resource-usage")
+        subprocess.check_call(cmd)
+        objs.append(o)
+    for s in CPP_SOURCES:
+        o = os.path.join(bdir, s + ".o")
+        subprocess.check_call([cc, *common, "-fvisibility=hidden", "-c", os.path.join(CSRC, s), "-o", o])
+        objs.append(o)
+    tmp = LIB + ".tmp"
+    subprocess.check_call([cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp, *objs, "-lpthread"])
+    os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

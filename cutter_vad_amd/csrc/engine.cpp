@@ -1,0 +1,473 @@
+// C ABI of the batched Silero-VAD engine (include/vad_engine.h): stream pool, device state,
+// host<->device staging and kernel launches.  Plain C++ over the HIP runtime API; the kernels
+// live in silero_v5.hip / silero_v4.hip / resample.hip and are reached through
+// vadk_launch_* so that this file never needs device compilation.
+//
+// Reference behaviour mirrored here (paths under /root/reference/src/real_time_vad/):
+//   core/silero_model.py:276-334  model load            -> vad_engine_create
+//   core/silero_model.py:384-401  zero-initialised state -> vad_stream_open / vad_stream_reset
+//   core/silero_model.py:403-447  predict               -> vad_step*
+//   core/silero_model.py:548-566  get_model_info        -> vad_engine_info
+// There is deliberately no CPU execution path in this file.
+#include "../../include/vad_engine.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pack_weights.h"
+#include "vad_layout.h"
+
+extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream_t stream);
+
+namespace {
+
+thread_local std::string g_create_error;
+
+const vadk::SmSlot kDefaultSm = [] {
+    vadk::SmSlot s;
+    std::memset(&s, 0, sizeof s);
+    // VADConfig defaults, core/config.py:54-94
+    s.start_prob = 0.7f; s.end_prob = 0.7f; s.start_ratio = 0.8f; s.end_ratio = 0.95f;
+    s.start_count = 10; s.end_count = 50;
+    s.seg_frames = -1;
+    return s;
+}();
+
+}  // namespace
+
+struct vad_engine {
+    int version = 5;
+    int device = 0;
+    int max_streams = 0;
+    hipStream_t stream = nullptr;
+    float *d_wstream = nullptr;
+    size_t wbytes = 0;
+    float *d_state = nullptr;
+    vadk::SmSlot *d_sm = nullptr;
+    // staging for the host-pointer entry points (grown on demand)
+    void *d_frames = nullptr;  size_t d_frames_cap = 0;
+    float *d_probs = nullptr;  size_t d_probs_cap = 0;
+    uint8_t *d_events = nullptr; size_t d_events_cap = 0;
+    int32_t *d_seg = nullptr;  size_t d_seg_cap = 0;
+    int32_t *d_slots = nullptr; size_t d_slots_cap = 0;
+    vadk::StepParams base{};
+    std::vector<uint8_t> open;
+    std::vector<int64_t> free_list;
+    std::vector<uint32_t> stamp;   // duplicate detection per step
+    uint32_t stamp_gen = 0;
+    int open_count = 0;
+    int64_t steps = 0, frames = 0;
+    hipDeviceProp_t prop{};
+    mutable std::mutex mu;
+    mutable std::string err;
+
+    int fail(int code, const char *fmt, ...) const {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+    int hip_fail(hipError_t e, const char *what) const {
+        return fail(VAD_ERR_HIP, "Model prediction failed: %s: %s", what, hipGetErrorString(e));
+    }
+};
+
+#define HIP_TRY(e, call)                                         \
+    do {                                                         \
+        hipError_t _r = (call);                                  \
+        if (_r != hipSuccess) return (e)->hip_fail(_r, #call);   \
+    } while (0)
+
+namespace {
+
+template <class T>
+int ensure(vad_engine *e, T *&ptr, size_t &cap, size_t need) {
+    if (need <= cap) return VAD_OK;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    void *p = nullptr;
+    hipError_t r = hipMalloc(&p, need);
+    if (r != hipSuccess) return e->hip_fail(r, "hipMalloc(staging)");
+    ptr = static_cast<T *>(p);
+    cap = need;
+    return VAD_OK;
+}
+
+size_t frame_bytes(int fmt) { return fmt == VAD_FMT_F32 ? 4u * VAD_FRAME_SAMPLES : 2u * VAD_FRAME_SAMPLES; }
+
+int check_slots(vad_engine *e, const int64_t *slots, int64_t n) {
+    if (++e->stamp_gen == 0) {
+        std::fill(e->stamp.begin(), e->stamp.end(), 0u);
+        e->stamp_gen = 1;
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t s = slots[i];
+        if (s < 0 || s >= e->max_streams || !e->open[(size_t)s])
+            return e->fail(VAD_ERR_BAD_SLOT, "Model prediction failed: slot %lld is not an open stream", (long long)s);
+        if (e->stamp[(size_t)s] == e->stamp_gen)
+            return e->fail(VAD_ERR_BAD_SLOT, "Model prediction failed: slot %lld appears twice in one step", (long long)s);
+        e->stamp[(size_t)s] = e->stamp_gen;
+    }
+    return VAD_OK;
+}
+
+int launch(vad_engine *e, const vadk::StepParams &p, hipStream_t s) {
+    hipError_t r = hipErrorInvalidValue;
+    if (e->version == 5) r = vadk_launch_silero_v5(&p, s);
+    if (r != hipSuccess) return e->hip_fail(r, "kernel launch");
+    e->steps += 1;
+    e->frames += (int64_t)p.n * p.T;
+    return VAD_OK;
+}
+
+// shared body of vad_step / vad_step_events / vad_step_multi
+int step_host(vad_engine *e, const int64_t *slots, int64_t n, int32_t T, const void *frames, int fmt, float thr,
+              float *probs, uint8_t *events, int32_t *seg) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (n < 0 || T < 1 || (n > 0 && (!slots || !frames || !probs)))
+        return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: null buffer or bad count");
+    if (fmt < VAD_FMT_F32 || fmt > VAD_FMT_I16_32768)
+        return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: unknown frame format %d", fmt);
+    if (n == 0) return VAD_OK;
+    if (n > e->max_streams) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: n exceeds max_streams");
+    if (int rc = check_slots(e, slots, n)) return rc;
+    HIP_TRY(e, hipSetDevice(e->device));
+    const size_t fb = frame_bytes(fmt) * (size_t)n * T;
+    if (int rc = ensure(e, e->d_frames, e->d_frames_cap, fb)) return rc;
+    if (int rc = ensure(e, e->d_probs, e->d_probs_cap, sizeof(float) * n * T)) return rc;
+    if (int rc = ensure(e, e->d_events, e->d_events_cap, (size_t)n * T)) return rc;
+    if (int rc = ensure(e, e->d_seg, e->d_seg_cap, sizeof(int32_t) * n)) return rc;
+    if (int rc = ensure(e, e->d_slots, e->d_slots_cap, sizeof(int32_t) * n)) return rc;
+    std::vector<int32_t> s32((size_t)n);
+    for (int64_t i = 0; i < n; ++i) s32[(size_t)i] = (int32_t)slots[i];
+    HIP_TRY(e, hipMemcpyAsync(e->d_slots, s32.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->d_frames, frames, fb, hipMemcpyHostToDevice, e->stream));
+    vadk::StepParams p = e->base;
+    p.slots = e->d_slots;
+    p.frames = e->d_frames;
+    p.probs = e->d_probs;
+    p.events = e->d_events;
+    p.seg_frames = e->d_seg;
+    p.n = (int32_t)n;
+    p.T = T;
+    p.fmt = fmt;
+    p.thresh = thr;
+    // the pageable-memory H2D copies above must not be overwritten before they are consumed
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (int rc = launch(e, p, e->stream)) return rc;
+    HIP_TRY(e, hipMemcpyAsync(probs, e->d_probs, sizeof(float) * n * T, hipMemcpyDeviceToHost, e->stream));
+    if (events) HIP_TRY(e, hipMemcpyAsync(events, e->d_events, (size_t)n * T, hipMemcpyDeviceToHost, e->stream));
+    if (seg) HIP_TRY(e, hipMemcpyAsync(seg, e->d_seg, sizeof(int32_t) * n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return VAD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vad_last_create_error(void) { return g_create_error.c_str(); }
+const char *vad_last_error(const vad_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
+    g_create_error.clear();
+    if (!desc || !out || desc->struct_size < sizeof(vad_engine_desc)) {
+        g_create_error = "Failed to load model: bad vad_engine_desc";
+        return VAD_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    if (desc->model_version != 4 && desc->model_version != 5) {
+        g_create_error = "Failed to load model: model_version must be 4 or 5";
+        return VAD_ERR_INVALID_ARG;
+    }
+    if (desc->sample_rate != 16000) {
+        // the graphs' sr != 16000 branch cannot run on 512-sample frames
+        g_create_error = "Failed to load model: only the 16 kHz branch is implemented (resample first)";
+        return VAD_ERR_UNSUPPORTED;
+    }
+    if (desc->max_streams < 1) {
+        g_create_error = "Failed to load model: max_streams must be >= 1";
+        return VAD_ERR_INVALID_ARG;
+    }
+    vadk::PackedWeights pw;
+    std::string perr;
+    const bool ok = desc->model_version == 5 ? vadk::pack_silero_v5(desc->weights, desc->weights_len, pw, perr)
+                                             : vadk::pack_silero_v4(desc->weights, desc->weights_len, pw, perr);
+    if (!ok) {
+        g_create_error = perr;
+        return VAD_ERR_BAD_WEIGHTS;
+    }
+    int ndev = 0;
+    hipError_t r = hipGetDeviceCount(&ndev);
+    if (r != hipSuccess || ndev < 1) {
+        g_create_error = "Failed to load model: no HIP device available (this engine has no CPU fallback)";
+        return VAD_ERR_NO_DEVICE;
+    }
+    if (desc->device_id < 0 || desc->device_id >= ndev) {
+        g_create_error = "Failed to load model: device_id out of range";
+        return VAD_ERR_INVALID_ARG;
+    }
+    vad_engine *e = new vad_engine();
+    e->version = desc->model_version;
+    e->device = desc->device_id;
+    e->max_streams = desc->max_streams;
+    auto bail = [&](hipError_t hr, const char *what) {
+        g_create_error = std::string("Failed to load model: ") + what + ": " + hipGetErrorString(hr);
+        vad_engine_destroy(e);
+        return VAD_ERR_HIP;
+    };
+    if ((r = hipSetDevice(e->device)) != hipSuccess) return bail(r, "hipSetDevice");
+    if ((r = hipGetDeviceProperties(&e->prop, e->device)) != hipSuccess) return bail(r, "hipGetDeviceProperties");
+    if (std::strncmp(e->prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("Failed to load model: kernels are built for gfx950 only, device is ") + e->prop.gcnArchName;
+        vad_engine_destroy(e);
+        return VAD_ERR_NO_DEVICE;
+    }
+    if ((r = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess) return bail(r, "hipStreamCreate");
+    e->wbytes = pw.data.size() * sizeof(float);
+    if ((r = hipMalloc((void **)&e->d_wstream, e->wbytes)) != hipSuccess) return bail(r, "hipMalloc(weights)");
+    if ((r = hipMemcpy(e->d_wstream, pw.data.data(), e->wbytes, hipMemcpyHostToDevice)) != hipSuccess)
+        return bail(r, "hipMemcpy(weights)");
+    const size_t sb = sizeof(float) * VAD_STATE_FLOATS * (size_t)e->max_streams;
+    if ((r = hipMalloc((void **)&e->d_state, sb)) != hipSuccess) return bail(r, "hipMalloc(state)");
+    if ((r = hipMemset(e->d_state, 0, sb)) != hipSuccess) return bail(r, "hipMemset(state)");
+    if ((r = hipMalloc((void **)&e->d_sm, sizeof(vadk::SmSlot) * (size_t)e->max_streams)) != hipSuccess)
+        return bail(r, "hipMalloc(sm)");
+    {
+        std::vector<vadk::SmSlot> init((size_t)e->max_streams, kDefaultSm);
+        if ((r = hipMemcpy(e->d_sm, init.data(), sizeof(vadk::SmSlot) * init.size(), hipMemcpyHostToDevice)) != hipSuccess)
+            return bail(r, "hipMemcpy(sm)");
+    }
+    e->base.wstream = e->d_wstream;
+    std::memcpy(e->base.sect, pw.sect, sizeof pw.sect);
+    e->base.state = e->d_state;
+    e->base.sm = e->d_sm;
+    e->open.assign((size_t)e->max_streams, 0);
+    e->stamp.assign((size_t)e->max_streams, 0);
+    e->free_list.reserve((size_t)e->max_streams);
+    for (int64_t s = e->max_streams - 1; s >= 0; --s) e->free_list.push_back(s);
+    *out = e;
+    return VAD_OK;
+}
+
+void vad_engine_destroy(vad_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    void *bufs[] = {e->d_wstream, e->d_state, e->d_sm, e->d_frames, e->d_probs, e->d_events, e->d_seg, e->d_slots};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int vad_engine_info(const vad_engine *e, vad_info *info) {
+    if (!e || !info || info->struct_size < sizeof(vad_info)) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    const uint32_t sz = info->struct_size;
+    std::memset(info, 0, sizeof *info);
+    info->struct_size = sz;
+    info->abi_version = VAD_ABI_VERSION;
+    info->model_version = e->version;
+    info->device_id = e->device;
+    info->max_streams = e->max_streams;
+    info->open_streams = e->open_count;
+    info->compute_units = e->prop.multiProcessorCount;
+    info->streams_per_workgroup = vadk::MT;
+    info->weight_bytes_device = (int64_t)e->wbytes;
+    info->state_bytes_device = (int64_t)(sizeof(float) * VAD_STATE_FLOATS + sizeof(vadk::SmSlot)) * e->max_streams;
+    info->steps = e->steps;
+    info->frames = e->frames;
+    std::strncpy(info->device_name, e->prop.name, sizeof info->device_name - 1);
+    std::strncpy(info->arch, e->prop.gcnArchName, sizeof info->arch - 1);
+    return VAD_OK;
+}
+
+int vad_stream_open(vad_engine *e, int64_t *slot) {
+    if (!e || !slot) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->free_list.empty()) return e->fail(VAD_ERR_NO_SLOT, "stream pool exhausted (%d slots)", e->max_streams);
+    const int64_t s = e->free_list.back();
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemsetAsync(e->d_state + (size_t)s * VAD_STATE_FLOATS, 0, sizeof(float) * VAD_STATE_FLOATS, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->d_sm + s, &kDefaultSm, sizeof kDefaultSm, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->free_list.pop_back();
+    e->open[(size_t)s] = 1;
+    e->open_count += 1;
+    *slot = s;
+    return VAD_OK;
+}
+
+int vad_stream_close(vad_engine *e, int64_t slot) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
+        return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
+    e->open[(size_t)slot] = 0;
+    e->open_count -= 1;
+    e->free_list.push_back(slot);
+    return VAD_OK;
+}
+
+int vad_stream_reset(vad_engine *e, const int64_t *slots, int64_t n) {
+    if (!e || (n > 0 && !slots) || n < 0) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (int rc = check_slots(e, slots, n)) return rc;
+    HIP_TRY(e, hipSetDevice(e->device));
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t s = slots[i];
+        // keep the slot's thresholds, reset the dynamic part (VADProcessor.reset, silero_model.py:951-968)
+        vadk::SmSlot cur;
+        HIP_TRY(e, hipMemcpyAsync(&cur, e->d_sm + s, sizeof cur, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        vadk::SmSlot fresh = kDefaultSm;
+        fresh.start_prob = cur.start_prob; fresh.end_prob = cur.end_prob;
+        fresh.start_ratio = cur.start_ratio; fresh.end_ratio = cur.end_ratio;
+        fresh.start_count = cur.start_count; fresh.end_count = cur.end_count;
+        HIP_TRY(e, hipMemcpyAsync(e->d_sm + s, &fresh, sizeof fresh, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipMemsetAsync(e->d_state + (size_t)s * VAD_STATE_FLOATS, 0, sizeof(float) * VAD_STATE_FLOATS, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+    }
+    return VAD_OK;
+}
+
+int vad_stream_get_state(vad_engine *e, int64_t slot, float *hc) {
+    if (!e || !hc) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
+        return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemcpyAsync(hc, e->d_state + (size_t)slot * VAD_STATE_FLOATS, sizeof(float) * VAD_STATE_FLOATS,
+                              hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return VAD_OK;
+}
+
+int vad_stream_set_state(vad_engine *e, int64_t slot, const float *hc) {
+    if (!e || !hc) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
+        return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemcpyAsync(e->d_state + (size_t)slot * VAD_STATE_FLOATS, hc, sizeof(float) * VAD_STATE_FLOATS,
+                              hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return VAD_OK;
+}
+
+int vad_stream_set_thresholds(vad_engine *e, int64_t slot, const vad_thresholds *t) {
+    if (!e || !t) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
+        return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
+    if (t->start_frame_count < 1 || t->end_frame_count < 1)
+        return e->fail(VAD_ERR_INVALID_ARG, "frame counts must be >= 1");
+    HIP_TRY(e, hipSetDevice(e->device));
+    // set_thresholds also resets the processor (vad_wrapper.py:412-413): dynamic part back to initial
+    vadk::SmSlot s = kDefaultSm;
+    s.start_prob = t->start_probability; s.end_prob = t->end_probability;
+    s.start_ratio = t->start_ratio; s.end_ratio = t->end_ratio;
+    s.start_count = t->start_frame_count; s.end_count = t->end_frame_count;
+    HIP_TRY(e, hipMemcpyAsync(e->d_sm + slot, &s, sizeof s, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return VAD_OK;
+}
+
+int vad_step(vad_engine *e, const int64_t *slots, int64_t n, const void *frames, int frame_fmt, float denoise_thresh,
+             float *probs_out) {
+    return step_host(e, slots, n, 1, frames, frame_fmt, denoise_thresh, probs_out, nullptr, nullptr);
+}
+
+int vad_step_events(vad_engine *e, const int64_t *slots, int64_t n, const void *frames, int frame_fmt,
+                    float denoise_thresh, float *probs_out, uint8_t *events_out, int32_t *seg_frames_out) {
+    if (e && n > 0 && !events_out) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: events_out is null");
+    }
+    return step_host(e, slots, n, 1, frames, frame_fmt, denoise_thresh, probs_out, events_out, seg_frames_out);
+}
+
+int vad_step_multi(vad_engine *e, const int64_t *slots, int64_t n, int32_t T, const void *frames, int frame_fmt,
+                   float denoise_thresh, float *probs_out, uint8_t *events_out) {
+    return step_host(e, slots, n, T, frames, frame_fmt, denoise_thresh, probs_out, events_out, nullptr);
+}
+
+int vad_step_device(vad_engine *e, const int32_t *d_slots, int64_t n, const void *d_frames, int frame_fmt,
+                    float denoise_thresh, float *d_probs, uint8_t *d_events, int32_t *d_seg_frames, void *stream) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (n < 0 || n > e->max_streams || (n > 0 && (!d_frames || !d_probs)))
+        return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: null buffer or bad count");
+    if (frame_fmt < VAD_FMT_F32 || frame_fmt > VAD_FMT_I16_32768)
+        return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: unknown frame format %d", frame_fmt);
+    if (n == 0) return VAD_OK;
+    vadk::StepParams p = e->base;
+    p.slots = d_slots;
+    p.frames = d_frames;
+    p.probs = d_probs;
+    p.events = d_events;
+    p.seg_frames = d_seg_frames;
+    p.n = (int32_t)n;
+    p.T = 1;
+    p.fmt = frame_fmt;
+    p.thresh = denoise_thresh;
+    return launch(e, p, stream ? static_cast<hipStream_t>(stream) : e->stream);
+}
+
+int vad_resample(vad_engine *e, const float *, int64_t, int32_t, int32_t, float *) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return e->fail(VAD_ERR_UNSUPPORTED, "resampler kernel not built yet");
+}
+
+int vad_resample_device(vad_engine *e, const float *, int64_t, int32_t, int32_t, float *, void *) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return e->fail(VAD_ERR_UNSUPPORTED, "resampler kernel not built yet");
+}
+
+int vad_debug_pack_weights(int32_t model_version, const void *weights, size_t weights_len, float *out,
+                           size_t out_floats, size_t *n_floats, uint32_t *sect_out) {
+    g_create_error.clear();
+    vadk::PackedWeights pw;
+    std::string perr;
+    const bool ok = model_version == 5   ? vadk::pack_silero_v5(weights, weights_len, pw, perr)
+                    : model_version == 4 ? vadk::pack_silero_v4(weights, weights_len, pw, perr)
+                                         : false;
+    if (!ok) {
+        g_create_error = perr.empty() ? "Failed to load model: model_version must be 4 or 5" : perr;
+        return VAD_ERR_BAD_WEIGHTS;
+    }
+    if (n_floats) *n_floats = pw.data.size();
+    if (sect_out) std::memcpy(sect_out, pw.sect, sizeof pw.sect);
+    if (out) {
+        if (out_floats < pw.data.size()) {
+            g_create_error = "vad_debug_pack_weights: output buffer too small";
+            return VAD_ERR_INVALID_ARG;
+        }
+        std::memcpy(out, pw.data.data(), pw.data.size() * sizeof(float));
+    }
+    return VAD_OK;
+}
+
+int vad_engine_synchronize(vad_engine *e) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return VAD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,199 @@
+// Host-side weight packing: SVW blob (canonical tensors) -> per-wave MFMA weight streams.
+//
+// The reference keeps Silero's weights inside the .onnx file and lets onnxruntime lay them out
+// (/root/reference/src/real_time_vad/core/silero_model.py:321-325).  Here every wave of the
+// fused kernel reads its weights as one linear stream of 1 KiB blocks (64 lanes x float4) in
+// consumption order; see vad_layout.h for the fragment convention this code must mirror:
+//   weight block (tile nt, k-iteration j):  lane (n' = l&31, hh = l>>5), component i
+//       = W[32*nt + n'][channel 8j + 4hh + i]
+//   bias / head block g:                    lane (any, hh), component i = b[32*nt + 8g + 4hh + i]
+#include "pack_weights.h"
+
+#include <cstring>
+
+namespace vadk {
+
+namespace {
+
+struct SvwEntry {
+    char name[48];
+    uint32_t ndim, dims[4], reserved;
+    uint64_t offset, nelem;
+};
+static_assert(sizeof(SvwEntry) == 88, "SVW entry layout (cutter_vad_amd/weights_io.py)");
+
+struct Blob {
+    const uint8_t *p;
+    size_t len;
+    uint32_t version, n;
+    const SvwEntry *tab;
+    std::string *err;
+
+    const float *get(const char *name, uint64_t expect) const {
+        for (uint32_t i = 0; i < n; ++i) {
+            if (std::strncmp(tab[i].name, name, sizeof tab[i].name) == 0) {
+                if (tab[i].nelem != expect || tab[i].offset + 4 * tab[i].nelem > len) break;
+                return reinterpret_cast<const float *>(p + tab[i].offset);
+            }
+        }
+        if (err->empty()) *err = std::string("Failed to load model: tensor '") + name + "' missing or of the wrong size";
+        return nullptr;
+    }
+};
+
+bool open_blob(const void *data, size_t len, Blob &b, std::string &err) {
+    b.p = static_cast<const uint8_t *>(data);
+    b.len = len;
+    b.err = &err;
+    if (!data || len < 16 || std::memcmp(data, "SVADW001", 8) != 0) {
+        err = "Failed to load model: not an SVW weight blob (bad magic)";
+        return false;
+    }
+    std::memcpy(&b.version, b.p + 8, 4);
+    std::memcpy(&b.n, b.p + 12, 4);
+    if (16 + (size_t)b.n * sizeof(SvwEntry) > len) {
+        err = "Failed to load model: truncated SVW tensor table";
+        return false;
+    }
+    b.tab = reinterpret_cast<const SvwEntry *>(b.p + 16);
+    return true;
+}
+
+class StreamBuilder {
+   public:
+    std::vector<float> data;
+    float *new_block() {
+        data.resize(data.size() + BLK_FLOATS, 0.f);
+        return data.data() + data.size() - BLK_FLOATS;
+    }
+    uint32_t blocks() const { return (uint32_t)(data.size() / BLK_FLOATS); }
+
+    // conv / linear weight block: rows = output channels of tile `row0`.., k = input channel
+    template <class F>
+    void weight_block(F &&value /* (row n', channel c) -> float */, int j) {
+        float *b = new_block();
+        for (int l = 0; l < 64; ++l) {
+            const int np = l & 31, hh = l >> 5;
+            for (int i = 0; i < 4; ++i) b[l * 4 + i] = value(np, 8 * j + 4 * hh + i);
+        }
+    }
+    // 4 lane-expanded blocks holding a per-output-channel vector for one 32-channel tile
+    template <class F>
+    void vector_blocks(F &&value /* (channel within tile) -> float */) {
+        for (int g = 0; g < 4; ++g) {
+            float *b = new_block();
+            for (int l = 0; l < 64; ++l) {
+                const int hh = l >> 5;
+                for (int i = 0; i < 4; ++i) b[l * 4 + i] = value(8 * g + 4 * hh + i);
+            }
+        }
+    }
+};
+
+}  // namespace
+
+bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::string &err) {
+    using namespace v5;
+    Blob B;
+    if (!open_blob(blob, len, B, err)) return false;
+    if (B.version != 5) {
+        err = "Failed to load model: weight blob is not Silero V5";
+        return false;
+    }
+    const float *stft = B.get("stft.basis", 258 * 256);
+    const float *ew[4], *eb[4];
+    static const int co[4] = {128, 64, 64, 128}, ci[4] = {129, 128, 64, 64};
+    for (int i = 0; i < 4; ++i) {
+        char nm[32];
+        std::snprintf(nm, sizeof nm, "enc%d.w", i);
+        ew[i] = B.get(nm, (uint64_t)co[i] * ci[i] * 3);
+        std::snprintf(nm, sizeof nm, "enc%d.b", i);
+        eb[i] = B.get(nm, co[i]);
+    }
+    const float *w_ih = B.get("lstm.w_ih", 512 * 128), *w_hh = B.get("lstm.w_hh", 512 * 128);
+    const float *b_ih = B.get("lstm.b_ih", 512), *b_hh = B.get("lstm.b_hh", 512);
+    const float *head_w = B.get("head.w", 128), *head_b = B.get("head.b", 1);
+    if (!err.empty()) return false;
+
+    StreamBuilder sb;
+    auto convw = [&](int layer, int o, int c, int tap) -> float {
+        return c < ci[layer] ? ew[layer][((size_t)o * ci[layer] + c) * 3 + tap] : 0.f;
+    };
+    for (int w = 0; w < NWAVES; ++w) {
+        // STFT: bins 32w..32w+31, {re, im} per k-iteration
+        out.sect[w][S_STFT] = sb.blocks();
+        for (int j = 0; j < 32; ++j) {
+            sb.weight_block([&](int np, int k) { return stft[(size_t)(32 * w + np) * 256 + k]; }, j);
+            sb.weight_block([&](int np, int k) { return stft[(size_t)(129 + 32 * w + np) * 256 + k]; }, j);
+        }
+        // bin 128 rows (same value on every lane of a half-wave), consumed by wave 3 on the VALU
+        out.sect[w][S_NYQ] = sb.blocks();
+        if (w == 3) {
+            for (int j = 0; j < 32; ++j) {
+                sb.weight_block([&](int, int k) { return stft[(size_t)128 * 256 + k]; }, j);
+                sb.weight_block([&](int, int k) { return stft[(size_t)257 * 256 + k]; }, j);
+            }
+        }
+        // enc0: out channels 32w.., taps 0..2 per k-iteration, then the Nyquist input channel
+        out.sect[w][S_ENC0] = sb.blocks();
+        sb.vector_blocks([&](int c) { return eb[0][32 * w + c]; });
+        for (int j = 0; j < 16; ++j)
+            for (int tap = 0; tap < 3; ++tap)
+                sb.weight_block([&](int np, int c) { return convw(0, 32 * w + np, c, tap); }, j);
+        for (int tout = 0; tout < 3; ++tout) {
+            // activation quad = (|X128| of column 0, 1, 2, 0) on the lower half-wave, zeros on the upper
+            float *b = sb.new_block();
+            for (int l = 0; l < 32; ++l)
+                for (int i = 0; i < 3; ++i) {
+                    const int tap = i - tout + 1;
+                    b[l * 4 + i] = (tap >= 0 && tap < 3) ? convw(0, 32 * w + l, 128, tap) : 0.f;
+                }
+        }
+        // enc1: n-tile w&1, output column w>>1; taps (1,2) for column 0, (0,1) for column 1
+        out.sect[w][S_ENC1] = sb.blocks();
+        {
+            const int nt = w & 1, tp = w >> 1;
+            sb.vector_blocks([&](int c) { return eb[1][32 * nt + c]; });
+            for (int ti = 0; ti < 2; ++ti) {
+                const int tap = (1 - tp) + ti;
+                for (int j = 0; j < 16; ++j)
+                    sb.weight_block([&](int np, int c) { return convw(1, 32 * nt + np, c, tap); }, j);
+            }
+        }
+        // enc2 (waves 0,1): n-tile w, taps 1,2 on input columns 0,1
+        out.sect[w][S_ENC2] = sb.blocks();
+        if (w < 2) {
+            sb.vector_blocks([&](int c) { return eb[2][32 * w + c]; });
+            for (int ti = 0; ti < 2; ++ti)
+                for (int j = 0; j < 8; ++j)
+                    sb.weight_block([&](int np, int c) { return convw(2, 32 * w + np, c, 1 + ti); }, j);
+        }
+        // enc3: n-tile w, centre tap only (single input column)
+        out.sect[w][S_ENC3] = sb.blocks();
+        sb.vector_blocks([&](int c) { return eb[3][32 * w + c]; });
+        for (int j = 0; j < 8; ++j) sb.weight_block([&](int np, int c) { return convw(3, 32 * w + np, c, 1); }, j);
+        // LSTM: hidden units 32w.., gates i,f,g,o (PyTorch row order), then the head weights
+        out.sect[w][S_LSTM] = sb.blocks();
+        for (int q = 0; q < 4; ++q)
+            sb.vector_blocks([&](int c) { const int r = q * 128 + 32 * w + c; return b_ih[r] + b_hh[r]; });
+        for (int j = 0; j < 16; ++j)
+            for (int q = 0; q < 4; ++q)
+                sb.weight_block([&](int np, int c) { return w_ih[(size_t)(q * 128 + 32 * w + np) * 128 + c]; }, j);
+        for (int j = 0; j < 16; ++j)
+            for (int q = 0; q < 4; ++q)
+                sb.weight_block([&](int np, int c) { return w_hh[(size_t)(q * 128 + 32 * w + np) * 128 + c]; }, j);
+        sb.vector_blocks([&](int c) { return head_w[32 * w + c]; });
+    }
+    const uint32_t hb = sb.blocks();
+    sb.new_block()[0] = head_b[0];
+    for (int w = 0; w < NWAVES; ++w) out.sect[w][S_HEADB] = hb;
+    out.data = std::move(sb.data);
+    return true;
+}
+
+bool pack_silero_v4(const void *, size_t, PackedWeights &, std::string &err) {
+    err = "Failed to load model: Silero V4 kernels are not built into this library yet";
+    return false;
+}
+
+}  // namespace vadk

@@ -1,0 +1,24 @@
+// Host-side weight packing (see pack_weights.cpp).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "vad_layout.h"
+
+namespace vadk {
+
+struct PackedWeights {
+    std::vector<float> data;        // concatenated per-wave streams, multiple of BLK_FLOATS
+    uint32_t sect[NWAVES][8] = {};  // block offset of every section
+};
+
+// blob: SVW container (cutter_vad_amd/weights_io.py).  On failure returns false and sets err
+// to a message starting with "Failed to load model" (matches the reference's
+// ModelInitializationError text, core/silero_model.py:330-334).
+bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::string &err);
+bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::string &err);
+
+}  // namespace vadk

@@ -1,0 +1,81 @@
+// Shared host/device layout constants of the fused Silero kernels (gfx950).
+//
+// Geometry common to every model kernel:
+//   * one workgroup = 4 wavefronts (256 threads) = one tile of MT = 32 streams;
+//   * every contraction runs on v_mfma_f32_32x32x2_f32 with the WEIGHTS as the A operand
+//     (32 output channels on the rows) and the ACTIVATIONS as the B operand (32 streams on
+//     the columns), so the D tile has the stream on the lane (col = lane & 31) and 16 output
+//     channels in the lane's registers: channel = 8*(r>>2) + 4*(lane>>5) + (r&3);
+//   * activations live in LDS as "quads": row q holds channels 4q..4q+3 of all 32 streams
+//     as 32 float4 (+1 float4 of padding, row stride QS = 33 float4 = 528 B, which makes both
+//     the transposing ds_write_b128 of the loader and the row reads conflict-free);
+//   * weights are pre-packed on the host into per-wave linear streams of 1 KiB blocks
+//     (64 lanes x float4) in exactly the order the wave consumes them, so a wave's weight
+//     traffic is one coalesced global_load_dwordx4 per 4 MFMAs, straight into VGPRs
+//     (each wave owns different output channels, so LDS staging would not be shared).
+//   One k-iteration j consumes quad 2j (lanes 0-31) and quad 2j+1 (lanes 32-63): MFMA
+//   k-step i in 0..3 contracts channel 8j+i (lower half-wave) and 8j+4+i (upper half).
+#pragma once
+#include <stdint.h>
+
+namespace vadk {
+
+constexpr int MT = 32;        // streams per workgroup
+constexpr int NWAVES = 4;     // wavefronts per workgroup
+constexpr int NTHREADS = 256;
+constexpr int QS = 33;        // float4 per LDS quad row
+constexpr int BLK_F4 = 64;    // float4 per weight block (one per lane)
+constexpr int BLK_FLOATS = 256;
+
+// ---- Silero V5 (16 kHz branch) -------------------------------------------------------
+namespace v5 {
+// weight-stream sections, in blocks, per wave
+constexpr int STFT_BLOCKS = 64;            // 32 k-iterations x {re, im}
+constexpr int NYQ_BLOCKS = 64;             // wave 3 only: bin 128 {re, im} per k-iteration
+constexpr int ENC0_BLOCKS = 4 + 16 * 3 + 3;  // bias, 16 k-iterations x 3 taps, Nyquist channel x 3 t_out
+constexpr int ENC1_BLOCKS = 4 + 2 * 16;
+constexpr int ENC2_BLOCKS = 4 + 2 * 8;     // waves 0,1 only
+constexpr int ENC3_BLOCKS = 4 + 8;
+constexpr int LSTM_BLOCKS = 16 + 64 + 64 + 4;  // bias(4 gates), W_ih, W_hh, head weights
+enum Section { S_STFT = 0, S_NYQ, S_ENC0, S_ENC1, S_ENC2, S_ENC3, S_LSTM, S_HEADB, S_COUNT };  // S_HEADB: 1 block, float 0 = head bias
+
+// LDS regions, in quad rows
+constexpr int ROWS_A = 128;                // x (128 quads) / enc0 out (96) / enc2 out (16)
+constexpr int ROWS_B = 98;                 // mag (96 + Nyquist quad + zero quad) / enc1 out (32) / enc3 out (32)
+constexpr int ROWS_H = 32;                 // h_{t-1}
+constexpr int LDS_F4 = (ROWS_A + ROWS_B + ROWS_H) * QS + 32;  // + 4x32 floats of head partials
+constexpr int LDS_BYTES = LDS_F4 * 16;
+}  // namespace v5
+
+// per-slot hysteresis state (VADProcessor fields, core/silero_model.py:596-639), 80 bytes
+struct SmSlot {
+    float start_prob, end_prob, start_ratio, end_ratio;
+    int32_t start_count, end_count;
+    int32_t active, n_start, n_end;
+    int32_t start_len;       // len(recent_start_frames), deque maxlen 20
+    uint32_t start_hist;     // its contents, newest in bit 0
+    int32_t end_len;         // len(recent_end_frames), deque maxlen 100
+    uint32_t end_hist[4];    // newest in bit 0 of word 0
+    int32_t buffered;        // len(voice_buffer) in frames
+    int32_t seg_frames;      // frames in current_voice_data (-1 = None)
+    int32_t pad[2];
+};
+static_assert(sizeof(SmSlot) == 80, "SmSlot layout");
+
+struct StepParams {
+    const float *wstream;          // packed weight streams
+    uint32_t sect[NWAVES][8];      // block offset of each section, per wave
+    float *state;                  // [max_streams][256]
+    SmSlot *sm;                    // [max_streams]
+    const int32_t *slots;          // [n] or nullptr (identity)
+    const void *frames;            // [n][T][512]
+    float *probs;                  // [n][T]
+    uint8_t *events;               // [n][T] or nullptr
+    int32_t *seg_frames;           // [n] or nullptr (last END of the call)
+    int32_t n;
+    int32_t T;                     // frames per stream in this call
+    int32_t fmt;                   // vad_frame_format
+    float thresh;                  // denoise gate, < 0 = off
+};
+
+}  // namespace vadk

@@ -1,0 +1,179 @@
+"""Python face of the C ABI (``include/vad_engine.h``): one :class:`Engine` = one GPU's stream pool.
+
+This is the multi-stream operator the reference lacks.  The reference owns one
+``SileroVADModel`` (one ORT session + one ``(h, c)``) per client
+(/root/reference/websocket_service/server/vad_websocket_server.py:277,
+/root/reference/src/real_time_vad/core/silero_model.py:238-566); here many streams share one
+engine and advance together in one kernel launch.  Errors are mapped onto the reference's
+exception classes with the same message prefixes (SURVEY §8 b).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _ffi
+from .core.exceptions import AudioProcessingError, ModelInitializationError, VADError
+
+_FMT = {np.dtype(np.float32): _ffi.VAD_FMT_F32, np.dtype(np.int16): _ffi.VAD_FMT_I16_32767}
+
+
+def _ptr(a: np.ndarray, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+class Engine:
+    """Stream pool + fused Silero kernels on one MI355X.
+
+    ``weights`` is an SVW blob (``weights_io.load_weight_blob``).  ``denoise`` is the gate
+    threshold of ``AudioUtils.denoise_audio`` (0.01) or ``None`` to disable it.
+    """
+
+    def __init__(self, weights: bytes, model_version: int = 5, device_id: int = 0, max_streams: int = 8192,
+                 sample_rate: int = 16000):
+        self._lib = _ffi.lib()
+        self._h = C.c_void_p()
+        self._weights = weights  # keep alive during create
+        desc = _ffi.EngineDesc(C.sizeof(_ffi.EngineDesc), model_version, C.cast(C.c_char_p(weights), C.c_void_p),
+                               len(weights), device_id, max_streams, sample_rate, 0)
+        rc = self._lib.vad_engine_create(C.byref(desc), C.byref(self._h))
+        if rc != _ffi.VAD_OK:
+            self._h = C.c_void_p()
+            msg = self._lib.vad_last_create_error().decode() or f"vad_engine_create failed ({rc})"
+            raise ModelInitializationError(f"v{model_version}", msg)
+        self.model_version = model_version
+        self.max_streams = max_streams
+        self.device_id = device_id
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self) -> None:
+        h, self._h = self._h, C.c_void_p()
+        if h:
+            self._lib.vad_engine_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int, exc=AudioProcessingError) -> None:
+        if rc != _ffi.VAD_OK:
+            msg = self._lib.vad_last_error(self._h).decode() or f"engine call failed ({rc})"
+            raise exc(msg)
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    def info(self) -> dict:
+        inf = _ffi.EngineInfo()
+        inf.struct_size = C.sizeof(_ffi.EngineInfo)
+        self._check(self._lib.vad_engine_info(self._h, C.byref(inf)), VADError)
+        out = {k: getattr(inf, k) for k, _ in _ffi.EngineInfo._fields_ if k != "struct_size"}
+        out["device_name"] = inf.device_name.decode()
+        out["arch"] = inf.arch.decode()
+        return out
+
+    def synchronize(self) -> None:
+        self._check(self._lib.vad_engine_synchronize(self._h))
+
+    # ------------------------------------------------------------------ streams
+    def open_stream(self) -> int:
+        s = C.c_int64()
+        self._check(self._lib.vad_stream_open(self._h, C.byref(s)), VADError)
+        return int(s.value)
+
+    def open_streams(self, n: int) -> np.ndarray:
+        return np.array([self.open_stream() for _ in range(n)], dtype=np.int64)
+
+    def close_stream(self, slot: int) -> None:
+        self._check(self._lib.vad_stream_close(self._h, int(slot)), VADError)
+
+    def reset(self, slots: Sequence[int]) -> None:
+        s = np.ascontiguousarray(slots, dtype=np.int64)
+        self._check(self._lib.vad_stream_reset(self._h, _ptr(s, C.c_int64), s.size), VADError)
+
+    def get_state(self, slot: int) -> np.ndarray:
+        out = np.empty(_ffi.VAD_STATE_FLOATS, np.float32)
+        self._check(self._lib.vad_stream_get_state(self._h, int(slot), _ptr(out, C.c_float)), VADError)
+        return out
+
+    def set_state(self, slot: int, hc: np.ndarray) -> None:
+        hc = np.ascontiguousarray(hc, np.float32).reshape(_ffi.VAD_STATE_FLOATS)
+        self._check(self._lib.vad_stream_set_state(self._h, int(slot), _ptr(hc, C.c_float)), VADError)
+
+    def set_thresholds(self, slot: int, start_probability=0.7, end_probability=0.7, start_ratio=0.8, end_ratio=0.95,
+                       start_frame_count=10, end_frame_count=50) -> None:
+        t = _ffi.Thresholds(start_probability, end_probability, start_ratio, end_ratio, start_frame_count,
+                            end_frame_count)
+        self._check(self._lib.vad_stream_set_thresholds(self._h, int(slot), C.byref(t)), VADError)
+
+    # ------------------------------------------------------------------ hot path
+    @staticmethod
+    def _prep(slots, frames, T: Optional[int]) -> Tuple[np.ndarray, np.ndarray, int]:
+        s = np.ascontiguousarray(slots, dtype=np.int64).reshape(-1)
+        f = np.asarray(frames)
+        if f.dtype not in _FMT:
+            f = f.astype(np.float32)
+        f = np.ascontiguousarray(f)
+        want = (s.size, 512) if T is None else (s.size, T, 512)
+        if f.shape != want:
+            raise AudioProcessingError(f"Model prediction failed: frames have shape {f.shape}, expected {want}")
+        return s, f, _FMT[f.dtype]
+
+    def step(self, slots, frames, denoise: Optional[float] = 0.01, i16_scale: int = 32767) -> np.ndarray:
+        """One 512-sample frame per listed stream -> probabilities [n]."""
+        s, f, fmt = self._prep(slots, frames, None)
+        if fmt != _ffi.VAD_FMT_F32 and i16_scale == 32768:
+            fmt = _ffi.VAD_FMT_I16_32768
+        probs = np.empty(s.size, np.float32)
+        thr = -1.0 if denoise is None else float(denoise)
+        self._check(self._lib.vad_step(self._h, _ptr(s, C.c_int64), s.size, f.ctypes.data_as(C.c_void_p), fmt, thr,
+                                       _ptr(probs, C.c_float)))
+        return probs
+
+    def step_events(self, slots, frames, denoise: Optional[float] = 0.01, i16_scale: int = 32767):
+        """-> (probs [n], event bits [n] uint8, finished-segment frames [n] int32)."""
+        s, f, fmt = self._prep(slots, frames, None)
+        if fmt != _ffi.VAD_FMT_F32 and i16_scale == 32768:
+            fmt = _ffi.VAD_FMT_I16_32768
+        probs = np.empty(s.size, np.float32)
+        ev = np.zeros(s.size, np.uint8)
+        seg = np.zeros(s.size, np.int32)
+        thr = -1.0 if denoise is None else float(denoise)
+        self._check(self._lib.vad_step_events(self._h, _ptr(s, C.c_int64), s.size, f.ctypes.data_as(C.c_void_p), fmt,
+                                              thr, _ptr(probs, C.c_float), _ptr(ev, C.c_uint8), _ptr(seg, C.c_int32)))
+        return probs, ev, seg
+
+    def step_multi(self, slots, frames, denoise: Optional[float] = 0.01, i16_scale: int = 32767):
+        """frames [n, T, 512]: T consecutive frames per stream -> (probs [n,T], events [n,T])."""
+        f0 = np.asarray(frames)
+        if f0.ndim != 3:
+            raise AudioProcessingError(f"Model prediction failed: frames must be [n, T, 512], got {f0.shape}")
+        T = int(f0.shape[1])
+        s, f, fmt = self._prep(slots, f0, T)
+        if fmt != _ffi.VAD_FMT_F32 and i16_scale == 32768:
+            fmt = _ffi.VAD_FMT_I16_32768
+        probs = np.empty((s.size, T), np.float32)
+        ev = np.zeros((s.size, T), np.uint8)
+        thr = -1.0 if denoise is None else float(denoise)
+        self._check(self._lib.vad_step_multi(self._h, _ptr(s, C.c_int64), s.size, T, f.ctypes.data_as(C.c_void_p), fmt,
+                                             thr, _ptr(probs, C.c_float), _ptr(ev, C.c_uint8)))
+        return probs, ev
+
+    def step_device(self, n: int, d_frames: int, d_probs: int, d_slots: int = 0, d_events: int = 0, d_seg: int = 0,
+                    fmt: int = _ffi.VAD_FMT_F32, denoise: Optional[float] = 0.01, stream: int = 0) -> None:
+        """Asynchronous launch on device pointers (integers, e.g. ``tensor.data_ptr()``)."""
+        thr = -1.0 if denoise is None else float(denoise)
+        self._check(self._lib.vad_step_device(self._h, d_slots or None, n, d_frames, fmt, thr, d_probs,
+                                              d_events or None, d_seg or None, stream or None))

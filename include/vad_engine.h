@@ -1,0 +1,198 @@
+/*
+ * vad_engine.h — C ABI of the MI355X-native batched Silero-VAD engine.
+ *
+ * This is the drop-in boundary for ONE hot path of Picurit/cutter-vad: the per-frame model
+ * operator and its pre/post steps.  Every entry point cites the reference interface it
+ * replaces (paths relative to /root/reference/src/real_time_vad/).  The reference is pure
+ * Python over onnxruntime; what it binds today is
+ *
+ *     ort.InferenceSession(path, sess_options, providers)          core/silero_model.py:321-325
+ *     session.run(None, {'input','state','sr'} | {'input','h','c','sr'})   core/silero_model.py:433
+ *
+ * one 512-sample frame, one stream, batch 1.  The engine keeps that contract per stream and
+ * adds the stream-batch axis: n independent streams advance one frame in one launch.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all sizes explicit; pointers are host pointers unless
+ *     the parameter name starts with d_ (device pointer, same GPU as the engine).
+ *   - return value: 0 = VAD_OK, negative = vad_status; the message for the last failure on
+ *     an engine is vad_last_error(e); for a failed vad_engine_create it is
+ *     vad_last_create_error() (thread-local).
+ *   - there is NO CPU fallback: if no HIP device is usable, vad_engine_create fails with
+ *     VAD_ERR_NO_DEVICE.
+ *   - ownership: the engine owns per-slot recurrent state (h,c) in device HBM and a private
+ *     copy of the weights; callers own every buffer they pass, for the duration of the call.
+ *   - threading: calls on one engine are serialised by an internal mutex; a slot may appear
+ *     at most once per step call (the same rule the reference's per-wrapper lock gives,
+ *     core/vad_wrapper.py:560).
+ */
+#ifndef VAD_ENGINE_H
+#define VAD_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define VAD_API __attribute__((visibility("default")))
+#else
+#define VAD_API
+#endif
+
+#define VAD_ABI_VERSION 1
+#define VAD_FRAME_SAMPLES 512   /* core/silero_model.py:464-468: frames are padded/truncated to 512 */
+#define VAD_STATE_FLOATS 256    /* V5: state[2][1][128]; V4: h[2][1][64] then c[2][1][64]  (silero_model.py:391-401) */
+
+typedef enum vad_status {
+    VAD_OK = 0,
+    VAD_ERR_INVALID_ARG = -1,   /* -> AudioProcessingError / ConfigurationError on the Python side */
+    VAD_ERR_NO_DEVICE = -2,     /* no usable HIP device: the product has no CPU path */
+    VAD_ERR_BAD_WEIGHTS = -3,   /* -> ModelInitializationError("Failed to load model ...") silero_model.py:330-334 */
+    VAD_ERR_HIP = -4,           /* a HIP runtime call failed -> AudioProcessingError("Model prediction failed: ...") :444-447 */
+    VAD_ERR_NO_SLOT = -5,       /* stream pool exhausted */
+    VAD_ERR_BAD_SLOT = -6,      /* slot not open / out of range / duplicated within one step */
+    VAD_ERR_UNSUPPORTED = -7    /* e.g. sample_rate != 16000 (the reference's 8 kHz graph branch) */
+} vad_status;
+
+typedef enum vad_frame_format {
+    VAD_FMT_F32 = 0,            /* float32 in [-1,1]: what VADWrapper.process_audio_data hands down (vad_wrapper.py:598) */
+    VAD_FMT_I16_32767 = 1,      /* int16 PCM scaled by 1/32767 (websocket server convention, vad_websocket_server.py:341) */
+    VAD_FMT_I16_32768 = 2       /* int16 PCM scaled by 1/32768 (AudioUtils.pcm_to_float32, utils/audio.py:308) */
+} vad_frame_format;
+
+/* event bits produced by the per-stream hysteresis state machine (core/silero_model.py:790-949) */
+enum { VAD_EV_START = 1, VAD_EV_END = 2, VAD_EV_CONTINUE = 4 };
+
+typedef struct vad_engine vad_engine;
+
+/* Replaces SileroVADModel.__init__/_load_model (core/silero_model.py:276-334). */
+typedef struct vad_engine_desc {
+    uint32_t struct_size;       /* sizeof(vad_engine_desc) */
+    int32_t model_version;      /* 4 | 5  (core/config.py:23-26) */
+    const void *weights;        /* SVW blob: the tensors of the .onnx file's 16 kHz branch (tools/extract_weights.py) */
+    size_t weights_len;
+    int32_t device_id;          /* HIP device ordinal; one engine drives one GPU */
+    int32_t max_streams;        /* capacity of the per-GPU stream pool (slots) */
+    int32_t sample_rate;        /* must be 16000 (core/silero_model.py:491) */
+    uint32_t flags;             /* reserved, 0 */
+} vad_engine_desc;
+
+typedef struct vad_info {
+    uint32_t struct_size;
+    int32_t abi_version;
+    int32_t model_version;
+    int32_t device_id;
+    int32_t max_streams;
+    int32_t open_streams;
+    int32_t compute_units;
+    int32_t streams_per_workgroup;
+    int64_t weight_bytes_device;   /* packed weight streams resident in HBM */
+    int64_t state_bytes_device;
+    int64_t steps;                 /* launches so far (SileroVADModel.prediction_count analogue, silero_model.py:440) */
+    int64_t frames;                /* frames processed so far */
+    char device_name[64];
+    char arch[32];                 /* "gfx950..." */
+} vad_info;
+
+/* thresholds of one stream's state machine: VADConfig fields core/config.py:54-94 */
+typedef struct vad_thresholds {
+    float start_probability;    /* vad_start_probability */
+    float end_probability;      /* vad_end_probability   */
+    float start_ratio;          /* voice_start_ratio (dead logic in the reference, kept: SURVEY a10) */
+    float end_ratio;            /* voice_end_ratio */
+    int32_t start_frame_count;  /* voice_start_frame_count */
+    int32_t end_frame_count;    /* voice_end_frame_count */
+} vad_thresholds;
+
+/* ---- lifetime ----------------------------------------------------------------------- */
+
+/* SileroVADModel(model_path, model_version)  core/silero_model.py:276-301 */
+VAD_API int vad_engine_create(const vad_engine_desc *desc, vad_engine **out);
+/* session release (the reference lets the GC drop the ORT session; vad_wrapper.py:747-762 cleanup) */
+VAD_API void vad_engine_destroy(vad_engine *e);
+VAD_API const char *vad_last_error(const vad_engine *e);
+VAD_API const char *vad_last_create_error(void);
+/* SileroVADModel.get_model_info  core/silero_model.py:548-566 */
+VAD_API int vad_engine_info(const vad_engine *e, vad_info *info);
+
+/* ---- per-stream recurrent state (ModelState, core/silero_model.py:33-83) ------------- */
+
+/* one VADWrapper/VADProcessor/SileroVADModel per client in the reference
+ * (websocket_service/server/vad_websocket_server.py:277) == one slot here */
+VAD_API int vad_stream_open(vad_engine *e, int64_t *slot);
+VAD_API int vad_stream_close(vad_engine *e, int64_t slot);
+/* SileroVADModel.reset / _reset_states  core/silero_model.py:384-401, 539-546 (also resets the slot's state machine) */
+VAD_API int vad_stream_reset(vad_engine *e, const int64_t *slots, int64_t n);
+/* ModelState.state / hidden_state+cell_state as ONNX lays them out: 256 floats */
+VAD_API int vad_stream_get_state(vad_engine *e, int64_t slot, float *hc);
+VAD_API int vad_stream_set_state(vad_engine *e, int64_t slot, const float *hc);
+/* VADWrapper.set_thresholds  core/vad_wrapper.py:367-419 (values only; validation lives in the host mirror) */
+VAD_API int vad_stream_set_thresholds(vad_engine *e, int64_t slot, const vad_thresholds *t);
+
+/* ---- the hot path ------------------------------------------------------------------- */
+
+/*
+ * SileroVADModel.predict for n streams at once (core/silero_model.py:403-447):
+ *   frames  [n][512] in `frame_fmt`; short frames must be right-zero-padded by the caller
+ *           exactly as _prepare_audio_input does (:464-468);
+ *   denoise_thresh >= 0 applies AudioUtils.denoise_audio's gate  x if |x| > thresh else 0
+ *           (utils/audio.py:117-118; VADProcessor._preprocess_audio_frame core/silero_model.py:782-783);
+ *           a negative value disables it (VADConfig.enable_denoising = False);
+ *   probs_out [n]: float(outputs[0][0][0]) per stream (:515); state is advanced in place (:533-537).
+ * Steps on one slot are applied in call order.
+ */
+VAD_API int vad_step(vad_engine *e, const int64_t *slots, int64_t n, const void *frames, int frame_fmt,
+             float denoise_thresh, float *probs_out);
+
+/*
+ * Same, plus VADProcessor._process_voice_state (core/silero_model.py:790-949) on the device:
+ * events_out[n] receives VAD_EV_* bits per stream for this frame; seg_frames_out[n] (may be NULL)
+ * receives, on VAD_EV_END, the finished segment's length in frames (pre-roll included), else 0.
+ */
+VAD_API int vad_step_events(vad_engine *e, const int64_t *slots, int64_t n, const void *frames, int frame_fmt,
+                    float denoise_thresh, float *probs_out, uint8_t *events_out, int32_t *seg_frames_out);
+
+/*
+ * T consecutive frames per stream in one call (VADWrapper._process_audio_frames' inner loop,
+ * core/vad_wrapper.py:632-644): frames [n][T][512], probs_out [n][T], events_out [n][T] or NULL.
+ */
+VAD_API int vad_step_multi(vad_engine *e, const int64_t *slots, int64_t n, int32_t T, const void *frames, int frame_fmt,
+                   float denoise_thresh, float *probs_out, uint8_t *events_out);
+
+/*
+ * Device-resident variant of vad_step_events for callers that already hold audio in HBM
+ * (bench.py, GPU decode pipelines): every d_* pointer is device memory on the engine's GPU;
+ * d_slots may be NULL (= slots 0..n-1); d_events / d_seg_frames may be NULL; `stream` is a
+ * hipStream_t (NULL = the engine's own stream).  Asynchronous: returns after enqueueing.
+ */
+VAD_API int vad_step_device(vad_engine *e, const int32_t *d_slots, int64_t n, const void *d_frames, int frame_fmt,
+                    float denoise_thresh, float *d_probs, uint8_t *d_events, int32_t *d_seg_frames, void *stream);
+
+/*
+ * AudioUtils.resample_audio (utils/audio.py:19-55 -> scipy.signal.resample, Fourier method)
+ * for n streams: in [n][n_in] float32 at sr_in -> out [n][512] float32 at 16 kHz, one
+ * 512-sample output chunk per call (n_in = 512 * sr_in / 16000: 256 / 768 / 1536).
+ */
+VAD_API int vad_resample(vad_engine *e, const float *in, int64_t n, int32_t n_in, int32_t sr_in, float *out);
+VAD_API int vad_resample_device(vad_engine *e, const float *d_in, int64_t n, int32_t n_in, int32_t sr_in, float *d_out,
+                        void *stream);
+
+/*
+ * Diagnostic (no GPU needed): run the host-side weight packer and return the per-wave MFMA
+ * weight streams exactly as vad_engine_create uploads them.  out may be NULL to query the size.
+ * sect_out receives [4 waves][8 sections] block offsets (1 block = 256 floats).  Used by the
+ * CPU test-suite to check the packed layout against a NumPy model of the kernel's dataflow.
+ */
+VAD_API int vad_debug_pack_weights(int32_t model_version, const void *weights, size_t weights_len, float *out,
+                                   size_t out_floats, size_t *n_floats, uint32_t *sect_out);
+
+/* block until everything enqueued on the engine's own stream has finished */
+VAD_API int vad_engine_synchronize(vad_engine *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAD_ENGINE_H */
