@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 512-sample frames/sec, Silero V5 16 kHz, batch = 8192 streams per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch: every one of the 8192 resident streams
+of this GPU advances by one 512-sample frame (denoise gate -> V5 -> probability -> state
+machine), inputs already resident in HBM (ring [32][B][512] f32).  Streams are independent
+(SURVEY §8 e): ranks shard them with NO data-path collective; torch.distributed is used only for
+the barrier around the timed region and the max-over-ranks of the elapsed time ("weak" scaling:
+per-GPU work is fixed).
+
+The JSON line carries, besides the driver's contract:
+  roofline     - dominant kernel (silero_v5_step) against the fp32 MFMA peak, from HIP events
+                 recorded on the launch stream around the timed region;
+  cpu_baseline - the oracle's C port (oracle/silero_oracle.c, float accumulators) timed on this
+                 host's cores on a bounded sample of the same workload (rank 0, N=1 only), which
+                 also yields the in-run parity figure.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B_PER_GPU = 8192
+RING = 32
+FLOP_PER_FRAME = 988160          # SURVEY §8 d: 494 080 valid-tap MAC, V5 16 kHz
+BYTES_PER_FRAME = 4100           # SURVEY §8 d: 2048 in + 1024 state R + 1024 state W + 4 prob
+PEAK_FP32_MFMA = 157.3e12        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM = 8.0e12                # same guide, HBM3E spec
+PARITY_STEPS = 4
+CPU_STREAMS = 2048
+
+
+def synth_ring(first_stream: int, n: int) -> np.ndarray:
+    """BASELINE.md §4 generator -> [RING][n][512] float32 (one contiguous [n,512] batch per step)."""
+    from tests.signals import make_streams
+    return np.ascontiguousarray(make_streams(n, RING, seed=1234, first_stream=first_stream).transpose(1, 0, 2))
+
+
+def cpu_leg(ring: np.ndarray, gpu_probs: np.ndarray, budget_s: float = 12.0) -> tuple:
+    """Time the oracle port on host cores (same frames, same gate) and compare with the GPU."""
+    from cutter_vad_amd import weights_io
+    from oracle import oracle
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        blob = f.read()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = min(cores, 256)
+    om = oracle.OracleModel(blob, "f32")
+    n = min(CPU_STREAMS, ring.shape[1])
+    st = np.zeros((n, 256), np.float32)
+    worst, total_dp, cnt = 0.0, 0.0, 0
+    frames_done, elapsed, step = 0, 0.0, 0
+    while True:
+        x = oracle.denoise(ring[step % RING, :n]).reshape(n, 512)
+        t0 = time.perf_counter()
+        p = om.step_batch(x, st, nthreads=threads)
+        elapsed += time.perf_counter() - t0
+        frames_done += n
+        if step < gpu_probs.shape[0]:
+            d = np.abs(p - gpu_probs[step, :n])
+            worst = max(worst, float(d.max()))
+            total_dp += float(d.sum())
+            cnt += d.size
+        step += 1
+        if (elapsed >= budget_s and step >= gpu_probs.shape[0]) or step >= 400:
+            break
+    base = {
+        "value": frames_done / elapsed,
+        "unit": "frames/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{n} streams x {step} steps of the same workload (oracle/silero_oracle.c, float accumulators, "
+                  f"{threads} pthreads; onnxruntime is not installed on this box)",
+    }
+    parity = {"max_abs_dp": worst, "mean_abs_dp": total_dp / max(cnt, 1), "frames": cnt,
+              "against": "oracle C port (f32) on identical inputs", "bar": 1e-4}
+    return base, parity
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--streams", type=int, default=B_PER_GPU, help="streams per GPU (headline: 8192)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from cutter_vad_amd import weights_io
+    from cutter_vad_amd.engine import Engine
+
+    B = args.streams
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        blob = f.read()
+    eng = Engine(blob, model_version=5, device_id=local_rank, max_streams=B)
+    eng.open_streams(B)                       # slots 0..B-1, zero state, default thresholds
+    ring_h = synth_ring(rank * B, B)
+    ring = torch.from_numpy(ring_h).cuda()
+    probs = torch.empty(B, device="cuda")
+    events = torch.empty(B, dtype=torch.uint8, device="cuda")
+    ts = torch.cuda.Stream()
+    torch.cuda.synchronize()
+
+    def step(i: int) -> None:
+        eng.step_device(B, ring[i % RING].data_ptr(), probs.data_ptr(), d_events=events.data_ptr(),
+                        denoise=0.01, stream=ts.cuda_stream)
+
+    with torch.cuda.stream(ts):
+        gpu_probs = torch.empty(PARITY_STEPS, B, device="cuda")
+        for i in range(PARITY_STEPS):       # from zero state: these frames are what the CPU leg replays
+            step(i)
+            gpu_probs[i].copy_(probs)
+        for i in range(args.warmup):
+            step(PARITY_STEPS + i)
+        ts.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(ts)
+        for i in range(args.steps):
+            step(PARITY_STEPS + args.warmup + i)
+        e1.record(ts)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+    kernel_s = e0.elapsed_time(e1) * 1e-3 / args.steps      # avg launch duration on the launch stream
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(probs).all()) and float(probs.min()) >= 0.0 and float(probs.max()) <= 1.0
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        achieved = FLOP_PER_FRAME * B / kernel_s
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "512-sample frames/sec, Silero V5 16kHz, batch=8192 streams per GPU",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[2]: batch=8192 concurrent streams per GPU, Silero V5, 16 kHz, "
+                            "one 512-sample frame per stream per step, denoise gate 0.01, state machine on",
+                "streams_per_gpu": B,
+                "frames_per_step_per_gpu": B,
+                "ring_frames": RING,
+                "sharding": f"{world} independent per-GPU stream pools, no collective",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "silero_v5_step",
+                "achieved": achieved / 1e12,
+                "peak": PEAK_FP32_MFMA / 1e12,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_MFMA,
+                "traffic": traffic,
+                "kernel_us": kernel_s * 1e6,
+                "algorithmic_flop_per_launch": FLOP_PER_FRAME * B,
+                "hbm_algorithmic_GBps": BYTES_PER_FRAME * B / kernel_s / 1e9,
+                "hbm_frac": BYTES_PER_FRAME * B / kernel_s / PEAK_HBM,
+            },
+        }
+        if world == 1 and not args.no_cpu:
+            base, parity = cpu_leg(ring_h, gpu_probs.cpu().numpy())
+            out["cpu_baseline"] = base
+            out["parity"] = parity
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,11 @@ eng.open_streams(B)
 g = torch.Generator(device="cuda").manual_seed(0)
 ring = (0.1 * torch.randn(32, B, 512, device="cuda", generator=g)).contiguous()
 probs = torch.empty(B, device="cuda")
-st = torch.cuda.current_stream().cuda_stream
+ts = torch.cuda.Stream()
+torch.cuda.synchronize()
+torch.cuda.set_stream(ts)
+st = ts.cuda_stream
+assert st != 0
 for i in range(20):
     eng.step_device(B, ring[i % 32].data_ptr(), probs.data_ptr(), stream=st)
 torch.cuda.synchronize()
