@@ -24,6 +24,8 @@
 #include "vad_layout.h"
 
 extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream_t stream);
+extern "C" hipError_t vadk_launch_sm_replay(vadk::SmSlot *sm, int slot, const float *probs, int n, uint8_t *events,
+                                            int32_t *seg, hipStream_t stream);
 
 namespace {
 
@@ -33,7 +35,7 @@ const vadk::SmSlot kDefaultSm = [] {
     vadk::SmSlot s;
     std::memset(&s, 0, sizeof s);
     // VADConfig defaults, core/config.py:54-94
-    s.start_prob = 0.7f; s.end_prob = 0.7f; s.start_ratio = 0.8f; s.end_ratio = 0.95f;
+    s.start_prob = 0.7; s.end_prob = 0.7; s.start_ratio = 0.8; s.end_ratio = 0.95;
     s.start_count = 10; s.end_count = 50;
     s.seg_frames = -1;
     return s;
@@ -459,6 +461,25 @@ int vad_debug_pack_weights(int32_t model_version, const void *weights, size_t we
         }
         std::memcpy(out, pw.data.data(), pw.data.size() * sizeof(float));
     }
+    return VAD_OK;
+}
+
+int vad_debug_sm_replay(vad_engine *e, int64_t slot, const float *probs, int64_t n, uint8_t *events_out,
+                        int32_t *seg_frames_out) {
+    if (!e || !probs || !events_out || !seg_frames_out || n < 1) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
+        return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (int rc = ensure(e, e->d_probs, e->d_probs_cap, sizeof(float) * n)) return rc;
+    if (int rc = ensure(e, e->d_events, e->d_events_cap, (size_t)n)) return rc;
+    if (int rc = ensure(e, e->d_seg, e->d_seg_cap, sizeof(int32_t) * n)) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->d_probs, probs, sizeof(float) * n, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, vadk_launch_sm_replay(e->d_sm, (int)slot, e->d_probs, (int)n, e->d_events, e->d_seg, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(events_out, e->d_events, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(seg_frames_out, e->d_seg, sizeof(int32_t) * n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
     return VAD_OK;
 }
 

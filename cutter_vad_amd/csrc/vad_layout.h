@@ -47,9 +47,10 @@ constexpr int LDS_F4 = (ROWS_A + ROWS_B + ROWS_H) * QS + 32;  // + 4x32 floats o
 constexpr int LDS_BYTES = LDS_F4 * 16;
 }  // namespace v5
 
-// per-slot hysteresis state (VADProcessor fields, core/silero_model.py:596-639), 80 bytes
+// per-slot hysteresis state (VADProcessor fields, core/silero_model.py:596-639), 96 bytes.
+// Thresholds are doubles: the reference compares Python floats (float(np.float32 p) >= 0.7).
 struct SmSlot {
-    float start_prob, end_prob, start_ratio, end_ratio;
+    double start_prob, end_prob, start_ratio, end_ratio;
     int32_t start_count, end_count;
     int32_t active, n_start, n_end;
     int32_t start_len;       // len(recent_start_frames), deque maxlen 20
@@ -60,7 +61,7 @@ struct SmSlot {
     int32_t seg_frames;      // frames in current_voice_data (-1 = None)
     int32_t pad[2];
 };
-static_assert(sizeof(SmSlot) == 80, "SmSlot layout");
+static_assert(sizeof(SmSlot) == 96, "SmSlot layout");
 
 struct StepParams {
     const float *wstream;          // packed weight streams

@@ -118,6 +118,15 @@ class Engine:
                             end_frame_count)
         self._check(self._lib.vad_stream_set_thresholds(self._h, int(slot), C.byref(t)), VADError)
 
+    def debug_sm_replay(self, slot: int, probs) -> Tuple[np.ndarray, np.ndarray]:
+        """Diagnostic: run scripted probabilities through one slot's device state machine."""
+        p = np.ascontiguousarray(probs, np.float32)
+        ev = np.zeros(p.size, np.uint8)
+        seg = np.zeros(p.size, np.int32)
+        self._check(self._lib.vad_debug_sm_replay(self._h, int(slot), _ptr(p, C.c_float), p.size, _ptr(ev, C.c_uint8),
+                                                  _ptr(seg, C.c_int32)), VADError)
+        return ev, seg
+
     # ------------------------------------------------------------------ hot path
     @staticmethod
     def _prep(slots, frames, T: Optional[int]) -> Tuple[np.ndarray, np.ndarray, int]:

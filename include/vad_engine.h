@@ -99,10 +99,10 @@ typedef struct vad_info {
 
 /* thresholds of one stream's state machine: VADConfig fields core/config.py:54-94 */
 typedef struct vad_thresholds {
-    float start_probability;    /* vad_start_probability */
-    float end_probability;      /* vad_end_probability   */
-    float start_ratio;          /* voice_start_ratio (dead logic in the reference, kept: SURVEY a10) */
-    float end_ratio;            /* voice_end_ratio */
+    double start_probability;   /* vad_start_probability (Python float: compared as double, like the reference) */
+    double end_probability;     /* vad_end_probability   */
+    double start_ratio;         /* voice_start_ratio (dead logic in the reference, kept: SURVEY a10) */
+    double end_ratio;           /* voice_end_ratio */
     int32_t start_frame_count;  /* voice_start_frame_count */
     int32_t end_frame_count;    /* voice_end_frame_count */
 } vad_thresholds;
@@ -188,6 +188,16 @@ VAD_API int vad_resample_device(vad_engine *e, const float *d_in, int64_t n, int
  */
 VAD_API int vad_debug_pack_weights(int32_t model_version, const void *weights, size_t weights_len, float *out,
                                    size_t out_floats, size_t *n_floats, uint32_t *sect_out);
+
+/*
+ * Diagnostic: replay a scripted probability sequence through ONE slot's device-side state
+ * machine (the code path vad_step_events runs after the model).  probs [n] -> events_out [n],
+ * seg_frames_out [n] (segment length in frames on END, else 0).  Lets the GPU test-suite check
+ * the hysteresis logic against the reference's own traces without needing audio that produces
+ * a given probability sequence.
+ */
+VAD_API int vad_debug_sm_replay(vad_engine *e, int64_t slot, const float *probs, int64_t n, uint8_t *events_out,
+                                int32_t *seg_frames_out);
 
 /* block until everything enqueued on the engine's own stream has finished */
 VAD_API int vad_engine_synchronize(vad_engine *e);

@@ -48,7 +48,7 @@ def _lib(acc: str = "f64") -> C.CDLL:
     lib.svo_split_frames.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p]
     lib.svo_resample.argtypes = [f32p, C.c_int, f32p, C.c_int]
     lib.svo_sm_sizeof.restype = C.c_size_t
-    lib.svo_sm_init.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+    lib.svo_sm_init.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
     lib.svo_sm_reset.argtypes = [C.c_void_p]
     lib.svo_sm_step.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_longlong)]
     lib.svo_sm_active.argtypes = [C.c_void_p]

@@ -460,7 +460,7 @@ SVO_API void svo_resample(const float *in, int n_in, float *out, int n_out) {
 
 typedef struct svo_sm {
     /* config (config.py:54-94) */
-    float start_prob, end_prob, start_ratio, end_ratio;
+    double start_prob, end_prob, start_ratio, end_ratio; /* Python floats */
     int start_count, end_count;
     /* silero_model.py:596-639 */
     int active;
@@ -487,7 +487,7 @@ SVO_API void svo_sm_reset(svo_sm *s) {
     s->seg_samples = -1;
 }
 
-SVO_API void svo_sm_init(svo_sm *s, float start_prob, float end_prob, float start_ratio, float end_ratio,
+SVO_API void svo_sm_init(svo_sm *s, double start_prob, double end_prob, double start_ratio, double end_ratio,
                          int start_count, int end_count) {
     memset(s, 0, sizeof *s);
     s->start_prob = start_prob; s->end_prob = end_prob;
@@ -520,7 +520,7 @@ SVO_API int svo_sm_step(svo_sm *s, double p, int frame_len, long long *seg_sampl
     if (seg_samples_out) *seg_samples_out = 0;
     if (!s->active) {
         /* _handle_voice_start_detection :818-858 */
-        int above = p >= (double)s->start_prob;
+        int above = p >= s->start_prob;
         dq_push(s->start_hist, 20, &s->start_len, &s->start_head, (uint8_t)above);
         if (above) {
             s->n_start += 1;
@@ -528,7 +528,7 @@ SVO_API int svo_sm_step(svo_sm *s, double p, int frame_len, long long *seg_sampl
             if (s->n_start >= s->start_count && s->start_len >= s->start_count) {
                 int k = s->start_count;
                 double ratio = (double)dq_sum_last(s->start_hist, 20, s->start_len, s->start_head, k) / (double)k;
-                if (ratio >= (double)s->start_ratio) {
+                if (ratio >= s->start_ratio) {
                     /* _confirm_voice_start :860-869 */
                     s->active = 1;
                     s->n_start = 0;
@@ -547,14 +547,14 @@ SVO_API int svo_sm_step(svo_sm *s, double p, int frame_len, long long *seg_sampl
         /* _handle_ongoing_voice_activity :877-923 */
         s->seg_samples = (s->seg_samples < 0 ? 0 : s->seg_samples) + frame_len; /* _accumulate_voice_data */
         ev |= SVO_EV_CONTINUE;
-        int below = p < (double)s->end_prob;
+        int below = p < s->end_prob;
         dq_push(s->end_hist, 100, &s->end_len, &s->end_head, (uint8_t)below);
         if (below) {
             s->n_end += 1;
             if (s->n_end >= s->end_count && s->end_len >= s->end_count) {
                 int k = s->end_count;
                 double ratio = (double)dq_sum_last(s->end_hist, 100, s->end_len, s->end_head, k) / (double)k;
-                if (ratio >= (double)s->end_ratio) {
+                if (ratio >= s->end_ratio) {
                     /* _finalize_voice_segment :932-949 */
                     if (seg_samples_out) *seg_samples_out = s->seg_samples;
                     s->active = 0;

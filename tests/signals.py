@@ -18,3 +18,29 @@ def make_streams(n: int, T: int, seed: int = 1234, first_stream: int = 0) -> np.
                        + 0.2 * np.sin(2 * np.pi * 600 * t)) + 0.03 * rng.standard_normal(t.size)
         out[i] = np.clip(x, -1.0, 1.0).astype(np.float32)
     return out.reshape(n, T, 512)
+
+
+def gate(x, thr=0.01):
+    return np.where(np.abs(x) > thr, x, 0.0).astype(np.float32)
+
+
+def model_cases(speech_i16: np.ndarray):
+    speech = (speech_i16.astype(np.float32) / np.float32(32767.0)).astype(np.float32)
+    n = speech.size // 512
+    sp = speech[: n * 512].reshape(n, 512)
+    rng = np.random.default_rng(4242)
+    cases = {}
+    cases["speech_gate"] = dict(frames=gate(sp), regen="speech16k int16 / 32767, 512-sample frames, gate 0.01")
+    cases["speech_nogate_first120"] = dict(frames=sp[:120], regen="speech16k int16 / 32767, first 120 frames, no gate")
+    for sigma in (0.005, 0.02, 0.3):
+        x = (sigma * np.random.default_rng(int(sigma * 1e4)).standard_normal((40, 512))).astype(np.float32)
+        cases[f"noise_{sigma}"] = dict(frames=gate(x), regen=f"default_rng({int(sigma*1e4)}).standard_normal((40,512))*{sigma}, gate 0.01")
+    cases["harmonic"] = dict(frames=gate(make_streams(2, 40, seed=1234)[1]), regen="tests.signals.make_streams(2,40,seed=1234)[1], gate 0.01")
+    cases["zeros"] = dict(frames=np.zeros((8, 512), np.float32), regen="zeros((8,512))")
+    sq = np.where(np.arange(512 * 8) % 64 < 32, 1.0, -1.0).astype(np.float32).reshape(8, 512)
+    cases["square_fullscale"] = dict(frames=sq, regen="where(arange(4096)%64<32,1,-1).reshape(8,512)")
+    short = (0.2 * rng.standard_normal((8, 400))).astype(np.float32)
+    cases["short400_padded"] = dict(frames=np.pad(short, ((0, 0), (0, 112))), regen="default_rng(4242): 0.2*standard_normal((8,400)) right-zero-padded to 512")
+    long_ = (0.2 * rng.standard_normal((8, 600))).astype(np.float32)
+    cases["long600_truncated"] = dict(frames=long_[:, :512].copy(), regen="default_rng(4242) (continued): 0.2*standard_normal((8,600))[:, :512]")
+    return cases

@@ -1,0 +1,109 @@
+"""The C-ABI boundary, without a GPU: the library loads, exports every symbol the header
+declares, the host-side packer produces the layout the kernel consumes, and nothing in the
+product routes through the oracle or any CPU fallback."""
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cutter_vad_amd import _ffi, weights_io
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    with open(os.path.join(ROOT, "include", "vad_engine.h")) as f:
+        src = f.read()
+    return re.findall(r"^VAD_API\s+[\w\s\*]+?\b(vad_\w+)\s*\(", src, flags=re.M)
+
+
+def test_library_exports_every_declared_symbol():
+    names = _header_symbols()
+    assert len(names) >= 20
+    lib = _ffi.lib()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vad_engine.h but not exported"
+    assert sorted(names) == sorted(_ffi.SIGNATURES), "ctypes table and header disagree"
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(_ffi.EngineDesc) == 40
+    assert C.sizeof(_ffi.Thresholds) == 40
+    assert C.sizeof(_ffi.EngineInfo) == 32 + 32 + 64 + 32
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cutter_vad_amd.core.exceptions import ModelInitializationError
+    from cutter_vad_amd.engine import Engine
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        blob = f.read()
+    with pytest.raises(ModelInitializationError, match="no HIP device|no CPU fallback|Failed to load model"):
+        Engine(blob, max_streams=8)
+
+
+def test_bad_weights_are_rejected():
+    lib = _ffi.lib()
+    n = C.c_size_t()
+    junk = b"not a blob" * 10
+    assert lib.vad_debug_pack_weights(5, junk, len(junk), None, 0, C.byref(n), None) == _ffi.VAD_ERR_BAD_WEIGHTS
+    assert b"Failed to load model" in lib.vad_last_create_error()
+    with open(weights_io.packaged_blob_path(4), "rb") as f:
+        v4 = f.read()
+    assert lib.vad_debug_pack_weights(5, v4, len(v4), None, 0, C.byref(n), None) == _ffi.VAD_ERR_BAD_WEIGHTS
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "cutter_vad_amd")
+    bad = []
+    for dp, _dn, fn in os.walk(pkg):
+        if "build" in dp.split(os.sep):
+            continue
+        for f in fn:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                src = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|liboracle|silero_oracle", src, flags=re.M):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, f"product code references the oracle: {bad}"
+
+
+def test_packed_layout_reproduces_the_oracle():
+    """NumPy model of the kernel's dataflow over the packed streams == oracle (V5)."""
+    from oracle import oracle
+    from tests import kernel_model as KM
+    from tests.signals import make_streams
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        blob = f.read()
+    W, sect = KM.packed_streams(5, blob)
+    om = oracle.OracleModel(blob, "f64")
+    x = make_streams(32, 3, seed=5)
+    hc = np.zeros((32, 256), np.float32)
+    hc_o = hc.copy()
+    with np.errstate(over="ignore"):
+        for t in range(3):
+            p, hc = KM.v5_step(W, sect, x[:, t], hc, gate=0.01)
+            po = om.step_batch(oracle.denoise(x[:, t]).reshape(32, 512), hc_o)
+            assert np.abs(p - po).max() <= 5e-6
+            assert np.abs(hc - hc_o).max() <= 1e-4
+
+
+def test_weights_blob_roundtrip_and_reference_arity_rule(tmp_path):
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        blob = f.read()
+    v, t = weights_io.unpack_svw(blob)
+    assert v == 5 and t["stft.basis"].shape == (258, 256) and t["lstm.w_ih"].shape == (512, 128)
+    assert sum(a.size for a in t.values()) == 309633
+    again = weights_io.pack_svw(5, t)
+    assert again == blob
+    with pytest.raises(weights_io.WeightFormatError):
+        weights_io.unpack_svw(b"garbage" * 4)
+    p = tmp_path / "w.svw"
+    p.write_bytes(blob)
+    assert weights_io.load_weight_blob(str(p), 5) == blob
+    with pytest.raises(weights_io.WeightFormatError):
+        weights_io.load_weight_blob(str(p), 4)
