@@ -377,8 +377,11 @@ int vad_stream_set_thresholds(vad_engine *e, int64_t slot, const vad_thresholds 
     if (t->start_frame_count < 1 || t->end_frame_count < 1)
         return e->fail(VAD_ERR_INVALID_ARG, "frame counts must be >= 1");
     HIP_TRY(e, hipSetDevice(e->device));
-    // set_thresholds also resets the processor (vad_wrapper.py:412-413): dynamic part back to initial
-    vadk::SmSlot s = kDefaultSm;
+    // values only: the dynamic part (counters, history) is untouched.  VADWrapper.set_thresholds resets the
+    // processor afterwards (vad_wrapper.py:412-413) through vad_stream_reset.
+    vadk::SmSlot s;
+    HIP_TRY(e, hipMemcpyAsync(&s, e->d_sm + slot, sizeof s, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
     s.start_prob = t->start_probability; s.end_prob = t->end_probability;
     s.start_ratio = t->start_ratio; s.end_ratio = t->end_ratio;
     s.start_count = t->start_frame_count; s.end_count = t->end_frame_count;

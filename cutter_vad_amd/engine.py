@@ -186,3 +186,14 @@ class Engine:
         thr = -1.0 if denoise is None else float(denoise)
         self._check(self._lib.vad_step_device(self._h, d_slots or None, n, d_frames, fmt, thr, d_probs,
                                               d_events or None, d_seg or None, stream or None))
+
+    # ------------------------------------------------------------------ resampler (a11)
+    def resample(self, chunks, sr_in: int) -> np.ndarray:
+        """chunks [n, n_in] float32 at ``sr_in`` -> [n, 512] at 16 kHz (``vad_resample``)."""
+        x = np.ascontiguousarray(chunks, np.float32)
+        if x.ndim != 2:
+            raise AudioProcessingError(f"Failed to resample audio: expected [n, n_in], got {x.shape}")
+        out = np.empty((x.shape[0], 512), np.float32)
+        self._check(self._lib.vad_resample(self._h, _ptr(x, C.c_float), x.shape[0], x.shape[1], int(sr_in),
+                                           _ptr(out, C.c_float)))
+        return out

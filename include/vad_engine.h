@@ -129,7 +129,8 @@ VAD_API int vad_stream_reset(vad_engine *e, const int64_t *slots, int64_t n);
 /* ModelState.state / hidden_state+cell_state as ONNX lays them out: 256 floats */
 VAD_API int vad_stream_get_state(vad_engine *e, int64_t slot, float *hc);
 VAD_API int vad_stream_set_state(vad_engine *e, int64_t slot, const float *hc);
-/* VADWrapper.set_thresholds  core/vad_wrapper.py:367-419 (values only; validation lives in the host mirror) */
+/* VADWrapper.set_thresholds  core/vad_wrapper.py:367-419: values only (validation lives in the host mirror);
+ * the counters/history of the slot are NOT reset here - the wrapper calls vad_stream_reset next, as :412-413 does */
 VAD_API int vad_stream_set_thresholds(vad_engine *e, int64_t slot, const vad_thresholds *t);
 
 /* ---- the hot path ------------------------------------------------------------------- */

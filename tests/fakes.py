@@ -1,0 +1,95 @@
+"""Test doubles (CPU): a scripted engine so that host logic can be exercised without a GPU.
+
+Plays the role the reference's tests give to ``Mock(spec=ort.InferenceSession)``
+(/root/reference/tests/test_silero_model.py:277-292): probabilities are canned, the device-side
+state machine is played by the oracle's restatement of it.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Dict, Iterable, Optional
+
+import numpy as np
+
+from oracle import oracle
+
+
+class FakeEngine:
+    def __init__(self, probs: Optional[Iterable[float]] = None, fn: Optional[Callable[[np.ndarray], float]] = None):
+        self._it = iter(probs) if probs is not None else None
+        self._fn = fn
+        self.handle = True
+        self.sm: Dict[int, oracle.StateMachine] = {}
+        self.thr: Dict[int, tuple] = {}
+        self.state: Dict[int, np.ndarray] = {}
+        self.frames_seen = []
+        self.denoise_seen = []
+        self._next = 0
+        self.closed = []
+        self.model_version = 5
+
+    def script(self, probs):
+        self._it = iter(probs)
+
+    def _p(self, frame):
+        if self._fn is not None:
+            return float(self._fn(frame))
+        return float(next(self._it))
+
+    def open_stream(self):
+        s = self._next
+        self._next += 1
+        self.thr[s] = (0.7, 0.7, 0.8, 0.95, 10, 50)
+        self.sm[s] = oracle.StateMachine(*self.thr[s])
+        self.state[s] = np.zeros(256, np.float32)
+        return s
+
+    def open_streams(self, n):
+        return np.array([self.open_stream() for _ in range(n)], np.int64)
+
+    def close_stream(self, s):
+        self.closed.append(int(s))
+        self.sm.pop(int(s), None)
+
+    def reset(self, slots):
+        for s in slots:
+            self.sm[int(s)] = oracle.StateMachine(*self.thr[int(s)])
+            self.state[int(s)] = np.zeros(256, np.float32)
+
+    def set_thresholds(self, s, *t):
+        # values only: rebuild the machine with the same dynamic state is not needed by these tests
+        self.thr[int(s)] = tuple(t)
+        self.sm[int(s)] = oracle.StateMachine(*t)
+
+    def get_state(self, s):
+        return self.state[int(s)].copy()
+
+    def set_state(self, s, hc):
+        self.state[int(s)] = np.asarray(hc, np.float32).copy()
+
+    def step(self, slots, frames, denoise=0.01, i16_scale=32767):
+        frames = np.asarray(frames, np.float32).reshape(len(slots), -1)
+        assert frames.shape[1] == 512, "callers must pad to 512"
+        self.frames_seen.append(frames.copy())
+        self.denoise_seen.append(denoise)
+        return np.array([self._p(f) for f in frames], np.float64)  # exact scripted values
+
+    def step_events(self, slots, frames, denoise=0.01, i16_scale=32767):
+        p = self.step(slots, frames, denoise)
+        ev = np.zeros(len(slots), np.uint8)
+        seg = np.zeros(len(slots), np.int32)
+        for i, s in enumerate(slots):
+            e, sg = self.sm[int(s)].step(float(p[i]), 1)
+            ev[i], seg[i] = e, sg
+        return p, ev, seg
+
+    def close(self):
+        self.handle = False
+
+
+class FakePool:
+    def __init__(self, engine: FakeEngine):
+        self.engine = engine
+
+    def engine_for(self, model_path, version, device_id=None, max_streams=None):
+        return self.engine

@@ -1,0 +1,131 @@
+"""GPU tests of the drop-in surface: VADWrapper / VADProcessor / StreamBatch over the HIP engine."""
+
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def speech():
+    return np.load(os.path.join(GOLD, "speech16k_i16.npz"))["pcm"]
+
+
+def test_device_state_machine_replays_reference_traces():
+    """Every scenario recorded from the reference's VADProcessor, replayed through the device-side
+    state machine (probabilities pass through float32, as they do from the model)."""
+    from cutter_vad_amd import weights_io
+    from cutter_vad_amd.engine import Engine
+    from oracle import oracle
+    with open(os.path.join(GOLD, "state_machine.json")) as f:
+        scen = json.load(f)["scenarios"]
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        blob = f.read()
+    with Engine(blob, max_streams=64) as eng:
+        for name, s in scen.items():
+            c = s["config"]
+            thr = (c.get("vad_start_probability", 0.7), c.get("vad_end_probability", 0.7),
+                   c.get("voice_start_ratio", 0.8), c.get("voice_end_ratio", 0.95),
+                   c.get("voice_start_frame_count", 10), c.get("voice_end_frame_count", 50))
+            slot = eng.open_stream()
+            eng.set_thresholds(slot, *thr)
+            p32 = np.asarray(s["probs"], np.float32)
+            ev, seg = eng.debug_sm_replay(slot, p32)
+            sm = oracle.StateMachine(*thr)
+            ref = [sm.step(float(p), 1) for p in p32]
+            assert list(ev) == [r[0] for r in ref], name
+            assert list(seg) == [r[1] if r[0] & 2 else 0 for r in ref], name
+            if all(float(np.float32(p)) == p or abs(p - thr[0]) > 1e-6 and abs(p - thr[1]) > 1e-6 for p in s["probs"]):
+                assert list(ev) == s["events"], name          # identical to the reference trace itself
+            eng.close_stream(slot)
+
+
+def test_vadwrapper_end_to_end_four_segments(speech):
+    """The reference's only real-model expectation (examples/test_python_vad_client.py:200-223),
+    through the real product path: VADWrapper -> VADProcessor -> C ABI -> HIP kernel."""
+    from cutter_vad_amd import SampleRate, SileroModelVersion, VADConfig, VADWrapper
+    g = np.load(os.path.join(GOLD, "e2e_client_config.npz"))
+    cfg = VADConfig(sample_rate=SampleRate(16000), model_version=SileroModelVersion.V5, vad_start_probability=0.4,
+                    vad_end_probability=0.3, voice_start_ratio=0.8, voice_end_ratio=0.95, voice_start_frame_count=6,
+                    voice_end_frame_count=12, enable_denoising=True, auto_convert_sample_rate=True, buffer_size=480)
+    log, wavs, probs = [], [], []
+    cur = [0]
+    with VADWrapper(config=cfg) as vad:
+        vad.set_callbacks(lambda: log.append((1, cur[0])), lambda w: (log.append((2, cur[0])), wavs.append(w)),
+                          lambda b: None)
+        for i in range(speech.size // 480):
+            cur[0] = i
+            vad.process_audio_data(speech[i * 480:(i + 1) * 480].astype(np.float32) / 32767.0)
+            probs.append(vad.processor.voice_probabilities[-1])
+        stats = vad.get_statistics()
+    assert np.abs(np.asarray(probs, np.float32) - g["probs"]).max() <= 2e-5      # bar: 1e-4
+    assert [k for k, _ in log] == list(g["event_kinds"]) and [f for _, f in log] == list(g["event_frames"])
+    assert len(wavs) == 4
+    assert [len(w) for w in wavs] == list(g["wav_sizes"])
+    assert [hashlib.sha256(w).hexdigest() for w in wavs] == [str(s) for s in g["wav_sha256"]]
+    assert stats["total_frames_processed"] == speech.size // 480
+
+
+def test_wrapper_overlapping_frames_and_shared_engine():
+    """1024-sample chunks advance the LSTM 3 times (hop = 1/2 frame); two
+    wrappers share one engine but keep independent state."""
+    from cutter_vad_amd import VADConfig, VADWrapper
+    from cutter_vad_amd import weights_io
+    from oracle import oracle
+    from tests.signals import make_streams
+    audio = make_streams(2, 8, seed=31).reshape(2, -1)
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        om = oracle.OracleModel(f.read(), "f64")
+    with VADWrapper(VADConfig()) as a, VADWrapper(VADConfig()) as b:
+        assert a.processor.model.engine is b.processor.model.engine
+        assert a.processor.model.slot != b.processor.model.slot
+        ref_state = [np.zeros(256, np.float32), np.zeros(256, np.float32)]
+        for k in range(4):
+            for i, w in enumerate((a, b)):
+                chunk = audio[i, k * 1024:(k + 1) * 1024]
+                w.process_audio_data(chunk)
+                got = list(w.processor.voice_probabilities)[-3:]
+                frames = oracle.split_frames(chunk, 512, 256)
+                ref = [om.step(oracle.denoise(fr), ref_state[i]) for fr in frames]
+                assert np.abs(np.array(got) - np.array(ref)).max() <= 2e-5
+        assert a.get_statistics()["total_frames_processed"] == 12
+        info = a.processor.get_model_info()
+        assert info["prediction_count"] == 12 and info["state_shape"]["state"] == (2, 1, 128)
+
+
+def test_stream_batch_events_match_oracle():
+    from cutter_vad_amd import StreamBatch, VADConfig
+    from cutter_vad_amd import weights_io
+    from oracle import oracle
+    from tests.signals import make_streams
+    n, T = 96, 40
+    cfg = VADConfig(vad_start_probability=0.5, vad_end_probability=0.35, voice_start_frame_count=3,
+                    voice_end_frame_count=4)
+    # alternate loud / quiet blocks so that segments start and end
+    frames = make_streams(n, T, seed=55)
+    frames[:, 15:25] *= 0.01
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        om = oracle.OracleModel(f.read(), "f64")
+    batch = StreamBatch(cfg)
+    try:
+        batch.add(n)
+        st = np.zeros((n, 256), np.float32)
+        sms = [oracle.StateMachine(0.5, 0.35, 0.8, 0.95, 3, 4) for _ in range(n)]
+        n_start = n_end = 0
+        for t in range(T):
+            p, ev, seg = batch.step(frames[:, t])
+            pr = om.step_batch(oracle.denoise(frames[:, t]).reshape(n, 512), st, nthreads=8)
+            assert np.abs(p - pr).max() <= 2e-5
+            for i in range(n):
+                e_ref, s_ref = sms[i].step(float(p[i]), 1)     # same float32 probability the device saw
+                assert ev[i] == e_ref and seg[i] == (s_ref if e_ref & 2 else 0), (t, i)
+            n_start += int((ev & 1).sum())
+            n_end += int(((ev & 2) != 0).sum())
+        assert n_start > 10 and n_end > 10, "the scenario must exercise both transitions"
+    finally:
+        batch.close()

