@@ -252,6 +252,7 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
             return bail(r, "hipMemcpy(sm)");
     }
     e->base.wstream = e->d_wstream;
+    e->base.wstream_bytes = (uint32_t)e->wbytes;
     std::memcpy(e->base.sect, pw.sect, sizeof pw.sect);
     e->base.state = e->d_state;
     e->base.sm = e->d_sm;

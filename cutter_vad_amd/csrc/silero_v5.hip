@@ -23,6 +23,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short i16x4 __attribute__((ext_vector_type(4)));
 
+#ifdef VADK_STAMPS
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        if (lane == 0) P.stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + (k)] = clock64();          \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ f32x16 mfma4(f32x4 w, f32x4 a, f32x16 acc) {
@@ -64,7 +73,34 @@ __device__ __forceinline__ void store_tile_relu(f32x4 *region, int row0, int m, 
     for (int g = 0; g < 4; ++g) region[(row0 + 2 * g + h) * QS + m] = relu4(quad_of(acc, g));
 }
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// v_exp_f32 / v_rcp_f32 / v_sqrt_f32 are 1-ulp hardware ops: |error| of sigmoid/tanh below 5e-7 absolute
+__device__ __forceinline__ float sigmoidf_(float v) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v));
+}
+__device__ __forceinline__ float tanhf_(float v) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * v));
+}
+__device__ __forceinline__ float mag_(float re, float im) { return __builtin_amdgcn_sqrtf(re * re + im * im); }
+
+__device__ __forceinline__ f32x16 acc_of(f32x4 b0, f32x4 b1, f32x4 b2, f32x4 b3) {
+    f32x16 a;
+    a.s0 = b0.x; a.s1 = b0.y; a.s2 = b0.z; a.s3 = b0.w;
+    a.s4 = b1.x; a.s5 = b1.y; a.s6 = b1.z; a.s7 = b1.w;
+    a.s8 = b2.x; a.s9 = b2.y; a.sa = b2.z; a.sb = b2.w;
+    a.sc = b3.x; a.sd = b3.y; a.se = b3.z; a.sf = b3.w;
+    return a;
+}
+
+// No instruction may be moved across this point by the compiler's scheduler.  The kernel's
+// software pipelining (weights for iteration i+1 are requested before the MFMAs of iteration i
+// are issued) only survives hipcc's machine scheduler when it is fenced like this.
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// one 1 KiB weight block: 16 bytes per lane at byte offset voff = lane*16, block index in SGPRs
+__device__ __forceinline__ f32x4 ldw(__amdgpu_buffer_rsrc_t rs, int voff, int blk) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, blk * 1024, 0));
+}
 
 __device__ __forceinline__ f32x4 gate4(f32x4 v, float thr) {
     // utils/audio.py:117-118: np.where(np.abs(x) > thr, x, 0.0); thr < 0 disables the gate
@@ -96,8 +132,18 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
     const int gf = tile0 + m;                     // this lane's stream index within the call
     const bool live = gf < P.n;
     const int slot = live ? (P.slots ? P.slots[gf] : gf) : 0;
-    const f32x4 *const wbase = reinterpret_cast<const f32x4 *>(P.wstream) + lane;
+    // Weight streams are read through ONE buffer descriptor (SGPRs, built from kernel arguments only):
+    // voffset = lane * 16 (a single VGPR for every load of the kernel), soffset = block * 1024 (SALU).
+    // With flat 64-bit VGPR addresses hipcc hoisted ~150 loop-invariant pointers out of the frame loop
+    // and spilled them (cdna_hip_programming.md T8/T20).
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wstream), 0, (int)P.wstream_bytes, 0x00020000);
+    const int lane16 = lane * 16;
+#define WL(blk) ldw(wrs, lane16, (blk))
+    const int o_stft = (int)P.sect[w][S_STFT], o_nyq = (int)P.sect[w][S_NYQ], o_e0 = (int)P.sect[w][S_ENC0];
+    const int o_e1 = (int)P.sect[w][S_ENC1], o_e2 = (int)P.sect[w][S_ENC2], o_e3 = (int)P.sect[w][S_ENC3];
+    const int o_l = (int)P.sect[w][S_LSTM];
     const int T = P.T;
+    const int hq = h * QS + m;                    // lane's offset inside a quad-row pair
 
     // ---- prologue: h_{t-1} -> LDS quads, c_{t-1} -> registers (this lane's 16 units) -------
     {
@@ -120,52 +166,68 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
             c4[g] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (live) c4[g] = *reinterpret_cast<const f32x4 *>(P.state + (size_t)slot * 256 + 128 + 32 * w + 8 * g + 4 * h);
         }
-        cst.s0 = c4[0].x; cst.s1 = c4[0].y; cst.s2 = c4[0].z; cst.s3 = c4[0].w;
-        cst.s4 = c4[1].x; cst.s5 = c4[1].y; cst.s6 = c4[1].z; cst.s7 = c4[1].w;
-        cst.s8 = c4[2].x; cst.s9 = c4[2].y; cst.sa = c4[2].z; cst.sb = c4[2].w;
-        cst.sc = c4[3].x; cst.sd = c4[3].y; cst.se = c4[3].z; cst.sf = c4[3].w;
+        cst = acc_of(c4[0], c4[1], c4[2], c4[3]);
     }
-    f32x16 hst = cst;  // overwritten before use; keeps the h' of the last frame for the HBM write-back
-    SmSlot sm;
     int seg_last = 0;
     const bool sm_thread = (tid < MT) && (tile0 + tid < P.n);
-    int sm_slot = 0;
-    if (sm_thread) {
-        sm_slot = P.slots ? P.slots[tile0 + tid] : tile0 + tid;
-        sm = P.sm[sm_slot];
-    }
+    const int sm_slot = sm_thread ? (P.slots ? P.slots[tile0 + tid] : tile0 + tid) : 0;
 
+    STAMP(0);
     for (int t = 0; t < T; ++t) {
+        // section offsets, made opaque per frame: otherwise every block offset of the kernel (~300 SGPR
+        // values) is hoisted out of this loop as loop-invariant and spilled
+        int ws_stft = o_stft, ws_nyq = o_nyq, ws_e0 = o_e0, ws_e1 = o_e1, ws_e2 = o_e2, ws_e3 = o_e3, ws_l = o_l;
+        asm volatile("" : "+s"(ws_stft), "+s"(ws_nyq), "+s"(ws_e0), "+s"(ws_e1), "+s"(ws_e2), "+s"(ws_e3), "+s"(ws_l));
         // ---- load + convert + gate one frame per stream into region A (transposed to quads) ----
+        // 8 requests of a thread are in flight before their LDS writes (two passes)
         {
             const float thr = P.thresh;
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int idx = it * NTHREADS + tid;
-                const int fm = idx >> 7, q = idx & 127;
-                const int g2 = tile0 + fm;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (g2 < P.n) {
-                    const size_t fo = ((size_t)g2 * T + t) * 128 + q;   // in units of 4 samples
-                    if (P.fmt == 0) {
-                        v = reinterpret_cast<const f32x4 *>(P.frames)[fo];
-                    } else {
-                        const i16x4 s = reinterpret_cast<const i16x4 *>(P.frames)[fo];
-                        const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
-                        // the reference divides (np.int16 -> float32 / 32767.0), keep a true division
-                        v = f32x4{(float)s.x / sc, (float)s.y / sc, (float)s.z / sc, (float)s.w / sc};
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                f32x4 xv[8];
+                if (P.fmt == 0) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int idx = (half * 8 + it) * NTHREADS + tid;
+                        const int g2 = tile0 + (idx >> 7);
+                        xv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (g2 < P.n) xv[it] = reinterpret_cast<const f32x4 *>(P.frames)[((size_t)g2 * T + t) * 128 + (idx & 127)];
                     }
-                    v = gate4(v, thr);
+                } else {
+                    const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
+#pragma unroll 1
+                    for (int it = 0; it < 8; ++it) {
+                        const int idx = (half * 8 + it) * NTHREADS + tid;
+                        const int g2 = tile0 + (idx >> 7);
+                        i16x4 s = i16x4{0, 0, 0, 0};
+                        if (g2 < P.n) s = reinterpret_cast<const i16x4 *>(P.frames)[((size_t)g2 * T + t) * 128 + (idx & 127)];
+                        // the reference divides (np.int16 -> float32 / 32767.0), keep a true division
+                        const f32x4 v = f32x4{(float)s.x / sc, (float)s.y / sc, (float)s.z / sc, (float)s.w / sc};
+                        RA[(idx & 127) * QS + (idx >> 7)] = gate4(v, thr);
+                    }
                 }
-                RA[q * QS + fm] = v;
+                if (P.fmt == 0) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int idx = (half * 8 + it) * NTHREADS + tid;
+                        RA[(idx & 127) * QS + (idx >> 7)] = gate4(xv[it], thr);
+                    }
+                }
             }
         }
+        // weights of the first STFT iteration are requested before the barrier (they never depend on LDS)
+        f32x4 Are = WL(ws_stft), Aim = WL(ws_stft + 1);
+        f32x4 Anr = f32x4{0.f, 0.f, 0.f, 0.f}, Ani = Anr;
+        if (w == 3) { Anr = WL(ws_nyq); Ani = WL(ws_nyq + 1); }
+        SB();
+        STAMP(1);
         __syncthreads();   // (1) x and h visible
+        STAMP(2);
 
         // ---- STFT: wave w computes bins 32w..32w+31 (re and im) for the 3 columns ----------
+        // enc0's bias and first weights ride along (requested at the end of this phase)
+        f32x4 e0b0, e0b1, e0b2, e0b3, E0w0, E0w1, E0w2;
         {
-            const f32x4 *ws = wbase + (size_t)P.sect[w][S_STFT] * BLK_F4;
-            const f32x4 *wn = wbase + (size_t)P.sect[w][S_NYQ] * BLK_F4;
             f32x16 are[3], aim[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -173,214 +235,276 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
                 aim[c] = (f32x16)(0.f);
             }
             float nre[3] = {0.f, 0.f, 0.f}, nim[3] = {0.f, 0.f, 0.f};
-            f32x4 wre = ws[0], wim = ws[BLK_F4];
-            f32x4 x0 = RA[(0 + h) * QS + m], x1 = RA[(32 + h) * QS + m], x2 = RA[(64 + h) * QS + m];
-            f32x4 wnr = f32x4{0.f, 0.f, 0.f, 0.f}, wni = wnr;
-            if (w == 3) { wnr = wn[0]; wni = wn[BLK_F4]; }
-            for (int j = 0; j < 32; ++j) {
-                const int jn = j < 31 ? j + 1 : 31;
-                const f32x4 nwre = ws[(2 * jn) * BLK_F4], nwim = ws[(2 * jn + 1) * BLK_F4];
-                const f32x4 nx0 = RA[(2 * jn + h) * QS + m];
-                const f32x4 nx1 = RA[(32 + 2 * jn + h) * QS + m];
-                const f32x4 nx2 = RA[(64 + 2 * jn + h) * QS + m];
-                f32x4 nwnr = wnr, nwni = wni;
-                if (w == 3) { nwnr = wn[(2 * jn) * BLK_F4]; nwni = wn[(2 * jn + 1) * BLK_F4]; }
-                are[0] = mfma4(wre, x0, are[0]);
-                are[1] = mfma4(wre, x1, are[1]);
-                are[2] = mfma4(wre, x2, are[2]);
-                aim[0] = mfma4(wim, x0, aim[0]);
-                aim[1] = mfma4(wim, x1, aim[1]);
-                aim[2] = mfma4(wim, x2, aim[2]);
-                if (w == 3) {   // bin 128 (Nyquist) on the VALU, hidden under the MFMAs
-                    nre[0] += wnr.x * x0.x + wnr.y * x0.y + wnr.z * x0.z + wnr.w * x0.w;
-                    nre[1] += wnr.x * x1.x + wnr.y * x1.y + wnr.z * x1.z + wnr.w * x1.w;
-                    nre[2] += wnr.x * x2.x + wnr.y * x2.y + wnr.z * x2.z + wnr.w * x2.w;
-                    nim[0] += wni.x * x0.x + wni.y * x0.y + wni.z * x0.z + wni.w * x0.w;
-                    nim[1] += wni.x * x1.x + wni.y * x1.y + wni.z * x1.z + wni.w * x1.w;
-                    nim[2] += wni.x * x2.x + wni.y * x2.y + wni.z * x2.z + wni.w * x2.w;
-                }
-                wre = nwre; wim = nwim; x0 = nx0; x1 = nx1; x2 = nx2; wnr = nwnr; wni = nwni;
+            f32x4 Ax0 = RA[0 * QS + hq], Ax1 = RA[32 * QS + hq], Ax2 = RA[64 * QS + hq];
+            f32x4 Bre, Bim, Bx0, Bx1, Bx2, Bnr = Anr, Bni = Ani;
+#define STFT_LD(S, jj)                                                                     \
+    S##re = WL(ws_stft + (2 * (jj))); S##im = WL(ws_stft + (2 * (jj) + 1));        \
+    if (w == 3) { S##nr = WL(ws_nyq + (2 * (jj))); S##ni = WL(ws_nyq + (2 * (jj) + 1)); } \
+    S##x0 = RA[(2 * (jj)) * QS + hq]; S##x1 = RA[(32 + 2 * (jj)) * QS + hq]; S##x2 = RA[(64 + 2 * (jj)) * QS + hq];
+#define STFT_MMA(S)                                                                        \
+    are[0] = mfma4(S##re, S##x0, are[0]); are[1] = mfma4(S##re, S##x1, are[1]); are[2] = mfma4(S##re, S##x2, are[2]); \
+    aim[0] = mfma4(S##im, S##x0, aim[0]); aim[1] = mfma4(S##im, S##x1, aim[1]); aim[2] = mfma4(S##im, S##x2, aim[2]); \
+    if (w == 3) { /* bin 128 (Nyquist) on the VALU */                                       \
+        nre[0] += S##nr.x * S##x0.x + S##nr.y * S##x0.y + S##nr.z * S##x0.z + S##nr.w * S##x0.w; \
+        nre[1] += S##nr.x * S##x1.x + S##nr.y * S##x1.y + S##nr.z * S##x1.z + S##nr.w * S##x1.w; \
+        nre[2] += S##nr.x * S##x2.x + S##nr.y * S##x2.y + S##nr.z * S##x2.z + S##nr.w * S##x2.w; \
+        nim[0] += S##ni.x * S##x0.x + S##ni.y * S##x0.y + S##ni.z * S##x0.z + S##ni.w * S##x0.w; \
+        nim[1] += S##ni.x * S##x1.x + S##ni.y * S##x1.y + S##ni.z * S##x1.z + S##ni.w * S##x1.w; \
+        nim[2] += S##ni.x * S##x2.x + S##ni.y * S##x2.y + S##ni.z * S##x2.z + S##ni.w * S##x2.w; \
+    }
+            for (int j = 0; j < 32; j += 2) {
+                STFT_LD(B, j + 1) SB();
+                STFT_MMA(A) SB();
+                const int jn = j + 2 < 32 ? j + 2 : 30;
+                STFT_LD(A, jn) SB();
+                STFT_MMA(B) SB();
             }
+#undef STFT_LD
+#undef STFT_MMA
+            // request enc0's bias + first weights now: they land while the magnitudes are written
+            e0b0 = WL(ws_e0); e0b1 = WL(ws_e0 + 1); e0b2 = WL(ws_e0 + 2); e0b3 = WL(ws_e0 + 3);
+            E0w0 = WL(ws_e0 + 4); E0w1 = WL(ws_e0 + 5); E0w2 = WL(ws_e0 + 6);
+            SB();
+            STAMP(16);
             // magnitude -> region B rows c*32 + 8w + 2g + h
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 r = quad_of(are[c], g), i = quad_of(aim[c], g);
-                    RB[(c * 32 + 8 * w + 2 * g + h) * QS + m] =
-                        f32x4{sqrtf(r.x * r.x + i.x * i.x), sqrtf(r.y * r.y + i.y * i.y),
-                              sqrtf(r.z * r.z + i.z * i.z), sqrtf(r.w * r.w + i.w * i.w)};
+                    RB[(c * 32 + 8 * w + 2 * g) * QS + hq] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
                 }
             }
             if (w == 3) {
                 float mg[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float r = nre[c] + __shfl_xor(nre[c], 32);
-                    const float i = nim[c] + __shfl_xor(nim[c], 32);
-                    mg[c] = sqrtf(r * r + i * i);
-                }
+                for (int c = 0; c < 3; ++c) mg[c] = mag_(nre[c] + __shfl_xor(nre[c], 32), nim[c] + __shfl_xor(nim[c], 32));
                 // row 96: (|X128| of column 0,1,2, 0) ; row 97: zeros (pairs with row 96 in the MFMA k-step)
-                RB[(96 + h) * QS + m] = h == 0 ? f32x4{mg[0], mg[1], mg[2], 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
+                RB[96 * QS + hq] = h == 0 ? f32x4{mg[0], mg[1], mg[2], 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        STAMP(3);
         __syncthreads();   // (2) mag complete; region A free
+        STAMP(4);
 
         // ---- enc0: 129 -> 128 ch, k3 s1 p1, 3 -> 3 columns; wave w: channels 32w.. ---------
+        f32x4 e1b0, e1b1, e1b2, e1b3, E1w0, E1w1, E1w2, E1w3;
         {
-            const f32x4 *ws = wbase + (size_t)P.sect[w][S_ENC0] * BLK_F4;
+            const int ws = ws_e0 + 4;
             f32x16 acc[3];
-            acc[0] = acc_from(ws);
+            acc[0] = acc_of(e0b0, e0b1, e0b2, e0b3);
             acc[1] = acc[0];
             acc[2] = acc[0];
-            ws += 4 * BLK_F4;
-            f32x4 w0 = ws[0], w1 = ws[BLK_F4], w2 = ws[2 * BLK_F4];
-            f32x4 a0 = RB[(0 + h) * QS + m], a1 = RB[(32 + h) * QS + m], a2 = RB[(64 + h) * QS + m];
-            for (int j = 0; j < 16; ++j) {
-                const int jn = j < 15 ? j + 1 : 15;
-                const f32x4 nw0 = ws[(3 * jn) * BLK_F4], nw1 = ws[(3 * jn + 1) * BLK_F4], nw2 = ws[(3 * jn + 2) * BLK_F4];
-                const f32x4 na0 = RB[(2 * jn + h) * QS + m];
-                const f32x4 na1 = RB[(32 + 2 * jn + h) * QS + m];
-                const f32x4 na2 = RB[(64 + 2 * jn + h) * QS + m];
-                // out[c] += W[tap] * in[c + tap - 1]
-                acc[0] = mfma4(w1, a0, acc[0]);
-                acc[1] = mfma4(w0, a0, acc[1]);
-                acc[2] = mfma4(w0, a1, acc[2]);
-                acc[0] = mfma4(w2, a1, acc[0]);
-                acc[1] = mfma4(w1, a1, acc[1]);
-                acc[2] = mfma4(w1, a2, acc[2]);
-                acc[1] = mfma4(w2, a2, acc[1]);
-                w0 = nw0; w1 = nw1; w2 = nw2; a0 = na0; a1 = na1; a2 = na2;
+            f32x4 Aw0 = E0w0, Aw1 = E0w1, Aw2 = E0w2, Bw0, Bw1, Bw2;
+            f32x4 Aa0 = RB[0 * QS + hq], Aa1 = RB[32 * QS + hq], Aa2 = RB[64 * QS + hq], Ba0, Ba1, Ba2;
+#define E0_LD(S, jj)                                                                       \
+    S##w0 = WL(ws + (3 * (jj))); S##w1 = WL(ws + (3 * (jj) + 1)); S##w2 = WL(ws + (3 * (jj) + 2)); \
+    S##a0 = RB[(2 * (jj)) * QS + hq]; S##a1 = RB[(32 + 2 * (jj)) * QS + hq]; S##a2 = RB[(64 + 2 * (jj)) * QS + hq];
+            // out[c] += W[tap] * in[c + tap - 1]
+#define E0_MMA(S)                                                                          \
+    acc[0] = mfma4(S##w1, S##a0, acc[0]); acc[1] = mfma4(S##w0, S##a0, acc[1]); acc[2] = mfma4(S##w0, S##a1, acc[2]); \
+    acc[0] = mfma4(S##w2, S##a1, acc[0]); acc[1] = mfma4(S##w1, S##a1, acc[1]); acc[2] = mfma4(S##w1, S##a2, acc[2]); \
+    acc[1] = mfma4(S##w2, S##a2, acc[1]);
+            for (int j = 0; j < 16; j += 2) {
+                E0_LD(B, j + 1) SB();
+                E0_MMA(A) SB();
+                const int jn = j + 2 < 16 ? j + 2 : 14;
+                E0_LD(A, jn) SB();
+                E0_MMA(B) SB();
             }
+#undef E0_LD
+#undef E0_MMA
+            STAMP(17);
             {   // input channel 128 (Nyquist bin): one k-iteration against per-column weight blocks
-                const f32x4 an = RB[(96 + h) * QS + m];
-                acc[0] = mfma4(ws[48 * BLK_F4], an, acc[0]);
-                acc[1] = mfma4(ws[49 * BLK_F4], an, acc[1]);
-                acc[2] = mfma4(ws[50 * BLK_F4], an, acc[2]);
+                const f32x4 an = RB[96 * QS + hq];
+                const f32x4 wn0 = WL(ws + 48), wn1 = WL(ws + 49), wn2 = WL(ws + 50);
+                // enc1's bias and first group of weights
+                e1b0 = WL(ws_e1); e1b1 = WL(ws_e1 + 1); e1b2 = WL(ws_e1 + 2); e1b3 = WL(ws_e1 + 3);
+                E1w0 = WL(ws_e1 + 4); E1w1 = WL(ws_e1 + 5); E1w2 = WL(ws_e1 + 6); E1w3 = WL(ws_e1 + 7);
+                SB();
+                acc[0] = mfma4(wn0, an, acc[0]);
+                acc[1] = mfma4(wn1, an, acc[1]);
+                acc[2] = mfma4(wn2, an, acc[2]);
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) store_tile_relu(RA, c * 32 + 8 * w, m, h, acc[c]);
         }
+        STAMP(5);
         __syncthreads();   // (3) enc0 out in A; region B free
+        STAMP(6);
+
+        // thin layers: one accumulator chain per wave; a "group" = 4 k-iterations (4 weight blocks,
+        // 4 activation quads, 16 MFMAs), ping-pong between two register sets
+#define G_LDW(S, ws_, g4)                                                                  \
+    S##w0 = WL((ws_) + (4 * (g4))); S##w1 = WL((ws_) + (4 * (g4) + 1));            \
+    S##w2 = WL((ws_) + (4 * (g4) + 2)); S##w3 = WL((ws_) + (4 * (g4) + 3));
+#define G_MMA(S) acc = mfma4(S##w0, S##a0, acc); acc = mfma4(S##w1, S##a1, acc); acc = mfma4(S##w2, S##a2, acc); acc = mfma4(S##w3, S##a3, acc);
 
         // ---- enc1: 128 -> 64 ch, k3 s2 p1, 3 -> 2 columns; wave w: n-tile w&1, column w>>1 ----
+        f32x4 e2b0, e2b1, e2b2, e2b3, E2w0, E2w1, E2w2, E2w3;
+        f32x4 e3b0, e3b1, e3b2, e3b3, E3w0, E3w1, E3w2, E3w3;
         {
             const int nt = w & 1, tp = w >> 1;
-            const f32x4 *ws = wbase + (size_t)P.sect[w][S_ENC1] * BLK_F4;
-            f32x16 acc = acc_from(ws);
-            ws += 4 * BLK_F4;
+            const int ws = ws_e1 + 4;
+            f32x16 acc = acc_of(e1b0, e1b1, e1b2, e1b3);
             // valid taps: tp=0 -> taps 1,2 on input columns 0,1 ; tp=1 -> taps 0,1 on columns 1,2
-#pragma unroll 8
-            for (int it = 0; it < 32; ++it) {
-                const int ti = it >> 4, j = it & 15;
-                const f32x4 wv = ws[it * BLK_F4];
-                const f32x4 av = RA[((tp + ti) * 32 + 2 * j + h) * QS + m];
-                acc = mfma4(wv, av, acc);
+            // iteration it in 0..31: column tp + (it>>4), quad pair it&15
+#define E1_ROW(it) ((tp + ((it) >> 4)) * 32 + 2 * ((it) & 15))
+#define E1_LDA(S, g4)                                                                      \
+    S##a0 = RA[E1_ROW(4 * (g4)) * QS + hq]; S##a1 = RA[E1_ROW(4 * (g4) + 1) * QS + hq];    \
+    S##a2 = RA[E1_ROW(4 * (g4) + 2) * QS + hq]; S##a3 = RA[E1_ROW(4 * (g4) + 3) * QS + hq];
+            f32x4 Aw0 = E1w0, Aw1 = E1w1, Aw2 = E1w2, Aw3 = E1w3, Bw0, Bw1, Bw2, Bw3;
+            f32x4 Aa0, Aa1, Aa2, Aa3, Ba0, Ba1, Ba2, Ba3;
+            E1_LDA(A, 0)
+            for (int g4 = 0; g4 < 8; g4 += 2) {
+                G_LDW(B, ws, g4 + 1) E1_LDA(B, g4 + 1) SB();
+                G_MMA(A) SB();
+                const int gn = g4 + 2 < 8 ? g4 + 2 : 6;
+                G_LDW(A, ws, gn) E1_LDA(A, gn) SB();
+                if (g4 == 6) {   // last pass: request enc2's (waves 0,1) and enc3's first blocks
+                    if (w < 2) {
+                        e2b0 = WL(ws_e2); e2b1 = WL(ws_e2 + 1); e2b2 = WL(ws_e2 + 2); e2b3 = WL(ws_e2 + 3);
+                        E2w0 = WL(ws_e2 + 4); E2w1 = WL(ws_e2 + 5); E2w2 = WL(ws_e2 + 6); E2w3 = WL(ws_e2 + 7);
+                    }
+                    e3b0 = WL(ws_e3); e3b1 = WL(ws_e3 + 1); e3b2 = WL(ws_e3 + 2); e3b3 = WL(ws_e3 + 3);
+                    E3w0 = WL(ws_e3 + 4); E3w1 = WL(ws_e3 + 5); E3w2 = WL(ws_e3 + 6); E3w3 = WL(ws_e3 + 7);
+                    SB();
+                }
+                G_MMA(B) SB();
             }
+#undef E1_ROW
+#undef E1_LDA
             store_tile_relu(RB, tp * 16 + 8 * nt, m, h, acc);
         }
+        STAMP(7);
         __syncthreads();   // (4) enc1 out in B; region A free
+        STAMP(8);
 
         // ---- enc2: 64 -> 64 ch, k3 s2 p1, 2 -> 1 column (taps 1,2 on columns 0,1); waves 0,1 ----
         if (w < 2) {
-            const f32x4 *ws = wbase + (size_t)P.sect[w][S_ENC2] * BLK_F4;
-            f32x16 acc = acc_from(ws);
-            ws += 4 * BLK_F4;
-#pragma unroll 8
-            for (int it = 0; it < 16; ++it) {
-                const int ti = it >> 3, j = it & 7;
-                const f32x4 wv = ws[it * BLK_F4];
-                const f32x4 av = RB[(ti * 16 + 2 * j + h) * QS + m];
-                acc = mfma4(wv, av, acc);
+            const int ws = ws_e2 + 4;
+            f32x16 acc = acc_of(e2b0, e2b1, e2b2, e2b3);
+            // iteration it in 0..15: column it>>3, quad pair it&7
+#define E2_ROW(it) (((it) >> 3) * 16 + 2 * ((it) & 7))
+#define E2_LDA(S, g4)                                                                      \
+    S##a0 = RB[E2_ROW(4 * (g4)) * QS + hq]; S##a1 = RB[E2_ROW(4 * (g4) + 1) * QS + hq];    \
+    S##a2 = RB[E2_ROW(4 * (g4) + 2) * QS + hq]; S##a3 = RB[E2_ROW(4 * (g4) + 3) * QS + hq];
+            f32x4 Aw0 = E2w0, Aw1 = E2w1, Aw2 = E2w2, Aw3 = E2w3, Bw0, Bw1, Bw2, Bw3;
+            f32x4 Aa0, Aa1, Aa2, Aa3, Ba0, Ba1, Ba2, Ba3;
+            E2_LDA(A, 0)
+            for (int g4 = 0; g4 < 4; g4 += 2) {
+                G_LDW(B, ws, g4 + 1) E2_LDA(B, g4 + 1) SB();
+                G_MMA(A) SB();
+                const int gn = g4 + 2 < 4 ? g4 + 2 : 2;
+                G_LDW(A, ws, gn) E2_LDA(A, gn) SB();
+                G_MMA(B) SB();
             }
+#undef E2_ROW
+#undef E2_LDA
             store_tile_relu(RA, 8 * w, m, h, acc);
         }
+        STAMP(9);
         __syncthreads();   // (5) enc2 out in A
+        STAMP(10);
 
         // ---- enc3: 64 -> 128 ch, k3 s1 p1 on a single column: centre tap only ------------------
+        f32x4 lb[16], Lw0, Lw1, Lw2, Lw3;
         {
-            const f32x4 *ws = wbase + (size_t)P.sect[w][S_ENC3] * BLK_F4;
-            f32x16 acc = acc_from(ws);
-            ws += 4 * BLK_F4;
+            const int ws = ws_e3 + 4;
+            f32x16 acc = acc_of(e3b0, e3b1, e3b2, e3b3);
+            f32x4 Aw0 = E3w0, Aw1 = E3w1, Aw2 = E3w2, Aw3 = E3w3, Bw0, Bw1, Bw2, Bw3;
+            f32x4 Aa0 = RA[0 * QS + hq], Aa1 = RA[2 * QS + hq], Aa2 = RA[4 * QS + hq], Aa3 = RA[6 * QS + hq];
+            G_LDW(B, ws, 1)
+            const f32x4 Ba0 = RA[8 * QS + hq], Ba1 = RA[10 * QS + hq], Ba2 = RA[12 * QS + hq], Ba3 = RA[14 * QS + hq];
+            // the LSTM's gate biases and first weight blocks
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const f32x4 wv = ws[j * BLK_F4];
-                const f32x4 av = RA[(2 * j + h) * QS + m];
-                acc = mfma4(wv, av, acc);
-            }
+            for (int k = 0; k < 16; ++k) lb[k] = WL(ws_l + k);
+            Lw0 = WL(ws_l + 16); Lw1 = WL(ws_l + 17); Lw2 = WL(ws_l + 18); Lw3 = WL(ws_l + 19);
+            SB();
+            G_MMA(A) SB();
+            G_MMA(B) SB();
             store_tile_relu(RB, 8 * w, m, h, acc);
         }
+#undef G_LDW
+#undef G_MMA
+        STAMP(11);
         __syncthreads();   // (6) enc3 out (LSTM input x) in B rows 0..31
+        STAMP(12);
 
         // ---- LSTM cell: wave w owns hidden units 32w..32w+31, all four gates -------------------
-        f32x16 gi, gfo, gg, go;
         {
-            const f32x4 *ws = wbase + (size_t)P.sect[w][S_LSTM] * BLK_F4;
-            gi = acc_from(ws);
-            gfo = acc_from(ws + 4 * BLK_F4);
-            gg = acc_from(ws + 8 * BLK_F4);
-            go = acc_from(ws + 12 * BLK_F4);
-            ws += 16 * BLK_F4;
-            const f32x4 *src = RB;
-#pragma unroll 1
-            for (int half = 0; half < 2; ++half) {
-                f32x4 wi = ws[0], wf = ws[BLK_F4], wg = ws[2 * BLK_F4], wo = ws[3 * BLK_F4];
-                f32x4 av = src[h * QS + m];
-                for (int j = 0; j < 16; ++j) {
-                    const int jn = j < 15 ? j + 1 : 15;
-                    const f32x4 nwi = ws[(4 * jn) * BLK_F4], nwf = ws[(4 * jn + 1) * BLK_F4];
-                    const f32x4 nwg = ws[(4 * jn + 2) * BLK_F4], nwo = ws[(4 * jn + 3) * BLK_F4];
-                    const f32x4 nav = src[(2 * jn + h) * QS + m];
-                    gi = mfma4(wi, av, gi);
-                    gfo = mfma4(wf, av, gfo);
-                    gg = mfma4(wg, av, gg);
-                    go = mfma4(wo, av, go);
-                    wi = nwi; wf = nwf; wg = nwg; wo = nwo; av = nav;
+            const int ws = ws_l + 16;
+            f32x16 gi = acc_of(lb[0], lb[1], lb[2], lb[3]);
+            f32x16 gfo = acc_of(lb[4], lb[5], lb[6], lb[7]);
+            f32x16 gg = acc_of(lb[8], lb[9], lb[10], lb[11]);
+            f32x16 go = acc_of(lb[12], lb[13], lb[14], lb[15]);
+            // iteration it in 0..31: it < 16 contracts x (region B rows 0..31), then h_{t-1} (region H)
+#define L_ROW(it) ((it) < 16 ? (RB + (2 * (it)) * QS + hq) : (RH + (2 * ((it) - 16)) * QS + hq))
+#define L_LD(S, it)                                                                        \
+    S##wi = WL(ws + (4 * (it))); S##wf = WL(ws + (4 * (it) + 1));                  \
+    S##wg = WL(ws + (4 * (it) + 2)); S##wo = WL(ws + (4 * (it) + 3)); S##av = *L_ROW(it);
+#define L_MMA(S) gi = mfma4(S##wi, S##av, gi); gfo = mfma4(S##wf, S##av, gfo); gg = mfma4(S##wg, S##av, gg); go = mfma4(S##wo, S##av, go);
+            f32x4 Awi = Lw0, Awf = Lw1, Awg = Lw2, Awo = Lw3, Aav = RB[hq], Bwi, Bwf, Bwg, Bwo, Bav;
+            f32x4 hw0, hw1, hw2, hw3;
+            for (int it = 0; it < 32; it += 2) {
+                L_LD(B, it + 1) SB();
+                L_MMA(A) SB();
+                const int itn = it + 2 < 32 ? it + 2 : 30;
+                L_LD(A, itn) SB();
+                if (it == 30) {   // head weights for the epilogue
+                    hw0 = WL(ws + 128); hw1 = WL(ws + 129); hw2 = WL(ws + 130); hw3 = WL(ws + 131);
+                    SB();
                 }
-                ws += 64 * BLK_F4;
-                src = RH;
+                L_MMA(B) SB();
             }
-            // ws now points at the 4 head-weight blocks
+#undef L_ROW
+#undef L_LD
+#undef L_MMA
+            STAMP(18);
+            STAMP(13);
             __syncthreads();   // (7) every wave is done reading h_{t-1}; region A free for the next frame
+            STAMP(14);
             float part = 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 i4 = quad_of(gi, g), f4 = quad_of(gfo, g), g4 = quad_of(gg, g), o4 = quad_of(go, g);
                 const f32x4 c4 = quad_of(cst, g);
-                const f32x4 hw = ws[g * BLK_F4];
+                const f32x4 hw = g == 0 ? hw0 : (g == 1 ? hw1 : (g == 2 ? hw2 : hw3));
                 f32x4 cn, hn;
 #define CELL(k)                                                             \
-    cn.k = sigmoidf_(f4.k) * c4.k + sigmoidf_(i4.k) * tanhf(g4.k);        \
-    hn.k = sigmoidf_(o4.k) * tanhf(cn.k);                                 \
+    cn.k = sigmoidf_(f4.k) * c4.k + sigmoidf_(i4.k) * tanhf_(g4.k);       \
+    hn.k = sigmoidf_(o4.k) * tanhf_(cn.k);                                \
     part += hw.k * fmaxf(hn.k, 0.f);
                 CELL(x) CELL(y) CELL(z) CELL(w)
 #undef CELL
-                RH[(8 * w + 2 * g + h) * QS + m] = hn;
+                RH[(8 * w + 2 * g) * QS + hq] = hn;
+                if (t == T - 1 && live)   // last frame of the call: h' goes back to HBM (c' follows after the loop)
+                    *reinterpret_cast<f32x4 *>(P.state + (size_t)slot * 256 + 32 * w + 8 * g + 4 * h) = hn;
                 switch (g) {
-                    case 0: cst.s0 = cn.x; cst.s1 = cn.y; cst.s2 = cn.z; cst.s3 = cn.w;
-                            hst.s0 = hn.x; hst.s1 = hn.y; hst.s2 = hn.z; hst.s3 = hn.w; break;
-                    case 1: cst.s4 = cn.x; cst.s5 = cn.y; cst.s6 = cn.z; cst.s7 = cn.w;
-                            hst.s4 = hn.x; hst.s5 = hn.y; hst.s6 = hn.z; hst.s7 = hn.w; break;
-                    case 2: cst.s8 = cn.x; cst.s9 = cn.y; cst.sa = cn.z; cst.sb = cn.w;
-                            hst.s8 = hn.x; hst.s9 = hn.y; hst.sa = hn.z; hst.sb = hn.w; break;
-                    default: cst.sc = cn.x; cst.sd = cn.y; cst.se = cn.z; cst.sf = cn.w;
-                             hst.sc = hn.x; hst.sd = hn.y; hst.se = hn.z; hst.sf = hn.w; break;
+                    case 0: cst.s0 = cn.x; cst.s1 = cn.y; cst.s2 = cn.z; cst.s3 = cn.w; break;
+                    case 1: cst.s4 = cn.x; cst.s5 = cn.y; cst.s6 = cn.z; cst.s7 = cn.w; break;
+                    case 2: cst.s8 = cn.x; cst.s9 = cn.y; cst.sa = cn.z; cst.sb = cn.w; break;
+                    default: cst.sc = cn.x; cst.sd = cn.y; cst.se = cn.z; cst.sf = cn.w; break;
                 }
             }
             part += __shfl_xor(part, 32);
             if (h == 0) headp[w * 32 + m] = part;
         }
         __syncthreads();   // (8) head partials + new h visible
+        STAMP(15);
 
         // ---- head: p = sigmoid(b + sum_j w_j relu(h'_j)); then the state machine ---------------
         if (tid < MT) {
             const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];
             const float z = hb + ((headp[tid] + headp[32 + tid]) + (headp[64 + tid] + headp[96 + tid]));
-            const float p = sigmoidf_(z);
+            const float p = fminf(sigmoidf_(z), 1.0f);
             if (sm_thread) {
                 P.probs[(size_t)(tile0 + tid) * T + t] = p;
+                // the slot's state machine lives in HBM between frames (96 B, 32 threads per tile)
+                SmSlot sm = P.sm[sm_slot];
                 int seg = 0;
                 const int ev = sm_step(sm, p, &seg);
+                P.sm[sm_slot] = sm;
                 if (ev & 2) seg_last = seg;
                 if (P.events) P.events[(size_t)(tile0 + tid) * T + t] = (uint8_t)ev;
             }
@@ -393,15 +517,9 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
     if (live) {
         float *st = P.state + (size_t)slot * 256;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            *reinterpret_cast<f32x4 *>(st + 32 * w + 8 * g + 4 * h) = quad_of(hst, g);
-            *reinterpret_cast<f32x4 *>(st + 128 + 32 * w + 8 * g + 4 * h) = quad_of(cst, g);
-        }
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(st + 128 + 32 * w + 8 * g + 4 * h) = quad_of(cst, g);
     }
-    if (sm_thread) {
-        P.sm[sm_slot] = sm;
-        if (P.seg_frames) P.seg_frames[tile0 + tid] = seg_last;
-    }
+    if (sm_thread && P.seg_frames) P.seg_frames[tile0 + tid] = seg_last;
 }
 
 // host-callable launcher (engine.cpp is plain C++ and never sees <<<>>>)

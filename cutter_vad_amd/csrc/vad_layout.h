@@ -65,6 +65,7 @@ static_assert(sizeof(SmSlot) == 96, "SmSlot layout");
 
 struct StepParams {
     const float *wstream;          // packed weight streams
+    uint32_t wstream_bytes;
     uint32_t sect[NWAVES][8];      // block offset of each section, per wave
     float *state;                  // [max_streams][256]
     SmSlot *sm;                    // [max_streams]
@@ -77,6 +78,9 @@ struct StepParams {
     int32_t T;                     // frames per stream in this call
     int32_t fmt;                   // vad_frame_format
     float thresh;                  // denoise gate, < 0 = off
+#ifdef VADK_STAMPS
+    unsigned long long *stamps;    // diagnostic builds only (tools/kbench.cpp): [block][wave][16] s_memtime stamps
+#endif
 };
 
 }  // namespace vadk
