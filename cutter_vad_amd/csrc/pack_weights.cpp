@@ -114,25 +114,30 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
     const float *b_ih = B.get("lstm.b_ih", 512), *b_hh = B.get("lstm.b_hh", 512);
     const float *head_w = B.get("head.w", 128), *head_b = B.get("head.b", 1);
     if (!err.empty()) return false;
+    // the folded STFT relies on exact symmetries of the stored basis; refuse weights that lack them
+    for (int k = 0; k <= 128; ++k) {
+        const float *c = stft + (size_t)k * 256, *sn = stft + (size_t)(129 + k) * 256;
+        bool ok = c[0] == 0.f && sn[0] == 0.f && sn[128] == 0.f;
+        for (int n = 1; n < 128 && ok; ++n) ok = c[n] == c[256 - n] && sn[n] == -sn[256 - n];
+        if (k == 0 || k == 128)
+            for (int n = 0; n < 256 && ok; ++n) ok = sn[n] == 0.f;
+        if (!ok) {
+            err = "Failed to load model: STFT basis is not the symmetric windowed DFT the kernel assumes";
+            return false;
+        }
+    }
 
     StreamBuilder sb;
     auto convw = [&](int layer, int o, int c, int tap) -> float {
         return c < ci[layer] ? ew[layer][((size_t)o * ci[layer] + c) * 3 + tap] : 0.f;
     };
     for (int w = 0; w < NWAVES; ++w) {
-        // STFT: bins 32w..32w+31, {re, im} per k-iteration
+        // STFT on the folded input (vad_layout.h): bins 32w..32w+31, {re, im} per k-iteration;
+        // k-iteration j contracts n = 8j+1 .. 8j+8 (quad 2j on the lower half-wave, 2j+1 on the upper)
         out.sect[w][S_STFT] = sb.blocks();
-        for (int j = 0; j < 32; ++j) {
-            sb.weight_block([&](int np, int k) { return stft[(size_t)(32 * w + np) * 256 + k]; }, j);
-            sb.weight_block([&](int np, int k) { return stft[(size_t)(129 + 32 * w + np) * 256 + k]; }, j);
-        }
-        // bin 128 rows (same value on every lane of a half-wave), consumed by wave 3 on the VALU
-        out.sect[w][S_NYQ] = sb.blocks();
-        if (w == 3) {
-            for (int j = 0; j < 32; ++j) {
-                sb.weight_block([&](int, int k) { return stft[(size_t)128 * 256 + k]; }, j);
-                sb.weight_block([&](int, int k) { return stft[(size_t)257 * 256 + k]; }, j);
-            }
+        for (int j = 0; j < 16; ++j) {
+            sb.weight_block([&](int np, int k) { return stft[(size_t)(32 * w + np) * 256 + k + 1]; }, j);
+            sb.weight_block([&](int np, int k) { return stft[(size_t)(129 + 32 * w + np) * 256 + k + 1]; }, j);
         }
         // enc0: out channels 32w.., taps 0..2 per k-iteration, then the Nyquist input channel
         out.sect[w][S_ENC0] = sb.blocks();
@@ -186,7 +191,16 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
     }
     const uint32_t hb = sb.blocks();
     sb.new_block()[0] = head_b[0];
-    for (int w = 0; w < NWAVES; ++w) out.sect[w][S_HEADB] = hb;
+    // bin 128 of the folded STFT (VALU): floats 0..127 = C[128][1..128]; its sine row is exactly zero
+    const uint32_t nb = sb.blocks();
+    {
+        float *b = sb.new_block();
+        for (int n = 1; n <= 128; ++n) b[n - 1] = stft[(size_t)128 * 256 + n];
+    }
+    for (int w = 0; w < NWAVES; ++w) {
+        out.sect[w][S_HEADB] = hb;
+        out.sect[w][S_NYQ] = nb;
+    }
     out.data = std::move(sb.data);
     return true;
 }

@@ -118,10 +118,11 @@ __device__ __forceinline__ f32x4 gate4(f32x4 v, float thr) {
 extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P) {
     using namespace vadk::v5;
     __shared__ f32x4 lds[LDS_F4];
-    f32x4 *const RA = lds;                       // x / enc0 / enc2
-    f32x4 *const RB = lds + ROWS_A * QS;         // mag / enc1 / enc3
-    f32x4 *const RH = RB + ROWS_B * QS;          // h
+    f32x4 *const RX = lds;                       // the activation region (row map: vad_layout.h)
+    f32x4 *const RE = lds + ROW_E * QS;          // its upper half
+    f32x4 *const RH = lds + ROWS_X * QS;         // h
     float *const headp = reinterpret_cast<float *>(RH + ROWS_H * QS);   // [4][32]
+    float *const nyqv = headp + 128;             // [3][32] |X128| per column
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -178,53 +179,83 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
         // values) is hoisted out of this loop as loop-invariant and spilled
         int ws_stft = o_stft, ws_nyq = o_nyq, ws_e0 = o_e0, ws_e1 = o_e1, ws_e2 = o_e2, ws_e3 = o_e3, ws_l = o_l;
         asm volatile("" : "+s"(ws_stft), "+s"(ws_nyq), "+s"(ws_e0), "+s"(ws_e1), "+s"(ws_e2), "+s"(ws_e3), "+s"(ws_l));
-        // ---- load + convert + gate one frame per stream into region A (transposed to quads) ----
-        // 8 requests of a thread are in flight before their LDS writes (two passes)
+        // ---- load + convert + gate + FOLD one frame per stream (vad_layout.h) -----------------
+        // output o = (column c, stream m, quad q): u/v of n = 4q+1..4q+4 from the column's quads q, q+1
+        // (direct, shifted by one sample) and 63-q (mirrored).  Lanes run over q: 512 contiguous bytes
+        // per half-wave for the direct reads and for the mirrored ones.
         {
             const float thr = P.thresh;
+            const int q = tid & 31;
 #pragma unroll 1
-            for (int half = 0; half < 2; ++half) {
-                f32x4 xv[8];
+            for (int c = 0; c < 3; ++c) {
+                f32x4 da[4], db[4], mi[4];
                 if (P.fmt == 0) {
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int idx = (half * 8 + it) * NTHREADS + tid;
-                        const int g2 = tile0 + (idx >> 7);
-                        xv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (g2 < P.n) xv[it] = reinterpret_cast<const f32x4 *>(P.frames)[((size_t)g2 * T + t) * 128 + (idx & 127)];
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int ms = rr * 8 + (tid >> 5);
+                        const int g2 = tile0 + ms;
+                        da[rr] = db[rr] = mi[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (g2 < P.n) {
+                            const f32x4 *fr = reinterpret_cast<const f32x4 *>(P.frames) + ((size_t)g2 * T + t) * 128 + 32 * c;
+                            da[rr] = fr[q]; db[rr] = fr[q + 1]; mi[rr] = fr[63 - q];
+                        }
                     }
                 } else {
                     const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
 #pragma unroll 1
-                    for (int it = 0; it < 8; ++it) {
-                        const int idx = (half * 8 + it) * NTHREADS + tid;
-                        const int g2 = tile0 + (idx >> 7);
-                        i16x4 s = i16x4{0, 0, 0, 0};
-                        if (g2 < P.n) s = reinterpret_cast<const i16x4 *>(P.frames)[((size_t)g2 * T + t) * 128 + (idx & 127)];
-                        // the reference divides (np.int16 -> float32 / 32767.0), keep a true division
-                        const f32x4 v = f32x4{(float)s.x / sc, (float)s.y / sc, (float)s.z / sc, (float)s.w / sc};
-                        RA[(idx & 127) * QS + (idx >> 7)] = gate4(v, thr);
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int ms = rr * 8 + (tid >> 5);
+                        const int g2 = tile0 + ms;
+                        da[rr] = db[rr] = mi[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (g2 < P.n) {
+                            const i16x4 *fr = reinterpret_cast<const i16x4 *>(P.frames) + ((size_t)g2 * T + t) * 128 + 32 * c;
+                            const i16x4 a = fr[q], b2 = fr[q + 1], d = fr[63 - q];
+                            // the reference divides (np.int16 -> float32 / 32767.0), keep a true division
+                            da[rr] = f32x4{(float)a.x / sc, (float)a.y / sc, (float)a.z / sc, (float)a.w / sc};
+                            db[rr] = f32x4{(float)b2.x / sc, (float)b2.y / sc, (float)b2.z / sc, (float)b2.w / sc};
+                            mi[rr] = f32x4{(float)d.x / sc, (float)d.y / sc, (float)d.z / sc, (float)d.w / sc};
+                        }
                     }
                 }
-                if (P.fmt == 0) {
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int idx = (half * 8 + it) * NTHREADS + tid;
-                        RA[(idx & 127) * QS + (idx >> 7)] = gate4(xv[it], thr);
-                    }
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int ms = rr * 8 + (tid >> 5);
+                    const f32x4 a = gate4(da[rr], thr), b2 = gate4(db[rr], thr), d = gate4(mi[rr], thr);
+                    f32x4 u = f32x4{a.y + d.w, a.z + d.z, a.w + d.y, b2.x + d.x};
+                    f32x4 v = f32x4{a.y - d.w, a.z - d.z, a.w - d.y, b2.x - d.x};
+                    if (q == 31) { u.w = b2.x; v.w = 0.f; }   // n = 128 is its own mirror
+                    RX[(64 * c + q) * QS + ms] = u;
+                    RX[(64 * c + 32 + q) * QS + ms] = v;
                 }
             }
         }
         // weights of the first STFT iteration are requested before the barrier (they never depend on LDS)
         f32x4 Are = WL(ws_stft), Aim = WL(ws_stft + 1);
-        f32x4 Anr = f32x4{0.f, 0.f, 0.f, 0.f}, Ani = Anr;
-        if (w == 3) { Anr = WL(ws_nyq); Ani = WL(ws_nyq + 1); }
         SB();
         STAMP(1);
-        __syncthreads();   // (1) x and h visible
+        __syncthreads();   // (1) folded x and h visible
         STAMP(2);
 
-        // ---- STFT: wave w computes bins 32w..32w+31 (re and im) for the 3 columns ----------
+        // ---- bin 128 (Nyquist) on the VALU: re = sum_n C[128][n] u[n], im == 0; 2 lanes per (column, stream)
+        {
+            const int pr = lane >> 1, half = lane & 1;
+            const int pair = w * 24 + pr;                 // 96 (column, stream) pairs, 24 per wave
+            const int c = pair >> 5, ms = pair & 31;
+            float a = 0.f;
+            if (pr < 24) {
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i) {
+                    const int qq = half * 16 + i;
+                    const f32x4 cf = ldw(wrs, qq * 16, ws_nyq);
+                    const f32x4 uu = RX[(64 * c + qq) * QS + ms];
+                    a += cf.x * uu.x + cf.y * uu.y + cf.z * uu.z + cf.w * uu.w;
+                }
+            }
+            a += __shfl_xor(a, 1);
+            if (pr < 24 && half == 0) nyqv[c * 32 + ms] = fabsf(a);
+        }
+
+        // ---- STFT: wave w computes bins 32w..32w+31 (re on u, im on v) for the 3 columns -------
         // enc0's bias and first weights ride along (requested at the end of this phase)
         f32x4 e0b0, e0b1, e0b2, e0b3, E0w0, E0w1, E0w2;
         {
@@ -234,28 +265,20 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
                 are[c] = (f32x16)(0.f);
                 aim[c] = (f32x16)(0.f);
             }
-            float nre[3] = {0.f, 0.f, 0.f}, nim[3] = {0.f, 0.f, 0.f};
-            f32x4 Ax0 = RA[0 * QS + hq], Ax1 = RA[32 * QS + hq], Ax2 = RA[64 * QS + hq];
-            f32x4 Bre, Bim, Bx0, Bx1, Bx2, Bnr = Anr, Bni = Ani;
+            f32x4 Au0 = RX[0 * QS + hq], Au1 = RX[64 * QS + hq], Au2 = RX[128 * QS + hq];
+            f32x4 Av0 = RX[32 * QS + hq], Av1 = RX[96 * QS + hq], Av2 = RX[160 * QS + hq];
+            f32x4 Bre, Bim, Bu0, Bu1, Bu2, Bv0, Bv1, Bv2;
 #define STFT_LD(S, jj)                                                                     \
-    S##re = WL(ws_stft + (2 * (jj))); S##im = WL(ws_stft + (2 * (jj) + 1));        \
-    if (w == 3) { S##nr = WL(ws_nyq + (2 * (jj))); S##ni = WL(ws_nyq + (2 * (jj) + 1)); } \
-    S##x0 = RA[(2 * (jj)) * QS + hq]; S##x1 = RA[(32 + 2 * (jj)) * QS + hq]; S##x2 = RA[(64 + 2 * (jj)) * QS + hq];
+    S##re = WL(ws_stft + 2 * (jj)); S##im = WL(ws_stft + 2 * (jj) + 1);                    \
+    S##u0 = RX[(2 * (jj)) * QS + hq]; S##u1 = RX[(64 + 2 * (jj)) * QS + hq]; S##u2 = RX[(128 + 2 * (jj)) * QS + hq]; \
+    S##v0 = RX[(32 + 2 * (jj)) * QS + hq]; S##v1 = RX[(96 + 2 * (jj)) * QS + hq]; S##v2 = RX[(160 + 2 * (jj)) * QS + hq];
 #define STFT_MMA(S)                                                                        \
-    are[0] = mfma4(S##re, S##x0, are[0]); are[1] = mfma4(S##re, S##x1, are[1]); are[2] = mfma4(S##re, S##x2, are[2]); \
-    aim[0] = mfma4(S##im, S##x0, aim[0]); aim[1] = mfma4(S##im, S##x1, aim[1]); aim[2] = mfma4(S##im, S##x2, aim[2]); \
-    if (w == 3) { /* bin 128 (Nyquist) on the VALU */                                       \
-        nre[0] += S##nr.x * S##x0.x + S##nr.y * S##x0.y + S##nr.z * S##x0.z + S##nr.w * S##x0.w; \
-        nre[1] += S##nr.x * S##x1.x + S##nr.y * S##x1.y + S##nr.z * S##x1.z + S##nr.w * S##x1.w; \
-        nre[2] += S##nr.x * S##x2.x + S##nr.y * S##x2.y + S##nr.z * S##x2.z + S##nr.w * S##x2.w; \
-        nim[0] += S##ni.x * S##x0.x + S##ni.y * S##x0.y + S##ni.z * S##x0.z + S##ni.w * S##x0.w; \
-        nim[1] += S##ni.x * S##x1.x + S##ni.y * S##x1.y + S##ni.z * S##x1.z + S##ni.w * S##x1.w; \
-        nim[2] += S##ni.x * S##x2.x + S##ni.y * S##x2.y + S##ni.z * S##x2.z + S##ni.w * S##x2.w; \
-    }
-            for (int j = 0; j < 32; j += 2) {
+    are[0] = mfma4(S##re, S##u0, are[0]); are[1] = mfma4(S##re, S##u1, are[1]); are[2] = mfma4(S##re, S##u2, are[2]); \
+    aim[0] = mfma4(S##im, S##v0, aim[0]); aim[1] = mfma4(S##im, S##v1, aim[1]); aim[2] = mfma4(S##im, S##v2, aim[2]);
+            for (int j = 0; j < 16; j += 2) {
                 STFT_LD(B, j + 1) SB();
                 STFT_MMA(A) SB();
-                const int jn = j + 2 < 32 ? j + 2 : 30;
+                const int jn = j + 2 < 16 ? j + 2 : 14;
                 STFT_LD(A, jn) SB();
                 STFT_MMA(B) SB();
             }
@@ -266,25 +289,21 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
             E0w0 = WL(ws_e0 + 4); E0w1 = WL(ws_e0 + 5); E0w2 = WL(ws_e0 + 6);
             SB();
             STAMP(16);
-            // magnitude -> region B rows c*32 + 8w + 2g + h
+            __syncthreads();   // (1b) every wave is done reading u/v: the magnitudes may overwrite them
+            // magnitude -> rows 32c + 8w + 2g + h
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 r = quad_of(are[c], g), i = quad_of(aim[c], g);
-                    RB[(c * 32 + 8 * w + 2 * g) * QS + hq] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
+                    RX[(c * 32 + 8 * w + 2 * g) * QS + hq] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
                 }
             }
-            if (w == 3) {
-                float mg[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) mg[c] = mag_(nre[c] + __shfl_xor(nre[c], 32), nim[c] + __shfl_xor(nim[c], 32));
-                // row 96: (|X128| of column 0,1,2, 0) ; row 97: zeros (pairs with row 96 in the MFMA k-step)
-                RB[96 * QS + hq] = h == 0 ? f32x4{mg[0], mg[1], mg[2], 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            // row 96: (|X128| of column 0,1,2, 0) ; row 97: zeros (pairs with row 96 in the MFMA k-step)
+            if (tid < 64) RX[96 * QS + hq] = h == 0 ? f32x4{nyqv[m], nyqv[32 + m], nyqv[64 + m], 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         STAMP(3);
-        __syncthreads();   // (2) mag complete; region A free
+        __syncthreads();   // (2) magnitudes complete
         STAMP(4);
 
         // ---- enc0: 129 -> 128 ch, k3 s1 p1, 3 -> 3 columns; wave w: channels 32w.. ---------
@@ -296,10 +315,10 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
             acc[1] = acc[0];
             acc[2] = acc[0];
             f32x4 Aw0 = E0w0, Aw1 = E0w1, Aw2 = E0w2, Bw0, Bw1, Bw2;
-            f32x4 Aa0 = RB[0 * QS + hq], Aa1 = RB[32 * QS + hq], Aa2 = RB[64 * QS + hq], Ba0, Ba1, Ba2;
+            f32x4 Aa0 = RX[0 * QS + hq], Aa1 = RX[32 * QS + hq], Aa2 = RX[64 * QS + hq], Ba0, Ba1, Ba2;
 #define E0_LD(S, jj)                                                                       \
     S##w0 = WL(ws + (3 * (jj))); S##w1 = WL(ws + (3 * (jj) + 1)); S##w2 = WL(ws + (3 * (jj) + 2)); \
-    S##a0 = RB[(2 * (jj)) * QS + hq]; S##a1 = RB[(32 + 2 * (jj)) * QS + hq]; S##a2 = RB[(64 + 2 * (jj)) * QS + hq];
+    S##a0 = RX[(2 * (jj)) * QS + hq]; S##a1 = RX[(32 + 2 * (jj)) * QS + hq]; S##a2 = RX[(64 + 2 * (jj)) * QS + hq];
             // out[c] += W[tap] * in[c + tap - 1]
 #define E0_MMA(S)                                                                          \
     acc[0] = mfma4(S##w1, S##a0, acc[0]); acc[1] = mfma4(S##w0, S##a0, acc[1]); acc[2] = mfma4(S##w0, S##a1, acc[2]); \
@@ -316,7 +335,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
 #undef E0_MMA
             STAMP(17);
             {   // input channel 128 (Nyquist bin): one k-iteration against per-column weight blocks
-                const f32x4 an = RB[96 * QS + hq];
+                const f32x4 an = RX[96 * QS + hq];
                 const f32x4 wn0 = WL(ws + 48), wn1 = WL(ws + 49), wn2 = WL(ws + 50);
                 // enc1's bias and first group of weights
                 e1b0 = WL(ws_e1); e1b1 = WL(ws_e1 + 1); e1b2 = WL(ws_e1 + 2); e1b3 = WL(ws_e1 + 3);
@@ -327,7 +346,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
                 acc[2] = mfma4(wn2, an, acc[2]);
             }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) store_tile_relu(RA, c * 32 + 8 * w, m, h, acc[c]);
+            for (int c = 0; c < 3; ++c) store_tile_relu(RE, c * 32 + 8 * w, m, h, acc[c]);
         }
         STAMP(5);
         __syncthreads();   // (3) enc0 out in A; region B free
@@ -351,8 +370,8 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
             // iteration it in 0..31: column tp + (it>>4), quad pair it&15
 #define E1_ROW(it) ((tp + ((it) >> 4)) * 32 + 2 * ((it) & 15))
 #define E1_LDA(S, g4)                                                                      \
-    S##a0 = RA[E1_ROW(4 * (g4)) * QS + hq]; S##a1 = RA[E1_ROW(4 * (g4) + 1) * QS + hq];    \
-    S##a2 = RA[E1_ROW(4 * (g4) + 2) * QS + hq]; S##a3 = RA[E1_ROW(4 * (g4) + 3) * QS + hq];
+    S##a0 = RE[E1_ROW(4 * (g4)) * QS + hq]; S##a1 = RE[E1_ROW(4 * (g4) + 1) * QS + hq];    \
+    S##a2 = RE[E1_ROW(4 * (g4) + 2) * QS + hq]; S##a3 = RE[E1_ROW(4 * (g4) + 3) * QS + hq];
             f32x4 Aw0 = E1w0, Aw1 = E1w1, Aw2 = E1w2, Aw3 = E1w3, Bw0, Bw1, Bw2, Bw3;
             f32x4 Aa0, Aa1, Aa2, Aa3, Ba0, Ba1, Ba2, Ba3;
             E1_LDA(A, 0)
@@ -374,7 +393,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
             }
 #undef E1_ROW
 #undef E1_LDA
-            store_tile_relu(RB, tp * 16 + 8 * nt, m, h, acc);
+            store_tile_relu(RX, tp * 16 + 8 * nt, m, h, acc);
         }
         STAMP(7);
         __syncthreads();   // (4) enc1 out in B; region A free
@@ -387,8 +406,8 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
             // iteration it in 0..15: column it>>3, quad pair it&7
 #define E2_ROW(it) (((it) >> 3) * 16 + 2 * ((it) & 7))
 #define E2_LDA(S, g4)                                                                      \
-    S##a0 = RB[E2_ROW(4 * (g4)) * QS + hq]; S##a1 = RB[E2_ROW(4 * (g4) + 1) * QS + hq];    \
-    S##a2 = RB[E2_ROW(4 * (g4) + 2) * QS + hq]; S##a3 = RB[E2_ROW(4 * (g4) + 3) * QS + hq];
+    S##a0 = RX[E2_ROW(4 * (g4)) * QS + hq]; S##a1 = RX[E2_ROW(4 * (g4) + 1) * QS + hq];    \
+    S##a2 = RX[E2_ROW(4 * (g4) + 2) * QS + hq]; S##a3 = RX[E2_ROW(4 * (g4) + 3) * QS + hq];
             f32x4 Aw0 = E2w0, Aw1 = E2w1, Aw2 = E2w2, Aw3 = E2w3, Bw0, Bw1, Bw2, Bw3;
             f32x4 Aa0, Aa1, Aa2, Aa3, Ba0, Ba1, Ba2, Ba3;
             E2_LDA(A, 0)
@@ -401,7 +420,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
             }
 #undef E2_ROW
 #undef E2_LDA
-            store_tile_relu(RA, 8 * w, m, h, acc);
+            store_tile_relu(RE, 8 * w, m, h, acc);
         }
         STAMP(9);
         __syncthreads();   // (5) enc2 out in A
@@ -413,9 +432,9 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
             const int ws = ws_e3 + 4;
             f32x16 acc = acc_of(e3b0, e3b1, e3b2, e3b3);
             f32x4 Aw0 = E3w0, Aw1 = E3w1, Aw2 = E3w2, Aw3 = E3w3, Bw0, Bw1, Bw2, Bw3;
-            f32x4 Aa0 = RA[0 * QS + hq], Aa1 = RA[2 * QS + hq], Aa2 = RA[4 * QS + hq], Aa3 = RA[6 * QS + hq];
+            f32x4 Aa0 = RE[0 * QS + hq], Aa1 = RE[2 * QS + hq], Aa2 = RE[4 * QS + hq], Aa3 = RE[6 * QS + hq];
             G_LDW(B, ws, 1)
-            const f32x4 Ba0 = RA[8 * QS + hq], Ba1 = RA[10 * QS + hq], Ba2 = RA[12 * QS + hq], Ba3 = RA[14 * QS + hq];
+            const f32x4 Ba0 = RE[8 * QS + hq], Ba1 = RE[10 * QS + hq], Ba2 = RE[12 * QS + hq], Ba3 = RE[14 * QS + hq];
             // the LSTM's gate biases and first weight blocks
 #pragma unroll
             for (int k = 0; k < 16; ++k) lb[k] = WL(ws_l + k);
@@ -423,7 +442,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
             SB();
             G_MMA(A) SB();
             G_MMA(B) SB();
-            store_tile_relu(RB, 8 * w, m, h, acc);
+            store_tile_relu(RX, 8 * w, m, h, acc);
         }
 #undef G_LDW
 #undef G_MMA
@@ -439,12 +458,12 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
             f32x16 gg = acc_of(lb[8], lb[9], lb[10], lb[11]);
             f32x16 go = acc_of(lb[12], lb[13], lb[14], lb[15]);
             // iteration it in 0..31: it < 16 contracts x (region B rows 0..31), then h_{t-1} (region H)
-#define L_ROW(it) ((it) < 16 ? (RB + (2 * (it)) * QS + hq) : (RH + (2 * ((it) - 16)) * QS + hq))
+#define L_ROW(it) ((it) < 16 ? (RX + (2 * (it)) * QS + hq) : (RH + (2 * ((it) - 16)) * QS + hq))
 #define L_LD(S, it)                                                                        \
     S##wi = WL(ws + (4 * (it))); S##wf = WL(ws + (4 * (it) + 1));                  \
     S##wg = WL(ws + (4 * (it) + 2)); S##wo = WL(ws + (4 * (it) + 3)); S##av = *L_ROW(it);
 #define L_MMA(S) gi = mfma4(S##wi, S##av, gi); gfo = mfma4(S##wf, S##av, gfo); gg = mfma4(S##wg, S##av, gg); go = mfma4(S##wo, S##av, go);
-            f32x4 Awi = Lw0, Awf = Lw1, Awg = Lw2, Awo = Lw3, Aav = RB[hq], Bwi, Bwf, Bwg, Bwo, Bav;
+            f32x4 Awi = Lw0, Awf = Lw1, Awg = Lw2, Awo = Lw3, Aav = RX[hq], Bwi, Bwf, Bwg, Bwo, Bav;
             f32x4 hw0, hw1, hw2, hw3;
             for (int it = 0; it < 32; it += 2) {
                 L_LD(B, it + 1) SB();

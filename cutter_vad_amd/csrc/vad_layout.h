@@ -29,9 +29,13 @@ constexpr int BLK_FLOATS = 256;
 
 // ---- Silero V5 (16 kHz branch) -------------------------------------------------------
 namespace v5 {
+// The windowed-DFT basis is exactly symmetric in the stored weights: C[k][n] == C[k][256-n],
+// S[k][n] == -S[k][256-n], C[k][0] == S[k][0] == S[k][128] == 0.  The loader therefore folds each
+// 256-sample column into u[n] = x[n] + x[256-n], v[n] = x[n] - x[256-n] (n = 1..127), u[128] = x[128],
+// v[128] = 0, and the STFT contracts K = 128 instead of 256:  re = C[:,1:129] u,  im = S[:,1:129] v.
 // weight-stream sections, in blocks, per wave
-constexpr int STFT_BLOCKS = 64;            // 32 k-iterations x {re, im}
-constexpr int NYQ_BLOCKS = 64;             // wave 3 only: bin 128 {re, im} per k-iteration
+constexpr int STFT_BLOCKS = 32;            // 16 k-iterations x {re, im}
+constexpr int NYQ_BLOCKS = 1;              // shared: floats 0..127 = C[128][1..128]  (bin 128, VALU)
 constexpr int ENC0_BLOCKS = 4 + 16 * 3 + 3;  // bias, 16 k-iterations x 3 taps, Nyquist channel x 3 t_out
 constexpr int ENC1_BLOCKS = 4 + 2 * 16;
 constexpr int ENC2_BLOCKS = 4 + 2 * 8;     // waves 0,1 only
@@ -39,11 +43,15 @@ constexpr int ENC3_BLOCKS = 4 + 8;
 constexpr int LSTM_BLOCKS = 16 + 64 + 64 + 4;  // bias(4 gates), W_ih, W_hh, head weights
 enum Section { S_STFT = 0, S_NYQ, S_ENC0, S_ENC1, S_ENC2, S_ENC3, S_LSTM, S_HEADB, S_COUNT };  // S_HEADB: 1 block, float 0 = head bias
 
-// LDS regions, in quad rows
-constexpr int ROWS_A = 128;                // x (128 quads) / enc0 out (96) / enc2 out (16)
-constexpr int ROWS_B = 98;                 // mag (96 + Nyquist quad + zero quad) / enc1 out (32) / enc3 out (32)
+// LDS, in quad rows.  One activation region X, reused by every layer:
+//   loader : u of column c -> rows 64c + q, v -> rows 64c + 32 + q        (q = 0..31, n = 4q+1 .. 4q+4)
+//   |STFT| : rows 32c + bin/4 (c = 0..2), row 96 = (|X128| of columns 0,1,2, 0), row 97 = 0
+//   enc0   : rows 98 + 32c + ch/4          enc1 : rows 16c + ch/4
+//   enc2   : rows 98 + ch/4                enc3 : rows ch/4 (LSTM input)
+constexpr int ROWS_X = 194;
+constexpr int ROW_E = 98;                  // first row of the upper half (enc0 / enc2 outputs)
 constexpr int ROWS_H = 32;                 // h_{t-1}
-constexpr int LDS_F4 = (ROWS_A + ROWS_B + ROWS_H) * QS + 32;  // + 4x32 floats of head partials
+constexpr int LDS_F4 = (ROWS_X + ROWS_H) * QS + 32 + 24;  // + head partials [4][32] + Nyquist magnitudes [3][32]
 constexpr int LDS_BYTES = LDS_F4 * 16;
 }  // namespace v5
 

@@ -62,41 +62,49 @@ def _store_tile(region, row0, acc, relu=True):
 
 
 def v5_step(W, sect, x, hc, gate=0.01):
-    """x [32,512] f32, hc [32,256] -> (prob [32], new hc [32,256]).  float64 contractions."""
+    """x [32,512] f32, hc [32,256] -> (prob [32], new hc [32,256]).  float64 contractions.
+    Mirrors silero_v5.hip: folded loader, one activation region RX (row map in vad_layout.h)."""
     x = x.astype(np.float64)
     if gate is not None and gate >= 0:
         x = np.where(np.abs(x) > gate, x, 0.0)
-    RA = np.zeros((128, 32, 4))
-    RB = np.zeros((98, 32, 4))
+    RX = np.zeros((194, 32, 4))
     RH = np.zeros((32, 32, 4))
-    RA[:] = x.reshape(32, 128, 4).transpose(1, 0, 2)
+    RE = RX[98:]
+    # loader: fold every column (c = 0..2): u[n] = x[n] + x[256-n], v[n] = x[n] - x[256-n], n = 1..128
+    for c in range(3):
+        col = x[:, 128 * c:128 * c + 256] if c < 2 else np.concatenate([x[:, 256:512]], axis=1)
+        n = np.arange(1, 129)
+        mir = np.where(n < 128, 256 - n, 0)
+        xm = np.where(n[None, :] < 128, col[:, mir], 0.0)
+        u = col[:, n] + xm
+        v = np.where(n[None, :] < 128, col[:, n] - xm, 0.0)
+        RX[64 * c:64 * c + 32] = u.reshape(32, 32, 4).transpose(1, 0, 2)
+        RX[64 * c + 32:64 * c + 64] = v.reshape(32, 32, 4).transpose(1, 0, 2)
     RH[:] = hc[:, :128].astype(np.float64).reshape(32, 32, 4).transpose(1, 0, 2)
     c_prev = hc[:, 128:].astype(np.float64)
+    # bin 128 on the VALU
+    nq = W[sect[0][S_NYQ]].reshape(-1)[:128].astype(np.float64)
+    nyq = np.zeros((3, 32))
+    for c in range(3):
+        u = RX[64 * c:64 * c + 32].transpose(1, 0, 2).reshape(32, 128)
+        nyq[c] = np.abs(u @ nq)
     # STFT
+    mags = {}
     for w in range(4):
         ws = sect[w][S_STFT]
         are = [np.zeros((32, 32)) for _ in range(3)]
         aim = [np.zeros((32, 32)) for _ in range(3)]
-        nre = np.zeros((3, 64))
-        nim = np.zeros((3, 64))
-        for j in range(32):
+        for j in range(16):
             wre, wim = W[ws + 2 * j], W[ws + 2 * j + 1]
             for c in range(3):
-                a = _rows(RA, 32 * c + 2 * j, 32 * c + 2 * j + 1)
-                are[c] += _mfma4(wre, a)
-                aim[c] += _mfma4(wim, a)
-                if w == 3:
-                    wn = sect[w][S_NYQ]
-                    nre[c] += (W[wn + 2 * j].astype(np.float64) * a).sum(1)
-                    nim[c] += (W[wn + 2 * j + 1].astype(np.float64) * a).sum(1)
+                are[c] += _mfma4(wre, _rows(RX, 64 * c + 2 * j, 64 * c + 2 * j + 1))
+                aim[c] += _mfma4(wim, _rows(RX, 64 * c + 32 + 2 * j, 64 * c + 32 + 2 * j + 1))
+        mags[w] = [np.sqrt(are[c] ** 2 + aim[c] ** 2) for c in range(3)]
+    for w in range(4):
         for c in range(3):
-            _store_tile(RB, c * 32 + 8 * w, np.sqrt(are[c] ** 2 + aim[c] ** 2), relu=False)
-        if w == 3:
-            r = nre[:, :32] + nre[:, 32:]
-            i = nim[:, :32] + nim[:, 32:]
-            mg = np.sqrt(r * r + i * i)  # [3, 32]
-            RB[96] = np.concatenate([mg.T, np.zeros((32, 1))], axis=1)
-            RB[97] = 0
+            _store_tile(RX, c * 32 + 8 * w, mags[w][c], relu=False)
+    RX[96] = np.concatenate([nyq.T, np.zeros((32, 1))], axis=1)
+    RX[97] = 0
     # enc0
     E0 = {}
     for w in range(4):
@@ -106,17 +114,17 @@ def v5_step(W, sect, x, hc, gate=0.01):
         ws += 4
         for j in range(16):
             wt = [W[ws + 3 * j + t] for t in range(3)]
-            a = [_rows(RB, 32 * c + 2 * j, 32 * c + 2 * j + 1) for c in range(3)]
+            a = [_rows(RX, 32 * c + 2 * j, 32 * c + 2 * j + 1) for c in range(3)]
             acc[0] += _mfma4(wt[1], a[0]) + _mfma4(wt[2], a[1])
             acc[1] += _mfma4(wt[0], a[0]) + _mfma4(wt[1], a[1]) + _mfma4(wt[2], a[2])
             acc[2] += _mfma4(wt[0], a[1]) + _mfma4(wt[1], a[2])
-        an = _rows(RB, 96, 97)
+        an = _rows(RX, 96, 97)
         for c in range(3):
             acc[c] += _mfma4(W[ws + 48 + c], an)
         E0[w] = acc
     for w in range(4):
         for c in range(3):
-            _store_tile(RA, c * 32 + 8 * w, E0[w][c])
+            _store_tile(RE, c * 32 + 8 * w, E0[w][c])
     # enc1
     E1 = {}
     for w in range(4):
@@ -127,10 +135,10 @@ def v5_step(W, sect, x, hc, gate=0.01):
         for it in range(32):
             ti, j = it >> 4, it & 15
             r = (tp + ti) * 32 + 2 * j
-            acc += _mfma4(W[ws + it], _rows(RA, r, r + 1))
+            acc += _mfma4(W[ws + it], _rows(RE, r, r + 1))
         E1[w] = acc
     for w in range(4):
-        _store_tile(RB, (w >> 1) * 16 + 8 * (w & 1), E1[w])
+        _store_tile(RX, (w >> 1) * 16 + 8 * (w & 1), E1[w])
     # enc2
     E2 = {}
     for w in range(2):
@@ -140,10 +148,10 @@ def v5_step(W, sect, x, hc, gate=0.01):
         for it in range(16):
             ti, j = it >> 3, it & 7
             r = ti * 16 + 2 * j
-            acc += _mfma4(W[ws + it], _rows(RB, r, r + 1))
+            acc += _mfma4(W[ws + it], _rows(RX, r, r + 1))
         E2[w] = acc
     for w in range(2):
-        _store_tile(RA, 8 * w, E2[w])
+        _store_tile(RE, 8 * w, E2[w])
     # enc3
     E3 = {}
     for w in range(4):
@@ -151,10 +159,10 @@ def v5_step(W, sect, x, hc, gate=0.01):
         acc = np.repeat(_vec(W[ws:ws + 4])[:, None], 32, 1)
         ws += 4
         for j in range(8):
-            acc += _mfma4(W[ws + j], _rows(RA, 2 * j, 2 * j + 1))
+            acc += _mfma4(W[ws + j], _rows(RE, 2 * j, 2 * j + 1))
         E3[w] = acc
     for w in range(4):
-        _store_tile(RB, 8 * w, E3[w])
+        _store_tile(RX, 8 * w, E3[w])
     # LSTM + head
     sig = lambda v: 1.0 / (1.0 + np.exp(-v))
     h_new = np.zeros((32, 128))
@@ -164,7 +172,7 @@ def v5_step(W, sect, x, hc, gate=0.01):
         ws = sect[w][S_LSTM]
         g = [np.repeat(_vec(W[ws + 4 * q:ws + 4 * q + 4])[:, None], 32, 1) for q in range(4)]
         ws += 16
-        for src in (RB, RH):
+        for src in (RX, RH):
             for j in range(16):
                 a = _rows(src, 2 * j, 2 * j + 1)
                 for q in range(4):
