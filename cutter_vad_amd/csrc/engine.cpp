@@ -24,6 +24,7 @@
 #include "vad_layout.h"
 
 extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream_t stream);
+extern "C" hipError_t vadk_launch_resample(const vadk::ResampleParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_sm_replay(vadk::SmSlot *sm, int slot, const float *probs, int n, uint8_t *events,
                                             int32_t *seg, hipStream_t stream);
 
@@ -59,6 +60,15 @@ struct vad_engine {
     int32_t *d_seg = nullptr;  size_t d_seg_cap = 0;
     int32_t *d_slots = nullptr; size_t d_slots_cap = 0;
     vadk::StepParams base{};
+    struct ResampleOp {
+        int n_in = 0;
+        float *d_w = nullptr;
+        size_t bytes = 0;
+        uint32_t wave_blocks = 0;
+    };
+    std::vector<ResampleOp> resample_ops;   // built lazily, one per input rate
+    float *d_rs_in = nullptr;  size_t d_rs_in_cap = 0;
+    float *d_rs_out = nullptr; size_t d_rs_out_cap = 0;
     std::vector<uint8_t> open;
     std::vector<int64_t> free_list;
     std::vector<uint32_t> stamp;   // duplicate detection per step
@@ -268,9 +278,12 @@ void vad_engine_destroy(vad_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void *bufs[] = {e->d_wstream, e->d_state, e->d_sm, e->d_frames, e->d_probs, e->d_events, e->d_seg, e->d_slots};
+    void *bufs[] = {e->d_wstream, e->d_state, e->d_sm, e->d_frames, e->d_probs, e->d_events, e->d_seg, e->d_slots,
+                    e->d_rs_in, e->d_rs_out};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    for (auto &op : e->resample_ops)
+        if (op.d_w) (void)hipFree(op.d_w);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -432,16 +445,103 @@ int vad_step_device(vad_engine *e, const int32_t *d_slots, int64_t n, const void
     return launch(e, p, stream ? static_cast<hipStream_t>(stream) : e->stream);
 }
 
-int vad_resample(vad_engine *e, const float *, int64_t, int32_t, int32_t, float *) {
-    if (!e) return VAD_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
-    return e->fail(VAD_ERR_UNSUPPORTED, "resampler kernel not built yet");
+namespace {
+
+// chunk length that yields 512 samples at 16 kHz (AudioUtils.resample_audio: int(len * 16000 / sr), audio.py:46)
+int resample_chunk_len(int sr_in) {
+    switch (sr_in) {
+        case 8000: return 256;
+        case 24000: return 768;
+        case 48000: return 1536;
+        default: return 0;
+    }
 }
 
-int vad_resample_device(vad_engine *e, const float *, int64_t, int32_t, int32_t, float *, void *) {
+int get_resample_op(vad_engine *e, int n_in, vad_engine::ResampleOp **out) {
+    for (auto &op : e->resample_ops)
+        if (op.n_in == n_in) {
+            *out = &op;
+            return VAD_OK;
+        }
+    std::vector<float> R, packed;
+    vadk::build_resample_operator(n_in, R);
+    vad_engine::ResampleOp op;
+    op.n_in = n_in;
+    op.wave_blocks = vadk::pack_resample_operator(R, n_in, packed);
+    op.bytes = packed.size() * sizeof(float);
+    hipError_t r = hipMalloc((void **)&op.d_w, op.bytes);
+    if (r != hipSuccess) return e->hip_fail(r, "hipMalloc(resample operator)");
+    r = hipMemcpy(op.d_w, packed.data(), op.bytes, hipMemcpyHostToDevice);
+    if (r != hipSuccess) {
+        (void)hipFree(op.d_w);
+        return e->hip_fail(r, "hipMemcpy(resample operator)");
+    }
+    e->resample_ops.push_back(op);
+    *out = &e->resample_ops.back();
+    return VAD_OK;
+}
+
+int resample_launch(vad_engine *e, const float *d_in, int64_t n, int32_t n_in, int32_t sr_in, float *d_out, hipStream_t s) {
+    const int want = resample_chunk_len(sr_in);
+    if (want == 0)
+        return e->fail(VAD_ERR_UNSUPPORTED, "Failed to resample audio from %dHz to 16000Hz: supported input rates are 8000, 24000, 48000", sr_in);
+    if (n_in != want)
+        return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio from %dHz to 16000Hz: a chunk must hold %d samples, got %d", sr_in, want, n_in);
+    vad_engine::ResampleOp *op = nullptr;
+    if (int rc = get_resample_op(e, n_in, &op)) return rc;
+    vadk::ResampleParams p{};
+    p.wstream = op->d_w;
+    p.wstream_bytes = (uint32_t)op->bytes;
+    p.wave_blocks = op->wave_blocks;
+    p.in = d_in;
+    p.out = d_out;
+    p.n = (int32_t)n;
+    p.n_in = n_in;
+    hipError_t r = vadk_launch_resample(&p, s);
+    if (r != hipSuccess) return e->hip_fail(r, "resample kernel launch");
+    return VAD_OK;
+}
+
+}  // namespace
+
+int vad_resample(vad_engine *e, const float *in, int64_t n, int32_t n_in, int32_t sr_in, float *out) {
     if (!e) return VAD_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
-    return e->fail(VAD_ERR_UNSUPPORTED, "resampler kernel not built yet");
+    if (n < 0 || (n > 0 && (!in || !out))) return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio: null buffer or bad count");
+    if (n == 0) return VAD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    const size_t ib = sizeof(float) * (size_t)n * n_in, ob = sizeof(float) * (size_t)n * VAD_FRAME_SAMPLES;
+    if (resample_chunk_len(sr_in) != n_in)
+        return resample_launch(e, nullptr, n, n_in, sr_in, nullptr, e->stream);   // reports the precise error
+    if (int rc = ensure(e, e->d_rs_in, e->d_rs_in_cap, ib)) return rc;
+    if (int rc = ensure(e, e->d_rs_out, e->d_rs_out_cap, ob)) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->d_rs_in, in, ib, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (int rc = resample_launch(e, e->d_rs_in, n, n_in, sr_in, e->d_rs_out, e->stream)) return rc;
+    HIP_TRY(e, hipMemcpyAsync(out, e->d_rs_out, ob, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return VAD_OK;
+}
+
+int vad_resample_device(vad_engine *e, const float *d_in, int64_t n, int32_t n_in, int32_t sr_in, float *d_out, void *stream) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (n < 0 || (n > 0 && (!d_in || !d_out))) return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio: null buffer or bad count");
+    if (n == 0) return VAD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    return resample_launch(e, d_in, n, n_in, sr_in, d_out, stream ? static_cast<hipStream_t>(stream) : e->stream);
+}
+
+int vad_debug_resample_operator(int32_t n_in, float *R, size_t r_floats) {
+    g_create_error.clear();
+    if (n_in < 8 || n_in % 8 || !R || r_floats < (size_t)n_in * VAD_FRAME_SAMPLES) {
+        g_create_error = "vad_debug_resample_operator: n_in must be a positive multiple of 8 and R must hold 512*n_in floats";
+        return VAD_ERR_INVALID_ARG;
+    }
+    std::vector<float> op;
+    vadk::build_resample_operator(n_in, op);
+    std::memcpy(R, op.data(), op.size() * sizeof(float));
+    return VAD_OK;
 }
 
 int vad_debug_pack_weights(int32_t model_version, const void *weights, size_t weights_len, float *out,

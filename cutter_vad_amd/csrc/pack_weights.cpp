@@ -9,6 +9,7 @@
 //   bias / head block g:                    lane (any, hh), component i = b[32*nt + 8g + 4hh + i]
 #include "pack_weights.h"
 
+#include <cmath>
 #include <cstring>
 
 namespace vadk {
@@ -203,6 +204,51 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
     }
     out.data = std::move(sb.data);
     return true;
+}
+
+void build_resample_operator(int n_in, std::vector<float> &R) {
+    // scipy.signal.resample, real input, window=None:
+    //   X = rfft(x); Y[0:N/2+1] = X[0:N/2+1] with N = min(n_in, n_out); if N is even the bin N/2 is
+    //   doubled when down-sampling and halved when up-sampling; y = irfft(Y, n_out) * n_out / n_in.
+    // Hence y[o] = (1/n_in) * sum_i x[i] * ( D_M(theta) + nyquist term ),  theta = 2 pi (o/n_out - i/n_in),
+    // D_M(theta) = 1 + 2 sum_{k=1..M} cos(k theta) = sin((M + 1/2) theta) / sin(theta / 2).
+    const int n_out = 512;
+    const int N = n_in < n_out ? n_in : n_out;
+    const int M = (N % 2 == 0) ? N / 2 - 1 : (N - 1) / 2;
+    const double two_pi = 6.283185307179586476925286766559;
+    const long long period = (long long)n_in * n_out;
+    R.assign((size_t)n_out * n_in, 0.f);
+    for (int o = 0; o < n_out; ++o) {
+        for (int i = 0; i < n_in; ++i) {
+            long long p = ((long long)o * n_in - (long long)i * n_out) % period;   // exact phase reduction
+            if (p < 0) p += period;
+            const double theta = two_pi * (double)p / (double)period;
+            const double sh = std::sin(0.5 * theta);
+            double v = std::fabs(sh) < 1e-13 ? (double)(2 * M + 1) : std::sin((M + 0.5) * theta) / sh;
+            if (N % 2 == 0 && n_in != n_out) {
+                const int kq = N / 2;
+                const double ci = std::cos(two_pi * (double)(((long long)kq * i) % n_in) / (double)n_in);
+                const double co = std::cos(two_pi * (double)(((long long)kq * o) % n_out) / (double)n_out);
+                // down: Y[kq] = 2 X[kq] and kq is the output Nyquist bin (irfft weight 1, real part only)
+                // up  : Y[kq] = X[kq] / 2 (X[kq] is the real input Nyquist bin), a regular output bin (weight 2)
+                v += (n_out < n_in) ? 2.0 * ci * co : ci * co;
+            }
+            R[(size_t)o * n_in + i] = (float)(v / (double)n_in);
+        }
+    }
+}
+
+uint32_t pack_resample_operator(const std::vector<float> &R, int n_in, std::vector<float> &out) {
+    const int nchunks = n_in / 256;
+    StreamBuilder sb;
+    for (int w = 0; w < NWAVES; ++w)
+        for (int c = 0; c < nchunks; ++c)
+            for (int j = 0; j < 32; ++j)
+                for (int tt = 0; tt < 4; ++tt)
+                    sb.weight_block([&](int np, int k) { return R[(size_t)(32 * (4 * w + tt) + np) * n_in + 256 * c + k]; }, j);
+    const uint32_t per_wave = sb.blocks() / NWAVES;
+    out = std::move(sb.data);
+    return per_wave;
 }
 
 bool pack_silero_v4(const void *, size_t, PackedWeights &, std::string &err) {

@@ -91,4 +91,15 @@ struct StepParams {
 #endif
 };
 
+// resampler launch parameters (csrc/resample.hip)
+struct ResampleParams {
+    const float *wstream;     // packed operator R[512][n_in]: per wave, per 256-sample chunk, per k-iteration: 4 tile blocks
+    uint32_t wstream_bytes;
+    uint32_t wave_blocks;     // blocks per wave = (n_in / 8) * 4
+    const float *in;          // [n][n_in]
+    float *out;               // [n][512]
+    int32_t n;
+    int32_t n_in;             // multiple of 256
+};
+
 }  // namespace vadk

@@ -191,6 +191,12 @@ VAD_API int vad_debug_pack_weights(int32_t model_version, const void *weights, s
                                    size_t out_floats, size_t *n_floats, uint32_t *sect_out);
 
 /*
+ * Diagnostic (no GPU needed): the dense operator R[512][n_in] (row-major) the resampler kernel
+ * applies for chunks of n_in samples; the CPU test-suite checks R @ x against scipy.signal.resample.
+ */
+VAD_API int vad_debug_resample_operator(int32_t n_in, float *R, size_t r_floats);
+
+/*
  * Diagnostic: replay a scripted probability sequence through ONE slot's device-side state
  * machine (the code path vad_step_events runs after the model).  probs [n] -> events_out [n],
  * seg_frames_out [n] (segment length in frames on END, else 0).  Lets the GPU test-suite check

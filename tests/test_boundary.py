@@ -107,3 +107,19 @@ def test_weights_blob_roundtrip_and_reference_arity_rule(tmp_path):
     assert weights_io.load_weight_blob(str(p), 5) == blob
     with pytest.raises(weights_io.WeightFormatError):
         weights_io.load_weight_blob(str(p), 4)
+
+
+def test_resample_operator_matches_scipy_and_reference_fixture():
+    """R[512][n_in] applied on the host == scipy.signal.resample == AudioUtils.resample_audio fixture."""
+    import scipy.signal
+    lib = _ffi.lib()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "utils.npz"))
+    for sr, n_in in ((8000, 256), (24000, 768), (48000, 1536)):
+        R = np.empty((512, n_in), np.float32)
+        assert lib.vad_debug_resample_operator(n_in, R.ctypes.data_as(C.POINTER(C.c_float)), R.size) == 0
+        x = (0.5 * np.random.default_rng(sr).standard_normal((5, n_in))).astype(np.float32)
+        got = (x.astype(np.float64) @ R.astype(np.float64).T).astype(np.float32)
+        assert np.abs(got - g[f"resample_{sr}"]).max() <= 2e-6
+        live = np.stack([scipy.signal.resample(r, 512).astype(np.float32) for r in x])
+        assert np.abs(got - live).max() <= 2e-6
+    assert lib.vad_debug_resample_operator(100, None, 0) == _ffi.VAD_ERR_INVALID_ARG

@@ -1,0 +1,92 @@
+"""GPU parity of the resampler kernel (a11) and of config 4: mixed 8/24/48 kHz -> resample -> V5."""
+
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RATES = ((8000, 256), (24000, 768), (48000, 1536))
+TOL = 1e-5   # SURVEY §8 d, config 4: resample stage <= 1e-5 abs vs scipy.signal.resample
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from cutter_vad_amd import weights_io
+    from cutter_vad_amd.engine import Engine
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        e = Engine(f.read(), max_streams=2048)
+    yield e
+    e.close()
+
+
+def test_kernel_matches_reference_fixture_and_scipy(engine):
+    import scipy.signal
+    g = np.load(os.path.join(GOLD, "utils.npz"))
+    for sr, n_in in RATES:
+        x = (0.5 * np.random.default_rng(sr).standard_normal((5, n_in))).astype(np.float32)
+        got = engine.resample(x, sr)
+        assert got.shape == (5, 512) and got.dtype == np.float32
+        assert np.abs(got - g[f"resample_{sr}"]).max() <= TOL          # the reference's AudioUtils.resample_audio
+        for n in (1, 31, 32, 33, 200):                                  # ragged tiles
+            xs = (0.3 * np.random.default_rng(n).standard_normal((n, n_in))).astype(np.float32)
+            ref = np.stack([scipy.signal.resample(r, 512).astype(np.float32) for r in xs])
+            assert np.abs(engine.resample(xs, sr) - ref).max() <= TOL
+
+
+def test_oracle_agrees_and_linearity(engine):
+    from oracle import oracle
+    rng = np.random.default_rng(3)
+    for sr, n_in in RATES:
+        a = rng.standard_normal((40, n_in)).astype(np.float32)
+        b = rng.standard_normal((40, n_in)).astype(np.float32)
+        ya, yb, yab = engine.resample(a, sr), engine.resample(b, sr), engine.resample(a + 2 * b, sr)
+        assert np.abs(yab - (ya + 2 * yb)).max() <= 2e-5                # a linear operator
+        ref = np.stack([oracle.resample(r, 512) for r in a[:6]])
+        assert np.abs(ya[:6] - ref).max() <= TOL
+        const = engine.resample(np.full((3, n_in), 0.25, np.float32), sr)
+        assert np.abs(const - 0.25).max() <= TOL                        # DC is preserved (fp32 operator rows)
+
+
+def test_audio_utils_resample_goes_through_the_engine(engine):
+    from cutter_vad_amd import AudioProcessingError, AudioUtils
+    import scipy.signal
+    x = (0.5 * np.random.default_rng(11).standard_normal(1536)).astype(np.float32)
+    y = AudioUtils.resample_audio(x, 48000, 16000)
+    assert y.shape == (512,) and y.dtype == np.float32
+    assert np.abs(y - scipy.signal.resample(x, 512).astype(np.float32)).max() <= TOL
+    y2 = AudioUtils.resample_audio(np.concatenate([x, x]), 48000, 16000)   # two independent chunks
+    assert np.abs(y2[:512] - y).max() == 0 and np.abs(y2[512:] - y).max() == 0
+    with pytest.raises(AudioProcessingError, match="Failed to resample audio from 48000Hz to 16000Hz"):
+        AudioUtils.resample_audio(x[:1000], 48000, 16000)
+
+
+def test_config4_mixed_rates_resample_then_v5(engine):
+    """4096-stream config scaled down: thirds at 8/24/48 kHz, on-GPU resample, V5; oracle on the same chain."""
+    from cutter_vad_amd import weights_io
+    from oracle import oracle
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        om = oracle.OracleModel(f.read(), "f64")
+    per, T = 40, 5
+    slots = engine.open_streams(3 * per)
+    try:
+        st = np.zeros((3 * per, 256), np.float32)
+        rng = np.random.default_rng(8)
+        for t in range(T):
+            frames16, ref16 = [], []
+            for k, (sr, n_in) in enumerate(RATES):
+                tt = (np.arange(n_in) + t * n_in) / sr
+                x = (0.3 * np.sin(2 * np.pi * (150 + 10 * np.arange(per))[:, None] * tt[None, :])
+                     + 0.03 * rng.standard_normal((per, n_in))).astype(np.float32)
+                frames16.append(engine.resample(x, sr))
+                ref16.append(np.stack([oracle.resample(r, 512) for r in x]))
+            f16 = np.concatenate(frames16)
+            r16 = np.concatenate(ref16)
+            assert np.abs(f16 - r16).max() <= TOL
+            p = engine.step(slots, f16)
+            pr = om.step_batch(oracle.denoise(r16).reshape(-1, 512), st, nthreads=8)
+            assert np.abs(p - pr).max() <= 1e-4                       # the north-star bar for the full chain
+    finally:
+        for s in slots:
+            engine.close_stream(s)
