@@ -49,14 +49,31 @@ def synth_ring(first_stream: int, n: int) -> np.ndarray:
     return np.ascontiguousarray(make_streams(n, RING, seed=1234, first_stream=first_stream).transpose(1, 0, 2))
 
 
+def usable_cores() -> int:
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pe = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                cores = max(1, min(cores, int(q / pe + 0.5)))
+        except Exception:
+            pass
+    return cores
+
+
 def cpu_leg(ring: np.ndarray, gpu_probs: np.ndarray, budget_s: float = 12.0) -> tuple:
     """Time the oracle port on host cores (same frames, same gate) and compare with the GPU."""
     from cutter_vad_amd import weights_io
     from oracle import oracle
     with open(weights_io.packaged_blob_path(5), "rb") as f:
         blob = f.read()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = min(cores, 256)
+    threads = min(usable_cores(), 256)
     om = oracle.OracleModel(blob, "f32")
     n = min(CPU_STREAMS, ring.shape[1])
     st = np.zeros((n, 256), np.float32)
@@ -99,18 +116,15 @@ def main() -> None:
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from cutter_vad_amd import sharding
+    info = sharding.RankInfo.from_env()
+    rank, local_rank, world = info.rank, info.local_rank, info.world
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dist = sharding.init_process_group(info, "nccl", torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
     from cutter_vad_amd import weights_io
     from cutter_vad_amd.engine import Engine
@@ -120,7 +134,8 @@ def main() -> None:
         blob = f.read()
     eng = Engine(blob, model_version=5, device_id=local_rank, max_streams=B)
     eng.open_streams(B)                       # slots 0..B-1, zero state, default thresholds
-    ring_h = synth_ring(rank * B, B)
+    first_stream, _ = sharding.stream_shard(world * B, world, rank)   # weak scaling: B streams per rank
+    ring_h = synth_ring(first_stream, B)
     ring = torch.from_numpy(ring_h).cuda()
     probs = torch.empty(B, device="cuda")
     events = torch.empty(B, dtype=torch.uint8, device="cuda")
@@ -139,28 +154,20 @@ def main() -> None:
         for i in range(args.warmup):
             step(PARITY_STEPS + i)
         ts.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record(ts)
-        for i in range(args.steps):
-            step(PARITY_STEPS + args.warmup + i)
-        e1.record(ts)
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            dist.barrier()
+
+        def run() -> None:
+            e0.record(ts)
+            for i in range(args.steps):
+                step(PARITY_STEPS + args.warmup + i)
+            e1.record(ts)
+
+        elapsed = sharding.timed_region(dist, run, torch.cuda.synchronize, device="cuda")
     kernel_s = e0.elapsed_time(e1) * 1e-3 / args.steps      # avg launch duration on the launch stream
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     assert bool(torch.isfinite(probs).all()) and float(probs.min()) >= 0.0 and float(probs.max()) <= 1.0
 
     if rank == 0:
-        value = world * B * args.steps / elapsed
+        value = sharding.aggregate_rate(B, args.steps, world, elapsed)
         achieved = FLOP_PER_FRAME * B / kernel_s
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")

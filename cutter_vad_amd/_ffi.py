@@ -81,6 +81,7 @@ SIGNATURES = {
     "vad_last_create_error": (C.c_char_p, []),
     "vad_engine_info": (C.c_int, [_vp, C.POINTER(EngineInfo)]),
     "vad_stream_open": (C.c_int, [_vp, _i64p]),
+    "vad_stream_open_many": (C.c_int, [_vp, C.c_int64, _i64p]),
     "vad_stream_close": (C.c_int, [_vp, C.c_int64]),
     "vad_stream_reset": (C.c_int, [_vp, _i64p, C.c_int64]),
     "vad_stream_get_state": (C.c_int, [_vp, C.c_int64, _f32p]),

@@ -326,6 +326,29 @@ int vad_stream_open(vad_engine *e, int64_t *slot) {
     return VAD_OK;
 }
 
+int vad_stream_open_many(vad_engine *e, int64_t n, int64_t *slots_out) {
+    if (!e || n < 0 || (n > 0 && !slots_out)) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if ((int64_t)e->free_list.size() < n)
+        return e->fail(VAD_ERR_NO_SLOT, "stream pool exhausted (%d slots, %d open, %lld requested)", e->max_streams,
+                       e->open_count, (long long)n);
+    HIP_TRY(e, hipSetDevice(e->device));
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t s = e->free_list[e->free_list.size() - 1 - (size_t)i];
+        HIP_TRY(e, hipMemsetAsync(e->d_state + (size_t)s * VAD_STATE_FLOATS, 0, sizeof(float) * VAD_STATE_FLOATS, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(e->d_sm + s, &kDefaultSm, sizeof kDefaultSm, hipMemcpyHostToDevice, e->stream));
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t s = e->free_list.back();
+        e->free_list.pop_back();
+        e->open[(size_t)s] = 1;
+        slots_out[i] = s;
+    }
+    e->open_count += (int)n;
+    return VAD_OK;
+}
+
 int vad_stream_close(vad_engine *e, int64_t slot) {
     if (!e) return VAD_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);

@@ -94,7 +94,9 @@ class Engine:
         return int(s.value)
 
     def open_streams(self, n: int) -> np.ndarray:
-        return np.array([self.open_stream() for _ in range(n)], dtype=np.int64)
+        out = np.empty(int(n), np.int64)
+        self._check(self._lib.vad_stream_open_many(self._h, int(n), _ptr(out, C.c_int64)), VADError)
+        return out
 
     def close_stream(self, slot: int) -> None:
         self._check(self._lib.vad_stream_close(self._h, int(slot)), VADError)

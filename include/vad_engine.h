@@ -123,6 +123,8 @@ VAD_API int vad_engine_info(const vad_engine *e, vad_info *info);
 /* one VADWrapper/VADProcessor/SileroVADModel per client in the reference
  * (websocket_service/server/vad_websocket_server.py:277) == one slot here */
 VAD_API int vad_stream_open(vad_engine *e, int64_t *slot);
+/* n streams at once (one device synchronisation for the lot); slots_out [n] */
+VAD_API int vad_stream_open_many(vad_engine *e, int64_t n, int64_t *slots_out);
 VAD_API int vad_stream_close(vad_engine *e, int64_t slot);
 /* SileroVADModel.reset / _reset_states  core/silero_model.py:384-401, 539-546 (also resets the slot's state machine) */
 VAD_API int vad_stream_reset(vad_engine *e, const int64_t *slots, int64_t n);

@@ -1,0 +1,74 @@
+"""N > 1 path on CPU: two gloo ranks run the same plumbing bench.py uses on RCCL — static stream
+shards with no data-path collective, barrier + MAX-reduced timing, whole-job aggregation."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from cutter_vad_amd import sharding
+
+
+def test_stream_shards_partition_the_streams():
+    for total, world in ((65536, 8), (8192, 1), (10, 3), (7, 8), (0, 2)):
+        seen = []
+        for r in range(world):
+            lo, hi = sharding.stream_shard(total, world, r)
+            assert 0 <= lo <= hi <= total
+            seen.extend(range(lo, hi))
+            for s in (lo, hi - 1):
+                if lo < hi:
+                    assert sharding.owner_of(s, total, world) == r
+        assert seen == list(range(total))
+    assert sharding.stream_shard(65536, 8, 3) == (3 * 8192, 4 * 8192)     # config 5: 8192 per GPU
+    with pytest.raises(ValueError):
+        sharding.stream_shard(10, 2, 2)
+    assert sharding.aggregate_rate(8192, 200, 8, 0.02) == pytest.approx(8 * 8192 * 200 / 0.02)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    info = sharding.RankInfo.from_env()
+    dist = sharding.init_process_group(info, "gloo")
+    per_rank = 64
+    lo, hi = sharding.stream_shard(world * per_rank, world, info.rank)
+    # a rank only ever touches its own streams: a fake "step" that advances per-stream counters
+    state = np.zeros(hi - lo, np.int64)
+    calls = {"n": 0}
+
+    def run():
+        import time
+        for _ in range(5):
+            state[:] += 1
+            calls["n"] += 1
+        time.sleep(0.05 * (rank + 1))          # uneven ranks: the MAX must win
+
+    elapsed = sharding.timed_region(dist, run, lambda: None)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([lo, hi, elapsed, calls["n"], state.sum()], np.float64))
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_share_nothing_but_the_clock(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"r{k}.npy") for k in range(world)]
+    assert (r[0][0], r[0][1], r[1][0], r[1][1]) == (0, 64, 64, 128)           # disjoint, covering
+    assert r[0][2] == r[1][2] and r[0][2] >= 0.1                              # both see the slowest rank's time
+    assert r[0][3] == r[1][3] == 5 and r[0][4] == r[1][4] == 5 * 64
+    assert sharding.aggregate_rate(64, 5, world, r[0][2]) == pytest.approx(2 * 64 * 5 / r[0][2])
+
+
+def test_single_process_needs_no_process_group():
+    assert sharding.init_process_group(sharding.RankInfo(0, 0, 1), "gloo") is None
+    t = sharding.timed_region(None, lambda: None, lambda: None)
+    assert 0 <= t < 0.1
