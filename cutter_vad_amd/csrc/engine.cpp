@@ -24,6 +24,7 @@
 #include "vad_layout.h"
 
 extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream_t stream);
+extern "C" hipError_t vadk_launch_silero_v4(const vadk::StepParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_resample(const vadk::ResampleParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_sm_replay(vadk::SmSlot *sm, int slot, const float *probs, int n, uint8_t *events,
                                             int32_t *seg, hipStream_t stream);
@@ -53,6 +54,7 @@ struct vad_engine {
     size_t wbytes = 0;
     float *d_state = nullptr;
     vadk::SmSlot *d_sm = nullptr;
+    float *d_scratch = nullptr;   // V4: |STFT| hand-off between the two launches of a frame
     // staging for the host-pointer entry points (grown on demand)
     void *d_frames = nullptr;  size_t d_frames_cap = 0;
     float *d_probs = nullptr;  size_t d_probs_cap = 0;
@@ -136,6 +138,7 @@ int check_slots(vad_engine *e, const int64_t *slots, int64_t n) {
 int launch(vad_engine *e, const vadk::StepParams &p, hipStream_t s) {
     hipError_t r = hipErrorInvalidValue;
     if (e->version == 5) r = vadk_launch_silero_v5(&p, s);
+    else if (e->version == 4) r = vadk_launch_silero_v4(&p, s);
     if (r != hipSuccess) return e->hip_fail(r, "kernel launch");
     e->steps += 1;
     e->frames += (int64_t)p.n * p.T;
@@ -261,6 +264,12 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
         if ((r = hipMemcpy(e->d_sm, init.data(), sizeof(vadk::SmSlot) * init.size(), hipMemcpyHostToDevice)) != hipSuccess)
             return bail(r, "hipMemcpy(sm)");
     }
+    if (e->version == 4) {
+        const size_t tiles = ((size_t)e->max_streams + vadk::MT - 1) / vadk::MT;
+        if ((r = hipMalloc((void **)&e->d_scratch, tiles * vadk::v4::SCRATCH_F4_PER_TILE * 16)) != hipSuccess)
+            return bail(r, "hipMalloc(v4 scratch)");
+        e->base.scratch = e->d_scratch;
+    }
     e->base.wstream = e->d_wstream;
     e->base.wstream_bytes = (uint32_t)e->wbytes;
     std::memcpy(e->base.sect, pw.sect, sizeof pw.sect);
@@ -278,7 +287,7 @@ void vad_engine_destroy(vad_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void *bufs[] = {e->d_wstream, e->d_state, e->d_sm, e->d_frames, e->d_probs, e->d_events, e->d_seg, e->d_slots,
+    void *bufs[] = {e->d_wstream, e->d_state, e->d_sm, e->d_scratch, e->d_frames, e->d_probs, e->d_events, e->d_seg, e->d_slots,
                     e->d_rs_in, e->d_rs_out};
     for (void *b : bufs)
         if (b) (void)hipFree(b);

@@ -9,6 +9,7 @@
 //   bias / head block g:                    lane (any, hh), component i = b[32*nt + 8g + 4hh + i]
 #include "pack_weights.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -91,6 +92,39 @@ class StreamBuilder {
     }
 };
 
+// the folded STFT relies on exact symmetries of the stored basis; refuse weights that lack them
+bool check_stft_symmetry(const float *stft, std::string &err) {
+    for (int k = 0; k <= 128; ++k) {
+        const float *c = stft + (size_t)k * 256, *sn = stft + (size_t)(129 + k) * 256;
+        bool ok = c[0] == 0.f && sn[0] == 0.f && sn[128] == 0.f;
+        for (int n = 1; n < 128 && ok; ++n) ok = c[n] == c[256 - n] && sn[n] == -sn[256 - n];
+        if (k == 0 || k == 128)
+            for (int n = 0; n < 256 && ok; ++n) ok = sn[n] == 0.f;
+        if (!ok) {
+            err = "Failed to load model: STFT basis is not the symmetric windowed DFT the kernel assumes";
+            return false;
+        }
+    }
+    return true;
+}
+
+// STFT on the folded input (vad_layout.h): wave w owns bins 32w..32w+31, {re, im} per k-iteration;
+// k-iteration j contracts n = 8j+1 .. 8j+8 (quad 2j on the lower half-wave, 2j+1 on the upper)
+void pack_stft_wave(StreamBuilder &sb, const float *stft, int w) {
+    for (int j = 0; j < 16; ++j) {
+        sb.weight_block([&](int np, int k) { return stft[(size_t)(32 * w + np) * 256 + k + 1]; }, j);
+        sb.weight_block([&](int np, int k) { return stft[(size_t)(129 + 32 * w + np) * 256 + k + 1]; }, j);
+    }
+}
+
+// bin 128 (VALU): floats 0..127 = C[128][1..128]; its sine row is exactly zero
+uint32_t pack_nyquist_block(StreamBuilder &sb, const float *stft) {
+    const uint32_t nb = sb.blocks();
+    float *b = sb.new_block();
+    for (int n = 1; n <= 128; ++n) b[n - 1] = stft[(size_t)128 * 256 + n];
+    return nb;
+}
+
 }  // namespace
 
 bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::string &err) {
@@ -115,18 +149,7 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
     const float *b_ih = B.get("lstm.b_ih", 512), *b_hh = B.get("lstm.b_hh", 512);
     const float *head_w = B.get("head.w", 128), *head_b = B.get("head.b", 1);
     if (!err.empty()) return false;
-    // the folded STFT relies on exact symmetries of the stored basis; refuse weights that lack them
-    for (int k = 0; k <= 128; ++k) {
-        const float *c = stft + (size_t)k * 256, *sn = stft + (size_t)(129 + k) * 256;
-        bool ok = c[0] == 0.f && sn[0] == 0.f && sn[128] == 0.f;
-        for (int n = 1; n < 128 && ok; ++n) ok = c[n] == c[256 - n] && sn[n] == -sn[256 - n];
-        if (k == 0 || k == 128)
-            for (int n = 0; n < 256 && ok; ++n) ok = sn[n] == 0.f;
-        if (!ok) {
-            err = "Failed to load model: STFT basis is not the symmetric windowed DFT the kernel assumes";
-            return false;
-        }
-    }
+    if (!check_stft_symmetry(stft, err)) return false;
 
     StreamBuilder sb;
     auto convw = [&](int layer, int o, int c, int tap) -> float {
@@ -136,10 +159,7 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
         // STFT on the folded input (vad_layout.h): bins 32w..32w+31, {re, im} per k-iteration;
         // k-iteration j contracts n = 8j+1 .. 8j+8 (quad 2j on the lower half-wave, 2j+1 on the upper)
         out.sect[w][S_STFT] = sb.blocks();
-        for (int j = 0; j < 16; ++j) {
-            sb.weight_block([&](int np, int k) { return stft[(size_t)(32 * w + np) * 256 + k + 1]; }, j);
-            sb.weight_block([&](int np, int k) { return stft[(size_t)(129 + 32 * w + np) * 256 + k + 1]; }, j);
-        }
+        pack_stft_wave(sb, stft, w);
         // enc0: out channels 32w.., taps 0..2 per k-iteration, then the Nyquist input channel
         out.sect[w][S_ENC0] = sb.blocks();
         sb.vector_blocks([&](int c) { return eb[0][32 * w + c]; });
@@ -193,11 +213,7 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
     const uint32_t hb = sb.blocks();
     sb.new_block()[0] = head_b[0];
     // bin 128 of the folded STFT (VALU): floats 0..127 = C[128][1..128]; its sine row is exactly zero
-    const uint32_t nb = sb.blocks();
-    {
-        float *b = sb.new_block();
-        for (int n = 1; n <= 128; ++n) b[n - 1] = stft[(size_t)128 * 256 + n];
-    }
+    const uint32_t nb = pack_nyquist_block(sb, stft);
     for (int w = 0; w < NWAVES; ++w) {
         out.sect[w][S_HEADB] = hb;
         out.sect[w][S_NYQ] = nb;
@@ -251,9 +267,145 @@ uint32_t pack_resample_operator(const std::vector<float> &R, int n_in, std::vect
     return per_wave;
 }
 
-bool pack_silero_v4(const void *, size_t, PackedWeights &, std::string &err) {
-    err = "Failed to load model: Silero V4 kernels are not built into this library yet";
-    return false;
+bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::string &err) {
+    using namespace v4;
+    Blob B;
+    if (!open_blob(blob, len, B, err)) return false;
+    if (B.version != 4) {
+        err = "Failed to load model: weight blob is not Silero V4";
+        return false;
+    }
+    static const int ci[4] = {258, 16, 32, 32}, co[4] = {16, 32, 32, 64}, sc[4] = {16, 32, 32, 64};
+    const float *stft = B.get("stft.basis", 258 * 256), *filt = B.get("norm.filter", 7);
+    const float *dww[4], *dwb[4], *pww[4], *pwb[4], *pjw[4] = {nullptr, nullptr, nullptr, nullptr}, *pjb[4] = {nullptr, nullptr, nullptr, nullptr};
+    const float *sw[4], *sbias[4];
+    char nm[32];
+    for (int i = 0; i < 4; ++i) {
+        std::snprintf(nm, sizeof nm, "l%d.dw.w", i); dww[i] = B.get(nm, (uint64_t)ci[i] * 5);
+        std::snprintf(nm, sizeof nm, "l%d.dw.b", i); dwb[i] = B.get(nm, ci[i]);
+        std::snprintf(nm, sizeof nm, "l%d.pw.w", i); pww[i] = B.get(nm, (uint64_t)co[i] * ci[i]);
+        std::snprintf(nm, sizeof nm, "l%d.pw.b", i); pwb[i] = B.get(nm, co[i]);
+        if (i != 2) {
+            std::snprintf(nm, sizeof nm, "l%d.proj.w", i); pjw[i] = B.get(nm, (uint64_t)co[i] * ci[i]);
+            std::snprintf(nm, sizeof nm, "l%d.proj.b", i); pjb[i] = B.get(nm, co[i]);
+        }
+        std::snprintf(nm, sizeof nm, "s%d.w", i); sw[i] = B.get(nm, (uint64_t)sc[i] * sc[i]);
+        std::snprintf(nm, sizeof nm, "s%d.b", i); sbias[i] = B.get(nm, sc[i]);
+    }
+    const float *lwi[2], *lwh[2], *lbi[2], *lbh[2];
+    for (int l = 0; l < 2; ++l) {
+        std::snprintf(nm, sizeof nm, "lstm%d.w_ih", l); lwi[l] = B.get(nm, 256 * 64);
+        std::snprintf(nm, sizeof nm, "lstm%d.w_hh", l); lwh[l] = B.get(nm, 256 * 64);
+        std::snprintf(nm, sizeof nm, "lstm%d.b_ih", l); lbi[l] = B.get(nm, 256);
+        std::snprintf(nm, sizeof nm, "lstm%d.b_hh", l); lbh[l] = B.get(nm, 256);
+    }
+    const float *head_w = B.get("head.w", 64), *head_b = B.get("head.b", 1);
+    if (!err.empty()) return false;
+    if (!check_stft_symmetry(stft, err)) return false;
+
+    StreamBuilder sb;
+    uint32_t sec[S_COUNT] = {};
+    // depthwise taps (k = 0..4) + bias (k = 5) per channel quad as float4 rows: row = (q * 6 + k), value i = channel 4q + i
+    auto dw_table = [&](const float *w5, const float *b, int C, int c0, int nquads) {
+        const uint32_t first = sb.blocks();
+        std::vector<float> tab((size_t)nquads * 6 * 4, 0.f);
+        for (int q = 0; q < nquads; ++q)
+            for (int k = 0; k < 6; ++k)
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 4 * q + i;
+                    if (c < C) tab[((size_t)q * 6 + k) * 4 + i] = k < 5 ? w5[(size_t)(c0 + c) * 5 + k] : b[c0 + c];
+                }
+        for (size_t off = 0; off < tab.size(); off += BLK_FLOATS) {
+            float *blk = sb.new_block();
+            std::memcpy(blk, tab.data() + off, sizeof(float) * std::min<size_t>(BLK_FLOATS, tab.size() - off));
+        }
+        return first;
+    };
+    // S_DW0: part 0 = magnitude channels 0..128 (34 quads), part 1 = normalised channels 129..257, then the 7-tap filter
+    {
+        sec[S_DW0] = sb.blocks();
+        std::vector<float> tab((size_t)(2 * 34 * 6 + 2) * 4, 0.f);
+        for (int p = 0; p < 2; ++p)
+            for (int q = 0; q < 34; ++q)
+                for (int k = 0; k < 6; ++k)
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = 4 * q + i;
+                        if (c < 129) tab[(((size_t)p * 34 + q) * 6 + k) * 4 + i] = k < 5 ? dww[0][(size_t)(129 * p + c) * 5 + k] : dwb[0][129 * p + c];
+                    }
+        for (int k = 0; k < 7; ++k) tab[(size_t)(2 * 34 * 6) * 4 + k] = filt[k];
+        for (size_t off = 0; off < tab.size(); off += BLK_FLOATS) {
+            float *blk = sb.new_block();
+            std::memcpy(blk, tab.data() + off, sizeof(float) * std::min<size_t>(BLK_FLOATS, tab.size() - off));
+        }
+    }
+    // S_L0: 16 outputs on rows 0..15 of the tile; per k-iteration: pw|mag, proj|mag, pw|norm, proj|norm
+    sec[S_L0] = sb.blocks();
+    sb.vector_blocks([&](int c) { return c < 16 ? pwb[0][c] + pjb[0][c] : 0.f; });
+    for (int j = 0; j < 17; ++j)
+        for (int p = 0; p < 2; ++p) {
+            sb.weight_block([&](int np, int c) { return (np < 16 && c < 129) ? pww[0][(size_t)np * 258 + 129 * p + c] : 0.f; }, j);
+            sb.weight_block([&](int np, int c) { return (np < 16 && c < 129) ? pjw[0][(size_t)np * 258 + 129 * p + c] : 0.f; }, j);
+        }
+    // S_S0: 16 -> 16 (rows 0..15)
+    sec[S_S0] = sb.blocks();
+    sb.vector_blocks([&](int c) { return c < 16 ? sbias[0][c] : 0.f; });
+    for (int j = 0; j < 2; ++j) sb.weight_block([&](int np, int c) { return np < 16 ? sw[0][(size_t)np * 16 + c] : 0.f; }, j);
+    // S_L1: dw table (4 quads), bias, pw (2 it), proj (2 it): 16 -> 32
+    sec[S_L1] = dw_table(dww[1], dwb[1], 16, 0, 4);
+    sb.vector_blocks([&](int c) { return pwb[1][c] + pjb[1][c]; });
+    for (int j = 0; j < 2; ++j) sb.weight_block([&](int np, int c) { return pww[1][(size_t)np * 16 + c]; }, j);
+    for (int j = 0; j < 2; ++j) sb.weight_block([&](int np, int c) { return pjw[1][(size_t)np * 16 + c]; }, j);
+    // S_S1: 32 -> 32
+    sec[S_S1] = sb.blocks();
+    sb.vector_blocks([&](int c) { return sbias[1][c]; });
+    for (int j = 0; j < 4; ++j) sb.weight_block([&](int np, int c) { return sw[1][(size_t)np * 32 + c]; }, j);
+    // S_L2: dw table (8 quads), bias (pw only: identity residual), pw (4 it)
+    sec[S_L2] = dw_table(dww[2], dwb[2], 32, 0, 8);
+    sb.vector_blocks([&](int c) { return pwb[2][c]; });
+    for (int j = 0; j < 4; ++j) sb.weight_block([&](int np, int c) { return pww[2][(size_t)np * 32 + c]; }, j);
+    // S_S2
+    sec[S_S2] = sb.blocks();
+    sb.vector_blocks([&](int c) { return sbias[2][c]; });
+    for (int j = 0; j < 4; ++j) sb.weight_block([&](int np, int c) { return sw[2][(size_t)np * 32 + c]; }, j);
+    // S_L3: dw table (8 quads), then per output tile nt: bias, pw (4 it), proj (4 it): 32 -> 64
+    sec[S_L3] = dw_table(dww[3], dwb[3], 32, 0, 8);
+    for (int nt = 0; nt < 2; ++nt) {
+        sb.vector_blocks([&](int c) { return pwb[3][32 * nt + c] + pjb[3][32 * nt + c]; });
+        for (int j = 0; j < 4; ++j) sb.weight_block([&](int np, int c) { return pww[3][(size_t)(32 * nt + np) * 32 + c]; }, j);
+        for (int j = 0; j < 4; ++j) sb.weight_block([&](int np, int c) { return pjw[3][(size_t)(32 * nt + np) * 32 + c]; }, j);
+    }
+    // S_S3: per output tile: bias, 8 it: 64 -> 64
+    sec[S_S3] = sb.blocks();
+    for (int nt = 0; nt < 2; ++nt) {
+        sb.vector_blocks([&](int c) { return sbias[3][32 * nt + c]; });
+        for (int j = 0; j < 8; ++j) sb.weight_block([&](int np, int c) { return sw[3][(size_t)(32 * nt + np) * 64 + c]; }, j);
+    }
+    // S_LSTM{0,1}: per unit half u: bias (4 gates x 4 blocks), W_ih (8 it x 4 gates), W_hh (8 it x 4 gates); gate order i,f,g,o
+    for (int l = 0; l < 2; ++l) {
+        sec[l == 0 ? S_LSTM0 : S_LSTM1] = sb.blocks();
+        for (int u = 0; u < 2; ++u) {
+            for (int q = 0; q < 4; ++q)
+                sb.vector_blocks([&](int c) { const int r = q * 64 + 32 * u + c; return lbi[l][r] + lbh[l][r]; });
+            for (int j = 0; j < 8; ++j)
+                for (int q = 0; q < 4; ++q)
+                    sb.weight_block([&](int np, int c) { return lwi[l][(size_t)(q * 64 + 32 * u + np) * 64 + c]; }, j);
+            for (int j = 0; j < 8; ++j)
+                for (int q = 0; q < 4; ++q)
+                    sb.weight_block([&](int np, int c) { return lwh[l][(size_t)(q * 64 + 32 * u + np) * 64 + c]; }, j);
+        }
+    }
+    // S_HEADB: block 0 float 0 = head bias; then head weights per unit half (4 vector blocks each)
+    sec[S_HEADB] = sb.blocks();
+    sb.new_block()[0] = head_b[0];
+    for (int u = 0; u < 2; ++u) sb.vector_blocks([&](int c) { return head_w[32 * u + c]; });
+    sec[S_NYQ] = pack_nyquist_block(sb, stft);
+    for (int w = 0; w < NWAVES; ++w) {
+        for (int k = 0; k < S_COUNT; ++k) out.sect[w][k] = sec[k];
+        out.sect[w][S_STFT] = sb.blocks();
+        pack_stft_wave(sb, stft, w);
+    }
+    out.data = std::move(sb.data);
+    return true;
 }
 
 }  // namespace vadk

@@ -12,7 +12,7 @@ namespace vadk {
 
 struct PackedWeights {
     std::vector<float> data;        // concatenated per-wave streams, multiple of BLK_FLOATS
-    uint32_t sect[NWAVES][8] = {};  // block offset of every section
+    uint32_t sect[NWAVES][16] = {};  // block offset of every section
 };
 
 // blob: SVW container (cutter_vad_amd/weights_io.py).  On failure returns false and sets err

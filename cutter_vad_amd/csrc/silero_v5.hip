@@ -16,12 +16,9 @@
 #include <hip/hip_runtime.h>
 #include "vad_layout.h"
 #include "sm_device.h"
+#include "vadk_device.h"
 
 using namespace vadk;
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short i16x4 __attribute__((ext_vector_type(4)));
 
 #ifdef VADK_STAMPS
 #define STAMP(k)                                                                                   \
@@ -32,88 +29,7 @@ typedef short i16x4 __attribute__((ext_vector_type(4)));
 #define STAMP(k) do { } while (0)
 #endif
 
-namespace {
-
-__device__ __forceinline__ f32x16 mfma4(f32x4 w, f32x4 a, f32x16 acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, a.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, a.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, a.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, a.w, acc, 0, 0, 0);
-    return acc;
-}
-
-// accumulator initialised from 4 "lane-expanded" bias blocks (regs 4g..4g+3 <- block g)
-__device__ __forceinline__ f32x16 acc_from(const f32x4 *ws) {
-    f32x4 b0 = ws[0], b1 = ws[BLK_F4], b2 = ws[2 * BLK_F4], b3 = ws[3 * BLK_F4];
-    f32x16 a;
-    a.s0 = b0.x; a.s1 = b0.y; a.s2 = b0.z; a.s3 = b0.w;
-    a.s4 = b1.x; a.s5 = b1.y; a.s6 = b1.z; a.s7 = b1.w;
-    a.s8 = b2.x; a.s9 = b2.y; a.sa = b2.z; a.sb = b2.w;
-    a.sc = b3.x; a.sd = b3.y; a.se = b3.z; a.sf = b3.w;
-    return a;
-}
-
-__device__ __forceinline__ f32x4 relu4(f32x4 v) {
-    return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
-}
-
-__device__ __forceinline__ f32x4 quad_of(const f32x16 &a, int g) {
-    switch (g) {
-        case 0: return f32x4{a.s0, a.s1, a.s2, a.s3};
-        case 1: return f32x4{a.s4, a.s5, a.s6, a.s7};
-        case 2: return f32x4{a.s8, a.s9, a.sa, a.sb};
-        default: return f32x4{a.sc, a.sd, a.se, a.sf};
-    }
-}
-
-// write a 32-channel output tile (relu'd) as 8 quad rows starting at row `row0`;
-// lane (m,h) owns quads row0 + 2g + h
-__device__ __forceinline__ void store_tile_relu(f32x4 *region, int row0, int m, int h, const f32x16 &acc) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) region[(row0 + 2 * g + h) * QS + m] = relu4(quad_of(acc, g));
-}
-
-// v_exp_f32 / v_rcp_f32 / v_sqrt_f32 are 1-ulp hardware ops: |error| of sigmoid/tanh below 5e-7 absolute
-__device__ __forceinline__ float sigmoidf_(float v) {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v));
-}
-__device__ __forceinline__ float tanhf_(float v) {
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * v));
-}
-__device__ __forceinline__ float mag_(float re, float im) { return __builtin_amdgcn_sqrtf(re * re + im * im); }
-
-__device__ __forceinline__ f32x16 acc_of(f32x4 b0, f32x4 b1, f32x4 b2, f32x4 b3) {
-    f32x16 a;
-    a.s0 = b0.x; a.s1 = b0.y; a.s2 = b0.z; a.s3 = b0.w;
-    a.s4 = b1.x; a.s5 = b1.y; a.s6 = b1.z; a.s7 = b1.w;
-    a.s8 = b2.x; a.s9 = b2.y; a.sa = b2.z; a.sb = b2.w;
-    a.sc = b3.x; a.sd = b3.y; a.se = b3.z; a.sf = b3.w;
-    return a;
-}
-
-// No instruction may be moved across this point by the compiler's scheduler.  The kernel's
-// software pipelining (weights for iteration i+1 are requested before the MFMAs of iteration i
-// are issued) only survives hipcc's machine scheduler when it is fenced like this.
-#define SB() __builtin_amdgcn_sched_barrier(0)
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-// one 1 KiB weight block: 16 bytes per lane at byte offset voff = lane*16, block index in SGPRs
-__device__ __forceinline__ f32x4 ldw(__amdgpu_buffer_rsrc_t rs, int voff, int blk) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, blk * 1024, 0));
-}
-
-__device__ __forceinline__ f32x4 gate4(f32x4 v, float thr) {
-    // utils/audio.py:117-118: np.where(np.abs(x) > thr, x, 0.0); thr < 0 disables the gate
-    if (thr >= 0.f) {
-        v.x = fabsf(v.x) > thr ? v.x : 0.f;
-        v.y = fabsf(v.y) > thr ? v.y : 0.f;
-        v.z = fabsf(v.z) > thr ? v.z : 0.f;
-        v.w = fabsf(v.w) > thr ? v.w : 0.f;
-    }
-    return v;
-}
-
-}  // namespace
+using namespace vadk::dev;
 
 extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P) {
     using namespace vadk::v5;

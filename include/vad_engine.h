@@ -186,7 +186,7 @@ VAD_API int vad_resample_device(vad_engine *e, const float *d_in, int64_t n, int
 /*
  * Diagnostic (no GPU needed): run the host-side weight packer and return the per-wave MFMA
  * weight streams exactly as vad_engine_create uploads them.  out may be NULL to query the size.
- * sect_out receives [4 waves][8 sections] block offsets (1 block = 256 floats).  Used by the
+ * sect_out receives [4 waves][16 sections] block offsets (1 block = 256 floats).  Used by the
  * CPU test-suite to check the packed layout against a NumPy model of the kernel's dataflow.
  */
 VAD_API int vad_debug_pack_weights(int32_t model_version, const void *weights, size_t weights_len, float *out,

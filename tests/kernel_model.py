@@ -22,7 +22,7 @@ MT = 32
 def packed_streams(version: int, blob: bytes):
     lib = _ffi.lib()
     n = C.c_size_t()
-    sect = (C.c_uint32 * 32)()
+    sect = (C.c_uint32 * 64)()
     rc = lib.vad_debug_pack_weights(version, blob, len(blob), None, 0, C.byref(n), sect)
     if rc != 0:
         raise RuntimeError(lib.vad_last_create_error().decode())
@@ -30,7 +30,7 @@ def packed_streams(version: int, blob: bytes):
     rc = lib.vad_debug_pack_weights(version, blob, len(blob), out.ctypes.data_as(C.POINTER(C.c_float)), out.size,
                                     C.byref(n), sect)
     assert rc == 0
-    return out.reshape(-1, 64, 4), np.array(sect, dtype=np.int64).reshape(4, 8)
+    return out.reshape(-1, 64, 4), np.array(sect, dtype=np.int64).reshape(4, 16)
 
 
 def _mfma4(wblk, a):
@@ -188,3 +188,238 @@ def v5_step(W, sect, x, hc, gate=0.01):
     hb = W[sect[0][S_HEADB]][0, 0]
     prob = sig(z + hb)
     return prob.astype(np.float32), np.concatenate([h_new, c_new], axis=1).astype(np.float32)
+
+
+# ======================================================================================
+#  Silero V4: model of silero_v4_stft + silero_v4_tail over the packed streams
+# ======================================================================================
+V4 = dict(S_STFT=0, S_NYQ=1, S_DW0=2, S_L0=3, S_S0=4, S_L1=5, S_S1=6, S_L2=7, S_S2=8, S_L3=9, S_S3=10, S_LSTM0=11,
+          S_LSTM1=12, S_HEADB=13)
+
+
+def _table_row(W, blk, row):
+    """float4 row `row` of a VALU table that starts at block `blk` (16 bytes per row)."""
+    return W[blk:].reshape(-1, 4)[row].astype(np.float64)
+
+
+def _bias_tile(W, blk):
+    return np.repeat(_vec(W[blk:blk + 4])[:, None], 32, 1)
+
+
+def v4_step(W, sect, x, hc, gate=0.01):
+    """x [32,512], hc [32,256] (h0 h1 c0 c1) -> (prob [32], new hc)."""
+    x = x.astype(np.float64)
+    if gate is not None and gate >= 0:
+        x = np.where(np.abs(x) > gate, x, 0.0)
+    S = V4
+    # ---- launch 1: reflect pad, fold, STFT, magnitudes -> scratch rows 33 t + q
+    xp = np.pad(x, ((0, 0), (96, 96)), mode="reflect")                    # [32, 704]
+    scratch = np.zeros((264, 32, 4))
+    nq = W[sect[0][S["S_NYQ"]]].reshape(-1)[:128].astype(np.float64)
+    n = np.arange(1, 129)
+    for grp in range(4):
+        UV = np.zeros((128, 32, 4))
+        for cp in range(2):
+            t = 2 * grp + cp
+            col = xp[:, 64 * t:64 * t + 256]
+            mir = np.where(n < 128, 256 - n, 0)
+            xm = np.where(n[None, :] < 128, col[:, mir], 0.0)
+            u = col[:, n] + xm
+            v = np.where(n[None, :] < 128, col[:, n] - xm, 0.0)
+            UV[64 * cp:64 * cp + 32] = u.reshape(32, 32, 4).transpose(1, 0, 2)
+            UV[64 * cp + 32:64 * cp + 64] = v.reshape(32, 32, 4).transpose(1, 0, 2)
+            scratch[33 * t + 32, :, 0] = np.abs(u @ nq)
+        for w in range(4):
+            ws = sect[w][S["S_STFT"]]
+            are = [np.zeros((32, 32)) for _ in range(2)]
+            aim = [np.zeros((32, 32)) for _ in range(2)]
+            for j in range(16):
+                for cp in range(2):
+                    are[cp] += _mfma4(W[ws + 2 * j], _rows(UV, 64 * cp + 2 * j, 64 * cp + 2 * j + 1))
+                    aim[cp] += _mfma4(W[ws + 2 * j + 1], _rows(UV, 64 * cp + 32 + 2 * j, 64 * cp + 32 + 2 * j + 1))
+            for cp in range(2):
+                _store_tile(scratch, 33 * (2 * grp + cp) + 8 * w, np.sqrt(are[cp] ** 2 + aim[cp] ** 2), relu=False)
+    # ---- launch 2
+    RX = np.zeros((280, 32, 4))
+    RX[:264] = scratch
+    lg = lambda mg: np.log(1.0 + mg * 1048576.0)
+    o_dw0 = sect[0][S["S_DW0"]]
+    colmean = np.zeros((8, 32))
+    for t in range(8):
+        sp = lg(RX[33 * t:33 * t + 33])                                     # [33, 32, 4]
+        colmean[t] = (sp[:32].sum(axis=(0, 2)) + sp[32, :, 0]) / 129.0
+    f0, f1 = _table_row(W, o_dw0, 2 * 34 * 6), _table_row(W, o_dw0, 2 * 34 * 6 + 1)
+    filt = np.concatenate([f0, f1[:3]])
+    mp = np.concatenate([colmean[[3, 2, 1]], colmean, colmean[[6, 5, 4]]])  # [14, 32]
+    mm = np.mean([sum(filt[k] * mp[t + k] for k in range(7)) for t in range(8)], axis=0)   # [32]
+    # P2 first layer
+    o_l0 = sect[0][S["S_L0"]]
+    A16 = {}
+    for w in range(4):
+        tcol = 2 * w
+        acc = _bias_tile(W, o_l0)
+        ws = o_l0 + 4
+        for j in range(17):
+            frag = {k: np.zeros((64, 4)) for k in ("dm", "xm", "dn", "xn")}
+            for h in range(2):
+                q = 2 * j + h
+                dm = np.repeat(_table_row(W, o_dw0, q * 6 + 5)[None], 32, 0)
+                dn = np.repeat(_table_row(W, o_dw0, (34 + q) * 6 + 5)[None], 32, 0)
+                xm = np.zeros((32, 4))
+                xn = np.zeros((32, 4))
+                for k in range(5):
+                    tc = tcol + k - 2
+                    if 0 <= tc < 8 and q < 33:
+                        mg = RX[33 * tc + q]
+                        sp = lg(mg) - mm[:, None]
+                        dm = dm + _table_row(W, o_dw0, q * 6 + k)[None] * mg
+                        dn = dn + _table_row(W, o_dw0, (34 + q) * 6 + k)[None] * sp
+                        if k == 2:
+                            xm, xn = mg, sp
+                sl = slice(32 * h, 32 * h + 32)
+                frag["dm"][sl], frag["xm"][sl] = np.maximum(dm, 0), xm
+                frag["dn"][sl], frag["xn"][sl] = np.maximum(dn, 0), xn
+            for i, k in enumerate(("dm", "xm", "dn", "xn")):
+                acc += _mfma4(W[ws + 4 * j + i], frag[k])
+        A16[w] = np.maximum(acc, 0)
+    for w in range(4):
+        for g in range(2):
+            for h in range(2):
+                RX[264 + 4 * w + 2 * g + h] = A16[w][8 * g + 4 * h:8 * g + 4 * h + 4].T
+    hprev = hc[:, :128].astype(np.float64)
+    RX[120:152] = hprev.reshape(32, 32, 4).transpose(1, 0, 2)
+
+    def store16(row0, acc):                       # rows 0..15 of the tile only
+        v = np.maximum(acc, 0)
+        for g in range(2):
+            for h in range(2):
+                RX[row0 + 2 * g + h] = v[8 * g + 4 * h:8 * g + 4 * h + 4].T
+
+    def dwq(tab_blk, q, taps):
+        """taps: list of (k, quad [32,4])"""
+        d = np.repeat(_table_row(W, tab_blk, q * 6 + 5)[None], 32, 0)
+        for k, quad in taps:
+            d = d + _table_row(W, tab_blk, q * 6 + k)[None] * quad
+        return np.maximum(d, 0)
+
+    # P3 s0
+    o = sect[0][S["S_S0"]]
+    res = {}
+    for w in range(4):
+        acc = _bias_tile(W, o)
+        acc += _mfma4(W[o + 4], _rows(RX, 264 + 4 * w, 264 + 4 * w + 1))
+        acc += _mfma4(W[o + 5], _rows(RX, 264 + 4 * w + 2, 264 + 4 * w + 3))
+        res[w] = acc
+    for w in range(4):
+        store16(0 + 4 * w, res[w])
+    # P4 block 1
+    o = sect[0][S["S_L1"]]
+    res = {}
+    for w in range(4):
+        acc = _bias_tile(W, o + 1)
+        d, y = [], []
+        for j in range(2):
+            fd = np.zeros((64, 4))
+            for h in range(2):
+                q = 2 * j + h
+                taps = [(k, RX[0 + 4 * (w + k - 2) + q]) for k in range(5) if 0 <= w + k - 2 < 4]
+                fd[32 * h:32 * h + 32] = dwq(o, q, taps)
+            d.append(fd)
+            y.append(_rows(RX, 0 + 4 * w + 2 * j, 0 + 4 * w + 2 * j + 1))
+        for i, fr in enumerate(d + y):
+            acc += _mfma4(W[o + 5 + i], fr)
+        res[w] = acc
+    for w in range(4):
+        _store_tile(RX, 16 + 8 * w, res[w])
+    # P5 s1 (columns 0 and 2)
+    o = sect[0][S["S_S1"]]
+    res = {}
+    for w in range(2):
+        acc = _bias_tile(W, o)
+        r = 16 + 8 * (2 * w)
+        for j in range(4):
+            acc += _mfma4(W[o + 4 + j], _rows(RX, r + 2 * j, r + 2 * j + 1))
+        res[w] = acc
+    for w in range(2):
+        _store_tile(RX, 48 + 8 * w, res[w])
+    # P6 block 2 (identity residual)
+    o = sect[0][S["S_L2"]]
+    res = {}
+    for w in range(2):
+        acc = _bias_tile(W, o + 1)
+        for j in range(4):
+            fd = np.zeros((64, 4))
+            for h in range(2):
+                q = 2 * j + h
+                taps = [(k, RX[48 + 8 * (w + k - 2) + q]) for k in range(5) if 0 <= w + k - 2 < 2]
+                fd[32 * h:32 * h + 32] = dwq(o, q, taps)
+            acc += _mfma4(W[o + 5 + j], fd)
+        resid = np.zeros((32, 32))
+        for g in range(4):
+            for h in range(2):
+                resid[8 * g + 4 * h:8 * g + 4 * h + 4] = RX[48 + 8 * w + 2 * g + h].T
+        res[w] = acc + resid
+    for w in range(2):
+        _store_tile(RX, 64 + 8 * w, res[w])
+    # P7 s2 (column 0)
+    o = sect[0][S["S_S2"]]
+    acc = _bias_tile(W, o)
+    for j in range(4):
+        acc += _mfma4(W[o + 4 + j], _rows(RX, 64 + 2 * j, 64 + 2 * j + 1))
+    _store_tile(RX, 80, acc)
+    # P8 block 3
+    o = sect[0][S["S_L3"]]
+    res = {}
+    for w in range(2):
+        ob = o + 1 + 12 * w
+        acc = _bias_tile(W, ob)
+        for j in range(4):
+            fd = np.zeros((64, 4))
+            for h in range(2):
+                q = 2 * j + h
+                fd[32 * h:32 * h + 32] = dwq(o, q, [(2, RX[80 + q])])
+            acc += _mfma4(W[ob + 4 + j], fd)
+            acc += _mfma4(W[ob + 8 + j], _rows(RX, 80 + 2 * j, 80 + 2 * j + 1))
+        res[w] = acc
+    for w in range(2):
+        _store_tile(RX, 88 + 8 * w, res[w])
+    # P9 s3
+    o = sect[0][S["S_S3"]]
+    res = {}
+    for w in range(2):
+        ob = o + 12 * w
+        acc = _bias_tile(W, ob)
+        for j in range(8):
+            acc += _mfma4(W[ob + 4 + j], _rows(RX, 88 + 2 * j, 88 + 2 * j + 1))
+        res[w] = acc
+    for w in range(2):
+        _store_tile(RX, 104 + 8 * w, res[w])
+    # LSTMs
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    new = hc.astype(np.float64).copy()
+    z = np.zeros(32)
+    oh = sect[0][S["S_HEADB"]]
+    for layer in range(2):
+        o = sect[0][S["S_LSTM0" if layer == 0 else "S_LSTM1"]]
+        xin = 104 if layer == 0 else 152
+        hin = 120 if layer == 0 else 136
+        hn_all = np.zeros((64, 32))
+        for u in range(2):
+            ob = o + 80 * u
+            g = [_bias_tile(W, ob + 4 * q) for q in range(4)]
+            for it in range(8):
+                for q in range(4):
+                    g[q] += _mfma4(W[ob + 16 + 4 * it + q], _rows(RX, xin + 2 * it, xin + 2 * it + 1))
+                    g[q] += _mfma4(W[ob + 48 + 4 * it + q], _rows(RX, hin + 2 * it, hin + 2 * it + 1))
+            cp = hc[:, 128 + 64 * layer + 32 * u:128 + 64 * layer + 32 * u + 32].astype(np.float64).T
+            cn = sig(g[1]) * cp + sig(g[0]) * np.tanh(g[2])
+            hn = sig(g[3]) * np.tanh(cn)
+            new[:, 128 + 64 * layer + 32 * u:128 + 64 * layer + 32 * u + 32] = cn.T
+            new[:, 64 * layer + 32 * u:64 * layer + 32 * u + 32] = hn.T
+            hn_all[32 * u:32 * u + 32] = hn
+            if layer == 1:
+                z += (_vec(W[oh + 1 + 4 * u:oh + 5 + 4 * u])[:, None] * np.maximum(hn, 0)).sum(0)
+        if layer == 0:
+            RX[152:168] = hn_all.T.reshape(32, 16, 4).transpose(1, 0, 2)
+    prob = sig(z + W[oh][0, 0])
+    return prob.astype(np.float32), new.astype(np.float32)

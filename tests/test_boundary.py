@@ -123,3 +123,23 @@ def test_resample_operator_matches_scipy_and_reference_fixture():
         live = np.stack([scipy.signal.resample(r, 512).astype(np.float32) for r in x])
         assert np.abs(got - live).max() <= 2e-6
     assert lib.vad_debug_resample_operator(100, None, 0) == _ffi.VAD_ERR_INVALID_ARG
+
+
+def test_packed_layout_reproduces_the_oracle_v4():
+    """NumPy model of the two V4 launches over the packed streams == oracle."""
+    from oracle import oracle
+    from tests import kernel_model as KM
+    from tests.signals import make_streams
+    with open(weights_io.packaged_blob_path(4), "rb") as f:
+        blob = f.read()
+    W, sect = KM.packed_streams(4, blob)
+    om = oracle.OracleModel(blob, "f64")
+    x = make_streams(32, 2, seed=6)
+    hc = np.zeros((32, 256), np.float32)
+    hc_o = hc.copy()
+    with np.errstate(over="ignore"):
+        for t in range(2):
+            p, hc = KM.v4_step(W, sect, x[:, t], hc, gate=0.01)
+            po = om.step_batch(oracle.denoise(x[:, t]).reshape(32, 512), hc_o)
+            assert np.abs(p - po).max() <= 5e-6
+            assert np.abs(hc - hc_o).max() <= 1e-4

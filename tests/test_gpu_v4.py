@@ -1,0 +1,126 @@
+"""GPU parity of the Silero V4 path (a8): silero_v4_stft + silero_v4_tail through the C ABI vs the oracle."""
+
+import numpy as np
+import pytest
+
+from cutter_vad_amd import weights_io
+from tests.signals import make_streams
+
+pytestmark = pytest.mark.gpu
+TOL_P = 2e-5      # bar: 1e-4
+TOL_S = 5e-4
+
+
+@pytest.fixture(scope="module")
+def blob():
+    with open(weights_io.packaged_blob_path(4), "rb") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="module")
+def om(blob):
+    from oracle import oracle
+    return oracle.OracleModel(blob, "f64")
+
+
+@pytest.fixture(scope="module")
+def engine(blob):
+    from cutter_vad_amd.engine import Engine
+    e = Engine(blob, model_version=4, max_streams=2048)
+    yield e
+    e.close()
+
+
+def _oracle_run(om, frames, gate):
+    from oracle import oracle
+    n, T, _ = frames.shape
+    st = np.zeros((n, 256), np.float32)
+    out = np.empty((n, T), np.float32)
+    for t in range(T):
+        x = np.ascontiguousarray(frames[:, t])
+        if gate is not None:
+            x = oracle.denoise(x, gate).reshape(n, 512)
+        out[:, t] = om.step_batch(x, st, nthreads=8)
+    return out, st
+
+
+@pytest.mark.parametrize("n", [1, 7, 32, 33, 200])
+def test_step_matches_oracle(engine, om, n):
+    T = 10
+    frames = make_streams(n, T, seed=400 + n)
+    slots = engine.open_streams(n)
+    try:
+        ref_p, ref_s = _oracle_run(om, frames, 0.01)
+        got = np.stack([engine.step(slots, frames[:, t]) for t in range(T)], axis=1)
+        assert np.abs(got - ref_p).max() <= TOL_P
+        st = np.stack([engine.get_state(s) for s in slots])          # ONNX order: h[2][64] then c[2][64]
+        assert np.abs(st - ref_s).max() <= TOL_S
+    finally:
+        for s in slots:
+            engine.close_stream(s)
+
+
+def test_speech_golden(engine):
+    """the interpreter golden on the reference's speech sample, 530 frames"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "model_v4.npz"))
+    pcm = np.load(os.path.join(os.path.dirname(__file__), "golden", "speech16k_i16.npz"))["pcm"]
+    sp = (pcm.astype(np.float32) / np.float32(32767.0)).astype(np.float32)
+    frames = sp[:(sp.size // 512) * 512].reshape(-1, 512)
+    s = engine.open_stream()
+    try:
+        got = np.array([engine.step([s], f[None])[0] for f in frames], np.float32)
+        assert np.abs(got - g["speech_gate.probs"]).max() <= TOL_P
+    finally:
+        engine.close_stream(s)
+
+
+def test_multi_int16_gate_off_and_events(engine, om):
+    n, T = 37, 6
+    frames = make_streams(n, T, seed=77)
+    a, b, c = engine.open_streams(n), engine.open_streams(n), engine.open_streams(n)
+    try:
+        single = np.stack([engine.step(a, frames[:, t]) for t in range(T)], axis=1)
+        multi, ev = engine.step_multi(b, frames)
+        assert np.abs(single - multi).max() <= 1e-6 and ev.shape == (n, T)
+        ref_p, _ = _oracle_run(om, frames, None)
+        nog = np.stack([engine.step(c, frames[:, t], denoise=None) for t in range(T)], axis=1)
+        assert np.abs(nog - ref_p).max() <= TOL_P
+        i16 = np.clip(np.round(frames * 32767.0), -32768, 32767).astype(np.int16)
+        as_f32 = (i16.astype(np.float32) / np.float32(32767.0)).astype(np.float32)
+        ref_i, _ = _oracle_run(om, as_f32, 0.01)
+        engine.reset(a)
+        got_i = np.stack([engine.step(a, i16[:, t]) for t in range(T)], axis=1)
+        assert np.abs(got_i - ref_i).max() <= TOL_P
+    finally:
+        for s in list(a) + list(b) + list(c):
+            engine.close_stream(s)
+
+
+def test_edge_inputs(engine, om):
+    T = 4
+    z = np.zeros((1, T, 512), np.float32)
+    quiet = (0.005 * np.random.default_rng(5).standard_normal((1, T, 512))).astype(np.float32)
+    imp = np.zeros((1, T, 512), np.float32)
+    imp[0, :, 100] = 1.0
+    sq = np.where(np.arange(512 * T) % 64 < 32, 1.0, -1.0).astype(np.float32).reshape(1, T, 512)
+    frames = np.concatenate([z, quiet, imp, sq])
+    slots = engine.open_streams(4)
+    try:
+        ref_p, _ = _oracle_run(om, frames, 0.01)
+        got = np.stack([engine.step(slots, frames[:, t]) for t in range(T)], axis=1)
+        assert np.abs(got[:3] - ref_p[:3]).max() <= TOL_P
+        # exact spectral nulls x 2^20 inside a log: any fp32 evaluation is order dependent here (Numerics)
+        assert np.abs(got[3] - ref_p[3]).max() <= 5e-3
+    finally:
+        for s in slots:
+            engine.close_stream(s)
+
+
+def test_wrapper_with_v4(engine):
+    from cutter_vad_amd import SileroModelVersion, VADConfig, VADWrapper
+    with VADWrapper(VADConfig(model_version=SileroModelVersion.V4)) as w:
+        w.process_audio_data(make_streams(1, 4, seed=2).reshape(-1))
+        st = w.processor.model.model_state
+        assert st.hidden_state.shape == (2, 1, 64) and st.cell_state.shape == (2, 1, 64)
+        assert w.get_statistics()["total_frames_processed"] == 7

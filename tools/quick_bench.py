@@ -9,8 +9,9 @@ from cutter_vad_amd.engine import Engine
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-blob = open(weights_io.packaged_blob_path(5), "rb").read()
-eng = Engine(blob, max_streams=B)
+V = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+blob = open(weights_io.packaged_blob_path(V), "rb").read()
+eng = Engine(blob, model_version=V, max_streams=B)
 eng.open_streams(B)
 g = torch.Generator(device="cuda").manual_seed(0)
 ring = (0.1 * torch.randn(32, B, 512, device="cuda", generator=g)).contiguous()
@@ -31,5 +32,5 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / K
 fps = B / (ms * 1e-3)
-print(f"B={B} K={K}: {ms*1e3:.1f} us/step  {fps/1e6:.2f} M frames/s  "
+print(f"V{V} B={B} K={K}: {ms*1e3:.1f} us/step  {fps/1e6:.2f} M frames/s  "
       f"{fps*988160/1e12:.1f} TFLOP/s algorithmic ({fps*988160/157.3e12*100:.1f}% of fp32 peak)  probs mean {probs.mean().item():.4f}")
