@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""The other BASELINE.json configs on ONE GPU (bench.py measures the headline, configs[2]):
+
+  configs[1]  batch=1024 streams, V5
+  configs[3]  batch=4096 streams mixed 8/24/48 kHz -> on-GPU resample -> V5
+  configs[4]  per-GPU share of the 65 536-stream job: 4096 V4 + 4096 V5 streams (two engines, two HIP streams)
+
+Prints one JSON object per config (frames/s, us per step).  Device-resident inputs, HIP-event timing.
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from cutter_vad_amd import weights_io  # noqa: E402
+from cutter_vad_amd.engine import Engine  # noqa: E402
+
+K, WU = 100, 10
+
+
+def blob(v):
+    return open(weights_io.packaged_blob_path(v), "rb").read()
+
+
+def timed(fn, streams):
+    for i in range(WU):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(streams[0])
+    for i in range(K):
+        fn(WU + i)
+    for s in streams[1:]:
+        streams[0].wait_stream(s)
+    e1.record(streams[0])
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / K
+
+
+def config1():
+    B = 1024
+    eng = Engine(blob(5), max_streams=B)
+    eng.open_streams(B)
+    ring = (0.1 * torch.randn(32, B, 512, device="cuda")).contiguous()
+    probs = torch.empty(B, device="cuda")
+    ts = torch.cuda.Stream()
+    dt = timed(lambda i: eng.step_device(B, ring[i % 32].data_ptr(), probs.data_ptr(), stream=ts.cuda_stream), [ts])
+    eng.close()
+    return {"config": "configs[1]: batch=1024, V5, 16 kHz", "us_per_step": dt * 1e6, "frames_per_s": B / dt}
+
+
+def config3():
+    B = 4096
+    per = B // 3
+    eng = Engine(blob(5), max_streams=B)
+    eng.open_streams(B)
+    rates = ((8000, 256), (24000, 768), (48000, 1536))
+    rings = [(0.1 * torch.randn(8, per, n_in, device="cuda")).contiguous() for _, n_in in rates]
+    f16 = torch.empty(3 * per, 512, device="cuda")
+    probs = torch.empty(3 * per, device="cuda")
+    ts = torch.cuda.Stream()
+    lib = eng._lib
+
+    def step(i):
+        for k, (sr, n_in) in enumerate(rates):
+            rc = lib.vad_resample_device(eng.handle, rings[k][i % 8].data_ptr(), per, n_in, sr,
+                                         f16[k * per:(k + 1) * per].data_ptr(), ts.cuda_stream)
+            assert rc == 0
+        eng.step_device(3 * per, f16.data_ptr(), probs.data_ptr(), stream=ts.cuda_stream)
+
+    dt = timed(step, [ts])
+    eng.close()
+    return {"config": "configs[3]: batch=4095 (3 x 1365) mixed 8/24/48 kHz -> resample -> V5", "us_per_step": dt * 1e6,
+            "frames_per_s": 3 * per / dt}
+
+
+def config4_per_gpu():
+    B = 4096
+    e5, e4 = Engine(blob(5), max_streams=B), Engine(blob(4), model_version=4, max_streams=B)
+    e5.open_streams(B)
+    e4.open_streams(B)
+    ring = (0.1 * torch.randn(16, 2 * B, 512, device="cuda")).contiguous()
+    p5, p4 = torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    s5, s4 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def step(i):
+        e5.step_device(B, ring[i % 16, :B].data_ptr(), p5.data_ptr(), stream=s5.cuda_stream)
+        e4.step_device(B, ring[i % 16, B:].data_ptr(), p4.data_ptr(), stream=s4.cuda_stream)
+
+    dt = timed(step, [s5, s4])
+    e5.close()
+    e4.close()
+    return {"config": "configs[4] per GPU: 4096 V4 + 4096 V5 streams, two engines on two HIP streams",
+            "us_per_step": dt * 1e6, "frames_per_s": 2 * B / dt, "x8_gpus_frames_per_s": 16 * B / dt}
+
+
+if __name__ == "__main__":
+    for fn in (config1, config3, config4_per_gpu):
+        print(json.dumps(fn()), flush=True)
