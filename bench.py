@@ -123,8 +123,13 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    # rehearsal knobs for a 1-GPU box (never set by the driver): all ranks on device 0, gloo for the two
+    # control-plane collectives.  The real multi-GPU run is one rank per GPU over RCCL.
+    if os.environ.get("VAD_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("VAD_BENCH_BACKEND", "nccl")              # "nccl" == RCCL on ROCm
     torch.cuda.set_device(local_rank)
-    dist = sharding.init_process_group(info, "nccl", torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+    dist = sharding.init_process_group(info, backend, torch.device("cuda", local_rank) if backend == "nccl" else None)
 
     from cutter_vad_amd import weights_io
     from cutter_vad_amd.engine import Engine
@@ -162,7 +167,7 @@ def main() -> None:
                 step(PARITY_STEPS + args.warmup + i)
             e1.record(ts)
 
-        elapsed = sharding.timed_region(dist, run, torch.cuda.synchronize, device="cuda")
+        elapsed = sharding.timed_region(dist, run, torch.cuda.synchronize, device="cuda" if backend == "nccl" else "cpu")
     kernel_s = e0.elapsed_time(e1) * 1e-3 / args.steps      # avg launch duration on the launch stream
     assert bool(torch.isfinite(probs).all()) and float(probs.min()) >= 0.0 and float(probs.max()) <= 1.0
 
