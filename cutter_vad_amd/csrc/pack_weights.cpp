@@ -108,7 +108,35 @@ bool check_stft_symmetry(const float *stft, std::string &err) {
     return true;
 }
 
-// STFT on the folded input (vad_layout.h): wave w owns bins 32w..32w+31, {re, im} per k-iteration;
+// The 4-way folded DFT (vad_layout.h, v5) uses analytic cos/sin and the window taken from the k = 0 row: the stored
+// basis must BE that windowed DFT (it is for Silero: max |stored - w cos| = 5.7e-8)
+bool check_windowed_dft(const float *stft, std::string &err) {
+    const double two_pi = 6.283185307179586476925286766559;
+    double worst = 0;
+    for (int k = 0; k <= 128; ++k)
+        for (int n = 0; n < 256; ++n) {
+            const double ph = two_pi * (double)((k * n) & 255) / 256.0, w = stft[n];
+            worst = std::max(worst, std::fabs((double)stft[(size_t)k * 256 + n] - w * std::cos(ph)));
+            worst = std::max(worst, std::fabs((double)stft[(size_t)(129 + k) * 256 + n] + w * std::sin(ph)));
+        }
+    if (worst > 2e-7) {
+        err = "Failed to load model: STFT basis is not a windowed DFT (the V5 kernel evaluates it as a folded DFT)";
+        return false;
+    }
+    return true;
+}
+
+// cos / -sin blocks of the 4-way folded DFT: wave w owns the 32 bins bin_of_channel(32 w + r); k-iteration j
+// contracts n = 8j .. 8j+7 (n = 0 is an unused slot: weight 0)
+void pack_dft4_wave(StreamBuilder &sb, int w) {
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int j = 0; j < 8; ++j) {
+        sb.weight_block([&](int np, int n) { const int k = v5::bin_of_channel(32 * w + np); return n == 0 ? 0.f : (float)std::cos(two_pi * (double)((k * n) & 255) / 256.0); }, j);
+        sb.weight_block([&](int np, int n) { const int k = v5::bin_of_channel(32 * w + np); return n == 0 ? 0.f : (float)-std::sin(two_pi * (double)((k * n) & 255) / 256.0); }, j);
+    }
+}
+
+// STFT on the folded input (V4; vad_layout.h): wave w owns bins 32w..32w+31, {re, im} per k-iteration;
 // k-iteration j contracts n = 8j+1 .. 8j+8 (quad 2j on the lower half-wave, 2j+1 on the upper)
 void pack_stft_wave(StreamBuilder &sb, const float *stft, int w) {
     for (int j = 0; j < 16; ++j) {
@@ -150,22 +178,25 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
     const float *head_w = B.get("head.w", 128), *head_b = B.get("head.b", 1);
     if (!err.empty()) return false;
     if (!check_stft_symmetry(stft, err)) return false;
+    if (!check_windowed_dft(stft, err)) return false;
 
     StreamBuilder sb;
     auto convw = [&](int layer, int o, int c, int tap) -> float {
         return c < ci[layer] ? ew[layer][((size_t)o * ci[layer] + c) * 3 + tap] : 0.f;
     };
+    // enc0 reads the |STFT| channels in the kernel's even/odd bin order (vad_layout.h)
+    auto conv0 = [&](int o, int ch, int tap) -> float { return ew[0][((size_t)o * 129 + bin_of_channel(ch)) * 3 + tap]; };
     for (int w = 0; w < NWAVES; ++w) {
         // STFT on the folded input (vad_layout.h): bins 32w..32w+31, {re, im} per k-iteration;
         // k-iteration j contracts n = 8j+1 .. 8j+8 (quad 2j on the lower half-wave, 2j+1 on the upper)
         out.sect[w][S_STFT] = sb.blocks();
-        pack_stft_wave(sb, stft, w);
+        pack_dft4_wave(sb, w);
         // enc0: out channels 32w.., taps 0..2 per k-iteration, then the Nyquist input channel
         out.sect[w][S_ENC0] = sb.blocks();
         sb.vector_blocks([&](int c) { return eb[0][32 * w + c]; });
         for (int j = 0; j < 16; ++j)
             for (int tap = 0; tap < 3; ++tap)
-                sb.weight_block([&](int np, int c) { return convw(0, 32 * w + np, c, tap); }, j);
+                sb.weight_block([&](int np, int c) { return conv0(32 * w + np, c, tap); }, j);
         for (int tout = 0; tout < 3; ++tout) {
             // activation quad = (|X128| of column 0, 1, 2, 0) on the lower half-wave, zeros on the upper
             float *b = sb.new_block();
@@ -213,7 +244,9 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
     const uint32_t hb = sb.blocks();
     sb.new_block()[0] = head_b[0];
     // bin 128 of the folded STFT (VALU): floats 0..127 = C[128][1..128]; its sine row is exactly zero
-    const uint32_t nb = pack_nyquist_block(sb, stft);
+    // the window of the stored basis: its k = 0 cosine row
+    const uint32_t nb = sb.blocks();
+    std::memcpy(sb.new_block(), stft, 256 * sizeof(float));
     for (int w = 0; w < NWAVES; ++w) {
         out.sect[w][S_HEADB] = hb;
         out.sect[w][S_NYQ] = nb;

@@ -39,6 +39,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
     f32x4 *const RH = lds + ROWS_X * QS;         // h
     float *const headp = reinterpret_cast<float *>(RH + ROWS_H * QS);   // [4][32]
     float *const nyqv = headp + 128;             // [3][32] |X128| per column
+    float *const fcor = nyqv + 96;               // [3 columns][y128, a64, b64][32 streams]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -95,53 +96,67 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
         // values) is hoisted out of this loop as loop-invariant and spilled
         int ws_stft = o_stft, ws_nyq = o_nyq, ws_e0 = o_e0, ws_e1 = o_e1, ws_e2 = o_e2, ws_e3 = o_e3, ws_l = o_l;
         asm volatile("" : "+s"(ws_stft), "+s"(ws_nyq), "+s"(ws_e0), "+s"(ws_e1), "+s"(ws_e2), "+s"(ws_e3), "+s"(ws_l));
-        // ---- load + convert + gate + FOLD one frame per stream (vad_layout.h) -----------------
-        // output o = (column c, stream m, quad q): u/v of n = 4q+1..4q+4 from the column's quads q, q+1
-        // (direct, shifted by one sample) and 63-q (mirrored).  Lanes run over q: 512 contiguous bytes
-        // per half-wave for the direct reads and for the mirrored ones.
+        // ---- load + convert + gate + window + 4-way FOLD one frame per stream (vad_layout.h) ----------
+        // output (column c, stream ms, quad q): n = 4q..4q+3 from the column's quads q (y[n]), 32+q (y[128+n]),
+        // 32-q / 31-q (y[128-n], reversed) and 64-q / 63-q (y[256-n], reversed).  16 lanes run over q.
         {
             const float thr = P.thresh;
-            const int q = tid & 31;
+            const int q = tid & 15;
+            const f32x4 W1 = ldw(wrs, q * 16, ws_nyq), W3 = ldw(wrs, (32 + q) * 16, ws_nyq);   // w[n], w[128+n] = w[128-n]
+            const float w64 = ldw(wrs, 16 * 16, ws_nyq).x;                                         // w[64] = w[192]
 #pragma unroll 1
             for (int c = 0; c < 3; ++c) {
-                f32x4 da[4], db[4], mi[4];
-                if (P.fmt == 0) {
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int ms = rr * 8 + (tid >> 5);
-                        const int g2 = tile0 + ms;
-                        da[rr] = db[rr] = mi[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (g2 < P.n) {
-                            const f32x4 *fr = reinterpret_cast<const f32x4 *>(P.frames) + ((size_t)g2 * T + t) * 128 + 32 * c;
-                            da[rr] = fr[q]; db[rr] = fr[q + 1]; mi[rr] = fr[63 - q];
-                        }
-                    }
-                } else {
-                    const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
-#pragma unroll 1
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int ms = rr * 8 + (tid >> 5);
-                        const int g2 = tile0 + ms;
-                        da[rr] = db[rr] = mi[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (g2 < P.n) {
-                            const i16x4 *fr = reinterpret_cast<const i16x4 *>(P.frames) + ((size_t)g2 * T + t) * 128 + 32 * c;
-                            const i16x4 a = fr[q], b2 = fr[q + 1], d = fr[63 - q];
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int ms = rr * 16 + (tid >> 4);
+                    const int g2 = tile0 + ms;
+                    f32x4 xa, xb, r1a, r1b, r2a, r2b, mid;
+                    xa = xb = r1a = r1b = r2a = r2b = mid = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (g2 < P.n) {
+                        const size_t fo = ((size_t)g2 * T + t) * 128 + 32 * c;
+                        const int q2a = q == 0 ? 63 : 64 - q;          // quad 64 of column 2 does not exist; its only use (n = 0) is masked
+                        if (P.fmt == 0) {
+                            const f32x4 *fr = reinterpret_cast<const f32x4 *>(P.frames) + fo;
+                            xa = fr[q]; xb = fr[32 + q]; r1a = fr[32 - q]; r1b = fr[31 - q]; r2a = fr[q2a]; r2b = fr[63 - q];
+                            if (q == 0) mid = f32x4{fr[16].x, fr[48].x, 0.f, 0.f};
+                        } else {
+                            const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
+                            const i16x4 *fr = reinterpret_cast<const i16x4 *>(P.frames) + fo;
                             // the reference divides (np.int16 -> float32 / 32767.0), keep a true division
-                            da[rr] = f32x4{(float)a.x / sc, (float)a.y / sc, (float)a.z / sc, (float)a.w / sc};
-                            db[rr] = f32x4{(float)b2.x / sc, (float)b2.y / sc, (float)b2.z / sc, (float)b2.w / sc};
-                            mi[rr] = f32x4{(float)d.x / sc, (float)d.y / sc, (float)d.z / sc, (float)d.w / sc};
+#define CVT(v) f32x4{(float)(v).x / sc, (float)(v).y / sc, (float)(v).z / sc, (float)(v).w / sc}
+                            xa = CVT(fr[q]); xb = CVT(fr[32 + q]); r1a = CVT(fr[32 - q]); r1b = CVT(fr[31 - q]);
+                            r2a = CVT(fr[q2a]); r2b = CVT(fr[63 - q]);
+                            if (q == 0) mid = f32x4{(float)fr[16].x / sc, (float)fr[48].x / sc, 0.f, 0.f};
+#undef CVT
                         }
                     }
-                }
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int ms = rr * 8 + (tid >> 5);
-                    const f32x4 a = gate4(da[rr], thr), b2 = gate4(db[rr], thr), d = gate4(mi[rr], thr);
-                    f32x4 u = f32x4{a.y + d.w, a.z + d.z, a.w + d.y, b2.x + d.x};
-                    f32x4 v = f32x4{a.y - d.w, a.z - d.z, a.w - d.y, b2.x - d.x};
-                    if (q == 31) { u.w = b2.x; v.w = 0.f; }   // n = 128 is its own mirror
-                    RX[(64 * c + q) * QS + ms] = u;
-                    RX[(64 * c + 32 + q) * QS + ms] = v;
+                    xa = gate4(xa, thr); xb = gate4(xb, thr); r1a = gate4(r1a, thr); r1b = gate4(r1b, thr);
+                    r2a = gate4(r2a, thr); r2b = gate4(r2b, thr); mid = gate4(mid, thr);
+                    // y = w * x at the four mirrored positions
+                    const f32x4 y1 = f32x4{xa.x * W1.x, xa.y * W1.y, xa.z * W1.z, xa.w * W1.w};
+                    const f32x4 y3 = f32x4{xb.x * W3.x, xb.y * W3.y, xb.z * W3.z, xb.w * W3.w};
+                    const f32x4 y2 = f32x4{r1a.x * W3.x, r1b.w * W3.y, r1b.z * W3.z, r1b.y * W3.w};
+                    const f32x4 y4 = f32x4{r2a.x * W1.x, r2b.w * W1.y, r2b.z * W1.z, r2b.y * W1.w};
+                    f32x4 s14 = f32x4{y1.x + y4.x, y1.y + y4.y, y1.z + y4.z, y1.w + y4.w};
+                    f32x4 d14 = f32x4{y1.x - y4.x, y1.y - y4.y, y1.z - y4.z, y1.w - y4.w};
+                    f32x4 s23 = f32x4{y2.x + y3.x, y2.y + y3.y, y2.z + y3.z, y2.w + y3.w};
+                    f32x4 d23 = f32x4{y2.x - y3.x, y2.y - y3.y, y2.z - y3.z, y2.w - y3.w};
+                    f32x4 pe = f32x4{s14.x + s23.x, s14.y + s23.y, s14.z + s23.z, s14.w + s23.w};
+                    f32x4 po = f32x4{s14.x - s23.x, s14.y - s23.y, s14.z - s23.z, s14.w - s23.w};
+                    f32x4 qe = f32x4{d14.x - d23.x, d14.y - d23.y, d14.z - d23.z, d14.w - d23.w};
+                    f32x4 qo = f32x4{d14.x + d23.x, d14.y + d23.y, d14.z + d23.z, d14.w + d23.w};
+                    if (q == 0) {                 // n = 0 is not part of the folded sums
+                        pe.x = po.x = qe.x = qo.x = 0.f;
+                        // rank-1 terms of n = 0 / 64 / 128: y128, a64 = y[64] + y[192], b64 = y[64] - y[192]
+                        const float y64 = mid.x * w64, y192 = mid.y * w64;
+                        fcor[(c * 3 + 0) * 32 + ms] = xb.x * W3.x;      // y[128] (w[128] from the table)
+                        fcor[(c * 3 + 1) * 32 + ms] = y64 + y192;
+                        fcor[(c * 3 + 2) * 32 + ms] = y64 - y192;
+                    }
+                    RX[(64 * c + q) * QS + ms] = pe;
+                    RX[(64 * c + 16 + q) * QS + ms] = po;
+                    RX[(64 * c + 32 + q) * QS + ms] = qe;
+                    RX[(64 * c + 48 + q) * QS + ms] = qo;
                 }
             }
         }
@@ -152,26 +167,24 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
         __syncthreads();   // (1) folded x and h visible
         STAMP(2);
 
-        // ---- bin 128 (Nyquist) on the VALU: re = sum_n C[128][n] u[n], im == 0; 2 lanes per (column, stream)
+        // ---- bin 128 (even): re = sum_n pe[n] (-1)^n + y128 + a64, im == 0; 2 lanes per (column, stream)
         {
             const int pr = lane >> 1, half = lane & 1;
             const int pair = w * 24 + pr;                 // 96 (column, stream) pairs, 24 per wave
             const int c = pair >> 5, ms = pair & 31;
             float a = 0.f;
             if (pr < 24) {
-#pragma unroll 4
-                for (int i = 0; i < 16; ++i) {
-                    const int qq = half * 16 + i;
-                    const f32x4 cf = ldw(wrs, qq * 16, ws_nyq);
-                    const f32x4 uu = RX[(64 * c + qq) * QS + ms];
-                    a += cf.x * uu.x + cf.y * uu.y + cf.z * uu.z + cf.w * uu.w;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 pp = RX[(64 * c + half * 8 + i) * QS + ms];
+                    a += (pp.x - pp.y) + (pp.z - pp.w);
                 }
             }
             a += __shfl_xor(a, 1);
-            if (pr < 24 && half == 0) nyqv[c * 32 + ms] = fabsf(a);
+            if (pr < 24 && half == 0) nyqv[c * 32 + ms] = fabsf(a + fcor[(c * 3 + 0) * 32 + ms] + fcor[(c * 3 + 1) * 32 + ms]);
         }
 
-        // ---- STFT: wave w computes bins 32w..32w+31 (re on u, im on v) for the 3 columns -------
+        // ---- STFT: wave w owns the 32 bins bin_of_channel(32w + r): cos on pe|po, -sin on qe|qo, 3 columns ----
         // enc0's bias and first weights ride along (requested at the end of this phase)
         f32x4 e0b0, e0b1, e0b2, e0b3, E0w0, E0w1, E0w2;
         {
@@ -181,20 +194,22 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
                 are[c] = (f32x16)(0.f);
                 aim[c] = (f32x16)(0.f);
             }
-            f32x4 Au0 = RX[0 * QS + hq], Au1 = RX[64 * QS + hq], Au2 = RX[128 * QS + hq];
-            f32x4 Av0 = RX[32 * QS + hq], Av1 = RX[96 * QS + hq], Av2 = RX[160 * QS + hq];
+            const int rR = w < 2 ? 0 : 16, rI = w < 2 ? 32 : 48;     // even bins read pe / qe, odd bins po / qo
+            const f32x4 *const XR = RX + rR * QS + hq, *const XI = RX + rI * QS + hq;
+            f32x4 Au0 = XR[0], Au1 = XR[64 * QS], Au2 = XR[128 * QS];
+            f32x4 Av0 = XI[0], Av1 = XI[64 * QS], Av2 = XI[128 * QS];
             f32x4 Bre, Bim, Bu0, Bu1, Bu2, Bv0, Bv1, Bv2;
 #define STFT_LD(S, jj)                                                                     \
     S##re = WL(ws_stft + 2 * (jj)); S##im = WL(ws_stft + 2 * (jj) + 1);                    \
-    S##u0 = RX[(2 * (jj)) * QS + hq]; S##u1 = RX[(64 + 2 * (jj)) * QS + hq]; S##u2 = RX[(128 + 2 * (jj)) * QS + hq]; \
-    S##v0 = RX[(32 + 2 * (jj)) * QS + hq]; S##v1 = RX[(96 + 2 * (jj)) * QS + hq]; S##v2 = RX[(160 + 2 * (jj)) * QS + hq];
+    S##u0 = XR[(2 * (jj)) * QS]; S##u1 = XR[(64 + 2 * (jj)) * QS]; S##u2 = XR[(128 + 2 * (jj)) * QS]; \
+    S##v0 = XI[(2 * (jj)) * QS]; S##v1 = XI[(64 + 2 * (jj)) * QS]; S##v2 = XI[(128 + 2 * (jj)) * QS];
 #define STFT_MMA(S)                                                                        \
     are[0] = mfma4(S##re, S##u0, are[0]); are[1] = mfma4(S##re, S##u1, are[1]); are[2] = mfma4(S##re, S##u2, are[2]); \
     aim[0] = mfma4(S##im, S##v0, aim[0]); aim[1] = mfma4(S##im, S##v1, aim[1]); aim[2] = mfma4(S##im, S##v2, aim[2]);
-            for (int j = 0; j < 16; j += 2) {
+            for (int j = 0; j < 8; j += 2) {
                 STFT_LD(B, j + 1) SB();
                 STFT_MMA(A) SB();
-                const int jn = j + 2 < 16 ? j + 2 : 14;
+                const int jn = j + 2 < 8 ? j + 2 : 6;
                 STFT_LD(A, jn) SB();
                 STFT_MMA(B) SB();
             }
@@ -206,13 +221,18 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
             SB();
             STAMP(16);
             __syncthreads();   // (1b) every wave is done reading u/v: the magnitudes may overwrite them
-            // magnitude -> rows 32c + 8w + 2g + h
+            // rank-1 terms, then magnitude -> rows 32c + 8w + 2g + h.  Register 4g+i holds row r = 8g+4h+i: (-1)^r = (-1)^i
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
+                const float y128 = fcor[(c * 3 + 0) * 32 + m], a64 = fcor[(c * 3 + 1) * 32 + m], b64 = fcor[(c * 3 + 2) * 32 + m];
+                // even bins: re += y128 + a64 (-1)^r ; odd bins: re -= y128, im -= b64 (-1)^r
+                const float rp = w < 2 ? y128 + a64 : -y128, rm = w < 2 ? y128 - a64 : -y128;
+                const float ip = w < 2 ? 0.f : -b64, im_ = w < 2 ? 0.f : b64;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 r = quad_of(are[c], g), i = quad_of(aim[c], g);
-                    RX[(c * 32 + 8 * w + 2 * g) * QS + hq] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
+                    RX[(c * 32 + 8 * w + 2 * g) * QS + hq] = f32x4{mag_(r.x + rp, i.x + ip), mag_(r.y + rm, i.y + im_),
+                                                                  mag_(r.z + rp, i.z + ip), mag_(r.w + rm, i.w + im_)};
                 }
             }
             // row 96: (|X128| of column 0,1,2, 0) ; row 97: zeros (pairs with row 96 in the MFMA k-step)

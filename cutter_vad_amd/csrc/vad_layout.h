@@ -17,6 +17,10 @@
 //   k-step i in 0..3 contracts channel 8j+i (lower half-wave) and 8j+4+i (upper half).
 #pragma once
 #include <stdint.h>
+#if !defined(__HIPCC__) && !defined(__host__)
+#define __host__
+#define __device__
+#endif
 
 namespace vadk {
 
@@ -29,29 +33,38 @@ constexpr int BLK_FLOATS = 256;
 
 // ---- Silero V5 (16 kHz branch) -------------------------------------------------------
 namespace v5 {
-// The windowed-DFT basis is exactly symmetric in the stored weights: C[k][n] == C[k][256-n],
-// S[k][n] == -S[k][256-n], C[k][0] == S[k][0] == S[k][128] == 0.  The loader therefore folds each
-// 256-sample column into u[n] = x[n] + x[256-n], v[n] = x[n] - x[256-n] (n = 1..127), u[128] = x[128],
-// v[128] = 0, and the STFT contracts K = 128 instead of 256:  re = C[:,1:129] u,  im = S[:,1:129] v.
+// STFT as a 4-way folded DFT.  The stored basis is the windowed DFT w[n] cos/sin(2 pi k n / 256) (the packer
+// verifies this to 2e-7 and takes w[n] from its k = 0 row), so with y = w * x and, for n = 1..63,
+//   pe = y[n] + y[256-n] + y[128-n] + y[128+n]      po = y[n] + y[256-n] - y[128-n] - y[128+n]
+//   qe = y[n] - y[256-n] - y[128-n] + y[128+n]      qo = y[n] - y[256-n] + y[128-n] - y[128+n]
+//   re[k even] =  sum pe cos + y128 + a64 (-1)^(k/2)        re[k odd] =  sum po cos - y128
+//   im[k even] = -sum qe sin                                im[k odd] = -sum qo sin - b64 (-1)^((k-1)/2)
+// (y128 = y[128], a64 = y[64] + y[192], b64 = y[64] - y[192]): every contraction has K = 64 instead of 256.
+// Wave w owns 32 bins: w = 0: k = 0,2..62   w = 1: k = 64..126   w = 2: k = 1,3..63   w = 3: k = 65..127,
+// so |STFT| channel ch = 32 w + r holds bin  (w < 2 ? 64 w + 2 r : 64 (w - 2) + 2 r + 1); enc0's input
+// channels are permuted accordingly by the packer.  Bin 128 (even) is an alternating sum on the VALU.
 // weight-stream sections, in blocks, per wave
-constexpr int STFT_BLOCKS = 32;            // 16 k-iterations x {re, im}
-constexpr int NYQ_BLOCKS = 1;              // shared: floats 0..127 = C[128][1..128]  (bin 128, VALU)
+constexpr int STFT_BLOCKS = 16;            // 8 k-iterations x {cos, -sin}
+constexpr int NYQ_BLOCKS = 1;              // shared table: floats 0..255 = w[n] (the Hann window of the stored basis)
 constexpr int ENC0_BLOCKS = 4 + 16 * 3 + 3;  // bias, 16 k-iterations x 3 taps, Nyquist channel x 3 t_out
 constexpr int ENC1_BLOCKS = 4 + 2 * 16;
 constexpr int ENC2_BLOCKS = 4 + 2 * 8;     // waves 0,1 only
 constexpr int ENC3_BLOCKS = 4 + 8;
 constexpr int LSTM_BLOCKS = 16 + 64 + 64 + 4;  // bias(4 gates), W_ih, W_hh, head weights
 enum Section { S_STFT = 0, S_NYQ, S_ENC0, S_ENC1, S_ENC2, S_ENC3, S_LSTM, S_HEADB, S_COUNT };  // S_HEADB: 1 block, float 0 = head bias
+__host__ __device__ constexpr int bin_of_channel(int ch) {
+    return (ch >> 5) < 2 ? 64 * (ch >> 5) + 2 * (ch & 31) : 64 * ((ch >> 5) - 2) + 2 * (ch & 31) + 1;
+}
 
 // LDS, in quad rows.  One activation region X, reused by every layer:
-//   loader : u of column c -> rows 64c + q, v -> rows 64c + 32 + q        (q = 0..31, n = 4q+1 .. 4q+4)
-//   |STFT| : rows 32c + bin/4 (c = 0..2), row 96 = (|X128| of columns 0,1,2, 0), row 97 = 0
+//   loader : column c: pe -> rows 64c + q, po -> 64c + 16 + q, qe -> 64c + 32 + q, qo -> 64c + 48 + q   (q = 0..15, n = 4q..4q+3)
+//   |STFT| : rows 32c + ch/4 (c = 0..2), row 96 = (|X128| of columns 0,1,2, 0), row 97 = 0
 //   enc0   : rows 98 + 32c + ch/4          enc1 : rows 16c + ch/4
 //   enc2   : rows 98 + ch/4                enc3 : rows ch/4 (LSTM input)
 constexpr int ROWS_X = 194;
 constexpr int ROW_E = 98;                  // first row of the upper half (enc0 / enc2 outputs)
 constexpr int ROWS_H = 32;                 // h_{t-1}
-constexpr int LDS_F4 = (ROWS_X + ROWS_H) * QS + 32 + 24;  // + head partials [4][32] + Nyquist magnitudes [3][32]
+constexpr int LDS_F4 = (ROWS_X + ROWS_H) * QS + 32 + 24 + 72;  // + head partials [4][32], |X128| [3][32], fold corrections [3][3][32]
 constexpr int LDS_BYTES = LDS_F4 * 16;
 }  // namespace v5
 

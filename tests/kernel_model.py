@@ -70,36 +70,49 @@ def v5_step(W, sect, x, hc, gate=0.01):
     RX = np.zeros((194, 32, 4))
     RH = np.zeros((32, 32, 4))
     RE = RX[98:]
-    # loader: fold every column (c = 0..2): u[n] = x[n] + x[256-n], v[n] = x[n] - x[256-n], n = 1..128
+    # loader: window + 4-way fold of every column (vad_layout.h, v5): rows 64c + {0,16,32,48} + q hold pe, po, qe, qo
+    wtab = W[sect[0][S_NYQ]].reshape(-1)[:256].astype(np.float64)         # w[n], the k = 0 row of the stored basis
+    fcor = np.zeros((3, 3, 32))
     for c in range(3):
-        col = x[:, 128 * c:128 * c + 256] if c < 2 else np.concatenate([x[:, 256:512]], axis=1)
-        n = np.arange(1, 129)
-        mir = np.where(n < 128, 256 - n, 0)
-        xm = np.where(n[None, :] < 128, col[:, mir], 0.0)
-        u = col[:, n] + xm
-        v = np.where(n[None, :] < 128, col[:, n] - xm, 0.0)
-        RX[64 * c:64 * c + 32] = u.reshape(32, 32, 4).transpose(1, 0, 2)
-        RX[64 * c + 32:64 * c + 64] = v.reshape(32, 32, 4).transpose(1, 0, 2)
+        y = x[:, 128 * c:128 * c + 256] * wtab[None, :] if c < 2 else x[:, 256:512] * wtab[None, :]
+        n = np.arange(64)
+        y1, y2, y3, y4 = y[:, n], y[:, 128 - n], y[:, 128 + n], y[:, (256 - n) % 256]
+        pe, po = y1 + y4 + y2 + y3, y1 + y4 - y2 - y3
+        qe, qo = y1 - y4 - y2 + y3, y1 - y4 + y2 - y3
+        for k, arr in enumerate((pe, po, qe, qo)):
+            arr = arr.copy()
+            arr[:, 0] = 0.0                                                   # n = 0 is not part of the folded sums
+            RX[64 * c + 16 * k:64 * c + 16 * k + 16] = arr.reshape(32, 16, 4).transpose(1, 0, 2)
+        fcor[c, 0], fcor[c, 1], fcor[c, 2] = y[:, 128], y[:, 64] + y[:, 192], y[:, 64] - y[:, 192]
     RH[:] = hc[:, :128].astype(np.float64).reshape(32, 32, 4).transpose(1, 0, 2)
     c_prev = hc[:, 128:].astype(np.float64)
-    # bin 128 on the VALU
-    nq = W[sect[0][S_NYQ]].reshape(-1)[:128].astype(np.float64)
+    # bin 128: alternating sum of pe + rank-1 terms
     nyq = np.zeros((3, 32))
     for c in range(3):
-        u = RX[64 * c:64 * c + 32].transpose(1, 0, 2).reshape(32, 128)
-        nyq[c] = np.abs(u @ nq)
-    # STFT
+        pe = RX[64 * c:64 * c + 16]                                           # [16, 32, 4]
+        alt = (pe[:, :, 0] - pe[:, :, 1] + pe[:, :, 2] - pe[:, :, 3]).sum(0)
+        nyq[c] = np.abs(alt + fcor[c, 0] + fcor[c, 1])
+    # STFT: wave w owns bins bin_of_channel(32w + r); even bins contract pe / qe, odd bins po / qo
     mags = {}
+    sgn = np.where(np.arange(32) % 2 == 0, 1.0, -1.0)[:, None]                # (-1)^r per tile row
     for w in range(4):
         ws = sect[w][S_STFT]
+        rR, rI = (0, 32) if w < 2 else (16, 48)
         are = [np.zeros((32, 32)) for _ in range(3)]
         aim = [np.zeros((32, 32)) for _ in range(3)]
-        for j in range(16):
+        for j in range(8):
             wre, wim = W[ws + 2 * j], W[ws + 2 * j + 1]
             for c in range(3):
-                are[c] += _mfma4(wre, _rows(RX, 64 * c + 2 * j, 64 * c + 2 * j + 1))
-                aim[c] += _mfma4(wim, _rows(RX, 64 * c + 32 + 2 * j, 64 * c + 32 + 2 * j + 1))
-        mags[w] = [np.sqrt(are[c] ** 2 + aim[c] ** 2) for c in range(3)]
+                are[c] += _mfma4(wre, _rows(RX, 64 * c + rR + 2 * j, 64 * c + rR + 2 * j + 1))
+                aim[c] += _mfma4(wim, _rows(RX, 64 * c + rI + 2 * j, 64 * c + rI + 2 * j + 1))
+        mags[w] = []
+        for c in range(3):
+            y128, a64, b64 = fcor[c, 0][None, :], fcor[c, 1][None, :], fcor[c, 2][None, :]
+            if w < 2:
+                re, im = are[c] + y128 + sgn * a64, aim[c]
+            else:
+                re, im = are[c] - y128, aim[c] - sgn * b64
+            mags[w].append(np.sqrt(re ** 2 + im ** 2))
     for w in range(4):
         for c in range(3):
             _store_tile(RX, c * 32 + 8 * w, mags[w][c], relu=False)
