@@ -90,75 +90,121 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
     const bool sm_thread = (tid < MT) && (tile0 + tid < P.n);
     const int sm_slot = sm_thread ? (P.slots ? P.slots[tile0 + tid] : tile0 + tid) : 0;
 
+    __syncthreads();   // h_{t-1} visible: the recurrent gate half starts before the first frame barrier
     STAMP(0);
     for (int t = 0; t < T; ++t) {
         // section offsets, made opaque per frame: otherwise every block offset of the kernel (~300 SGPR
         // values) is hoisted out of this loop as loop-invariant and spilled
         int ws_stft = o_stft, ws_nyq = o_nyq, ws_e0 = o_e0, ws_e1 = o_e1, ws_e2 = o_e2, ws_e3 = o_e3, ws_l = o_l;
         asm volatile("" : "+s"(ws_stft), "+s"(ws_nyq), "+s"(ws_e0), "+s"(ws_e1), "+s"(ws_e2), "+s"(ws_e3), "+s"(ws_l));
-        // ---- load + convert + gate + window + 4-way FOLD one frame per stream (vad_layout.h) ----------
-        // output (column c, stream ms, quad q): n = 4q..4q+3 from the column's quads q (y[n]), 32+q (y[128+n]),
-        // 32-q / 31-q (y[128-n], reversed) and 64-q / 63-q (y[256-n], reversed).  16 lanes run over q.
+        // ---- the frame is loaded in 3 rounds (one STFT column each) UNDER the recurrent half of the LSTM gates ----
+        // W_hh . h_{t-1} does not depend on the frame, so its 256 MFMAs per wave run while the column is in flight from
+        // HBM.  vmcnt retires in issue order: everything consumed during the flight (the round's W_hh blocks) is
+        // requested BEFORE the column's loads, so waiting for a weight block never waits for the frame.
+        // Fold: output (column c, stream ms, quad q), n = 4q..4q+3, from the column's quads q (y[n]), 32+q (y[128+n]),
+        // 32-q / 31-q (y[128-n], reversed) and 64-q / 63-q (y[256-n], reversed); 16 lanes run over q.
+        f32x16 gi = acc_of(WL(ws_l), WL(ws_l + 1), WL(ws_l + 2), WL(ws_l + 3));
+        f32x16 gfo = acc_of(WL(ws_l + 4), WL(ws_l + 5), WL(ws_l + 6), WL(ws_l + 7));
+        f32x16 gg = acc_of(WL(ws_l + 8), WL(ws_l + 9), WL(ws_l + 10), WL(ws_l + 11));
+        f32x16 go = acc_of(WL(ws_l + 12), WL(ws_l + 13), WL(ws_l + 14), WL(ws_l + 15));
         {
             const float thr = P.thresh;
             const int q = tid & 15;
+            const int q2a = q == 0 ? 63 : 64 - q;          // quad 64 of column 2 does not exist; its only use (n = 0) is masked
             const f32x4 W1 = ldw(wrs, q * 16, ws_nyq), W3 = ldw(wrs, (32 + q) * 16, ws_nyq);   // w[n], w[128+n] = w[128-n]
             const float w64 = ldw(wrs, 16 * 16, ws_nyq).x;                                         // w[64] = w[192]
-#pragma unroll 1
-            for (int c = 0; c < 3; ++c) {
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const int ms = rr * 16 + (tid >> 4);
-                    const int g2 = tile0 + ms;
-                    f32x4 xa, xb, r1a, r1b, r2a, r2b, mid;
-                    xa = xb = r1a = r1b = r2a = r2b = mid = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (g2 < P.n) {
-                        const size_t fo = ((size_t)g2 * T + t) * 128 + 32 * c;
-                        const int q2a = q == 0 ? 63 : 64 - q;          // quad 64 of column 2 does not exist; its only use (n = 0) is masked
-                        if (P.fmt == 0) {
-                            const f32x4 *fr = reinterpret_cast<const f32x4 *>(P.frames) + fo;
-                            xa = fr[q]; xb = fr[32 + q]; r1a = fr[32 - q]; r1b = fr[31 - q]; r2a = fr[q2a]; r2b = fr[63 - q];
-                            if (q == 0) mid = f32x4{fr[16].x, fr[48].x, 0.f, 0.f};
-                        } else {
-                            const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
-                            const i16x4 *fr = reinterpret_cast<const i16x4 *>(P.frames) + fo;
-                            // the reference divides (np.int16 -> float32 / 32767.0), keep a true division
-#define CVT(v) f32x4{(float)(v).x / sc, (float)(v).y / sc, (float)(v).z / sc, (float)(v).w / sc}
-                            xa = CVT(fr[q]); xb = CVT(fr[32 + q]); r1a = CVT(fr[32 - q]); r1b = CVT(fr[31 - q]);
-                            r2a = CVT(fr[q2a]); r2b = CVT(fr[63 - q]);
-                            if (q == 0) mid = f32x4{(float)fr[16].x / sc, (float)fr[48].x / sc, 0.f, 0.f};
-#undef CVT
-                        }
-                    }
-                    xa = gate4(xa, thr); xb = gate4(xb, thr); r1a = gate4(r1a, thr); r1b = gate4(r1b, thr);
-                    r2a = gate4(r2a, thr); r2b = gate4(r2b, thr); mid = gate4(mid, thr);
-                    // y = w * x at the four mirrored positions
-                    const f32x4 y1 = f32x4{xa.x * W1.x, xa.y * W1.y, xa.z * W1.z, xa.w * W1.w};
-                    const f32x4 y3 = f32x4{xb.x * W3.x, xb.y * W3.y, xb.z * W3.z, xb.w * W3.w};
-                    const f32x4 y2 = f32x4{r1a.x * W3.x, r1b.w * W3.y, r1b.z * W3.z, r1b.y * W3.w};
-                    const f32x4 y4 = f32x4{r2a.x * W1.x, r2b.w * W1.y, r2b.z * W1.z, r2b.y * W1.w};
-                    f32x4 s14 = f32x4{y1.x + y4.x, y1.y + y4.y, y1.z + y4.z, y1.w + y4.w};
-                    f32x4 d14 = f32x4{y1.x - y4.x, y1.y - y4.y, y1.z - y4.z, y1.w - y4.w};
-                    f32x4 s23 = f32x4{y2.x + y3.x, y2.y + y3.y, y2.z + y3.z, y2.w + y3.w};
-                    f32x4 d23 = f32x4{y2.x - y3.x, y2.y - y3.y, y2.z - y3.z, y2.w - y3.w};
-                    f32x4 pe = f32x4{s14.x + s23.x, s14.y + s23.y, s14.z + s23.z, s14.w + s23.w};
-                    f32x4 po = f32x4{s14.x - s23.x, s14.y - s23.y, s14.z - s23.z, s14.w - s23.w};
-                    f32x4 qe = f32x4{d14.x - d23.x, d14.y - d23.y, d14.z - d23.z, d14.w - d23.w};
-                    f32x4 qo = f32x4{d14.x + d23.x, d14.y + d23.y, d14.z + d23.z, d14.w + d23.w};
-                    if (q == 0) {                 // n = 0 is not part of the folded sums
-                        pe.x = po.x = qe.x = qo.x = 0.f;
-                        // rank-1 terms of n = 0 / 64 / 128: y128, a64 = y[64] + y[192], b64 = y[64] - y[192]
-                        const float y64 = mid.x * w64, y192 = mid.y * w64;
-                        fcor[(c * 3 + 0) * 32 + ms] = xb.x * W3.x;      // y[128] (w[128] from the table)
-                        fcor[(c * 3 + 1) * 32 + ms] = y64 + y192;
-                        fcor[(c * 3 + 2) * 32 + ms] = y64 - y192;
-                    }
-                    RX[(64 * c + q) * QS + ms] = pe;
-                    RX[(64 * c + 16 + q) * QS + ms] = po;
-                    RX[(64 * c + 32 + q) * QS + ms] = qe;
-                    RX[(64 * c + 48 + q) * QS + ms] = qo;
+            const int wh = ws_l + 16 + 64;                 // W_hh blocks: iteration it at wh + 4 it
+            const bool f32in = P.fmt == 0;
+            const int qsh = f32in ? 4 : 3;                 // log2(bytes per 4-sample quad)
+            const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
+            const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
+            u32x4 xr[14];                                  // raw quads of one column, both stream halves, as bits (int16: 8 bytes in .xy)
+            // The column is read through a buffer descriptor over the whole frames array: streams past the end of the
+            // batch read zeros (hardware range check) WITHOUT a branch.  Every path issues exactly 14 loads per round,
+            // so the compiler's vmcnt bookkeeping stays exact (a conditional load made it wait for vmcnt(0), i.e. for
+            // the frame, in the middle of the MFMAs).
+#define X_ISSUE(c)                                                                                              \
+    _Pragma("unroll") for (int rr = 0; rr < 2; ++rr) {                                                          \
+        const int fq = ((tile0 + rr * 16 + (tid >> 4)) * T + t) * 128 + 32 * (c);      /* first quad of the column */ \
+        const int idx[7] = {q, 32 + q, 32 - q, 31 - q, q2a, 63 - q, 16 + 32 * (q & 1)};  /* last: samples 64 / 192 on lanes q = 0 / 1 */ \
+        /* ONE instruction stream for both formats: a quad is 16 bytes (f32) or 8 bytes (int16, the upper 8 bytes     \
+           of the 16 loaded are ignored); a format branch here breaks the compiler's vmcnt bookkeeping */        \
+        _Pragma("unroll") for (int k = 0; k < 7; ++k)                                                           \
+            xr[rr * 7 + k] = __builtin_amdgcn_raw_buffer_load_b128(frs, (fq + idx[k]) << qsh, 0, 0);            \
+    }
+            // int16 payloads were loaded as raw bits: decode (true division, like np.int16 -> float32 / 32767.0), then gate
+            auto decode = [&](u32x4 b) -> f32x4 {
+                f32x4 v = __builtin_bit_cast(f32x4, b);
+                if (!f32in) {
+                    const int s0 = (int)(short)(b.x & 0xffffu), s1 = (int)(short)(b.x >> 16);
+                    const int s2 = (int)(short)(b.y & 0xffffu), s3 = (int)(short)(b.y >> 16);
+                    v = f32x4{(float)s0 / sc, (float)s1 / sc, (float)s2 / sc, (float)s3 / sc};
                 }
-            }
+                return gate4(v, thr);
+            };
+            // lane q = 0 loaded the quad holding sample 64, lane q = 1 the quad holding sample 192 (component 0 each)
+            auto decode_mid = [&](u32x4 b) -> f32x4 {
+                const f32x4 v = decode(b);
+                return f32x4{v.x, __shfl_down(v.x, 1), 0.f, 0.f};
+            };
+#define X_FOLD(c)                                                                                               \
+    _Pragma("unroll") for (int rr = 0; rr < 2; ++rr) {                                                          \
+        const int ms = rr * 16 + (tid >> 4);                                                                    \
+        const f32x4 xa = decode(xr[rr * 7 + 0]), xb = decode(xr[rr * 7 + 1]), r1a = decode(xr[rr * 7 + 2]);      \
+        const f32x4 r1b = decode(xr[rr * 7 + 3]), r2a = decode(xr[rr * 7 + 4]), r2b = decode(xr[rr * 7 + 5]);    \
+        const f32x4 mid = decode_mid(xr[rr * 7 + 6]);                                                           \
+        const f32x4 y1 = f32x4{xa.x * W1.x, xa.y * W1.y, xa.z * W1.z, xa.w * W1.w};                             \
+        const f32x4 y3 = f32x4{xb.x * W3.x, xb.y * W3.y, xb.z * W3.z, xb.w * W3.w};                             \
+        const f32x4 y2 = f32x4{r1a.x * W3.x, r1b.w * W3.y, r1b.z * W3.z, r1b.y * W3.w};                         \
+        const f32x4 y4 = f32x4{r2a.x * W1.x, r2b.w * W1.y, r2b.z * W1.z, r2b.y * W1.w};                         \
+        const f32x4 s14 = f32x4{y1.x + y4.x, y1.y + y4.y, y1.z + y4.z, y1.w + y4.w};                            \
+        const f32x4 d14 = f32x4{y1.x - y4.x, y1.y - y4.y, y1.z - y4.z, y1.w - y4.w};                            \
+        const f32x4 s23 = f32x4{y2.x + y3.x, y2.y + y3.y, y2.z + y3.z, y2.w + y3.w};                            \
+        const f32x4 d23 = f32x4{y2.x - y3.x, y2.y - y3.y, y2.z - y3.z, y2.w - y3.w};                            \
+        f32x4 pe = f32x4{s14.x + s23.x, s14.y + s23.y, s14.z + s23.z, s14.w + s23.w};                           \
+        f32x4 po = f32x4{s14.x - s23.x, s14.y - s23.y, s14.z - s23.z, s14.w - s23.w};                           \
+        f32x4 qe = f32x4{d14.x - d23.x, d14.y - d23.y, d14.z - d23.z, d14.w - d23.w};                           \
+        f32x4 qo = f32x4{d14.x + d23.x, d14.y + d23.y, d14.z + d23.z, d14.w + d23.w};                           \
+        if (q == 0) {                 /* n = 0 is not part of the folded sums; rank-1 terms of n = 0 / 64 / 128 */ \
+            pe.x = po.x = qe.x = qo.x = 0.f;                                                                    \
+            const float y64 = mid.x * w64, y192 = mid.y * w64;                                                  \
+            fcor[((c) * 3 + 0) * 32 + ms] = xb.x * W3.x;      /* y[128] */                                       \
+            fcor[((c) * 3 + 1) * 32 + ms] = y64 + y192;       /* a64 */                                          \
+            fcor[((c) * 3 + 2) * 32 + ms] = y64 - y192;       /* b64 */                                          \
+        }                                                                                                       \
+        RX[(64 * (c) + q) * QS + ms] = pe;                                                                      \
+        RX[(64 * (c) + 16 + q) * QS + ms] = po;                                                                 \
+        RX[(64 * (c) + 32 + q) * QS + ms] = qe;                                                                 \
+        RX[(64 * (c) + 48 + q) * QS + ms] = qo;                                                                 \
+    }
+            // one round: request the W_hh blocks of iterations [it0, it0+nit), then the column, contract, fold
+#define H_ROUND(c, it0, nit)                                                                                    \
+    {                                                                                                           \
+        f32x4 wq[4 * (nit)];                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < 4 * (nit); ++k) wq[k] = WL(wh + 4 * (it0) + k);                   \
+        SB();                                                                                                   \
+        X_ISSUE(c)                                                                                              \
+        SB();                                                                                                   \
+        f32x4 av = RH[(2 * (it0)) * QS + hq];                                                                   \
+        _Pragma("unroll") for (int i = 0; i < (nit); ++i) {                                                     \
+            const f32x4 nav = RH[(2 * ((it0) + (i + 1 < (nit) ? i + 1 : i))) * QS + hq];                        \
+            gi = mfma4(wq[4 * i], av, gi); gfo = mfma4(wq[4 * i + 1], av, gfo);                                 \
+            gg = mfma4(wq[4 * i + 2], av, gg); go = mfma4(wq[4 * i + 3], av, go);                               \
+            av = nav;                                                                                           \
+        }                                                                                                       \
+        /* the fold (LDS stores, waits for the column) must stay BEHIND this round's MFMAs: tie it to the accumulators */ \
+        asm volatile("" : "+a"(gi), "+a"(gfo), "+a"(gg), "+a"(go) : : "memory");                                \
+        SB();                                                                                                   \
+        X_FOLD(c)                                                                                               \
+        SB();                                                                                                   \
+    }
+            H_ROUND(0, 0, 6)
+            H_ROUND(1, 6, 5)
+            H_ROUND(2, 11, 5)
+#undef H_ROUND
+#undef X_FOLD
+#undef X_ISSUE
         }
         // weights of the first STFT iteration are requested before the barrier (they never depend on LDS)
         f32x4 Are = WL(ws_stft), Aim = WL(ws_stft + 1);
@@ -363,7 +409,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
         STAMP(10);
 
         // ---- enc3: 64 -> 128 ch, k3 s1 p1 on a single column: centre tap only ------------------
-        f32x4 lb[16], Lw0, Lw1, Lw2, Lw3;
+        f32x4 Lw0, Lw1, Lw2, Lw3;
         {
             const int ws = ws_e3 + 4;
             f32x16 acc = acc_of(e3b0, e3b1, e3b2, e3b3);
@@ -371,9 +417,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
             f32x4 Aa0 = RE[0 * QS + hq], Aa1 = RE[2 * QS + hq], Aa2 = RE[4 * QS + hq], Aa3 = RE[6 * QS + hq];
             G_LDW(B, ws, 1)
             const f32x4 Ba0 = RE[8 * QS + hq], Ba1 = RE[10 * QS + hq], Ba2 = RE[12 * QS + hq], Ba3 = RE[14 * QS + hq];
-            // the LSTM's gate biases and first weight blocks
-#pragma unroll
-            for (int k = 0; k < 16; ++k) lb[k] = WL(ws_l + k);
+            // the first weight blocks of the LSTM's input half
             Lw0 = WL(ws_l + 16); Lw1 = WL(ws_l + 17); Lw2 = WL(ws_l + 18); Lw3 = WL(ws_l + 19);
             SB();
             G_MMA(A) SB();
@@ -389,24 +433,21 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
         // ---- LSTM cell: wave w owns hidden units 32w..32w+31, all four gates -------------------
         {
             const int ws = ws_l + 16;
-            f32x16 gi = acc_of(lb[0], lb[1], lb[2], lb[3]);
-            f32x16 gfo = acc_of(lb[4], lb[5], lb[6], lb[7]);
-            f32x16 gg = acc_of(lb[8], lb[9], lb[10], lb[11]);
-            f32x16 go = acc_of(lb[12], lb[13], lb[14], lb[15]);
-            // iteration it in 0..31: it < 16 contracts x (region B rows 0..31), then h_{t-1} (region H)
-#define L_ROW(it) ((it) < 16 ? (RX + (2 * (it)) * QS + hq) : (RH + (2 * ((it) - 16)) * QS + hq))
+            // the recurrent half (W_hh . h_{t-1}, + bias) was accumulated while the frame was loading;
+            // iteration it in 0..15 contracts x = enc3 output (rows 0..31)
+#define L_ROW(it) (RX + (2 * (it)) * QS + hq)
 #define L_LD(S, it)                                                                        \
     S##wi = WL(ws + (4 * (it))); S##wf = WL(ws + (4 * (it) + 1));                  \
     S##wg = WL(ws + (4 * (it) + 2)); S##wo = WL(ws + (4 * (it) + 3)); S##av = *L_ROW(it);
 #define L_MMA(S) gi = mfma4(S##wi, S##av, gi); gfo = mfma4(S##wf, S##av, gfo); gg = mfma4(S##wg, S##av, gg); go = mfma4(S##wo, S##av, go);
             f32x4 Awi = Lw0, Awf = Lw1, Awg = Lw2, Awo = Lw3, Aav = RX[hq], Bwi, Bwf, Bwg, Bwo, Bav;
             f32x4 hw0, hw1, hw2, hw3;
-            for (int it = 0; it < 32; it += 2) {
+            for (int it = 0; it < 16; it += 2) {
                 L_LD(B, it + 1) SB();
                 L_MMA(A) SB();
-                const int itn = it + 2 < 32 ? it + 2 : 30;
+                const int itn = it + 2 < 16 ? it + 2 : 14;
                 L_LD(A, itn) SB();
-                if (it == 30) {   // head weights for the epilogue
+                if (it == 14) {   // head weights for the epilogue
                     hw0 = WL(ws + 128); hw1 = WL(ws + 129); hw2 = WL(ws + 130); hw3 = WL(ws + 131);
                     SB();
                 }
