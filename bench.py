@@ -147,9 +147,12 @@ def main() -> None:
     ts = torch.cuda.Stream()
     torch.cuda.synchronize()
 
+    ring_ptrs = [ring[i].data_ptr() for i in range(RING)]
+    probs_ptr, events_ptr, stream_handle = probs.data_ptr(), events.data_ptr(), ts.cuda_stream
+    host_enqueue = [0.0]
+
     def step(i: int) -> None:
-        eng.step_device(B, ring[i % RING].data_ptr(), probs.data_ptr(), d_events=events.data_ptr(),
-                        denoise=0.01, stream=ts.cuda_stream)
+        eng.step_device(B, ring_ptrs[i % RING], probs_ptr, d_events=events_ptr, denoise=0.01, stream=stream_handle)
 
     with torch.cuda.stream(ts):
         gpu_probs = torch.empty(PARITY_STEPS, B, device="cuda")
@@ -163,8 +166,10 @@ def main() -> None:
 
         def run() -> None:
             e0.record(ts)
+            h0 = time.perf_counter()
             for i in range(args.steps):
                 step(PARITY_STEPS + args.warmup + i)
+            host_enqueue[0] = time.perf_counter() - h0
             e1.record(ts)
 
         elapsed = sharding.timed_region(dist, run, torch.cuda.synchronize, device="cuda" if backend == "nccl" else "cpu")
@@ -211,6 +216,7 @@ def main() -> None:
                 "frac": achieved / PEAK_FP32_MFMA,
                 "traffic": traffic,
                 "kernel_us": kernel_s * 1e6,
+                "host_enqueue_us_per_launch": host_enqueue[0] / args.steps * 1e6,
                 "algorithmic_flop_per_launch": FLOP_PER_FRAME * B,
                 "hbm_algorithmic_GBps": BYTES_PER_FRAME * B / kernel_s / 1e9,
                 "hbm_frac": BYTES_PER_FRAME * B / kernel_s / PEAK_HBM,

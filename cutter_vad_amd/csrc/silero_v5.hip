@@ -31,7 +31,10 @@ using namespace vadk;
 
 using namespace vadk::dev;
 
-extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P) {
+// F32IN: frames are float32 (else int16).  A template parameter, not a branch: the frame fold must stay in one basic
+// block with the recurrent-half MFMAs for the instruction interleave below to be possible.
+template <bool F32IN>
+__global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P) {
     using namespace vadk::v5;
     __shared__ f32x4 lds[LDS_F4];
     f32x4 *const RX = lds;                       // the activation region (row map: vad_layout.h)
@@ -40,6 +43,8 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
     float *const headp = reinterpret_cast<float *>(RH + ROWS_H * QS);   // [4][32]
     float *const nyqv = headp + 128;             // [3][32] |X128| per column
     float *const fcor = nyqv + 96;               // [3 columns][y128, a64, b64][32 streams]
+    SmSlot *const smL = reinterpret_cast<SmSlot *>(fcor + 288 + 64);   // the tile's 32 state machines, resident for the call
+    constexpr int FCOR_SINK = 288;               // [64] floats after fcor: where lanes q != 0 drop their (unused) correction terms
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -63,32 +68,62 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
     const int T = P.T;
     const int hq = h * QS + m;                    // lane's offset inside a quad-row pair
 
+    // ---- frame ingest set-up (loop-invariant) ----
+    const float thr = P.thresh;
+    const int q = tid & 15;
+    const bool q0 = q == 0;
+    constexpr bool f32in = F32IN;
+    constexpr int qsh = f32in ? 4 : 3;             // log2(bytes per 4-sample quad)
+    const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
+    u32x4 xa_[8], xb_[8];                          // raw quads of a column (both 16-stream halves), as bits
+    // Column c of frame tt -> XR: lane q of a 16-lane row (one stream per row) loads quads q, 16+q, 32+q, 48+q of the
+    // column: every sample once, 4 branch-free 16-byte loads per lane and stream half.
+#define X_ISSUE(c, XR, tt)                                                                                      \
+    _Pragma("unroll") for (int rr = 0; rr < 2; ++rr) {                                                          \
+        const int fq = ((tile0 + rr * 16 + (tid >> 4)) * T + (tt)) * 128 + 32 * (c) + q;   /* quad q of the column */ \
+        /* ONE instruction stream for both formats: a quad is 16 bytes (f32) or 8 bytes (int16, the upper 8 bytes     \
+           of the 16 loaded are ignored); a format branch here breaks the compiler's vmcnt bookkeeping */        \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                           \
+            XR[rr * 4 + k] = __builtin_amdgcn_raw_buffer_load_b128(frs, (fq + 16 * k) << qsh, 0, 0);            \
+    }
+
     // ---- prologue: h_{t-1} -> LDS quads, c_{t-1} -> registers (this lane's 16 units) -------
+    f32x4 hv[4];
+    const int fm = tid & 31, part = tid >> 5;
     {
-        const int fm = tid & 31, part = tid >> 5;
         const int g2 = tile0 + fm;
-        const int s2 = g2 < P.n ? (P.slots ? P.slots[g2] : g2) : -1;
+        const bool ok = g2 < P.n;
+        const int s2 = ok ? (P.slots ? P.slots[g2] : g2) : 0;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            const int q = part * 4 + qq;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (s2 >= 0) v = reinterpret_cast<const f32x4 *>(P.state + (size_t)s2 * 256)[q];
-            RH[q * QS + fm] = v;
+            const f32x4 v = reinterpret_cast<const f32x4 *>(P.state + (size_t)s2 * 256)[part * 4 + qq];
+            hv[qq] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    const f32x4 W1 = ldw(wrs, q * 16, o_nyq), W3 = ldw(wrs, (32 + q) * 16, o_nyq);   // window w[n], w[128+n] = w[128-n]
+    const float w64 = ldw(wrs, 16 * 16, o_nyq).x;                                       // w[64] = w[192]
     f32x16 cst;   // c state of units 32w + 8g + 4h + i  (reg 4g+i)
     {
         f32x4 c4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            c4[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (live) c4[g] = *reinterpret_cast<const f32x4 *>(P.state + (size_t)slot * 256 + 128 + 32 * w + 8 * g + 4 * h);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(P.state + (size_t)slot * 256 + 128 + 32 * w + 8 * g + 4 * h);
+            c4[g] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         cst = acc_of(c4[0], c4[1], c4[2], c4[3]);
     }
+    SB();
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) RH[(part * 4 + qq) * QS + fm] = hv[qq];
     int seg_last = 0;
     const bool sm_thread = (tid < MT) && (tile0 + tid < P.n);
     const int sm_slot = sm_thread ? (P.slots ? P.slots[tile0 + tid] : tile0 + tid) : 0;
+    // the slot's state machine (96 B in HBM between calls) is fetched now, lives in LDS for the call and goes back
+    // with the last frame: its HBM latency is off the tail of the kernel
+    if (sm_thread) smL[tid] = P.sm[sm_slot];
+    const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];    // head bias
 
     __syncthreads();   // h_{t-1} visible: the recurrent gate half starts before the first frame barrier
     STAMP(0);
@@ -97,10 +132,10 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
         // values) is hoisted out of this loop as loop-invariant and spilled
         int ws_stft = o_stft, ws_nyq = o_nyq, ws_e0 = o_e0, ws_e1 = o_e1, ws_e2 = o_e2, ws_e3 = o_e3, ws_l = o_l;
         asm volatile("" : "+s"(ws_stft), "+s"(ws_nyq), "+s"(ws_e0), "+s"(ws_e1), "+s"(ws_e2), "+s"(ws_e3), "+s"(ws_l));
-        // ---- the frame is loaded in 3 rounds (one STFT column each) UNDER the recurrent half of the LSTM gates ----
-        // W_hh . h_{t-1} does not depend on the frame, so its 256 MFMAs per wave run while the column is in flight from
-        // HBM.  vmcnt retires in issue order: everything consumed during the flight (the round's W_hh blocks) is
-        // requested BEFORE the column's loads, so waiting for a weight block never waits for the frame.
+        // ---- the frame is ingested UNDER the recurrent half of the LSTM gates ----
+        // W_hh . h_{t-1} does not depend on the frame, so its 256 MFMAs per wave run while the columns are in flight from
+        // HBM and while they are folded.  vmcnt retires in issue order: the W_hh blocks of a group are requested BEFORE
+        // any column requested in the same group, so waiting for a weight block never waits for the frame.
         // Fold: output (column c, stream ms, quad q), n = 4q..4q+3, from the column's quads q (y[n]), 32+q (y[128+n]),
         // 32-q / 31-q (y[128-n], reversed) and 64-q / 63-q (y[256-n], reversed); 16 lanes run over q.
         f32x16 gi = acc_of(WL(ws_l), WL(ws_l + 1), WL(ws_l + 2), WL(ws_l + 3));
@@ -108,56 +143,43 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
         f32x16 gg = acc_of(WL(ws_l + 8), WL(ws_l + 9), WL(ws_l + 10), WL(ws_l + 11));
         f32x16 go = acc_of(WL(ws_l + 12), WL(ws_l + 13), WL(ws_l + 14), WL(ws_l + 15));
         {
-            const float thr = P.thresh;
-            const int q = tid & 15;
-            const int q2a = q == 0 ? 63 : 64 - q;          // quad 64 of column 2 does not exist; its only use (n = 0) is masked
-            const f32x4 W1 = ldw(wrs, q * 16, ws_nyq), W3 = ldw(wrs, (32 + q) * 16, ws_nyq);   // w[n], w[128+n] = w[128-n]
-            const float w64 = ldw(wrs, 16 * 16, ws_nyq).x;                                         // w[64] = w[192]
             const int wh = ws_l + 16 + 64;                 // W_hh blocks: iteration it at wh + 4 it
-            const bool f32in = P.fmt == 0;
-            const int qsh = f32in ? 4 : 3;                 // log2(bytes per 4-sample quad)
-            const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
-            const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
-            u32x4 xr[14];                                  // raw quads of one column, both stream halves, as bits (int16: 8 bytes in .xy)
-            // The column is read through a buffer descriptor over the whole frames array: streams past the end of the
-            // batch read zeros (hardware range check) WITHOUT a branch.  Every path issues exactly 14 loads per round,
-            // so the compiler's vmcnt bookkeeping stays exact (a conditional load made it wait for vmcnt(0), i.e. for
-            // the frame, in the middle of the MFMAs).
-#define X_ISSUE(c)                                                                                              \
-    _Pragma("unroll") for (int rr = 0; rr < 2; ++rr) {                                                          \
-        const int fq = ((tile0 + rr * 16 + (tid >> 4)) * T + t) * 128 + 32 * (c);      /* first quad of the column */ \
-        const int idx[7] = {q, 32 + q, 32 - q, 31 - q, q2a, 63 - q, 16 + 32 * (q & 1)};  /* last: samples 64 / 192 on lanes q = 0 / 1 */ \
-        /* ONE instruction stream for both formats: a quad is 16 bytes (f32) or 8 bytes (int16, the upper 8 bytes     \
-           of the 16 loaded are ignored); a format branch here breaks the compiler's vmcnt bookkeeping */        \
-        _Pragma("unroll") for (int k = 0; k < 7; ++k)                                                           \
-            xr[rr * 7 + k] = __builtin_amdgcn_raw_buffer_load_b128(frs, (fq + idx[k]) << qsh, 0, 0);            \
-    }
-            // int16 payloads were loaded as raw bits: decode (true division, like np.int16 -> float32 / 32767.0), then gate
+            // The recurrent half runs as 8 groups of 2 k-iterations (32 MFMAs, W_hh blocks ping-ponged one group
+            // ahead).  Columns 0, 1 and 2 are requested at groups 0, 1 and 4 (column 2 into column 0's buffer) and folded,
+            // one 16-stream half per group, at groups 2..7.  Inside a group the fold is interleaved between the MFMAs
+            // with sched_group_barrier: its LDS writes and the W_hh requests overlap the MFMAs; its VALU work does NOT
+            // (tools/ubench/mfma_valu.hip: an fp32 MFMA and VALU instructions of the same wave serialise, 64 + 4.4 n
+            // cycles), so the fold costs what its instruction count says.
+            // int16 payloads are raw bits: decode (true division, like np.int16 -> float32 / 32767.0), then gate
             auto decode = [&](u32x4 b) -> f32x4 {
                 f32x4 v = __builtin_bit_cast(f32x4, b);
-                if (!f32in) {
+                if constexpr (!f32in) {
                     const int s0 = (int)(short)(b.x & 0xffffu), s1 = (int)(short)(b.x >> 16);
                     const int s2 = (int)(short)(b.y & 0xffffu), s3 = (int)(short)(b.y >> 16);
                     v = f32x4{(float)s0 / sc, (float)s1 / sc, (float)s2 / sc, (float)s3 / sc};
                 }
                 return gate4(v, thr);
             };
-            // lane q = 0 loaded the quad holding sample 64, lane q = 1 the quad holding sample 192 (component 0 each)
-            auto decode_mid = [&](u32x4 b) -> f32x4 {
-                const f32x4 v = decode(b);
-                return f32x4{v.x, __shfl_down(v.x, 1), 0.f, 0.f};
+            // reversed reads come from the other lanes of the row: row_mirror hands lane q the value of lane 15 - q
+            // (quad 31 - q of B, 63 - q of D); one more row_shr:1 gives quad 32 - q / 64 - q (lane 0 keeps `edge`)
+            auto mirror = [](float v) -> float {
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
             };
-#define X_FOLD(c)                                                                                               \
-    _Pragma("unroll") for (int rr = 0; rr < 2; ++rr) {                                                          \
-        const int ms = rr * 16 + (tid >> 4);                                                                    \
-        const f32x4 xa = decode(xr[rr * 7 + 0]), xb = decode(xr[rr * 7 + 1]), r1a = decode(xr[rr * 7 + 2]);      \
-        const f32x4 r1b = decode(xr[rr * 7 + 3]), r2a = decode(xr[rr * 7 + 4]), r2b = decode(xr[rr * 7 + 5]);    \
-        const f32x4 mid = decode_mid(xr[rr * 7 + 6]);                                                           \
-        const f32x4 y1 = f32x4{xa.x * W1.x, xa.y * W1.y, xa.z * W1.z, xa.w * W1.w};                             \
-        const f32x4 y3 = f32x4{xb.x * W3.x, xb.y * W3.y, xb.z * W3.z, xb.w * W3.w};                             \
-        const f32x4 y2 = f32x4{r1a.x * W3.x, r1b.w * W3.y, r1b.z * W3.z, r1b.y * W3.w};                         \
-        const f32x4 y4 = f32x4{r2a.x * W1.x, r2b.w * W1.y, r2b.z * W1.z, r2b.y * W1.w};                         \
+            auto shr1 = [](float edge, float v) -> float {
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+            };
+            // Fold of (column c, stream half rr): n = 4q + j.  y1 = w[n] x[n] (A), y3 = w[128+n] x[128+n] (C),
+            // y2 = w[128-n] x[128-n] (B reversed), y4 = w[256-n] x[256-n] (D reversed); w is symmetric about 128.
+#define X_FOLD1(c, rr, XR)                                                                                      \
+    {                                                                                                           \
+        const int ms = (rr) * 16 + (tid >> 4);                                                                  \
+        const f32x4 xA = decode(XR[(rr) * 4 + 0]), xB = decode(XR[(rr) * 4 + 1]);                               \
+        const f32x4 xC = decode(XR[(rr) * 4 + 2]), xD = decode(XR[(rr) * 4 + 3]);                               \
+        const float mBx = mirror(xB.x), mDx = mirror(xD.x);                                                     \
+        const f32x4 y1 = f32x4{xA.x * W1.x, xA.y * W1.y, xA.z * W1.z, xA.w * W1.w};                             \
+        const f32x4 y3 = f32x4{xC.x * W3.x, xC.y * W3.y, xC.z * W3.z, xC.w * W3.w};                             \
+        const f32x4 y2 = f32x4{shr1(xC.x, mBx) * W3.x, mirror(xB.w) * W3.y, mirror(xB.z) * W3.z, mirror(xB.y) * W3.w}; \
+        const f32x4 y4 = f32x4{shr1(0.f, mDx) * W1.x, mirror(xD.w) * W1.y, mirror(xD.z) * W1.z, mirror(xD.y) * W1.w};  \
         const f32x4 s14 = f32x4{y1.x + y4.x, y1.y + y4.y, y1.z + y4.z, y1.w + y4.w};                            \
         const f32x4 d14 = f32x4{y1.x - y4.x, y1.y - y4.y, y1.z - y4.z, y1.w - y4.w};                            \
         const f32x4 s23 = f32x4{y2.x + y3.x, y2.y + y3.y, y2.z + y3.z, y2.w + y3.w};                            \
@@ -166,45 +188,48 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
         f32x4 po = f32x4{s14.x - s23.x, s14.y - s23.y, s14.z - s23.z, s14.w - s23.w};                           \
         f32x4 qe = f32x4{d14.x - d23.x, d14.y - d23.y, d14.z - d23.z, d14.w - d23.w};                           \
         f32x4 qo = f32x4{d14.x + d23.x, d14.y + d23.y, d14.z + d23.z, d14.w + d23.w};                           \
-        if (q == 0) {                 /* n = 0 is not part of the folded sums; rank-1 terms of n = 0 / 64 / 128 */ \
-            pe.x = po.x = qe.x = qo.x = 0.f;                                                                    \
-            const float y64 = mid.x * w64, y192 = mid.y * w64;                                                  \
-            fcor[((c) * 3 + 0) * 32 + ms] = xb.x * W3.x;      /* y[128] */                                       \
-            fcor[((c) * 3 + 1) * 32 + ms] = y64 + y192;       /* a64 */                                          \
-            fcor[((c) * 3 + 2) * 32 + ms] = y64 - y192;       /* b64 */                                          \
+        {                             /* n = 0 is not part of the folded sums; rank-1 terms of n = 0 / 64 / 128 (branch-free): */ \
+            /* lane q = 0 holds sample 64 (B.x), 128 (C.x) and 192 (D.x) of the column */                       \
+            pe.x = q0 ? 0.f : pe.x; po.x = q0 ? 0.f : po.x; qe.x = q0 ? 0.f : qe.x; qo.x = q0 ? 0.f : qo.x;        \
+            const float y64 = xB.x * w64, y192 = xD.x * w64;                                                    \
+            const int fo = q0 ? (c) * 96 + ms : FCOR_SINK + lane;                                               \
+            fcor[fo] = y3.x;                        /* y[128] */                                                 \
+            fcor[fo + (q0 ? 32 : 0)] = y64 + y192;  /* a64 */                                                    \
+            fcor[fo + (q0 ? 64 : 0)] = y64 - y192;  /* b64 */                                                    \
         }                                                                                                       \
         RX[(64 * (c) + q) * QS + ms] = pe;                                                                      \
         RX[(64 * (c) + 16 + q) * QS + ms] = po;                                                                 \
         RX[(64 * (c) + 32 + q) * QS + ms] = qe;                                                                 \
         RX[(64 * (c) + 48 + q) * QS + ms] = qo;                                                                 \
     }
-            // one round: request the W_hh blocks of iterations [it0, it0+nit), then the column, contract, fold
-#define H_ROUND(c, it0, nit)                                                                                    \
+#define H_LDW(WS, g) _Pragma("unroll") for (int k = 0; k < 8; ++k) WS[k] = WL(wh + 8 * (g) + k);
+#define H_MMA(WS, g)                                                                                            \
     {                                                                                                           \
-        f32x4 wq[4 * (nit)];                                                                                    \
-        _Pragma("unroll") for (int k = 0; k < 4 * (nit); ++k) wq[k] = WL(wh + 4 * (it0) + k);                   \
-        SB();                                                                                                   \
-        X_ISSUE(c)                                                                                              \
-        SB();                                                                                                   \
-        f32x4 av = RH[(2 * (it0)) * QS + hq];                                                                   \
-        _Pragma("unroll") for (int i = 0; i < (nit); ++i) {                                                     \
-            const f32x4 nav = RH[(2 * ((it0) + (i + 1 < (nit) ? i + 1 : i))) * QS + hq];                        \
-            gi = mfma4(wq[4 * i], av, gi); gfo = mfma4(wq[4 * i + 1], av, gfo);                                 \
-            gg = mfma4(wq[4 * i + 2], av, gg); go = mfma4(wq[4 * i + 3], av, go);                               \
-            av = nav;                                                                                           \
-        }                                                                                                       \
-        /* the fold (LDS stores, waits for the column) must stay BEHIND this round's MFMAs: tie it to the accumulators */ \
-        asm volatile("" : "+a"(gi), "+a"(gfo), "+a"(gg), "+a"(go) : : "memory");                                \
-        SB();                                                                                                   \
-        X_FOLD(c)                                                                                               \
-        SB();                                                                                                   \
+        const f32x4 av0 = RH[(4 * (g)) * QS + hq], av1 = RH[(4 * (g) + 2) * QS + hq];                           \
+        gi = mfma4(WS[0], av0, gi); gfo = mfma4(WS[1], av0, gfo); gg = mfma4(WS[2], av0, gg); go = mfma4(WS[3], av0, go); \
+        gi = mfma4(WS[4], av1, gi); gfo = mfma4(WS[5], av1, gfo); gg = mfma4(WS[6], av1, gg); go = mfma4(WS[7], av1, go); \
     }
-            H_ROUND(0, 0, 6)
-            H_ROUND(1, 6, 5)
-            H_ROUND(2, 11, 5)
-#undef H_ROUND
-#undef X_FOLD
-#undef X_ISSUE
+            // 32 x { 1 MFMA, up to NV VALU } in program order for the group that ends here
+#define H_MIX(NV)                                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 32; ++i_) {                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                                                     \
+    }
+            f32x4 wA[8], wB[8];                            // W_hh blocks of a group of 2 k-iterations, ping-pong
+            H_LDW(wA, 0)
+            SB();
+            H_LDW(wB, 1) X_ISSUE(0, xa_, t) SB(); H_MMA(wA, 0) SB(); STAMP(20);
+            H_LDW(wA, 2) X_ISSUE(1, xb_, t) SB(); H_MMA(wB, 1) SB(); STAMP(21);
+            H_LDW(wB, 3) SB(); H_MMA(wA, 2) X_FOLD1(0, 0, xa_) H_MIX(6) SB(); STAMP(22);
+            H_LDW(wA, 4) SB(); H_MMA(wB, 3) X_FOLD1(0, 1, xa_) H_MIX(6) SB(); STAMP(23);
+            H_LDW(wB, 5) X_ISSUE(2, xa_, t) SB(); H_MMA(wA, 4) X_FOLD1(1, 0, xb_) H_MIX(6) SB(); STAMP(24);
+            H_LDW(wA, 6) SB(); H_MMA(wB, 5) X_FOLD1(1, 1, xb_) H_MIX(6) SB(); STAMP(25);
+            H_LDW(wB, 7) SB(); H_MMA(wA, 6) X_FOLD1(2, 0, xa_) H_MIX(6) SB(); STAMP(26);
+            H_MMA(wB, 7) X_FOLD1(2, 1, xa_) H_MIX(6) SB(); STAMP(27);
+#undef H_MIX
+#undef H_MMA
+#undef H_LDW
+#undef X_FOLD1
         }
         // weights of the first STFT iteration are requested before the barrier (they never depend on LDS)
         f32x4 Are = WL(ws_stft), Aim = WL(ws_stft + 1);
@@ -474,8 +499,10 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
                 CELL(x) CELL(y) CELL(z) CELL(w)
 #undef CELL
                 RH[(8 * w + 2 * g) * QS + hq] = hn;
-                if (t == T - 1 && live)   // last frame of the call: h' goes back to HBM (c' follows after the loop)
+                if (t == T - 1 && live) {   // last frame of the call: h' and c' go back to HBM under barrier (8), head and state machine
                     *reinterpret_cast<f32x4 *>(P.state + (size_t)slot * 256 + 32 * w + 8 * g + 4 * h) = hn;
+                    *reinterpret_cast<f32x4 *>(P.state + (size_t)slot * 256 + 128 + 32 * w + 8 * g + 4 * h) = cn;
+                }
                 switch (g) {
                     case 0: cst.s0 = cn.x; cst.s1 = cn.y; cst.s2 = cn.z; cst.s3 = cn.w; break;
                     case 1: cst.s4 = cn.x; cst.s5 = cn.y; cst.s6 = cn.z; cst.s7 = cn.w; break;
@@ -491,16 +518,15 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
 
         // ---- head: p = sigmoid(b + sum_j w_j relu(h'_j)); then the state machine ---------------
         if (tid < MT) {
-            const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];
             const float z = hb + ((headp[tid] + headp[32 + tid]) + (headp[64 + tid] + headp[96 + tid]));
             const float p = fminf(sigmoidf_(z), 1.0f);
             if (sm_thread) {
                 P.probs[(size_t)(tile0 + tid) * T + t] = p;
-                // the slot's state machine lives in HBM between frames (96 B, 32 threads per tile)
-                SmSlot sm = P.sm[sm_slot];
+                SmSlot sm = smL[tid];
                 int seg = 0;
                 const int ev = sm_step(sm, p, &seg);
-                P.sm[sm_slot] = sm;
+                if (t == T - 1) P.sm[sm_slot] = sm;
+                else smL[tid] = sm;
                 if (ev & 2) seg_last = seg;
                 if (P.events) P.events[(size_t)(tile0 + tid) * T + t] = (uint8_t)ev;
             }
@@ -509,12 +535,8 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
         // headp is rewritten only after barriers (1)..(7) of the next frame.
     }
 
-    // ---- epilogue: state write-back ---------------------------------------------------------
-    if (live) {
-        float *st = P.state + (size_t)slot * 256;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(st + 128 + 32 * w + 8 * g + 4 * h) = quad_of(cst, g);
-    }
+#undef X_ISSUE
+    // ---- epilogue ----
     if (sm_thread && P.seg_frames) P.seg_frames[tile0 + tid] = seg_last;
 }
 
@@ -522,6 +544,9 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const S
 extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream_t stream) {
     const int tiles = (p->n + vadk::MT - 1) / vadk::MT;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(silero_v5_step, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+    if (p->fmt == 0)
+        hipLaunchKernelGGL(silero_v5_step<true>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+    else
+        hipLaunchKernelGGL(silero_v5_step<false>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
     return hipGetLastError();
 }

@@ -64,7 +64,7 @@ __host__ __device__ constexpr int bin_of_channel(int ch) {
 constexpr int ROWS_X = 194;
 constexpr int ROW_E = 98;                  // first row of the upper half (enc0 / enc2 outputs)
 constexpr int ROWS_H = 32;                 // h_{t-1}
-constexpr int LDS_F4 = (ROWS_X + ROWS_H) * QS + 32 + 24 + 72;  // + head partials [4][32], |X128| [3][32], fold corrections [3][3][32]
+constexpr int LDS_F4 = (ROWS_X + ROWS_H) * QS + 32 + 24 + 72 + 16 + 192;  // + head partials [4][32], |X128| [3][32], fold corrections [3][3][32], write sink [64], state machines [32] x 96 B
 constexpr int LDS_BYTES = LDS_F4 * 16;
 }  // namespace v5
 

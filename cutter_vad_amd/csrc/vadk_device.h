@@ -80,12 +80,12 @@ __device__ __forceinline__ f32x4 ldw(__amdgpu_buffer_rsrc_t rs, int voff, int bl
 
 __device__ __forceinline__ f32x4 gate4(f32x4 v, float thr) {
     // utils/audio.py:117-118: np.where(np.abs(x) > thr, x, 0.0); thr < 0 disables the gate
-    if (thr >= 0.f) {
-        v.x = fabsf(v.x) > thr ? v.x : 0.f;
-        v.y = fabsf(v.y) > thr ? v.y : 0.f;
-        v.z = fabsf(v.z) > thr ? v.z : 0.f;
-        v.w = fabsf(v.w) > thr ? v.w : 0.f;
-    }
+    // branch-free (a uniform branch here would split the caller's basic block and defeat its instruction interleave)
+    const bool off = !(thr >= 0.f);
+    v.x = ((fabsf(v.x) > thr) | off) ? v.x : 0.f;
+    v.y = ((fabsf(v.y) > thr) | off) ? v.y : 0.f;
+    v.z = ((fabsf(v.z) > thr) | off) ? v.z : 0.f;
+    v.w = ((fabsf(v.w) > thr) | off) ? v.w : 0.f;
     return v;
 }
 

@@ -58,10 +58,11 @@ int main(int argc, char **argv) {
     for (auto &s : sm) { memset(&s, 0, sizeof s); s.start_prob = s.end_prob = 0.7; s.start_ratio = 0.8; s.end_ratio = 0.95; s.start_count = 10; s.end_count = 50; s.seg_frames = -1; }
     CK(hipMalloc(&d_sm, sizeof(vadk::SmSlot) * B));
     CK(hipMemcpy(d_sm, sm.data(), sizeof(vadk::SmSlot) * B, hipMemcpyHostToDevice));
-    const int RING = 8;
+    const int RING = getenv("KB_RING") ? atoi(getenv("KB_RING")) : 8;
+    const float sigma = getenv("KB_SIGMA") ? (float)atof(getenv("KB_SIGMA")) : 0.1f;
     std::vector<float> fr((size_t)RING * B * T * 512);
     std::mt19937 rng(1);
-    std::normal_distribution<float> nd(0.f, 0.1f);
+    std::normal_distribution<float> nd(0.f, sigma);
     for (auto &v : fr) v = nd(rng);
     CK(hipMalloc(&d_frames, fr.size() * 4));
     CK(hipMemcpy(d_frames, fr.data(), fr.size() * 4, hipMemcpyHostToDevice));
@@ -71,6 +72,13 @@ int main(int argc, char **argv) {
     memcpy(p.sect, pw.sect, sizeof pw.sect);
     p.state = d_state; p.sm = d_sm; p.slots = nullptr; p.probs = d_probs; p.events = nullptr; p.seg_frames = nullptr;
     p.n = B; p.T = T; p.fmt = 0; p.thresh = 0.01f;
+    if (getenv("KB_SLOTS")) {          // identity slot map, like vad_step_device
+        std::vector<int> sl(B);
+        for (int i = 0; i < B; ++i) sl[i] = i;
+        int *d_sl; CK(hipMalloc(&d_sl, B * 4)); CK(hipMemcpy(d_sl, sl.data(), B * 4, hipMemcpyHostToDevice));
+        p.slots = d_sl;
+    }
+    if (getenv("KB_EVENTS")) { unsigned char *d_ev; CK(hipMalloc(&d_ev, (size_t)B * T)); p.events = d_ev; }
 #ifdef VADK_STAMPS
     const int tiles = (B + vadk::MT - 1) / vadk::MT;
     unsigned long long *d_st;
@@ -116,6 +124,13 @@ int main(int argc, char **argv) {
         double l1 = 0, l2 = 0, l3 = 0;
         for (int b = 0; b < tiles; ++b) { l1 += (double)(S(b, w, 16) - S(b, w, 2)); l2 += (double)(S(b, w, 17) - S(b, w, 4)); l3 += (double)(S(b, w, 18) - S(b, w, 12)); }
         printf("  total=%.0f | mainloops: stft=%.0f enc0=%.0f lstm=%.0f\n", tot, l1 / tiles, l2 / tiles, l3 / tiles);
+        printf("        ingest groups (cycles since frame start):");
+        for (int k = 20; k < 28; ++k) {
+            double acc = 0;
+            for (int b = 0; b < tiles; ++b) acc += (double)(S(b, w, k) - S(b, w, 0));
+            printf(" g%d=%.0f", k - 20, acc / tiles);
+        }
+        printf("\n");
     }
 #endif
     return 0;
