@@ -109,8 +109,8 @@ def cpu_leg(ring: np.ndarray, gpu_probs: np.ndarray, budget_s: float = 12.0) -> 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--streams", type=int, default=B_PER_GPU, help="streams per GPU (headline: 8192)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
