@@ -12,6 +12,7 @@ from .core.config import SampleRate, SileroModelVersion, VADConfig
 from .core.exceptions import (AudioProcessingError, CallbackError, ConfigurationError, ModelInitializationError,
                               ModelNotFoundError, VADError)
 from .core.vad_wrapper import VADWrapper
+from .core.async_vad_wrapper import AsyncVADWrapper
 from .engine import Engine
 from .pool import EnginePool, StreamBatch, default_pool
 from .utils.audio import AudioUtils
@@ -19,6 +20,6 @@ from .utils.wav_writer import WAVWriter
 
 __version__ = "0.1.0"
 
-__all__ = ["VADWrapper", "VADConfig", "SampleRate", "SileroModelVersion", "VADError", "ModelNotFoundError",
+__all__ = ["VADWrapper", "AsyncVADWrapper", "VADConfig", "SampleRate", "SileroModelVersion", "VADError", "ModelNotFoundError",
            "ConfigurationError", "AudioProcessingError", "ModelInitializationError", "CallbackError", "AudioUtils",
            "WAVWriter", "Engine", "EnginePool", "StreamBatch", "default_pool"]

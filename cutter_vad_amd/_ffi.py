@@ -27,6 +27,7 @@ VAD_FMT_F32, VAD_FMT_I16_32767, VAD_FMT_I16_32768 = 0, 1, 2
 VAD_EV_START, VAD_EV_END, VAD_EV_CONTINUE = 1, 2, 4
 VAD_FRAME_SAMPLES = 512
 VAD_STATE_FLOATS = 256
+VAD_STREAM_SAVE_BYTES = 1120
 
 
 class EngineDesc(C.Structure):
@@ -87,6 +88,8 @@ SIGNATURES = {
     "vad_stream_get_state": (C.c_int, [_vp, C.c_int64, _f32p]),
     "vad_stream_set_state": (C.c_int, [_vp, C.c_int64, _f32p]),
     "vad_stream_set_thresholds": (C.c_int, [_vp, C.c_int64, C.POINTER(Thresholds)]),
+    "vad_stream_save": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64]),
+    "vad_stream_restore": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64]),
     "vad_step": (C.c_int, [_vp, _i64p, C.c_int64, _vp, C.c_int, C.c_float, _f32p]),
     "vad_step_events": (C.c_int, [_vp, _i64p, C.c_int64, _vp, C.c_int, C.c_float, _f32p, _u8p, _i32p]),
     "vad_step_multi": (C.c_int, [_vp, _i64p, C.c_int64, C.c_int32, _vp, C.c_int, C.c_float, _f32p, _u8p]),

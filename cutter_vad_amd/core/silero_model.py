@@ -401,6 +401,72 @@ class VADProcessor:
         except Exception as e:
             raise AudioProcessingError(f"Frame processing failed: {e}")
 
+    def process_frames(self, frames: np.ndarray):
+        """The F frames of one chunk (``[F, 512]``, in order) in ONE launch (``vad_step_multi``): generator of the
+        ``ProcessingResult`` of each frame, in order, with the host bookkeeping applied as each result is taken.
+
+        The reference runs ``process_frame`` per frame (vad_wrapper.py:632-641) and a callback that raises leaves the
+        remaining frames of the chunk unprocessed (:646-647).  To keep that contract the stream is saved before the
+        launch; if the consumer stops after frame i (generator closed early) the stream is restored and frames
+        0..i are replayed, so the device ends exactly where the reference's model and counters would be.
+        A frame that fails validation raises when its turn comes, after the frames before it were delivered."""
+        frames = np.asarray(frames)
+        if frames.ndim != 2 or frames.shape[0] <= 1:
+            for f in frames.reshape(-1, frames.shape[-1]) if frames.ndim == 2 else [frames]:
+                yield self.process_frame(f)
+            return
+        if self.model is None:
+            raise ModelInitializationError(self.config.model_version.value, "Model not loaded")
+        kept, bad = [], None
+        for f in frames:
+            try:
+                kept.append(self._preprocess_audio_frame(f))
+            except AudioProcessingError as e:
+                bad = AudioProcessingError(f"Frame processing failed: {e}") if "Frame processing" not in str(e) else e
+                break
+        F = len(kept)
+        if F:
+            try:
+                self._sync_thresholds()
+                SileroVADModel._check_rate(self.config.sample_rate)
+                x = np.stack([SileroVADModel._prepare_audio_input(np.asarray(f))[0] for f in frames[:F]])[None]
+                thr = 0.01 if self.config.enable_denoising else None
+                eng, slot = self.model.engine, self.model.slot
+                saved = eng.save_stream(slot)
+                try:
+                    p, ev = eng.step_multi([slot], x, denoise=thr)
+                except AudioProcessingError:
+                    raise
+                except Exception as e:
+                    raise AudioProcessingError(f"Model prediction failed: {e}")
+            except (ModelInitializationError, AudioProcessingError):
+                raise
+            except Exception as e:
+                raise AudioProcessingError(f"Frame processing failed: {e}")
+            done = 0
+            try:
+                for i in range(F):
+                    try:
+                        probability = SileroVADModel._extract_probability(float(p[0, i]))
+                        self.model.prediction_count += 1
+                        self.voice_probabilities.append(probability)
+                        data = self._seg.push(probability, kept[i], int(ev[0, i]))
+                        data["probability"] = probability
+                        result = ProcessingResult(**data)
+                    except (ModelInitializationError, AudioProcessingError):
+                        raise
+                    except Exception as e:
+                        raise AudioProcessingError(f"Frame processing failed: {e}")
+                    done = i + 1
+                    yield result
+            finally:
+                if done < F:       # stopped early: put the device where the reference would be (after frame done-1)
+                    eng.restore_stream(slot, saved)
+                    if done:
+                        eng.step_multi([slot], x[:, :done], denoise=thr)
+        if bad is not None:
+            raise bad
+
     # -- silero_model.py:764-788: the frame that is KEPT for segments (the model gates in-kernel)
     def _preprocess_audio_frame(self, audio_frame: np.ndarray) -> np.ndarray:
         try:

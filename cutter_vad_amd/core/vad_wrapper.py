@@ -258,18 +258,27 @@ class VADWrapper:
         return AudioUtils.convert_to_mono(audio)
 
     def _process_audio_frames(self, audio_data: np.ndarray) -> None:
-        """vad_wrapper.py:610-647: frames of ``buffer_size`` at hop ``buffer_size // 2``, no carry-over;
-        a callback that raises aborts the remaining frames of this call (their state is NOT advanced),
-        which is why frames go to the engine one by one here."""
+        """vad_wrapper.py:610-647: frames of ``buffer_size`` at hop ``buffer_size // 2``, no carry-over; a callback
+        that raises aborts the remaining frames of this call (their state is NOT advanced).  The frames of a chunk
+        go to the engine in one launch (``VADProcessor.process_frames`` keeps the abort contract)."""
         try:
             frame_size = self._config.buffer_size
             hop = int(frame_size * self._DEFAULT_FRAME_OVERLAP_RATIO)
-            for frame in AudioUtils.split_into_frames(audio_data, frame_size, hop):
-                if len(frame) < frame_size:
-                    frame = np.pad(frame, (0, frame_size - len(frame)))
-                result = self._processor.process_frame(frame)
-                self._handle_callbacks(result)
-                self._state.total_frames_processed += 1
+            frames = [np.pad(f, (0, frame_size - len(f))) if len(f) < frame_size else f
+                      for f in AudioUtils.split_into_frames(audio_data, frame_size, hop)]
+            if not frames:
+                return
+            batched = getattr(self._processor, "process_frames", None)
+            if batched is None or len(frames) == 1:
+                results = (self._processor.process_frame(f) for f in frames)
+            else:
+                results = batched(np.stack(frames))
+            try:
+                for result in results:
+                    self._handle_callbacks(result)
+                    self._state.total_frames_processed += 1
+            finally:
+                results.close()
         except Exception as e:
             raise AudioProcessingError(f"Frame processing failed: {e}")
 

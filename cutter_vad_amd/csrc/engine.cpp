@@ -415,6 +415,42 @@ int vad_stream_set_state(vad_engine *e, int64_t slot, const float *hc) {
     return VAD_OK;
 }
 
+static_assert(VAD_STREAM_SAVE_BYTES == sizeof(float) * VAD_STATE_FLOATS + sizeof(vadk::SmSlot), "save blob layout");
+
+int vad_stream_save(vad_engine *e, int64_t slot, void *buf, int64_t cap) {
+    if (!e || !buf) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
+        return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
+    if (cap < VAD_STREAM_SAVE_BYTES) return e->fail(VAD_ERR_INVALID_ARG, "save buffer too small (%lld < %d)", (long long)cap, VAD_STREAM_SAVE_BYTES);
+    HIP_TRY(e, hipSetDevice(e->device));
+    char *b = static_cast<char *>(buf);
+    HIP_TRY(e, hipMemcpyAsync(b, e->d_state + (size_t)slot * VAD_STATE_FLOATS, sizeof(float) * VAD_STATE_FLOATS,
+                              hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(b + sizeof(float) * VAD_STATE_FLOATS, e->d_sm + slot, sizeof(vadk::SmSlot),
+                              hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return VAD_OK;
+}
+
+int vad_stream_restore(vad_engine *e, int64_t slot, const void *buf, int64_t nbytes) {
+    if (!e || !buf) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
+        return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
+    if (nbytes != VAD_STREAM_SAVE_BYTES) return e->fail(VAD_ERR_INVALID_ARG, "not a stream save blob (%lld bytes)", (long long)nbytes);
+    vadk::SmSlot s;
+    memcpy(&s, static_cast<const char *>(buf) + sizeof(float) * VAD_STATE_FLOATS, sizeof s);
+    if (s.start_count < 1 || s.end_count < 1 || s.start_len < 0 || s.start_len > 20 || s.end_len < 0 || s.end_len > 100)
+        return e->fail(VAD_ERR_INVALID_ARG, "corrupt stream save blob");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemcpyAsync(e->d_state + (size_t)slot * VAD_STATE_FLOATS, buf, sizeof(float) * VAD_STATE_FLOATS,
+                              hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->d_sm + slot, &s, sizeof s, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return VAD_OK;
+}
+
 int vad_stream_set_thresholds(vad_engine *e, int64_t slot, const vad_thresholds *t) {
     if (!e || !t) return VAD_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);

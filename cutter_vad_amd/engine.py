@@ -114,6 +114,15 @@ class Engine:
         hc = np.ascontiguousarray(hc, np.float32).reshape(_ffi.VAD_STATE_FLOATS)
         self._check(self._lib.vad_stream_set_state(self._h, int(slot), _ptr(hc, C.c_float)), VADError)
 
+    def save_stream(self, slot: int) -> bytes:
+        """(h, c) + state machine of one stream as an opaque blob (``vad_stream_save``)."""
+        buf = C.create_string_buffer(_ffi.VAD_STREAM_SAVE_BYTES)
+        self._check(self._lib.vad_stream_save(self._h, int(slot), buf, _ffi.VAD_STREAM_SAVE_BYTES), VADError)
+        return buf.raw
+
+    def restore_stream(self, slot: int, blob: bytes) -> None:
+        self._check(self._lib.vad_stream_restore(self._h, int(slot), blob, len(blob)), VADError)
+
     def set_thresholds(self, slot: int, start_probability=0.7, end_probability=0.7, start_ratio=0.8, end_ratio=0.95,
                        start_frame_count=10, end_frame_count=50) -> None:
         t = _ffi.Thresholds(start_probability, end_probability, start_ratio, end_ratio, start_frame_count,

@@ -1,0 +1,350 @@
+"""ASGI application with the reference server's wire protocol on the shared stream pool.
+
+Protocol (websocket_service/server/vad_websocket_server.py): ``GET /`` health (:751-759); websocket ``/vad`` with
+query parameters mode / sample_rate / channels / sample_width / frame_duration_ms / start_probability /
+end_probability / start_frame_count / end_frame_count / start_ratio / end_ratio / timeout (:532-548, :551-611);
+binary messages = one PCM frame of exactly ``sample_rate * frame_duration_ms/1000 * channels * sample_width``
+bytes, int16 little-endian scaled by 1/32767 or float32 (:326-347); text messages ``{"type": "CONFIG", ...}`` and
+``{"type": "HEARTBEAT"}`` (:702-722); events as JSON objects ``event`` / ``timestamp_ms`` / ``segment_index``
+(+ ``segment_start_ms`` / ``segment_end_ms`` / ``duration_ms`` on VOICE_END, ``message`` on INFO / ERROR /
+TIMEOUT) (:83-124).
+
+What differs from the reference is only where the model runs: the socket's receive loop just queues the frame
+on its :class:`PooledSession`; one ticker task steps ALL sessions per tick with a single launch and posts the
+events back to each socket.  Opus / AAC need PyAV, which this image does not have: those modes are refused with
+the reference's own message (:645-655).
+"""
+
+from __future__ import annotations
+
+import asyncio
+import contextlib
+import json
+import time
+import uuid
+from typing import Any, Dict, Optional
+from urllib.parse import parse_qs
+
+import numpy as np
+from fastapi import FastAPI, WebSocket, WebSocketDisconnect
+
+from ..core.config import SampleRate, SileroModelVersion, VADConfig
+from .shared_pool import PooledSession, SharedStreamPool
+
+_INT_KEYS = ("sample_rate", "channels", "sample_width", "frame_duration_ms", "start_frame_count", "end_frame_count")
+_FLOAT_KEYS = ("start_probability", "end_probability", "timeout")
+_AUDIO_KEYS = ("mode", "sample_rate", "channels", "sample_width", "frame_duration_ms")
+_VAD_KEYS = ("start_probability", "end_probability", "start_frame_count", "end_frame_count", "start_ratio", "end_ratio")
+_CONFIG_FIELDS = _AUDIO_KEYS + _VAD_KEYS + ("timeout",)
+
+
+def now_ms() -> int:
+    return int(time.time() * 1000)
+
+
+def parse_query_params(query_string: str) -> Dict[str, Any]:
+    """First value of each key; ints / floats for the keys the reference converts (:532-548) — start_ratio and
+    end_ratio stay strings there, and so they do here (pydantic coerces them later)."""
+    out: Dict[str, Any] = {}
+    for key, values in parse_qs(query_string or "").items():
+        if not values:
+            continue
+        v = values[0]
+        out[key] = int(v) if key in _INT_KEYS else float(v) if key in _FLOAT_KEYS else v
+    return out
+
+
+def default_client_config() -> Dict[str, Any]:
+    return {"audio": {"mode": "pcm", "sample_rate": 16000, "channels": 1, "sample_width": 2, "frame_duration_ms": 30},
+            "vad": {"start_probability": 0.4, "end_probability": 0.3, "start_frame_count": 6, "end_frame_count": 12,
+                    "start_ratio": 0.8, "end_ratio": 0.95},
+            "timeout": 0.0}
+
+
+def create_client_config(query_params: Dict[str, Any], config_message: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
+    """Defaults <- query parameters <- CONFIG message (:551-611)."""
+    cfg = default_client_config()
+    for layer in (query_params, {k: v for k, v in (config_message or {}).items() if v is not None}):
+        for k, v in layer.items():
+            if k in _AUDIO_KEYS:
+                cfg["audio"][k] = v
+            elif k in _VAD_KEYS:
+                cfg["vad"][k] = v
+            elif k == "timeout":
+                cfg["timeout"] = v
+    a, v = cfg["audio"], cfg["vad"]
+    a["mode"] = str(a["mode"])
+    for k in ("sample_rate", "channels", "sample_width", "frame_duration_ms"):
+        a[k] = int(a[k])
+    for k in ("start_probability", "end_probability", "start_ratio", "end_ratio"):
+        v[k] = float(v[k])
+    for k in ("start_frame_count", "end_frame_count"):
+        v[k] = int(v[k])
+    cfg["timeout"] = float(cfg["timeout"])
+    return cfg
+
+
+def frame_bytes(cfg: Dict[str, Any]) -> float:
+    a = cfg["audio"]
+    return a["sample_rate"] * (a["frame_duration_ms"] / 1000) * a["channels"] * a["sample_width"]
+
+
+def vad_config_of(cfg: Dict[str, Any]) -> VADConfig:
+    """ClientState._initialize_vad (:245-266): V5, denoising on, buffer_size = the client's frame length."""
+    a, v = cfg["audio"], cfg["vad"]
+    return VADConfig(sample_rate=SampleRate(a["sample_rate"]), model_version=SileroModelVersion.V5,
+                     vad_start_probability=v["start_probability"], vad_end_probability=v["end_probability"],
+                     voice_start_ratio=v["start_ratio"], voice_end_ratio=v["end_ratio"],
+                     voice_start_frame_count=v["start_frame_count"], voice_end_frame_count=v["end_frame_count"],
+                     enable_denoising=True, auto_convert_sample_rate=True,
+                     buffer_size=int(a["sample_rate"] * (a["frame_duration_ms"] / 1000)))
+
+
+class ClientSession:
+    """One websocket client: wire decoding, event encoding, timeout; the audio goes to the pool."""
+
+    def __init__(self, client_id: str, websocket: WebSocket, cfg: Dict[str, Any], pool: SharedStreamPool,
+                 loop: asyncio.AbstractEventLoop) -> None:
+        self.client_id = client_id
+        self.websocket = websocket
+        self.cfg = cfg
+        self.pool = pool
+        self.loop = loop
+        self.segment_index = 0
+        self.voice_start_time: Optional[float] = None
+        self.last_voice_time: Optional[float] = None
+        self.timeout_task: Optional[asyncio.Task] = None
+        self.expected_frame_bytes = int(frame_bytes(cfg)) if cfg["audio"]["mode"] == "pcm" else 0
+        self.outbox: "asyncio.Queue[Optional[str]]" = asyncio.Queue()
+        self.session: Optional[PooledSession] = None
+        self.session_error: Optional[str] = None
+        self._open(cfg)
+
+    def _open(self, cfg: Dict[str, Any]) -> None:
+        """The reference builds the wrapper for any SampleRate and only fails when a frame reaches the model
+        (the V5 graph's 8 kHz branch cannot take 512-sample frames): same here, frame by frame."""
+        try:
+            vc = vad_config_of(cfg)
+            if self.session is None:
+                self.session = self.pool.open_session(vc)
+                self._bind()
+            else:
+                self.pool.reconfigure(self.session, vc)
+            self.session_error = None
+        except Exception as e:
+            self.session_error = f"Audio processing failed: Frame processing failed: {e}"
+
+    def _bind(self) -> None:
+        # pool callbacks run on the ticker's thread: hand the event to the socket's loop, in order
+        post = self.loop.call_soon_threadsafe
+        self.session.set_callbacks(lambda: post(self._on_voice_start), lambda wav: post(self._on_voice_end),
+                                   lambda pcm: post(self._on_voice_continue),
+                                   lambda e: post(self.send_error, f"Audio processing error: {e}"))
+
+    # -- events (:83-124, :428-498)
+    def _emit(self, event: str, **fields) -> None:
+        msg = {"event": event, "timestamp_ms": fields.pop("timestamp_ms", now_ms()), "segment_index": None}
+        msg.update(fields)
+        self.outbox.put_nowait(json.dumps(msg))
+
+    def send_info(self, message: str) -> None:
+        self._emit("INFO", message=message)
+
+    def send_error(self, message: str) -> None:
+        self._emit("ERROR", message=message)
+
+    def _on_voice_start(self) -> None:
+        self.voice_start_time = time.time()
+        self._emit("VOICE_START", segment_index=self.segment_index)
+
+    def _on_voice_continue(self) -> None:
+        self._emit("VOICE_CONTINUE", segment_index=self.segment_index)
+
+    def _on_voice_end(self) -> None:
+        t = time.time()
+        end_ms = int(t * 1000)
+        start_ms = int(self.voice_start_time * 1000) if self.voice_start_time else end_ms
+        self._emit("VOICE_END", timestamp_ms=end_ms, segment_index=self.segment_index, segment_start_ms=start_ms,
+                   segment_end_ms=end_ms, duration_ms=end_ms - start_ms)
+        self.segment_index += 1
+        if self.timeout_task:
+            self.timeout_task.cancel()
+            self.timeout_task = None
+        if self.cfg["timeout"] > 0:
+            self.timeout_task = asyncio.ensure_future(self._timeout_monitor())
+
+    async def _timeout_monitor(self) -> None:
+        try:
+            while True:
+                await asyncio.sleep(1.0)
+                if self.last_voice_time and self.cfg["timeout"] > 0 and time.time() - self.last_voice_time >= self.cfg["timeout"]:
+                    self._emit("TIMEOUT", message="no voice detected in configured timeout")
+                    break
+        except asyncio.CancelledError:
+            pass
+
+    # -- audio (:326-380)
+    def process_audio_frame(self, data: bytes) -> None:
+        a = self.cfg["audio"]
+        if a["mode"] != "pcm":
+            self.send_error(f"No decoder available for {a['mode']}")
+            return
+        if len(data) != self.expected_frame_bytes:
+            self.send_error(f"Invalid frame size: expected {self.expected_frame_bytes}, got {len(data)}")
+            return
+        if a["sample_width"] == 2:
+            x = np.frombuffer(data, dtype=np.int16).astype(np.float32) / 32767.0
+        elif a["sample_width"] == 4:
+            x = np.frombuffer(data, dtype=np.float32)
+        else:
+            self.send_error(f"Unsupported sample width: {a['sample_width']}")
+            return
+        try:
+            # multi-channel frames go to the model interleaved, as the reference hands them over (:369)
+            if self.session_error is not None or self.session is None:
+                raise RuntimeError(self.session_error or "VAD wrapper not initialized")
+            self.session.submit(x)
+            self.last_voice_time = time.time()
+            if self.cfg["timeout"] > 0 and not self.timeout_task:
+                self.timeout_task = asyncio.ensure_future(self._timeout_monitor())
+        except Exception as e:
+            self.send_error(f"Audio processing error: {e}")
+
+    def update_config(self, cfg: Dict[str, Any]) -> None:
+        old, self.cfg = self.cfg, cfg
+        if old["audio"] != cfg["audio"]:
+            self.expected_frame_bytes = int(frame_bytes(cfg)) if cfg["audio"]["mode"] == "pcm" else 0
+        if old["vad"] != cfg["vad"] or old["audio"]["sample_rate"] != cfg["audio"]["sample_rate"] \
+                or old["audio"]["frame_duration_ms"] != cfg["audio"]["frame_duration_ms"]:
+            self._open(cfg)
+
+    def cleanup(self) -> None:
+        if self.timeout_task:
+            self.timeout_task.cancel()
+        if self.session is not None:
+            self.session.close()
+        self.outbox.put_nowait(None)
+
+
+def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0.010) -> FastAPI:
+    state: Dict[str, Any] = {"pool": pool, "clients": {}, "ticker": None}
+
+    @contextlib.asynccontextmanager
+    async def lifespan(_app: FastAPI):
+        yield
+        if state["ticker"] is not None:
+            state["ticker"].cancel()
+
+    app = FastAPI(title="VAD WebSocket Server", description="Real-time Voice Activity Detection WebSocket Server "
+                  "(shared MI355X stream pool)", version="1.0.0", lifespan=lifespan)
+    app.state.vad = state
+
+    def get_pool() -> SharedStreamPool:
+        if state["pool"] is None:
+            state["pool"] = SharedStreamPool(tick_interval=tick_interval)
+        return state["pool"]
+
+    async def ticker() -> None:
+        loop = asyncio.get_running_loop()
+        p = get_pool()
+        while True:
+            t0 = time.perf_counter()
+            if p.session_count:
+                await loop.run_in_executor(None, p.tick)        # the launch + fan-out never block the event loop
+            await asyncio.sleep(max(0.0, tick_interval - (time.perf_counter() - t0)))
+
+    def ensure_ticker() -> None:
+        if state["ticker"] is None or state["ticker"].done():
+            state["ticker"] = asyncio.ensure_future(ticker())
+
+    @app.get("/")
+    async def root():
+        return {"message": "VAD WebSocket Server", "status": "running", "connected_clients": len(state["clients"]),
+                "timestamp": now_ms()}
+
+    @app.get("/stats")
+    async def stats():
+        return get_pool().stats()
+
+    async def refuse(websocket: WebSocket, message: str) -> None:
+        await websocket.send_text(json.dumps({"event": "ERROR", "message": message, "timestamp_ms": now_ms()}))
+        await websocket.close()
+
+    @app.websocket("/vad")
+    async def websocket_endpoint(websocket: WebSocket):
+        client_id = str(uuid.uuid4())
+        client: Optional[ClientSession] = None
+        sender: Optional[asyncio.Task] = None
+        try:
+            await websocket.accept()
+            query = parse_query_params(str(websocket.query_params))
+            try:
+                cfg = create_client_config(query)
+            except (TypeError, ValueError) as e:
+                await refuse(websocket, f"Invalid configuration: {e}")
+                return
+            mode = cfg["audio"]["mode"]
+            if mode not in ("pcm", "opus", "aac"):
+                await refuse(websocket, f"Unsupported audio mode: {mode}")
+                return
+            if mode in ("opus", "aac"):
+                await refuse(websocket, f"PyAV is required for {mode} decoding but not installed")
+                return
+            fb = frame_bytes(cfg)
+            if fb != int(fb):
+                await refuse(websocket, f"Frame duration {cfg['audio']['frame_duration_ms']}ms produces non-integer bytes ({fb})")
+                return
+            ensure_ticker()
+            client = ClientSession(client_id, websocket, cfg, get_pool(), asyncio.get_running_loop())
+            state["clients"][client_id] = client
+
+            async def pump() -> None:
+                while True:
+                    msg = await client.outbox.get()
+                    if msg is None:
+                        return
+                    try:
+                        await websocket.send_text(msg)
+                    except Exception:
+                        return
+
+            sender = asyncio.ensure_future(pump())
+            client.send_info("VAD WebSocket server ready")
+            while True:
+                try:
+                    message = await websocket.receive()
+                    if message.get("type") == "websocket.disconnect":
+                        break
+                    if message.get("bytes") is not None:
+                        client.process_audio_frame(message["bytes"])
+                    elif message.get("text") is not None:
+                        try:
+                            data = json.loads(message["text"])
+                            kind = data.get("type") if isinstance(data, dict) else None
+                            if kind == "CONFIG":
+                                client.update_config(create_client_config(query, {k: data.get(k) for k in _CONFIG_FIELDS}))
+                                client.send_info("Configuration updated")
+                            elif kind == "HEARTBEAT":
+                                client.send_info("Heartbeat received")
+                            else:
+                                client.send_error(f"Unknown message type: {kind}")
+                        except json.JSONDecodeError as e:
+                            client.send_error(f"Invalid JSON: {e}")
+                        except (TypeError, ValueError) as e:
+                            client.send_error(f"Invalid message format: {e}")
+                except WebSocketDisconnect:
+                    break
+                except Exception as e:
+                    client.send_error(f"Server error: {e}")
+                    break
+        finally:
+            if client is not None:
+                client.cleanup()
+                state["clients"].pop(client_id, None)
+            if sender is not None:
+                try:
+                    await asyncio.wait_for(sender, 1.0)
+                except Exception:
+                    sender.cancel()
+
+    return app

@@ -1,0 +1,310 @@
+"""All client sessions of a process on ONE stream pool: the multi-stream caller the engine is built for.
+
+The reference gives every websocket client its own ``VADWrapper`` (own ORT session, own lock) and runs the
+model inline in the socket's receive loop, one frame at a time
+(/root/reference/websocket_service/server/vad_websocket_server.py:277, :369).  Here a session is one slot of
+the shared engine; ``submit()`` only queues a frame, and a ticker advances EVERY session that has a frame
+pending with one ``vad_step_events`` launch (gate + model + state machine on the device for the whole
+batch), then fans the events out to the sessions' callbacks.
+
+Per-session semantics are those of the reference's ``VADWrapper`` with ``buffer_size`` = the client's frame
+length (``vad_websocket_server.py:253-266``): frames shorter than 512 samples are zero-padded on the right
+(core/silero_model.py:464-468), longer ones truncated; the denoise gate applies to the model input (in the
+kernel) and to the audio kept for the segment (utils/audio.py:104-121); START / CONTINUE / END follow
+``_process_voice_state`` (core/silero_model.py:790-949) — the decisions come from the device state machine,
+the host only keeps the audio: pre-roll = the above-threshold frames before START (:838-869), CONTINUE
+carries the frame's float32 bytes (:891-895), END carries the WAV of the segment (:925-949).
+A session's frames are processed in submission order, at most one per tick.
+
+The host work per tick is vectorised over sessions; Python touches a session individually only when it has
+an event, is inside a segment or is collecting pre-roll.
+"""
+
+from __future__ import annotations
+
+import threading
+import time
+from collections import deque
+from typing import Callable, Deque, Dict, List, Optional
+
+import numpy as np
+
+from .. import _ffi
+from ..core.config import SileroModelVersion, VADConfig
+from ..core.exceptions import AudioProcessingError, CallbackError
+from ..core.silero_model import SileroVADModel
+from ..pool import EnginePool, default_pool, resolve_model_path
+from ..utils.audio import AudioUtils
+from ..utils.wav_writer import WAVWriter
+
+FRAME = 512
+
+
+class PooledSession:
+    """One client stream: a slot of the shared engine + the host half of its voice segments."""
+
+    __slots__ = ("pool", "slot", "config", "pending", "on_start", "on_end", "on_continue", "on_error", "active",
+                 "preroll", "segment", "frames_done", "last_probability", "closed", "wav_writer", "_thr", "user")
+
+    def __init__(self, pool: "SharedStreamPool", slot: int, config: VADConfig) -> None:
+        self.pool = pool
+        self.slot = slot
+        self.config = config
+        self.pending: Deque[np.ndarray] = deque()
+        self.on_start: Optional[Callable[[], None]] = None
+        self.on_end: Optional[Callable[[bytes], None]] = None
+        self.on_continue: Optional[Callable[[bytes], None]] = None
+        self.on_error: Optional[Callable[[Exception], None]] = None
+        self.active = False
+        self.preroll: List[np.ndarray] = []
+        self.segment: List[np.ndarray] = []
+        self.frames_done = 0
+        self.last_probability = 0.0
+        self.closed = False
+        self.wav_writer = WAVWriter(sample_rate=config.output_wav_sample_rate, bit_depth=config.output_wav_bit_depth,
+                                    channels=1)
+        self._thr = float(config.vad_start_probability)
+        self.user = None
+
+    def set_callbacks(self, voice_start_callback=None, voice_end_callback=None, voice_continue_callback=None,
+                      error_callback=None) -> None:
+        self.on_start, self.on_end, self.on_continue = voice_start_callback, voice_end_callback, voice_continue_callback
+        self.on_error = error_callback
+
+    def submit(self, frame) -> None:
+        self.pool.submit(self, frame)
+
+    def is_voice_active(self) -> bool:
+        return self.active
+
+    def close(self) -> None:
+        self.pool.close_session(self)
+
+
+class SharedStreamPool:
+    def __init__(self, model_version: SileroModelVersion = SileroModelVersion.V5, device_id: Optional[int] = None,
+                 max_streams: Optional[int] = None, pool: Optional[EnginePool] = None,
+                 tick_interval: float = 0.010) -> None:
+        self._base = VADConfig(model_version=model_version)
+        self._pool = pool or default_pool()
+        self.engine = self._pool.engine_for(resolve_model_path(self._base), model_version, device_id, max_streams)
+        self.tick_interval = tick_interval
+        self._lock = threading.Lock()              # sessions / pending queues
+        self._tick_lock = threading.Lock()         # one tick at a time
+        self._sessions: Dict[int, PooledSession] = {}
+        self._ready: Dict[int, PooledSession] = {}  # sessions with at least one pending frame (insertion-ordered)
+        self._thread: Optional[threading.Thread] = None
+        self._stop = threading.Event()
+        self.ticks = 0
+        self.frames = 0
+        self.launches = 0
+
+    # ------------------------------------------------------------------ sessions
+    def open_session(self, config: Optional[VADConfig] = None) -> PooledSession:
+        cfg = config or self._base
+        if cfg.model_version != self._base.model_version:
+            raise AudioProcessingError(f"this pool serves Silero {self._base.model_version.value} streams")
+        SileroVADModel._check_rate(cfg.sample_rate)        # same error as the reference's 8 kHz graph branch
+        slot = int(self.engine.open_stream())
+        try:
+            self.engine.set_thresholds(slot, cfg.vad_start_probability, cfg.vad_end_probability, cfg.voice_start_ratio,
+                                       cfg.voice_end_ratio, cfg.voice_start_frame_count, cfg.voice_end_frame_count)
+        except Exception:
+            self.engine.close_stream(slot)
+            raise
+        s = PooledSession(self, slot, cfg)
+        with self._lock:
+            self._sessions[slot] = s
+        return s
+
+    def close_session(self, s: PooledSession) -> None:
+        with self._tick_lock:                      # never under a running launch
+            with self._lock:
+                if s.closed:
+                    return
+                s.closed = True
+                s.pending.clear()
+                self._sessions.pop(s.slot, None)
+                self._ready.pop(s.slot, None)
+            self.engine.close_stream(s.slot)
+
+    def reconfigure(self, s: PooledSession, config: VADConfig) -> None:
+        """New thresholds / frame length for a live session; like ``ClientState.update_config`` rebuilding its
+        wrapper (vad_websocket_server.py:300-318) the stream starts from a clean state."""
+        SileroVADModel._check_rate(config.sample_rate)
+        with self._tick_lock:
+            with self._lock:
+                s.pending.clear()
+                self._ready.pop(s.slot, None)
+            self.engine.reset([s.slot])
+            self.engine.set_thresholds(s.slot, config.vad_start_probability, config.vad_end_probability,
+                                       config.voice_start_ratio, config.voice_end_ratio, config.voice_start_frame_count,
+                                       config.voice_end_frame_count)
+            s.config = config
+            s._thr = float(config.vad_start_probability)
+            s.active = False
+            s.preroll, s.segment = [], []
+            s.wav_writer = WAVWriter(sample_rate=config.output_wav_sample_rate, bit_depth=config.output_wav_bit_depth,
+                                     channels=1)
+
+    @property
+    def session_count(self) -> int:
+        return len(self._sessions)
+
+    # ------------------------------------------------------------------ ingest
+    def submit(self, s: PooledSession, frame) -> None:
+        """Queue one frame (float32 in [-1, 1], any length; the model sees it padded / truncated to 512)."""
+        x = np.asarray(frame)
+        if x.dtype != np.float32:
+            x = x.astype(np.float32)
+        if x.ndim != 1 or x.size == 0:
+            raise AudioProcessingError("Audio data cannot be empty" if x.size == 0 else
+                                       f"Audio data must be 1D, got {x.ndim}D array")
+        if not np.isfinite(x).all():
+            raise AudioProcessingError("Audio data contains NaN values" if np.isnan(x).any() else
+                                       "Audio data contains infinite values")
+        with self._lock:
+            if s.closed:
+                raise AudioProcessingError("session is closed")
+            s.pending.append(x)
+            self._ready[s.slot] = s
+
+    # ------------------------------------------------------------------ the tick
+    def tick(self) -> int:
+        """Advance every session that has a frame pending by ONE frame, in one launch.  Returns the number of
+        frames processed.  Callbacks run on the calling thread, outside the pool's locks, in slot order."""
+        with self._tick_lock:
+            with self._lock:
+                batch = list(self._ready.values())
+                frames = [s.pending.popleft() for s in batch]
+                for s in batch:
+                    if not s.pending:
+                        del self._ready[s.slot]
+            n = len(batch)
+            if n == 0:
+                return 0
+            x = np.zeros((n, FRAME), np.float32)
+            for i, f in enumerate(frames):
+                m = min(f.size, FRAME)
+                x[i, :m] = f[:m]
+            slots = np.fromiter((s.slot for s in batch), np.int64, n)
+            # the gate is a per-pool constant in the kernel call; sessions that disabled denoising are rare enough to
+            # get their own launch
+            groups = {}
+            for i, s in enumerate(batch):
+                groups.setdefault(bool(s.config.enable_denoising), []).append(i)
+            p = np.empty(n, np.float32)
+            ev = np.zeros(n, np.uint8)
+            err: Optional[Exception] = None
+            for gate_on, idx in groups.items():
+                ii = np.asarray(idx)
+                try:
+                    pp, ee, _ = self.engine.step_events(slots[ii], x[ii], denoise=0.01 if gate_on else None)
+                    p[ii], ev[ii] = pp, ee
+                    self.launches += 1
+                except Exception as e:              # engine failure: every session of the launch hears about it
+                    err = e
+                    p[ii], ev[ii] = np.nan, 0
+            self.ticks += 1
+            self.frames += n
+        self._fan_out(batch, frames, p, ev, err)
+        return n
+
+    def _fan_out(self, batch, frames, p, ev, err) -> None:
+        thr = np.fromiter((s._thr for s in batch), np.float64, len(batch))
+        act = np.fromiter((s.active for s in batch), bool, len(batch))
+        pre = np.fromiter((bool(s.preroll) for s in batch), bool, len(batch))
+        p64 = p.astype(np.float64)
+        busy = np.nonzero((ev != 0) | act | pre | (p64 >= thr) | ~np.isfinite(p64))[0]
+        for s, pi in zip(batch, p):
+            s.frames_done += 1
+            s.last_probability = float(pi)
+        for i in busy:
+            s = batch[i]
+            try:
+                if err is not None or not np.isfinite(p[i]):
+                    raise AudioProcessingError(f"Model prediction failed: {err}")
+                self._advance(s, frames[i], float(p[i]), int(ev[i]))
+            except Exception as e:
+                if s.on_error is not None:
+                    s.on_error(e)
+
+    @staticmethod
+    def _advance(s: PooledSession, frame: np.ndarray, p: float, ev: int) -> None:
+        kept = frame
+        if s.config.enable_denoising:
+            kept = AudioUtils.denoise_audio(frame)
+        if not s.active:
+            if p >= s._thr:
+                s.preroll.append(kept)
+            else:
+                s.preroll = []
+            if ev & _ffi.VAD_EV_START:
+                s.active = True
+                s.segment, s.preroll = s.preroll, []
+                SharedStreamPool._call(s.on_start, "voice_start")
+            elif ev:
+                raise AudioProcessingError(f"state machine divergence: device events {ev} on an idle session")
+            return
+        s.segment.append(kept)
+        wav = None
+        if ev & _ffi.VAD_EV_END:
+            wav = s.wav_writer.write_wav_data(np.concatenate(s.segment))
+            s.active = False
+            s.segment = []
+        # order on the END frame as the reference's wrapper delivers it: voice_end, then voice_continue
+        # (core/vad_wrapper.py:505-519)
+        if wav is not None:
+            SharedStreamPool._call(s.on_end, "voice_end", wav)
+        SharedStreamPool._call(s.on_continue, "voice_continue", kept.tobytes())
+
+    @staticmethod
+    def _call(cb, name: str, *args) -> None:
+        if cb is None:
+            return
+        try:
+            cb(*args)
+        except Exception as e:
+            raise CallbackError(name, e)
+
+    # ------------------------------------------------------------------ tickers
+    def drain(self, max_ticks: int = 1 << 30) -> int:
+        """Tick until no session has a pending frame (tests, offline use)."""
+        total = 0
+        for _ in range(max_ticks):
+            n = self.tick()
+            if n == 0:
+                break
+            total += n
+        return total
+
+    def start(self) -> None:
+        """Background ticker thread: one tick every ``tick_interval`` seconds (sooner never helps: a client sends
+        one frame per 30 ms)."""
+        if self._thread is not None:
+            return
+        self._stop.clear()
+
+        def loop():
+            while not self._stop.is_set():
+                t0 = time.perf_counter()
+                self.tick()
+                self._stop.wait(max(0.0, self.tick_interval - (time.perf_counter() - t0)))
+
+        self._thread = threading.Thread(target=loop, name="vad-pool-ticker", daemon=True)
+        self._thread.start()
+
+    def stop(self) -> None:
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+            self._thread = None
+
+    def close(self) -> None:
+        self.stop()
+        for s in list(self._sessions.values()):
+            self.close_session(s)
+
+    def stats(self) -> dict:
+        return {"sessions": self.session_count, "ticks": self.ticks, "frames": self.frames, "launches": self.launches,
+                "frames_per_launch": self.frames / self.launches if self.launches else 0.0}

@@ -134,6 +134,14 @@ VAD_API int vad_stream_set_state(vad_engine *e, int64_t slot, const float *hc);
 /* VADWrapper.set_thresholds  core/vad_wrapper.py:367-419: values only (validation lives in the host mirror);
  * the counters/history of the slot are NOT reset here - the wrapper calls vad_stream_reset next, as :412-413 does */
 VAD_API int vad_stream_set_thresholds(vad_engine *e, int64_t slot, const vad_thresholds *t);
+/* Everything a stream is between two frames, as one opaque blob: (h, c) + the state machine's thresholds,
+ * counters and history (VAD_STREAM_SAVE_BYTES).  No reference counterpart: the reference processes a chunk's frames
+ * one by one and a callback that raises leaves the later frames unprocessed (core/vad_wrapper.py:638-647); the host
+ * mirror runs a chunk's frames in ONE launch and uses save / restore to step back to that point.  Also what slot
+ * migration between engines / GPUs moves (1 120 B per stream). */
+#define VAD_STREAM_SAVE_BYTES 1120
+VAD_API int vad_stream_save(vad_engine *e, int64_t slot, void *buf, int64_t cap);
+VAD_API int vad_stream_restore(vad_engine *e, int64_t slot, const void *buf, int64_t nbytes);
 
 /* ---- the hot path ------------------------------------------------------------------- */
 

@@ -83,6 +83,31 @@ class FakeEngine:
             ev[i], seg[i] = e, sg
         return p, ev, seg
 
+    def step_multi(self, slots, frames, denoise=0.01, i16_scale=32767):
+        frames = np.asarray(frames, np.float32)
+        n, T = frames.shape[0], frames.shape[1]
+        p = np.empty((n, T), np.float64)
+        ev = np.zeros((n, T), np.uint8)
+        for t in range(T):
+            p[:, t], ev[:, t], _ = self.step_events(slots, frames[:, t], denoise)
+        self.multi_calls = getattr(self, "multi_calls", 0) + 1
+        return p, ev
+
+    def save_stream(self, s):
+        import ctypes
+        sm = self.sm[int(s)]
+        return (self.state[int(s)].copy(), ctypes.string_at(sm._buf, len(sm._buf)), self.thr[int(s)])
+
+    def restore_stream(self, s, blob):
+        import ctypes
+        st, raw, thr = blob
+        self.state[int(s)] = st.copy()
+        self.thr[int(s)] = thr
+        sm = oracle.StateMachine(*thr)
+        ctypes.memmove(sm._buf, raw, len(raw))
+        self.sm[int(s)] = sm
+        self.restores = getattr(self, "restores", 0) + 1
+
     def close(self):
         self.handle = False
 

@@ -1,0 +1,145 @@
+"""BASELINE.json's full size (8 192 streams per GPU) through the C ABI: size-independent properties.
+
+The oracle cannot run 8 192 x T frames in seconds, so at this size the HIP path is checked by
+  * a random sample of streams against the oracle (same tolerance as the small tests),
+  * tile-position independence (a stream's result does not depend on which workgroup / lane serves it, bit-exact),
+  * duplicate streams (same audio in two slots -> bit-identical probabilities and state),
+  * T frames in one launch == T launches of one frame (bit-exact, probabilities and state),
+  * int16 ingest == float32 ingest of the same quantised signal (bit-exact),
+  * the device state machine replayed by the oracle's on the device's own probabilities (exact events),
+  * reset -> the run repeats bit-exactly.
+Bit-exactness is the right bar for these: they compare the kernel with itself on identical arithmetic.
+"""
+
+import numpy as np
+import pytest
+
+from cutter_vad_amd import weights_io
+from tests.signals import make_streams
+
+pytestmark = pytest.mark.gpu
+
+B = 8192
+TOL_P = 2e-5
+
+
+@pytest.fixture(scope="module", params=[5, 4])
+def setup(request):
+    from cutter_vad_amd.engine import Engine
+    from oracle import oracle
+    v = request.param
+    with open(weights_io.packaged_blob_path(v), "rb") as f:
+        blob = f.read()
+    eng = Engine(blob, model_version=v, max_streams=B)
+    slots = eng.open_streams(B)
+    yield v, eng, slots, oracle.OracleModel(blob, "f64")
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def frames():
+    T = 6
+    x = make_streams(B // 2, T, seed=7)
+    return np.concatenate([x, x], axis=0)          # stream i + 4096 hears what stream i hears
+
+
+def test_sampled_streams_match_oracle_and_duplicates_are_identical(setup, frames):
+    from oracle import oracle
+    v, eng, slots, om = setup
+    eng.reset(slots)
+    T = frames.shape[1]
+    got = np.stack([eng.step(slots, frames[:, t]) for t in range(T)], axis=1)
+    assert np.isfinite(got).all() and (got >= 0).all() and (got <= 1).all()
+    # duplicates: different tiles, different lanes, same bits
+    assert np.array_equal(got[: B // 2], got[B // 2:])
+    assert np.array_equal(eng.get_state(int(slots[5])), eng.get_state(int(slots[5 + B // 2])))
+    # a random sample against the oracle
+    pick = np.random.default_rng(3).choice(B, 96, replace=False)
+    st = np.zeros((pick.size, 256), np.float32)
+    worst = 0.0
+    for t in range(T):
+        ref = om.step_batch(oracle.denoise(frames[pick, t]).reshape(pick.size, 512), st, nthreads=8)
+        worst = max(worst, float(np.abs(got[pick, t] - ref).max()))
+    assert worst <= TOL_P, worst
+    got_state = np.stack([eng.get_state(int(slots[i])) for i in pick[:8]])
+    assert np.abs(got_state - st[:8]).max() <= 2e-4
+
+
+def test_tile_position_independence(setup, frames):
+    v, eng, slots, _ = setup
+    T = 3
+    eng.reset(slots)
+    full = np.stack([eng.step(slots, frames[:, t]) for t in range(T)], axis=1)
+    # the same audio served alone, and as a ragged batch of 45 placed on other slots
+    pick = [0, 31, 32, 4095, 4097, 8191]
+    for i in pick:
+        eng.reset(slots[:1])
+        alone = np.array([eng.step(slots[:1], frames[i:i + 1, t])[0] for t in range(T)])
+        assert np.array_equal(alone, full[i]), i
+    sub = np.arange(100, 145)
+    eng.reset(slots[:45])
+    ragged = np.stack([eng.step(slots[:45], frames[sub, t]) for t in range(T)], axis=1)
+    assert np.array_equal(ragged, full[sub])
+
+
+def test_multi_frame_launch_equals_single_frame_launches(setup, frames):
+    v, eng, slots, _ = setup
+    T = frames.shape[1]
+    eng.reset(slots)
+    single = np.stack([eng.step(slots, frames[:, t]) for t in range(T)], axis=1)
+    s_single = eng.get_state(int(slots[777]))
+    eng.reset(slots)
+    multi, _ = eng.step_multi(slots, frames)
+    assert np.array_equal(multi, single)
+    assert np.array_equal(eng.get_state(int(slots[777])), s_single)
+
+
+def test_int16_ingest_is_bit_identical_to_float_ingest(setup, frames):
+    v, eng, slots, _ = setup
+    q = np.clip(np.round(frames[:, :2] * 32767.0), -32768, 32767).astype(np.int16)
+    for scale in (32767, 32768):
+        xf = (q.astype(np.float32) / np.float32(scale)).astype(np.float32)
+        eng.reset(slots)
+        a = np.stack([eng.step(slots, xf[:, t]) for t in range(2)], axis=1)
+        eng.reset(slots)
+        b = np.stack([eng.step(slots, q[:, t], i16_scale=scale) for t in range(2)], axis=1)
+        assert np.array_equal(a, b), scale
+
+
+def test_device_state_machines_follow_the_oracle_at_full_size(setup):
+    from oracle import oracle
+    v, eng, slots, _ = setup
+    T = 36
+    x = make_streams(B // 8, T, seed=21)
+    x[:, 14:24] *= 0.01                               # a quiet block: segments end and start again
+    x = np.tile(x, (8, 1, 1))
+    eng.reset(slots)
+    for s in slots:
+        eng.set_thresholds(int(s), 0.5, 0.35, 0.8, 0.95, 3, 4)
+    sms = [oracle.StateMachine(0.5, 0.35, 0.8, 0.95, 3, 4) for _ in range(B // 8)]
+    starts = ends = 0
+    try:
+        for t in range(T):
+            p, ev, seg = eng.step_events(slots, x[:, t])
+            for k in range(1, 8):                      # the 8 copies agree bit for bit
+                assert np.array_equal(ev[: B // 8], ev[k * (B // 8):(k + 1) * (B // 8)])
+            for i, sm in enumerate(sms):
+                e_ref, s_ref = sm.step(float(p[i]), 1)
+                assert ev[i] == e_ref and seg[i] == (s_ref if e_ref & 2 else 0), (t, i)
+            starts += int((ev & 1).sum())
+            ends += int(((ev & 2) != 0).sum())
+        assert starts > 1000 and ends > 1000, (starts, ends)
+    finally:
+        for s in slots:
+            eng.set_thresholds(int(s))
+
+
+def test_reset_repeats_the_run(setup, frames):
+    v, eng, slots, _ = setup
+    eng.reset(slots)
+    a = eng.step(slots, frames[:, 0])
+    b = eng.step(slots, frames[:, 1])
+    eng.reset(slots)
+    assert np.array_equal(eng.step(slots, frames[:, 0]), a)
+    assert np.array_equal(eng.step(slots, frames[:, 1]), b)
+    assert not np.array_equal(a, b)

@@ -176,3 +176,39 @@ def test_errors(engine):
             engine.step([s], np.zeros((1, 400), np.float32))          # caller must pad to 512
     finally:
         engine.close_stream(s)
+
+
+def test_stream_save_restore(engine):
+    from cutter_vad_amd import VADError
+    from cutter_vad_amd import _ffi
+    frames = make_streams(3, 6, seed=77)
+    slots = engine.open_streams(3)
+    try:
+        for s in slots:
+            engine.set_thresholds(int(s), 0.5, 0.35, 0.8, 0.95, 2, 3)
+        for t in range(3):
+            engine.step_events(slots, frames[:, t])
+        blobs = [engine.save_stream(int(s)) for s in slots]
+        assert all(len(b) == _ffi.VAD_STREAM_SAVE_BYTES for b in blobs)
+        a = [engine.step_events(slots, frames[:, t]) for t in range(3, 6)]
+        # rewind, also onto a different slot (migration): the continuation is bit-identical
+        other = engine.open_streams(3)
+        for s, o, b in zip(slots, other, blobs):
+            engine.restore_stream(int(s), b)
+            engine.restore_stream(int(o), b)
+        b1 = [engine.step_events(slots, frames[:, t]) for t in range(3, 6)]
+        b2 = [engine.step_events(other, frames[:, t]) for t in range(3, 6)]
+        for x, y, z in zip(a, b1, b2):
+            for k in range(3):
+                assert np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k])
+        with pytest.raises(VADError):
+            engine.restore_stream(int(slots[0]), blobs[0][:-4])
+        with pytest.raises(VADError):
+            engine.restore_stream(int(slots[0]), blobs[0][:1024] + b"\xff" * 96)
+        with pytest.raises(VADError):
+            engine.save_stream(4000)
+        for s in other:
+            engine.close_stream(int(s))
+    finally:
+        for s in slots:
+            engine.close_stream(int(s))

@@ -129,3 +129,53 @@ def test_stream_batch_events_match_oracle():
         assert n_start > 10 and n_end > 10, "the scenario must exercise both transitions"
     finally:
         batch.close()
+
+
+def test_chunk_in_one_launch_equals_frame_by_frame_and_keeps_the_abort_contract(speech):
+    """A chunk's F overlapping frames go through ``vad_step_multi`` in one launch.  It must be indistinguishable
+    from the reference's frame-by-frame loop: same probabilities (bit-exact: same kernel, same order), same
+    callbacks, and after a callback that raises at frame i the stream is where frame-by-frame processing of
+    frames 0..i leaves it (vad_wrapper.py:638-647)."""
+    from cutter_vad_amd import VADConfig, VADWrapper
+    cfg = dict(vad_start_probability=0.4, vad_end_probability=0.3, voice_start_frame_count=6, voice_end_frame_count=12)
+    x = speech[: 16000 * 12].astype(np.float32) / 32767.0
+    CH = 2048                                               # 7 frames per chunk
+    logs, probs = [[], []], [[], []]
+    with VADWrapper(VADConfig(**cfg)) as batched, VADWrapper(VADConfig(**cfg)) as serial:
+        serial.processor.process_frames = None               # forces the per-frame path of _process_audio_frames
+        for k, w in enumerate((batched, serial)):
+            w.set_callbacks(lambda k=k: logs[k].append("S"), lambda wav, k=k: logs[k].append(hashlib.sha256(wav).hexdigest()),
+                            lambda pcm, k=k: logs[k].append(len(pcm)))
+            for i in range(x.size // CH):
+                w.process_audio_data(x[i * CH:(i + 1) * CH])
+                probs[k].extend(list(w.processor.voice_probabilities)[-7:])
+        assert probs[0] == probs[1] and len(probs[0]) == 7 * (x.size // CH)
+        assert logs[0] == logs[1] and "S" in logs[0] and any(isinstance(e, str) and len(e) == 64 for e in logs[0])
+        eng = batched.processor.model.engine
+        assert np.array_equal(eng.get_state(batched.processor.model.slot), eng.get_state(serial.processor.model.slot))
+        assert eng.save_stream(batched.processor.model.slot) == eng.save_stream(serial.processor.model.slot)
+
+        # abort: START fires inside a chunk and its callback raises
+        def boom():
+            raise RuntimeError("cb")
+        for w in (batched, serial):
+            w.reset()
+            w.set_callbacks(voice_start_callback=boom)
+        from cutter_vad_amd import AudioProcessingError
+        failed_at = None
+        for i in range(x.size // CH):
+            outcome = []
+            for w in (batched, serial):
+                try:
+                    w.process_audio_data(x[i * CH:(i + 1) * CH])
+                    outcome.append(None)
+                except AudioProcessingError as e:
+                    outcome.append(str(e))
+            assert outcome[0] == outcome[1]
+            if outcome[0] is not None:
+                failed_at = i
+                break
+        assert failed_at is not None and "cb" in outcome[0]
+        assert eng.save_stream(batched.processor.model.slot) == eng.save_stream(serial.processor.model.slot)
+        assert batched.get_statistics()["total_frames_processed"] == serial.get_statistics()["total_frames_processed"]
+        assert batched.is_voice_active() and serial.is_voice_active()

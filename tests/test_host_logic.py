@@ -280,3 +280,103 @@ def test_wrapper_lifecycle_and_thread_safety(wrapper):
     assert wrapper._test_engine.closed, "cleanup must hand the slot back"
     with pytest.raises(VADError, match="VAD processor not initialized"):
         wrapper.process_audio_data(np.zeros(512, np.float32))
+
+
+# ------------------------------------------------------------------ asyncio façade
+def test_async_wrapper_surface_and_callbacks(monkeypatch):
+    import asyncio
+    from cutter_vad_amd import AsyncVADWrapper
+    from cutter_vad_amd.core.exceptions import CallbackError
+    eng = FakeEngine(fn=lambda fr: 0.9 if np.abs(fr).max() > 0.3 else 0.05)
+    monkeypatch.setattr(vw.VADWrapper, "_make_processor", staticmethod(lambda cfg: VADProcessor(cfg, pool=FakePool(eng))))
+    log, failures = [], []
+
+    async def on_start():
+        log.append("start")
+
+    async def on_end(wav: bytes):
+        log.append(("end", len(wav)))
+
+    async def on_continue(pcm: bytes):
+        log.append(("c", len(pcm)))
+        if len(log) > 1000:
+            raise RuntimeError("never")
+
+    async def scenario():
+        async with AsyncVADWrapper(VADConfig(), max_workers=2) as a:
+            a.set_async_callbacks(on_start, on_end, on_continue)
+            await a.set_thresholds_async(voice_start_frame_count=2, voice_end_frame_count=3)
+            assert a.get_config().voice_end_frame_count == 3
+            loud, quiet = np.full(512, 0.5, np.float32), np.zeros(512, np.float32)
+            for _ in range(3):
+                await a.process_audio_data_async(loud)
+            assert await a.is_voice_active_async()
+            await a.process_audio_data_with_buffer_async(np.concatenate([quiet, quiet]), 512)
+            for _ in range(2):
+                await a.process_audio_data_async(quiet)
+            await asyncio.sleep(0.05)                         # posted coroutines run on this loop
+            assert not a.is_voice_active()
+            st = await a.get_statistics_async()
+            assert st["total_frames_processed"] == 6
+            # a failing coroutine surfaces as CallbackError inside its own task, not in frame processing
+            async def boom():
+                raise RuntimeError("async cb failed")
+            a.set_async_callbacks(voice_start_callback=boom)
+            loop = asyncio.get_running_loop()
+            loop.set_exception_handler(lambda l, ctx: failures.append(ctx.get("exception")))
+            await a.reset_async()
+            for _ in range(2):
+                await a.process_audio_data_async(loud)         # does not raise
+            await asyncio.sleep(0.05)
+            await a.update_config_async(VADConfig(voice_start_frame_count=4))
+            assert a.get_config().voice_start_frame_count == 4
+            return a
+
+    a = asyncio.run(scenario())
+    assert log[0] == "start"
+    assert ("c", 2048) in log and any(isinstance(x, tuple) and x[0] == "end" for x in log)
+    end = [x for x in log if isinstance(x, tuple) and x[0] == "end"][0]
+    assert end[1] == 44 + 2 * 512 * (2 + 1 + 3)
+    assert a._closed and a.executor._shutdown
+    # synchronous use keeps working through the same object type
+    with AsyncVADWrapper(VADConfig(voice_start_frame_count=2)) as s:
+        s.process_audio_data(np.zeros(512, np.float32))
+        assert s.get_statistics()["total_frames_processed"] == 1 and not s.is_voice_active()
+        s.set_thresholds()
+        assert s.get_config().voice_end_frame_count == 57
+        s.reset()
+
+
+def test_chunk_batching_keeps_the_abort_contract(wrapper):
+    """A chunk's frames run in one launch; a callback that raises at frame i must leave the stream exactly where
+    the reference leaves it: frames 0..i processed, the rest never seen (vad_wrapper.py:638-647)."""
+    eng = wrapper._test_engine
+    wrapper.set_thresholds(voice_start_frame_count=2, voice_end_frame_count=5)
+    slot = wrapper.processor.model.slot
+
+    def boom():
+        raise RuntimeError("start cb failed")
+    wrapper.set_callbacks(voice_start_callback=boom)
+    loud4 = np.full(512 + 3 * 256, 0.5, np.float32)                 # 4 overlapping frames; START fires on the 2nd
+    with pytest.raises(AudioProcessingError, match="start cb failed"):
+        wrapper.process_audio_data(loud4)
+    assert eng.multi_calls == 2 and eng.restores == 1              # the launch of 4, then the replay of 2
+    assert wrapper.get_statistics()["total_frames_processed"] == 1   # frame 1's callback raised before its increment
+    c = eng.sm[slot].counts()
+    assert c["active"] and c["n_end"] == 0 and c["seg_samples"] == 2   # two frames in the segment, not four
+    assert wrapper.is_voice_active() and len(wrapper.processor.current_voice_data) == 1024
+    # and the stream carries on from there
+    log = []
+    wrapper.set_callbacks(voice_continue_callback=lambda b: log.append(len(b)))
+    wrapper.process_audio_data(loud4)
+    assert log == [2048] * 4 and eng.restores == 1
+    assert eng.sm[slot].counts()["seg_samples"] == 6
+    # an invalid frame inside a chunk: the frames before it are delivered, then it raises (per-frame validation order)
+    p = wrapper.processor
+    frames = np.full((3, 512), 0.5, np.float32)
+    frames[2, 7] = np.nan
+    got = []
+    with pytest.raises(AudioProcessingError):
+        for r in p.process_frames(frames):
+            got.append(r)
+    assert len(got) == 2 and eng.sm[slot].counts()["seg_samples"] == 8

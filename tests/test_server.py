@@ -1,0 +1,160 @@
+"""Shared-pool serving layer on CPU (scripted engine): batching, per-session semantics, wire protocol."""
+
+import json
+
+import numpy as np
+import pytest
+
+from cutter_vad_amd import VADConfig
+from cutter_vad_amd.core.exceptions import AudioProcessingError
+from cutter_vad_amd.server import SharedStreamPool
+from tests.fakes import FakeEngine, FakePool
+
+LOUD = np.full(480, 0.5, np.float32)
+QUIET = np.zeros(480, np.float32)
+
+
+def make_pool():
+    eng = FakeEngine(fn=lambda fr: 0.9 if np.abs(fr).max() > 0.3 else 0.05)
+    calls = []
+    orig = eng.step_events
+
+    def counting(slots, frames, denoise=0.01, i16_scale=32767):
+        calls.append(len(slots))
+        return orig(slots, frames, denoise, i16_scale)
+
+    eng.step_events = counting
+    return SharedStreamPool(pool=FakePool(eng)), eng, calls
+
+
+def test_one_launch_per_tick_and_reference_semantics():
+    pool, eng, calls = make_pool()
+    cfg = dict(vad_start_probability=0.4, vad_end_probability=0.3, voice_start_frame_count=2, voice_end_frame_count=3,
+               buffer_size=480)
+    sessions, logs = [], []
+    for k in range(5):
+        s = pool.open_session(VADConfig(**cfg))
+        log = []
+        s.set_callbacks(lambda log=log: log.append("S"), lambda wav, log=log: log.append(("E", len(wav))),
+                        lambda pcm, log=log: log.append(("C", len(pcm))))
+        sessions.append(s)
+        logs.append(log)
+    # session k talks from tick k on; 3 loud frames then silence.  Frames are queued ahead of the ticks.
+    for k, s in enumerate(sessions):
+        for f in [QUIET] * k + [LOUD] * 3 + [QUIET] * 4:
+            s.submit(f)
+    n = pool.drain()
+    assert n == sum(7 + k for k in range(5))
+    assert calls[:7] == [5] * 7 and calls[7:] == [4, 3, 2, 1]          # one launch per tick for everyone pending
+    for log in logs:
+        # START on the 2nd loud frame, CONTINUE for loud #3 and the 3 quiet frames, END on the 3rd quiet one:
+        # on the END frame voice_end comes before voice_continue (core/vad_wrapper.py:505-519)
+        assert log == ["S", ("C", 1920), ("C", 1920), ("C", 1920), ("E", 44 + 2 * 480 * 6), ("C", 1920)]
+    assert eng.frames_seen[0].shape == (5, 512) and np.all(eng.frames_seen[0][:, 480:] == 0)   # right zero-pad to 512
+    assert pool.stats()["frames_per_launch"] > 3
+    # per-session order and independence: a second utterance only on session 2
+    for f in [LOUD] * 2:
+        sessions[2].submit(f)
+    pool.drain()
+    assert logs[2][-1] == "S" and sessions[2].is_voice_active() and not sessions[1].is_voice_active()
+    # a failing callback reaches the session's error hook, the other sessions carry on
+    errs = []
+    sessions[2].set_callbacks(voice_continue_callback=lambda b: 1 / 0, error_callback=errs.append)
+    sessions[2].submit(LOUD)
+    sessions[3].submit(LOUD)
+    assert pool.tick() == 2 and len(errs) == 1 and "voice_continue" in str(errs[0])
+    # validation mirrors AudioUtils.validate_audio_data
+    with pytest.raises(AudioProcessingError, match="NaN"):
+        sessions[0].submit(np.array([np.nan] * 480, np.float32))
+    with pytest.raises(AudioProcessingError, match="empty"):
+        sessions[0].submit(np.zeros(0, np.float32))
+    sessions[0].close()
+    with pytest.raises(AudioProcessingError, match="closed"):
+        sessions[0].submit(LOUD)
+    assert pool.session_count == 4 and eng.closed == [sessions[0].slot]
+    pool.reconfigure(sessions[2], VADConfig(**{**cfg, "voice_start_frame_count": 1}))
+    assert not sessions[2].is_voice_active() and eng.thr[sessions[2].slot][4] == 1
+    pool.close()
+    assert pool.session_count == 0
+
+
+def test_background_ticker_thread():
+    import time
+    pool, eng, calls = make_pool()
+    pool.tick_interval = 0.002
+    s = pool.open_session(VADConfig(voice_start_frame_count=1, buffer_size=480))
+    got = []
+    s.set_callbacks(voice_start_callback=lambda: got.append("S"))
+    pool.start()
+    s.submit(LOUD)
+    t0 = time.time()
+    while not got and time.time() - t0 < 5:
+        time.sleep(0.005)
+    pool.close()
+    assert got == ["S"]
+
+
+def test_wire_protocol_over_asgi():
+    from fastapi.testclient import TestClient
+    from cutter_vad_amd.server.app import create_app, create_client_config, parse_query_params
+    q = parse_query_params("sample_rate=16000&start_probability=0.5&start_ratio=0.7&mode=pcm&x=1")
+    assert q == {"sample_rate": 16000, "start_probability": 0.5, "start_ratio": "0.7", "mode": "pcm", "x": "1"}
+    cfg = create_client_config(q, {"end_frame_count": 4, "timeout": None})
+    assert cfg["vad"]["start_ratio"] == 0.7 and cfg["vad"]["end_frame_count"] == 4 and cfg["audio"]["frame_duration_ms"] == 30
+
+    pool, eng, calls = make_pool()
+    app = create_app(pool, tick_interval=0.002)
+    loud = (np.full(480, 0.5) * 32767).astype("<i2").tobytes()
+    quiet = np.zeros(480, "<i2").tobytes()
+
+    def recv_until(ws, kind, limit=200):
+        seen = []
+        for _ in range(limit):
+            m = json.loads(ws.receive_text())
+            seen.append(m)
+            if m["event"] == kind:
+                return seen
+        raise AssertionError(f"no {kind} in {seen}")
+
+    with TestClient(app) as client:
+        assert client.get("/").json()["status"] == "running"
+        with client.websocket_connect("/vad?start_frame_count=2&end_frame_count=3") as ws:
+            hello = json.loads(ws.receive_text())
+            assert hello["event"] == "INFO" and hello["message"] == "VAD WebSocket server ready" and "timestamp_ms" in hello
+            assert client.get("/").json()["connected_clients"] == 1
+            ws.send_text(json.dumps({"type": "HEARTBEAT"}))
+            assert json.loads(ws.receive_text())["message"] == "Heartbeat received"
+            ws.send_bytes(b"\0" * 100)
+            m = json.loads(ws.receive_text())
+            assert m["event"] == "ERROR" and m["message"] == "Invalid frame size: expected 960, got 100"
+            for _ in range(3):
+                ws.send_bytes(loud)
+            seen = recv_until(ws, "VOICE_CONTINUE")
+            assert [m["event"] for m in seen] == ["VOICE_START", "VOICE_CONTINUE"] and seen[0]["segment_index"] == 0
+            for _ in range(3):
+                ws.send_bytes(quiet)
+            seen = recv_until(ws, "VOICE_END")
+            end = seen[-1]
+            assert end["segment_index"] == 0 and end["duration_ms"] == end["segment_end_ms"] - end["segment_start_ms"] >= 0
+            assert all(m["event"] == "VOICE_CONTINUE" for m in seen[:-1])
+            ws.send_text(json.dumps({"type": "CONFIG", "start_frame_count": 1, "frame_duration_ms": 20}))
+            assert recv_until(ws, "INFO")[-1]["message"] == "Configuration updated"
+            ws.send_bytes((np.full(320, 0.5) * 32767).astype("<i2").tobytes())          # 20 ms frames now
+            seen = recv_until(ws, "VOICE_START")
+            assert seen[-1]["segment_index"] == 1
+            ws.send_text("{not json")
+            assert recv_until(ws, "ERROR")[-1]["message"].startswith("Invalid JSON")
+            ws.send_text(json.dumps({"type": "NOPE"}))
+            assert recv_until(ws, "ERROR")[-1]["message"] == "Unknown message type: NOPE"
+        with client.websocket_connect("/vad?mode=opus") as ws:
+            m = json.loads(ws.receive_text())
+            assert m["event"] == "ERROR" and "PyAV is required for opus" in m["message"]
+        with client.websocket_connect("/vad?frame_duration_ms=1&sample_rate=16000&sample_width=2&channels=1") as ws:
+            assert json.loads(ws.receive_text())["event"] == "INFO"       # 32 bytes: integral
+        with client.websocket_connect("/vad?sample_rate=8000") as ws:
+            assert json.loads(ws.receive_text())["event"] == "INFO"
+            ws.send_bytes(np.zeros(240, "<i2").tobytes())
+            m = json.loads(ws.receive_text())
+            assert m["event"] == "ERROR" and m["message"].startswith("Audio processing error:")
+        assert client.get("/stats").json()["launches"] >= 5
+    assert pool.session_count == 0

@@ -17,7 +17,7 @@ import torch  # noqa: E402
 from cutter_vad_amd import weights_io  # noqa: E402
 from cutter_vad_amd.engine import Engine  # noqa: E402
 
-K, WU = 100, 10
+K, WU = 400, 50
 
 
 def blob(v):
@@ -96,6 +96,47 @@ def config4_per_gpu():
             "us_per_step": dt * 1e6, "frames_per_s": 2 * B / dt, "x8_gpus_frames_per_s": 16 * B / dt}
 
 
+def v4_alone():
+    B = 8192
+    eng = Engine(blob(4), model_version=4, max_streams=B)
+    eng.open_streams(B)
+    ring = (0.1 * torch.randn(16, B, 512, device="cuda")).contiguous()
+    probs = torch.empty(B, device="cuda")
+    ts = torch.cuda.Stream()
+    dt = timed(lambda i: eng.step_device(B, ring[i % 16].data_ptr(), probs.data_ptr(), stream=ts.cuda_stream), [ts])
+    eng.close()
+    return {"config": "batch=8192, V4, 16 kHz (device-resident)", "us_per_step": dt * 1e6, "frames_per_s": B / dt,
+            "frac_of_fp32_peak_at_1.38_MFLOP_per_frame": 1.38e6 * B / dt / 157.3e12}
+
+
+def host_api():
+    """PCIe-inclusive: vad_step with HOST pointers (pageable numpy arrays): H2D frames, kernel, D2H probs, sync."""
+    import time
+    import numpy as np
+    B = 8192
+    out = []
+    eng = Engine(blob(5), max_streams=B)
+    slots = eng.open_streams(B)
+    rng = np.random.default_rng(0)
+    x32 = (0.1 * rng.standard_normal((4, B, 512))).astype(np.float32)
+    x16 = np.clip(x32 * 32767.0, -32768, 32767).astype(np.int16)
+    for name, x in (("f32", x32), ("int16", x16)):
+        for i in range(5):
+            eng.step(slots, x[i % 4])
+        t0 = time.perf_counter()
+        n = 40
+        for i in range(n):
+            eng.step(slots, x[i % 4])
+        dt = (time.perf_counter() - t0) / n
+        out.append({"config": f"batch=8192, V5, host-pointer API (vad_step, {name} frames in pageable host memory, "
+                              "H2D + kernel + D2H + sync per step)", "us_per_step": dt * 1e6, "frames_per_s": B / dt,
+                    "h2d_GBps": x[0].nbytes / dt / 1e9})
+    eng.close()
+    return out
+
+
 if __name__ == "__main__":
-    for fn in (config1, config3, config4_per_gpu):
+    for r in host_api():
+        print(json.dumps(r), flush=True)
+    for fn in (config1, config3, config4_per_gpu, v4_alone):
         print(json.dumps(fn()), flush=True)

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Host-inclusive throughput of the shared stream pool: N sessions, one 30 ms int16 frame each per
+tick, as the websocket server receives them (bytes -> float32/32767 -> submit), then ONE tick = one launch
+(H2D + kernel + D2H) + vectorised fan-out.  Prints one JSON object per N.  Real time needs 33.3 ticks/s."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cutter_vad_amd import VADConfig  # noqa: E402
+from cutter_vad_amd.server import SharedStreamPool  # noqa: E402
+from tests.signals import make_streams  # noqa: E402
+
+
+def run(n, ticks=40):
+    pool = SharedStreamPool(max_streams=8192)
+    cfg = VADConfig(vad_start_probability=0.4, vad_end_probability=0.3, voice_start_frame_count=6,
+                    voice_end_frame_count=12, buffer_size=480)
+    sessions = [pool.open_session(cfg) for _ in range(n)]
+    counts = {"start": 0, "end": 0}
+    for s in sessions:
+        s.set_callbacks(lambda: counts.__setitem__("start", counts["start"] + 1),
+                        lambda wav: counts.__setitem__("end", counts["end"] + 1), None)
+    x = make_streams(min(n, 512), ticks + 5, seed=9)[:, :, :480]
+    pcm = np.clip(x * 32767.0, -32768, 32767).astype("<i2")
+    wire = [[pcm[k % pcm.shape[0], t].tobytes() for k in range(n)] for t in range(ticks + 5)]
+    t_sub = t_tick = 0.0
+    for t in range(ticks + 5):
+        a = time.perf_counter()
+        for k, s in enumerate(sessions):
+            s.submit(np.frombuffer(wire[t][k], dtype=np.int16).astype(np.float32) / 32767.0)
+        b = time.perf_counter()
+        pool.tick()
+        c = time.perf_counter()
+        if t >= 5:
+            t_sub += b - a
+            t_tick += c - b
+    pool.close()
+    return {"sessions": n, "ticks": ticks, "decode_submit_ms_per_tick": t_sub / ticks * 1e3,
+            "tick_ms": t_tick / ticks * 1e3, "frames_per_s_host_inclusive": n * ticks / (t_sub + t_tick),
+            "real_time_factor": (n * ticks / (t_sub + t_tick)) / (n * 1000 / 30), "events": counts}
+
+
+if __name__ == "__main__":
+    for n in (256, 2048, 8192):
+        print(json.dumps(run(n)), flush=True)
