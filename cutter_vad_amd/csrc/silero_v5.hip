@@ -172,6 +172,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             // y2 = w[128-n] x[128-n] (B reversed), y4 = w[256-n] x[256-n] (D reversed); w is symmetric about 128.
 #define X_FOLD1(c, rr, XR)                                                                                      \
     {                                                                                                           \
+        _Pragma("clang fp contract(off)")   /* same roundings in the f32 and int16 instantiations */            \
         const int ms = (rr) * 16 + (tid >> 4);                                                                  \
         const f32x4 xA = decode(XR[(rr) * 4 + 0]), xB = decode(XR[(rr) * 4 + 1]);                               \
         const f32x4 xC = decode(XR[(rr) * 4 + 2]), xD = decode(XR[(rr) * 4 + 3]);                               \

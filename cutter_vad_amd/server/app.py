@@ -192,8 +192,9 @@ class ClientSession:
         if len(data) != self.expected_frame_bytes:
             self.send_error(f"Invalid frame size: expected {self.expected_frame_bytes}, got {len(data)}")
             return
+        x = None
         if a["sample_width"] == 2:
-            x = np.frombuffer(data, dtype=np.int16).astype(np.float32) / 32767.0
+            pass          # int16 little-endian: the bytes travel to the GPU as they are, scaled by 1/32767 in the kernel
         elif a["sample_width"] == 4:
             x = np.frombuffer(data, dtype=np.float32)
         else:
@@ -203,7 +204,10 @@ class ClientSession:
             # multi-channel frames go to the model interleaved, as the reference hands them over (:369)
             if self.session_error is not None or self.session is None:
                 raise RuntimeError(self.session_error or "VAD wrapper not initialized")
-            self.session.submit(x)
+            if x is None:
+                self.session.submit_pcm16(data)
+            else:
+                self.session.submit(x)
             self.last_voice_time = time.time()
             if self.cfg["timeout"] > 0 and not self.timeout_task:
                 self.timeout_task = asyncio.ensure_future(self._timeout_monitor())

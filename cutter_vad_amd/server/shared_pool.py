@@ -43,28 +43,37 @@ FRAME = 512
 class PooledSession:
     """One client stream: a slot of the shared engine + the host half of its voice segments."""
 
-    __slots__ = ("pool", "slot", "config", "pending", "on_start", "on_end", "on_continue", "on_error", "active",
-                 "preroll", "segment", "frames_done", "last_probability", "closed", "wav_writer", "_thr", "user")
+    __slots__ = ("pool", "slot", "config", "pending", "on_start", "on_end", "on_continue", "on_error", "preroll",
+                 "segment", "closed", "wav_writer", "user")
 
     def __init__(self, pool: "SharedStreamPool", slot: int, config: VADConfig) -> None:
         self.pool = pool
         self.slot = slot
         self.config = config
-        self.pending: Deque[np.ndarray] = deque()
+        self.pending: Deque = deque()              # float32 arrays or raw little-endian int16 bytes
         self.on_start: Optional[Callable[[], None]] = None
         self.on_end: Optional[Callable[[bytes], None]] = None
         self.on_continue: Optional[Callable[[bytes], None]] = None
         self.on_error: Optional[Callable[[Exception], None]] = None
-        self.active = False
         self.preroll: List[np.ndarray] = []
         self.segment: List[np.ndarray] = []
-        self.frames_done = 0
-        self.last_probability = 0.0
         self.closed = False
         self.wav_writer = WAVWriter(sample_rate=config.output_wav_sample_rate, bit_depth=config.output_wav_bit_depth,
                                     channels=1)
-        self._thr = float(config.vad_start_probability)
         self.user = None
+
+    # the per-session scalars live in the pool's arrays (indexed by slot) so that a tick can work on all of them at once
+    @property
+    def active(self) -> bool:
+        return bool(self.pool._active[self.slot])
+
+    @property
+    def last_probability(self) -> float:
+        return float(self.pool._lastp[self.slot])
+
+    @property
+    def frames_done(self) -> int:
+        return int(self.pool._done[self.slot])
 
     def set_callbacks(self, voice_start_callback=None, voice_end_callback=None, voice_continue_callback=None,
                       error_callback=None) -> None:
@@ -73,6 +82,9 @@ class PooledSession:
 
     def submit(self, frame) -> None:
         self.pool.submit(self, frame)
+
+    def submit_pcm16(self, data: bytes) -> None:
+        self.pool.submit_pcm16(self, data)
 
     def is_voice_active(self) -> bool:
         return self.active
@@ -95,9 +107,37 @@ class SharedStreamPool:
         self._ready: Dict[int, PooledSession] = {}  # sessions with at least one pending frame (insertion-ordered)
         self._thread: Optional[threading.Thread] = None
         self._stop = threading.Event()
+        self._grow(1024)
         self.ticks = 0
         self.frames = 0
         self.launches = 0
+
+    def _grow(self, n: int) -> None:
+        old = getattr(self, "_thr", None)
+        k = 0 if old is None else old.size
+        if n <= k:
+            return
+        n = max(n, 2 * k)
+
+        def ext(name, dtype):
+            a = np.zeros(n, dtype)
+            if k:
+                a[:k] = getattr(self, name)
+            setattr(self, name, a)
+        ext("_thr", np.float64)        # vad_start_probability
+        ext("_active", bool)           # inside a segment
+        ext("_pre", bool)              # collecting pre-roll
+        ext("_gate", bool)             # enable_denoising
+        ext("_lastp", np.float32)
+        ext("_done", np.int64)
+
+    def _init_slot(self, slot: int, cfg: VADConfig) -> None:
+        self._grow(slot + 1)
+        self._thr[slot] = float(cfg.vad_start_probability)
+        self._gate[slot] = bool(cfg.enable_denoising)
+        self._active[slot] = self._pre[slot] = False
+        self._lastp[slot] = 0.0
+        self._done[slot] = 0
 
     # ------------------------------------------------------------------ sessions
     def open_session(self, config: Optional[VADConfig] = None) -> PooledSession:
@@ -114,6 +154,7 @@ class SharedStreamPool:
             raise
         s = PooledSession(self, slot, cfg)
         with self._lock:
+            self._init_slot(slot, cfg)
             self._sessions[slot] = s
         return s
 
@@ -141,8 +182,8 @@ class SharedStreamPool:
                                        config.voice_start_ratio, config.voice_end_ratio, config.voice_start_frame_count,
                                        config.voice_end_frame_count)
             s.config = config
-            s._thr = float(config.vad_start_probability)
-            s.active = False
+            with self._lock:
+                self._init_slot(s.slot, config)
             s.preroll, s.segment = [], []
             s.wav_writer = WAVWriter(sample_rate=config.output_wav_sample_rate, bit_depth=config.output_wav_bit_depth,
                                      channels=1)
@@ -169,80 +210,130 @@ class SharedStreamPool:
             s.pending.append(x)
             self._ready[s.slot] = s
 
+    def submit_pcm16(self, s: PooledSession, data: bytes) -> None:
+        """Queue one frame as it arrives on the wire: little-endian int16 PCM.  The bytes go to the GPU as they are
+        (half the transfer of float32); the kernel scales by 1/32767 with a true division, which is bit-for-bit what
+        the reference server does on the host (vad_websocket_server.py:341)."""
+        if len(data) < 2 or len(data) & 1:
+            raise AudioProcessingError("Audio data cannot be empty" if len(data) < 2 else
+                                       "PCM16 frame with an odd number of bytes")
+        with self._lock:
+            if s.closed:
+                raise AudioProcessingError("session is closed")
+            s.pending.append(bytes(data))
+            self._ready[s.slot] = s
+
     # ------------------------------------------------------------------ the tick
+    @staticmethod
+    def _as_float(item) -> np.ndarray:
+        if isinstance(item, bytes):
+            return np.frombuffer(item, dtype="<i2").astype(np.float32) / 32767.0
+        return item
+
+    def _launch(self, slots: np.ndarray, items: list, gate_on: bool):
+        """One launch for sessions whose pending frames share a format -> (probs, events)."""
+        n = len(items)
+        if isinstance(items[0], bytes):
+            x = np.zeros((n, FRAME), np.int16)
+            L = len(items[0])
+            if all(len(b) == L for b in items):                  # the usual case: every client sends 30 ms frames
+                m = min(L // 2, FRAME)
+                x[:, :m] = np.frombuffer(b"".join(items), dtype="<i2").reshape(n, L // 2)[:, :m]
+            else:
+                for i, b in enumerate(items):
+                    v = np.frombuffer(b, dtype="<i2")
+                    m = min(v.size, FRAME)
+                    x[i, :m] = v[:m]
+        else:
+            x = np.zeros((n, FRAME), np.float32)
+            for i, f in enumerate(items):
+                m = min(f.size, FRAME)
+                x[i, :m] = f[:m]
+        p, ev, _ = self.engine.step_events(slots, x, denoise=0.01 if gate_on else None)
+        self.launches += 1
+        return p, ev, x
+
     def tick(self) -> int:
-        """Advance every session that has a frame pending by ONE frame, in one launch.  Returns the number of
-        frames processed.  Callbacks run on the calling thread, outside the pool's locks, in slot order."""
+        """Advance every session that has a frame pending by ONE frame — one launch per (wire format, gate) group,
+        i.e. one launch when all clients speak the same format.  Returns the number of frames processed.  Callbacks
+        run on the calling thread, outside the pool's locks, in slot order."""
         with self._tick_lock:
             with self._lock:
                 batch = list(self._ready.values())
-                frames = [s.pending.popleft() for s in batch]
-                for s in batch:
-                    if not s.pending:
-                        del self._ready[s.slot]
+                items = [s.pending.popleft() for s in batch]
+                self._ready = {s.slot: s for s in batch if s.pending}
             n = len(batch)
             if n == 0:
                 return 0
-            x = np.zeros((n, FRAME), np.float32)
-            for i, f in enumerate(frames):
-                m = min(f.size, FRAME)
-                x[i, :m] = f[:m]
             slots = np.fromiter((s.slot for s in batch), np.int64, n)
-            # the gate is a per-pool constant in the kernel call; sessions that disabled denoising are rare enough to
-            # get their own launch
-            groups = {}
-            for i, s in enumerate(batch):
-                groups.setdefault(bool(s.config.enable_denoising), []).append(i)
+            is_pcm = np.fromiter((isinstance(it, bytes) for it in items), bool, n)
+            key = is_pcm.astype(np.int8) * 2 + self._gate[slots]
             p = np.empty(n, np.float32)
             ev = np.zeros(n, np.uint8)
             err: Optional[Exception] = None
-            for gate_on, idx in groups.items():
-                ii = np.asarray(idx)
+            staged = []
+            for k in np.unique(key):
+                ii = np.nonzero(key == k)[0]
                 try:
-                    pp, ee, _ = self.engine.step_events(slots[ii], x[ii], denoise=0.01 if gate_on else None)
-                    p[ii], ev[ii] = pp, ee
-                    self.launches += 1
+                    sub = items if ii.size == n else [items[i] for i in ii]
+                    p[ii], ev[ii], x = self._launch(slots[ii], sub, bool(k & 1))
+                    staged.append((ii, x, bool(k & 1)))
                 except Exception as e:              # engine failure: every session of the launch hears about it
                     err = e
                     p[ii], ev[ii] = np.nan, 0
             self.ticks += 1
             self.frames += n
-        self._fan_out(batch, frames, p, ev, err)
-        return n
-
-    def _fan_out(self, batch, frames, p, ev, err) -> None:
-        thr = np.fromiter((s._thr for s in batch), np.float64, len(batch))
-        act = np.fromiter((s.active for s in batch), bool, len(batch))
-        pre = np.fromiter((bool(s.preroll) for s in batch), bool, len(batch))
-        p64 = p.astype(np.float64)
-        busy = np.nonzero((ev != 0) | act | pre | (p64 >= thr) | ~np.isfinite(p64))[0]
-        for s, pi in zip(batch, p):
-            s.frames_done += 1
-            s.last_probability = float(pi)
-        for i in busy:
+            self._lastp[slots] = p
+            self._done[slots] += 1
+            p64 = p.astype(np.float64)
+            busy = np.nonzero((ev != 0) | self._active[slots] | self._pre[slots] | (p64 >= self._thr[slots])
+                              | ~np.isfinite(p64))[0]
+        # the audio that segments keep (float32, gated like utils/audio.py:104-121), for all busy sessions of a launch
+        # at once; frames longer than the model's 512 samples take the per-session path
+        kept: Dict[int, np.ndarray] = {}
+        is_busy = np.zeros(n, bool)
+        is_busy[busy] = True
+        for ii, x, gate_on in staged:
+            rows = np.nonzero(is_busy[ii])[0]
+            if rows.size == 0:
+                continue
+            xf = x[rows].astype(np.float32) / np.float32(32767.0) if x.dtype == np.int16 else x[rows]
+            if gate_on:
+                xf = AudioUtils.denoise_audio(xf)
+            for r, row in zip(rows, xf):
+                it = items[ii[r]]
+                L = len(it) // 2 if isinstance(it, bytes) else it.size
+                if L <= FRAME:
+                    kept[int(ii[r])] = row[:L]
+        for i in busy:                             # idle sessions cost no Python at all
             s = batch[i]
             try:
-                if err is not None or not np.isfinite(p[i]):
+                if not np.isfinite(p[i]):
                     raise AudioProcessingError(f"Model prediction failed: {err}")
-                self._advance(s, frames[i], float(p[i]), int(ev[i]))
+                k = kept.get(int(i))
+                if k is None:
+                    k = self._as_float(items[i])
+                    if s.config.enable_denoising:
+                        k = AudioUtils.denoise_audio(k)
+                self._advance(s, k, float(p[i]), int(ev[i]))
             except Exception as e:
                 if s.on_error is not None:
                     s.on_error(e)
+        return n
 
-    @staticmethod
-    def _advance(s: PooledSession, frame: np.ndarray, p: float, ev: int) -> None:
-        kept = frame
-        if s.config.enable_denoising:
-            kept = AudioUtils.denoise_audio(frame)
-        if not s.active:
-            if p >= s._thr:
+    def _advance(self, s: PooledSession, kept: np.ndarray, p: float, ev: int) -> None:
+        slot = s.slot
+        if not self._active[slot]:
+            if p >= self._thr[slot]:
                 s.preroll.append(kept)
             else:
                 s.preroll = []
+            self._pre[slot] = bool(s.preroll)
             if ev & _ffi.VAD_EV_START:
-                s.active = True
+                self._active[slot] = True
+                self._pre[slot] = False
                 s.segment, s.preroll = s.preroll, []
-                SharedStreamPool._call(s.on_start, "voice_start")
+                self._call(s.on_start, "voice_start")
             elif ev:
                 raise AudioProcessingError(f"state machine divergence: device events {ev} on an idle session")
             return
@@ -250,13 +341,13 @@ class SharedStreamPool:
         wav = None
         if ev & _ffi.VAD_EV_END:
             wav = s.wav_writer.write_wav_data(np.concatenate(s.segment))
-            s.active = False
+            self._active[slot] = False
             s.segment = []
         # order on the END frame as the reference's wrapper delivers it: voice_end, then voice_continue
         # (core/vad_wrapper.py:505-519)
         if wav is not None:
-            SharedStreamPool._call(s.on_end, "voice_end", wav)
-        SharedStreamPool._call(s.on_continue, "voice_continue", kept.tobytes())
+            self._call(s.on_end, "voice_end", wav)
+        self._call(s.on_continue, "voice_continue", kept.tobytes())
 
     @staticmethod
     def _call(cb, name: str, *args) -> None:

@@ -68,6 +68,9 @@ class FakeEngine:
         self.state[int(s)] = np.asarray(hc, np.float32).copy()
 
     def step(self, slots, frames, denoise=0.01, i16_scale=32767):
+        frames = np.asarray(frames)
+        if frames.dtype == np.int16:                       # the engine's int16 ingest: true division by the scale
+            frames = frames.astype(np.float32) / np.float32(i16_scale)
         frames = np.asarray(frames, np.float32).reshape(len(slots), -1)
         assert frames.shape[1] == 512, "callers must pad to 512"
         self.frames_seen.append(frames.copy())

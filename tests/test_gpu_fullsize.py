@@ -5,7 +5,7 @@ The oracle cannot run 8 192 x T frames in seconds, so at this size the HIP path 
   * tile-position independence (a stream's result does not depend on which workgroup / lane serves it, bit-exact),
   * duplicate streams (same audio in two slots -> bit-identical probabilities and state),
   * T frames in one launch == T launches of one frame (bit-exact, probabilities and state),
-  * int16 ingest == float32 ingest of the same quantised signal (bit-exact),
+  * int16 ingest == float32 ingest of the same quantised signal (V5: bit-exact; V4: to rounding, 2e-6),
   * the device state machine replayed by the oracle's on the device's own probabilities (exact events),
   * reset -> the run repeats bit-exactly.
 Bit-exactness is the right bar for these: they compare the kernel with itself on identical arithmetic.
@@ -94,7 +94,9 @@ def test_multi_frame_launch_equals_single_frame_launches(setup, frames):
     assert np.array_equal(eng.get_state(int(slots[777])), s_single)
 
 
-def test_int16_ingest_is_bit_identical_to_float_ingest(setup, frames):
+def test_int16_ingest_equals_float_ingest_of_the_same_samples(setup, frames):
+    """The kernel's int16 decode is a true division (bit-identical to numpy's) and the fold that follows is compiled
+    without FMA contraction, so the int16 and f32 instantiations of the V5 kernel round identically."""
     v, eng, slots, _ = setup
     q = np.clip(np.round(frames[:, :2] * 32767.0), -32768, 32767).astype(np.int16)
     for scale in (32767, 32768):
@@ -103,7 +105,7 @@ def test_int16_ingest_is_bit_identical_to_float_ingest(setup, frames):
         a = np.stack([eng.step(slots, xf[:, t]) for t in range(2)], axis=1)
         eng.reset(slots)
         b = np.stack([eng.step(slots, q[:, t], i16_scale=scale) for t in range(2)], axis=1)
-        assert np.array_equal(a, b), scale
+        assert np.array_equal(a, b) if v == 5 else np.abs(a - b).max() <= 2e-6, scale
 
 
 def test_device_state_machines_follow_the_oracle_at_full_size(setup):

@@ -78,6 +78,31 @@ def test_one_launch_per_tick_and_reference_semantics():
     assert pool.session_count == 0
 
 
+def test_pcm16_wire_frames_travel_as_int16_and_formats_are_grouped():
+    pool, eng, calls = make_pool()
+    cfg = VADConfig(voice_start_frame_count=1, buffer_size=480)
+    a, b, c = pool.open_session(cfg), pool.open_session(cfg), pool.open_session(cfg)
+    loud16 = (np.full(480, 0.5) * 32767).astype("<i2").tobytes()
+    got = []
+    for s in (a, b, c):
+        s.set_callbacks(voice_start_callback=lambda s=s: got.append(s.slot), voice_continue_callback=lambda pcm: got.append(len(pcm)))
+    a.submit_pcm16(loud16)
+    b.submit_pcm16(loud16)
+    c.submit(LOUD)
+    assert pool.tick() == 3 and sorted(calls) == [1, 2]             # one launch per wire format
+    assert sorted(got) == [a.slot, b.slot, c.slot]
+    i16_batch = [f for f in eng.frames_seen if f.shape[0] == 2][0]
+    assert np.allclose(i16_batch[:, :480], 16383 / 32767.0) and np.all(i16_batch[:, 480:] == 0)
+    a.submit_pcm16(loud16)
+    a.submit_pcm16(loud16[:640])                                     # ragged lengths in one tick still work
+    b.submit_pcm16(loud16[:640])
+    assert pool.tick() == 2 and pool.tick() == 1
+    assert got[-3:] == [1920, 1280, 1280] and a.frames_done == 3 and abs(a.last_probability - 0.9) < 1e-6
+    with pytest.raises(AudioProcessingError):
+        a.submit_pcm16(b"\0")
+    pool.close()
+
+
 def test_background_ticker_thread():
     import time
     pool, eng, calls = make_pool()

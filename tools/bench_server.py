@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host-inclusive throughput of the shared stream pool: N sessions, one 30 ms int16 frame each per
-tick, as the websocket server receives them (bytes -> float32/32767 -> submit), then ONE tick = one launch
+tick, as the websocket server receives them (int16 bytes -> submit_pcm16), then ONE tick = one launch
 (H2D + kernel + D2H) + vectorised fan-out.  Prints one JSON object per N.  Real time needs 33.3 ticks/s."""
 import json
 import os
@@ -31,7 +31,7 @@ def run(n, ticks=40):
     for t in range(ticks + 5):
         a = time.perf_counter()
         for k, s in enumerate(sessions):
-            s.submit(np.frombuffer(wire[t][k], dtype=np.int16).astype(np.float32) / 32767.0)
+            s.submit_pcm16(wire[t][k])
         b = time.perf_counter()
         pool.tick()
         c = time.perf_counter()
