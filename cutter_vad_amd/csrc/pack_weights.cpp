@@ -108,7 +108,7 @@ bool check_stft_symmetry(const float *stft, std::string &err) {
     return true;
 }
 
-// The 4-way folded DFT (vad_layout.h, v5) uses analytic cos/sin and the window taken from the k = 0 row: the stored
+// The 4-way folded DFT (vad_layout.h, v5; V4 uses the same) uses analytic cos/sin and the window taken from the k = 0 row: the stored
 // basis must BE that windowed DFT (it is for Silero: max |stored - w cos| = 5.7e-8)
 bool check_windowed_dft(const float *stft, std::string &err) {
     const double two_pi = 6.283185307179586476925286766559;
@@ -120,7 +120,7 @@ bool check_windowed_dft(const float *stft, std::string &err) {
             worst = std::max(worst, std::fabs((double)stft[(size_t)(129 + k) * 256 + n] + w * std::sin(ph)));
         }
     if (worst > 2e-7) {
-        err = "Failed to load model: STFT basis is not a windowed DFT (the V5 kernel evaluates it as a folded DFT)";
+        err = "Failed to load model: STFT basis is not a windowed DFT (the kernels evaluate it as a folded DFT)";
         return false;
     }
     return true;
@@ -134,23 +134,6 @@ void pack_dft4_wave(StreamBuilder &sb, int w) {
         sb.weight_block([&](int np, int n) { const int k = v5::bin_of_channel(32 * w + np); return n == 0 ? 0.f : (float)std::cos(two_pi * (double)((k * n) & 255) / 256.0); }, j);
         sb.weight_block([&](int np, int n) { const int k = v5::bin_of_channel(32 * w + np); return n == 0 ? 0.f : (float)-std::sin(two_pi * (double)((k * n) & 255) / 256.0); }, j);
     }
-}
-
-// STFT on the folded input (V4; vad_layout.h): wave w owns bins 32w..32w+31, {re, im} per k-iteration;
-// k-iteration j contracts n = 8j+1 .. 8j+8 (quad 2j on the lower half-wave, 2j+1 on the upper)
-void pack_stft_wave(StreamBuilder &sb, const float *stft, int w) {
-    for (int j = 0; j < 16; ++j) {
-        sb.weight_block([&](int np, int k) { return stft[(size_t)(32 * w + np) * 256 + k + 1]; }, j);
-        sb.weight_block([&](int np, int k) { return stft[(size_t)(129 + 32 * w + np) * 256 + k + 1]; }, j);
-    }
-}
-
-// bin 128 (VALU): floats 0..127 = C[128][1..128]; its sine row is exactly zero
-uint32_t pack_nyquist_block(StreamBuilder &sb, const float *stft) {
-    const uint32_t nb = sb.blocks();
-    float *b = sb.new_block();
-    for (int n = 1; n <= 128; ++n) b[n - 1] = stft[(size_t)128 * 256 + n];
-    return nb;
 }
 
 }  // namespace
@@ -335,6 +318,10 @@ bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::strin
     const float *head_w = B.get("head.w", 64), *head_b = B.get("head.b", 1);
     if (!err.empty()) return false;
     if (!check_stft_symmetry(stft, err)) return false;
+    if (!check_windowed_dft(stft, err)) return false;
+    // the STFT kernel emits its 128 regular bins in the even/odd order of the 4-way folded DFT (v5::bin_of_channel);
+    // the first layer's per-channel tables and weight columns follow that order.  Channel 128 (Nyquist) stays.
+    auto bin = [](int c) { return c < 128 ? v5::bin_of_channel(c) : c; };
 
     StreamBuilder sb;
     uint32_t sec[S_COUNT] = {};
@@ -363,7 +350,7 @@ bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::strin
                 for (int k = 0; k < 6; ++k)
                     for (int i = 0; i < 4; ++i) {
                         const int c = 4 * q + i;
-                        if (c < 129) tab[(((size_t)p * 34 + q) * 6 + k) * 4 + i] = k < 5 ? dww[0][(size_t)(129 * p + c) * 5 + k] : dwb[0][129 * p + c];
+                        if (c < 129) tab[(((size_t)p * 34 + q) * 6 + k) * 4 + i] = k < 5 ? dww[0][(size_t)(129 * p + bin(c)) * 5 + k] : dwb[0][129 * p + bin(c)];
                     }
         for (int k = 0; k < 7; ++k) tab[(size_t)(2 * 34 * 6) * 4 + k] = filt[k];
         for (size_t off = 0; off < tab.size(); off += BLK_FLOATS) {
@@ -376,8 +363,8 @@ bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::strin
     sb.vector_blocks([&](int c) { return c < 16 ? pwb[0][c] + pjb[0][c] : 0.f; });
     for (int j = 0; j < 17; ++j)
         for (int p = 0; p < 2; ++p) {
-            sb.weight_block([&](int np, int c) { return (np < 16 && c < 129) ? pww[0][(size_t)np * 258 + 129 * p + c] : 0.f; }, j);
-            sb.weight_block([&](int np, int c) { return (np < 16 && c < 129) ? pjw[0][(size_t)np * 258 + 129 * p + c] : 0.f; }, j);
+            sb.weight_block([&](int np, int c) { return (np < 16 && c < 129) ? pww[0][(size_t)np * 258 + 129 * p + bin(c)] : 0.f; }, j);
+            sb.weight_block([&](int np, int c) { return (np < 16 && c < 129) ? pjw[0][(size_t)np * 258 + 129 * p + bin(c)] : 0.f; }, j);
         }
     // S_S0: 16 -> 16 (rows 0..15)
     sec[S_S0] = sb.blocks();
@@ -431,11 +418,13 @@ bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::strin
     sec[S_HEADB] = sb.blocks();
     sb.new_block()[0] = head_b[0];
     for (int u = 0; u < 2; ++u) sb.vector_blocks([&](int c) { return head_w[32 * u + c]; });
-    sec[S_NYQ] = pack_nyquist_block(sb, stft);
+    // the window of the stored basis: its k = 0 cosine row (the kernel multiplies by it while it folds)
+    sec[S_NYQ] = sb.blocks();
+    std::memcpy(sb.new_block(), stft, 256 * sizeof(float));
     for (int w = 0; w < NWAVES; ++w) {
         for (int k = 0; k < S_COUNT; ++k) out.sect[w][k] = sec[k];
         out.sect[w][S_STFT] = sb.blocks();
-        pack_stft_wave(sb, stft, w);
+        pack_dft4_wave(sb, w);
     }
     out.data = std::move(sb.data);
     return true;

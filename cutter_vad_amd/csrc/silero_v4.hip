@@ -5,7 +5,7 @@
 // of :494-499; dataflow: SURVEY.md §8 a8), plus the per-frame pre-steps and the state machine, as
 // in silero_v5.hip.  Two launches per frame (vad_layout.h explains why):
 //
-//   silero_v4_stft : load + gate + reflect-pad(96,96) + fold -> 8-column windowed DFT (MFMA) -> |.|
+//   silero_v4_stft : load + gate + reflect-pad(96,96) + window + 4-way fold -> 8-column DFT (MFMA, K = 64) -> |.|
 //                    -> global scratch [tile][8][33 quads][32 streams]
 //   silero_v4_tail : log(1 + |X| 2^20), adaptive normalisation, first layer (dw k5 + pw + proj),
 //                    1x1 stride convs, 3 separable blocks, LSTM(64) x 2, head, state machine
@@ -46,6 +46,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
     f32x4 *const XS = lds;                          // raw frame, [32 streams][128 quads]
     f32x4 *const UV = lds + K1_XS_F4;               // u/v of the two columns in flight: rows 64c' + q | 64c' + 32 + q
     float *const nyqv = reinterpret_cast<float *>(UV + K1_UV_ROWS * QS);   // [2][32]
+    float *const fcor = nyqv + 64;                  // [2 columns][y128, a64, b64][32 streams]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -56,7 +57,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
     const int T = P.T;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wstream), 0, (int)P.wstream_bytes, 0x00020000);
     const int lane16 = lane * 16;
-    const int o_stft = (int)P.sect[w][S_STFT], o_nyq = (int)P.sect[w][S_NYQ];
+    const int o_stft = (int)P.sect[w][S_STFT];
     f32x4 *const scratch = reinterpret_cast<f32x4 *>(P.scratch) + (size_t)blockIdx.x * SCRATCH_F4_PER_TILE;
 
     // ---- raw frame -> LDS (gate + int16 scaling fused), lanes run along the frame ---------------
@@ -90,81 +91,113 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
     }
     __syncthreads();
 
+    // window of the stored basis (its k = 0 cosine row): w[n] and w[128 + n] = w[128 - n] for this lane's n = 4q .. 4q + 3
+    const int fq = tid & 15;
+    const int o_win = (int)P.sect[w][S_NYQ];
+    const f32x4 W1 = ldw(wrs, fq * 16, o_win), W3 = ldw(wrs, (32 + fq) * 16, o_win);
+    const float w64 = ldw(wrs, 16 * 16, o_win).x;                 // w[64] = w[192]
+
 #pragma unroll 1
     for (int grp = 0; grp < 4; ++grp) {              // STFT columns 2 grp, 2 grp + 1 (hop 64 on the padded frame)
-        int ws = o_stft, wn = o_nyq;
-        asm volatile("" : "+s"(ws), "+s"(wn));
-        // ---- fold: u[n] = xp[64t+n] + xp[64t+256-n], v = difference, n = 4q+1..4q+4; n = 128 is its own mirror
+        int ws = o_stft;
+        asm volatile("" : "+s"(ws));
+        // ---- window + 4-way fold (as silero_v5.hip): y = w . xp[64 t ..]; for n = 4q .. 4q + 3, q = 0..15:
+        //      pe, po = (y[n] + y[256-n]) +- (y[128-n] + y[128+n]);  qe, qo = (y[n] - y[256-n]) -+ (y[128-n] - y[128+n])
+        //      rows 64 c' + {0, 16, 32, 48} + q;  n = 0, 64, 128 enter as rank-1 corrections after the MFMAs
         {
-            const int q = tid & 31;
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int o = rr * 8 + (tid >> 5);       // (column c', stream): o = c' * 32 + stream
+            for (int rr = 0; rr < 4; ++rr) {
+                const int o = rr * 16 + (tid >> 4);      // (column c', stream): o = c' * 32 + stream
                 const int cp = o >> 5, ms = o & 31;
                 const int Q0 = 16 * (2 * grp + cp);      // first xp quad of the column
                 const f32x4 *xs = XS + ms * 128;
-                const f32x4 a = xp_quad(xs, Q0 + q), b2 = xp_quad(xs, Q0 + q + 1), d = xp_quad(xs, Q0 + 63 - q);
-                f32x4 u = f32x4{a.y + d.w, a.z + d.z, a.w + d.y, b2.x + d.x};
-                f32x4 v = f32x4{a.y - d.w, a.z - d.z, a.w - d.y, b2.x - d.x};
-                if (q == 31) { u.w = b2.x; v.w = 0.f; }
-                UV[(64 * cp + q) * QS + ms] = u;
-                UV[(64 * cp + 32 + q) * QS + ms] = v;
+                const f32x4 xA = xp_quad(xs, Q0 + fq), xC = xp_quad(xs, Q0 + 32 + fq);
+                const f32x4 r1a = xp_quad(xs, Q0 + 32 - fq), r1b = xp_quad(xs, Q0 + 31 - fq);
+                const f32x4 r2a = xp_quad(xs, fq == 0 ? Q0 + 63 : Q0 + 64 - fq), r2b = xp_quad(xs, Q0 + 63 - fq);   // quad 64 of the last column does not exist; its only use (n = 0) is masked
+                const f32x4 y1 = f32x4{xA.x * W1.x, xA.y * W1.y, xA.z * W1.z, xA.w * W1.w};
+                const f32x4 y3 = f32x4{xC.x * W3.x, xC.y * W3.y, xC.z * W3.z, xC.w * W3.w};
+                const f32x4 y2 = f32x4{r1a.x * W3.x, r1b.w * W3.y, r1b.z * W3.z, r1b.y * W3.w};
+                const f32x4 y4 = f32x4{r2a.x * W1.x, r2b.w * W1.y, r2b.z * W1.z, r2b.y * W1.w};
+                const f32x4 s14 = f32x4{y1.x + y4.x, y1.y + y4.y, y1.z + y4.z, y1.w + y4.w};
+                const f32x4 d14 = f32x4{y1.x - y4.x, y1.y - y4.y, y1.z - y4.z, y1.w - y4.w};
+                const f32x4 s23 = f32x4{y2.x + y3.x, y2.y + y3.y, y2.z + y3.z, y2.w + y3.w};
+                const f32x4 d23 = f32x4{y2.x - y3.x, y2.y - y3.y, y2.z - y3.z, y2.w - y3.w};
+                f32x4 pe = f32x4{s14.x + s23.x, s14.y + s23.y, s14.z + s23.z, s14.w + s23.w};
+                f32x4 po = f32x4{s14.x - s23.x, s14.y - s23.y, s14.z - s23.z, s14.w - s23.w};
+                f32x4 qe = f32x4{d14.x - d23.x, d14.y - d23.y, d14.z - d23.z, d14.w - d23.w};
+                f32x4 qo = f32x4{d14.x + d23.x, d14.y + d23.y, d14.z + d23.z, d14.w + d23.w};
+                if (fq == 0) {
+                    pe.x = po.x = qe.x = qo.x = 0.f;
+                    const float y64 = xp_quad(xs, Q0 + 16).x * w64, y192 = xp_quad(xs, Q0 + 48).x * w64;
+                    fcor[(cp * 3 + 0) * 32 + ms] = y3.x;           // y[128]
+                    fcor[(cp * 3 + 1) * 32 + ms] = y64 + y192;     // a64
+                    fcor[(cp * 3 + 2) * 32 + ms] = y64 - y192;     // b64
+                }
+                UV[(64 * cp + fq) * QS + ms] = pe;
+                UV[(64 * cp + 16 + fq) * QS + ms] = po;
+                UV[(64 * cp + 32 + fq) * QS + ms] = qe;
+                UV[(64 * cp + 48 + fq) * QS + ms] = qo;
             }
         }
         f32x4 Are = ldw(wrs, lane16, ws), Aim = ldw(wrs, lane16, ws + 1);
         SB();
         __syncthreads();
-        // ---- bin 128 on the VALU: 64 (column, stream) pairs, 4 lanes each
+        // ---- bin 128 on the VALU: re = sum_n pe[n] (-1)^n + y128 + a64, im == 0; 64 (column, stream) pairs, 4 lanes each
         {
             const int pair = tid >> 2, part = tid & 3;
             const int cp = pair >> 5, ms = pair & 31;
             float a = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int qq = part * 8 + i;
-                const f32x4 cf = ldw(wrs, qq * 16, wn);
-                const f32x4 uu = UV[(64 * cp + qq) * QS + ms];
-                a += cf.x * uu.x + cf.y * uu.y + cf.z * uu.z + cf.w * uu.w;
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 pp = UV[(64 * cp + part * 4 + i) * QS + ms];
+                a += (pp.x - pp.y) + (pp.z - pp.w);
             }
             a += __shfl_xor(a, 1);
             a += __shfl_xor(a, 2);
-            if (part == 0) nyqv[cp * 32 + ms] = fabsf(a);
+            if (part == 0) nyqv[cp * 32 + ms] = fabsf(a + fcor[(cp * 3 + 0) * 32 + ms] + fcor[(cp * 3 + 1) * 32 + ms]);
         }
-        // ---- MFMA: wave w = bins 32w..32w+31, re on u / im on v, two columns
+        // ---- MFMA: wave w = bins bin_of_channel(32 w + r): cos on pe | po, -sin on qe | qo (even | odd bins), two columns, K = 64
         f32x16 are[2], aim[2];
         are[0] = are[1] = aim[0] = aim[1] = (f32x16)(0.f);
         {
-            f32x4 Au0 = UV[0 * QS + hq], Au1 = UV[64 * QS + hq], Av0 = UV[32 * QS + hq], Av1 = UV[96 * QS + hq];
+            const int rR = w < 2 ? 0 : 16, rI = w < 2 ? 32 : 48;
+            const f32x4 *const XR = UV + rR * QS + hq, *const XI = UV + rI * QS + hq;
+            f32x4 Au0 = XR[0], Au1 = XR[64 * QS], Av0 = XI[0], Av1 = XI[64 * QS];
             f32x4 Bre, Bim, Bu0, Bu1, Bv0, Bv1;
 #define K1_LD(S, jj)                                                                        \
     S##re = ldw(wrs, lane16, ws + 2 * (jj)); S##im = ldw(wrs, lane16, ws + 2 * (jj) + 1);   \
-    S##u0 = UV[(2 * (jj)) * QS + hq]; S##u1 = UV[(64 + 2 * (jj)) * QS + hq];                \
-    S##v0 = UV[(32 + 2 * (jj)) * QS + hq]; S##v1 = UV[(96 + 2 * (jj)) * QS + hq];
+    S##u0 = XR[(2 * (jj)) * QS]; S##u1 = XR[(64 + 2 * (jj)) * QS];                          \
+    S##v0 = XI[(2 * (jj)) * QS]; S##v1 = XI[(64 + 2 * (jj)) * QS];
 #define K1_MMA(S)                                                                           \
     are[0] = mfma4(S##re, S##u0, are[0]); are[1] = mfma4(S##re, S##u1, are[1]);             \
     aim[0] = mfma4(S##im, S##v0, aim[0]); aim[1] = mfma4(S##im, S##v1, aim[1]);
-            for (int j = 0; j < 16; j += 2) {
+            for (int j = 0; j < 8; j += 2) {
                 K1_LD(B, j + 1) SB();
                 K1_MMA(A) SB();
-                const int jn = j + 2 < 16 ? j + 2 : 14;
+                const int jn = j + 2 < 8 ? j + 2 : 6;
                 K1_LD(A, jn) SB();
                 K1_MMA(B) SB();
             }
 #undef K1_LD
 #undef K1_MMA
         }
-        // ---- magnitudes -> global scratch, row (33 t + quad), 32 float4 per row
+        // ---- rank-1 terms, magnitudes -> global scratch, row (33 t + quad), 32 float4 per row.
+        //      Register 4g+i holds tile row r = 8g + 4h + i: (-1)^r = (-1)^i
 #pragma unroll
         for (int cp = 0; cp < 2; ++cp) {
             const int tcol = 2 * grp + cp;
+            const float y128 = fcor[(cp * 3 + 0) * 32 + m], a64 = fcor[(cp * 3 + 1) * 32 + m], b64 = fcor[(cp * 3 + 2) * 32 + m];
+            // even bins: re += y128 + a64 (-1)^r ; odd bins: re -= y128, im -= b64 (-1)^r
+            const float rp = w < 2 ? y128 + a64 : -y128, rm = w < 2 ? y128 - a64 : -y128;
+            const float ip = w < 2 ? 0.f : -b64, im_ = w < 2 ? 0.f : b64;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 r = quad_of(are[cp], g), i = quad_of(aim[cp], g);
                 scratch[(size_t)(MAG_Q * tcol + 8 * w + 2 * g + h) * 32 + m] =
-                    f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
+                    f32x4{mag_(r.x + rp, i.x + ip), mag_(r.y + rm, i.y + im_), mag_(r.z + rp, i.z + ip), mag_(r.w + rm, i.w + im_)};
             }
         }
-        __syncthreads();       // nyqv complete; every wave done with UV before the next fold overwrites it
+        __syncthreads();       // nyqv complete; every wave done with UV / fcor before the next fold overwrites them
         if (tid < 64) scratch[(size_t)(MAG_Q * (2 * grp + h) + 32) * 32 + m] = f32x4{nyqv[h * 32 + m], 0.f, 0.f, 0.f};
     }
 }
@@ -189,6 +222,8 @@ __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) {
 __device__ __forceinline__ float log1p20(float mag) {   // log(1 + mag * 2^20): Mul, Add, Log of the graph
     return __builtin_amdgcn_logf(1.0f + mag * 1048576.0f) * 0.69314718055994531f;
 }
+// the same minus the adaptive-normalisation mean: Sub of the graph
+__device__ __forceinline__ float lognorm(float mag, float mm) { return log1p20(mag) - mm; }
 
 }  // namespace
 
@@ -217,6 +252,30 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
 #define WL(blk) ldw(wrs, lane16, (blk))
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 *const scratch = reinterpret_cast<const f32x4 *>(P.scratch) + (size_t)blockIdx.x * SCRATCH_F4_PER_TILE;
+
+    // ---- early requests: everything that comes from HBM and is needed late is asked for now, under the 135 KB
+    //      magnitude load: the slot's state machine (-> LDS), c_{t-1} of both LSTM layers (registers), head weights
+    SmSlot *const smL = reinterpret_cast<SmSlot *>(misc + K2_MISC_FLOATS);
+    const bool sm_thread = tid < MT && tile0 + tid < P.n;
+    const int sm_slot = sm_thread ? (P.slots ? P.slots[tile0 + tid] : tile0 + tid) : 0;
+    if (sm_thread) smL[tid] = P.sm[sm_slot];
+    const int u = w & 1, kh = w >> 1;              // LSTM roles: unit half u; waves 0,1 contract the input, 2,3 h_{t-1}
+    f32x4 cprev[2][4], hwq[4];
+    {
+        const float *st = P.state + (size_t)slot * 256;
+        int oh = (int)P.sect[w][S_HEADB];
+        asm volatile("" : "+s"(oh));
+#pragma unroll
+        for (int layer = 0; layer < 2; ++layer)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(st + 128 + 64 * layer + 32 * u + 8 * g + 4 * h);
+                cprev[layer][g] = live ? v : zero4;
+            }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) hwq[g] = WL(oh + 1 + 4 * u + g);
+    }
+    const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];
 
     // ---- P0: magnitudes scratch -> LDS rows (33 t + q) ------------------------------------------------
 #pragma unroll 3
@@ -260,6 +319,54 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
     }
     __syncthreads();
 
+    // Weights and depthwise tables of the short phases P3..P9 and of the LSTM layers are requested one or two phases
+    // before they are used (sets A, B, C, L): every phase is only 16..32 MFMAs long, an L2 round trip at its start
+    // would cost more than the phase itself.  One wave per SIMD owns 512 registers, so holding them is free.
+    f32x4 p3w[6], p4w[8], p4t[12], p5w[8];       // set A: requested before the P2 loop
+    f32x4 p6w[8], p6t[24], p7w[8];               // set B: requested at P3
+    f32x4 p8w[12], p8t[8], p9w[12];              // set C: requested at P5
+    f32x4 lb[16], lw[4];                         // set L: LSTM gate biases (input waves) + first weight group, per layer
+#define PRE_A                                                                                     \
+    {                                                                                             \
+        int o_ = (int)P.sect[w][S_S0];                                                            \
+        _Pragma("unroll") for (int k = 0; k < 6; ++k) p3w[k] = WL(o_ + k);                        \
+        o_ = (int)P.sect[w][S_L1];                                                                \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) p4w[k] = WL(o_ + 1 + k);                    \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                             \
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) p4t[6 * j + k] = ldt(wrs, (2 * j + h) * 6 + k, o_); \
+        o_ = (int)P.sect[w][S_S1];                                                                \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) p5w[k] = WL(o_ + k);                        \
+    }
+#define PRE_B                                                                                     \
+    {                                                                                             \
+        int o_ = (int)P.sect[w][S_L2];                                                            \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) p6w[k] = WL(o_ + 1 + k);                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) p6t[6 * j + k] = ldt(wrs, (2 * j + h) * 6 + k, o_); \
+        o_ = (int)P.sect[w][S_S2];                                                                \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) p7w[k] = WL(o_ + k);                        \
+    }
+#define PRE_C                                                                                     \
+    {                                                                                             \
+        int o_ = (int)P.sect[w][S_L3];                                                            \
+        _Pragma("unroll") for (int k = 0; k < 12; ++k) p8w[k] = WL(o_ + 1 + 12 * u + k);          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+            p8t[2 * j] = ldt(wrs, (2 * j + h) * 6 + 2, o_);                                       \
+            p8t[2 * j + 1] = ldt(wrs, (2 * j + h) * 6 + 5, o_);                                   \
+        }                                                                                         \
+        o_ = (int)P.sect[w][S_S3];                                                                \
+        _Pragma("unroll") for (int k = 0; k < 12; ++k) p9w[k] = WL(o_ + 12 * u + k);              \
+    }
+    // LSTM layer `layer`: waves kh = 0 start from the bias and contract the layer input, waves kh = 1 contract h_{t-1}
+#define PRE_L(layer)                                                                              \
+    {                                                                                             \
+        const int ob_ = (int)P.sect[w][(layer) == 0 ? S_LSTM0 : S_LSTM1] + 80 * u;                \
+        if (kh == 0) {                                                                            \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) lb[k] = WL(ob_ + k);                   \
+        }                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) lw[k] = WL(ob_ + (kh == 0 ? 16 : 48) + k);  \
+    }
+
     // ---- P2: first layer; wave w produces output column t' = w (input column t = 2w), 16 channels ---------
     {
         const int tcol = 2 * w;
@@ -269,32 +376,52 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
         const int ws = o_l0 + 4;
         const float mm = mmv[m];
         f32x4 Wa = WL(ws), Wb = WL(ws + 1), Wc = WL(ws + 2), Wd = WL(ws + 3);
+        // depthwise taps + bias of this lane's channel quad for one k-iteration: 12 table rows, requested one iteration
+        // ahead (they come from L2: consumed in the iteration that asks for them they cost a round trip each time)
+        f32x4 tb[12], nt[12];
+#define P2_TABLES(T, jj)                                                                   \
+    {                                                                                      \
+        const int q_ = 2 * (jj) + h;                                                       \
+        T[0] = ldt(wrs, q_ * 6 + 5, o_dw0); T[1] = ldt(wrs, (34 + q_) * 6 + 5, o_dw0);     \
+        _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                    \
+            T[2 + 2 * k] = ldt(wrs, q_ * 6 + k, o_dw0);                                    \
+            T[3 + 2 * k] = ldt(wrs, (34 + q_) * 6 + k, o_dw0);                             \
+        }                                                                                  \
+    }
+        P2_TABLES(tb, 0)
+        // weights of the next phases (P3, P4, P5): they do not depend on LDS and land during this loop
+        PRE_A
 #pragma unroll 1
         for (int j = 0; j < 17; ++j) {
             const int q = 2 * j + h;                 // this lane's channel quad (33 -> all zero)
+            const int jn = j < 16 ? j + 1 : 16;
+            P2_TABLES(nt, jn)
+            const f32x4 nWa = WL(ws + 4 * jn), nWb = WL(ws + 4 * jn + 1), nWc = WL(ws + 4 * jn + 2), nWd = WL(ws + 4 * jn + 3);
+            SB();
             // depthwise k5 p2 over the 8 columns, magnitude part and normalised part, + the undelayed x1 quads
-            f32x4 dm = ldt(wrs, (q * 6 + 5), o_dw0), dn = ldt(wrs, ((34 + q) * 6 + 5), o_dw0);   // biases
+            f32x4 dm = tb[0], dn = tb[1];            // biases
             f32x4 xm = zero4, xn = zero4;
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 const int tc = tcol + k - 2;
                 if (tc >= 0 && tc < 8 && q < 33) {
                     const f32x4 mg = RX[(MAG_Q * tc + q) * QS + m];
-                    const f32x4 sp = f32x4{log1p20(mg.x) - mm, log1p20(mg.y) - mm, log1p20(mg.z) - mm, log1p20(mg.w) - mm};
-                    dm = fma4(ldt(wrs, q * 6 + k, o_dw0), mg, dm);
-                    dn = fma4(ldt(wrs, (34 + q) * 6 + k, o_dw0), sp, dn);
+                    const f32x4 sp = f32x4{lognorm(mg.x, mm), lognorm(mg.y, mm), lognorm(mg.z, mm), lognorm(mg.w, mm)};
+                    dm = fma4(tb[2 + 2 * k], mg, dm);
+                    dn = fma4(tb[3 + 2 * k], sp, dn);
                     if (k == 2) { xm = mg; xn = sp; }
                 }
             }
             dm = relu4(dm);
             dn = relu4(dn);
-            const int jn = j < 16 ? j + 1 : 16;
-            const f32x4 nWa = WL(ws + 4 * jn), nWb = WL(ws + 4 * jn + 1), nWc = WL(ws + 4 * jn + 2), nWd = WL(ws + 4 * jn + 3);
             SB();
             TG_MMA(acc, Wa, Wb, Wc, Wd, dm, xm, dn, xn)      // pw|mag . dm + proj|mag . xm + pw|norm . dn + proj|norm . xn
             SB();
             Wa = nWa; Wb = nWb; Wc = nWc; Wd = nWd;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) tb[k] = nt[k];
         }
+#undef P2_TABLES
         // rows 0..15 of the tile are the 16 channels: registers of g = 0,1
 #pragma unroll
         for (int g = 0; g < 2; ++g) RX[(R_A16 + 4 * w + 2 * g) * QS + hq] = relu4(quad_of(acc, g));
@@ -317,11 +444,11 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
 
     // ---- P3: s0 1x1 16 -> 16 on the 4 kept columns (stride 2 already applied: t = 0,2,4,6) -------------
     {
-        int o = (int)P.sect[w][S_S0];
-        asm volatile("" : "+s"(o));
-        f32x16 acc = acc_of(WL(o), WL(o + 1), WL(o + 2), WL(o + 3));
-        acc = mfma4(WL(o + 4), RX[(R_A16 + 4 * w + 0) * QS + hq], acc);
-        acc = mfma4(WL(o + 5), RX[(R_A16 + 4 * w + 2) * QS + hq], acc);
+        PRE_B
+        SB();
+        f32x16 acc = acc_of(p3w[0], p3w[1], p3w[2], p3w[3]);
+        acc = mfma4(p3w[4], RX[(R_A16 + 4 * w + 0) * QS + hq], acc);
+        acc = mfma4(p3w[5], RX[(R_A16 + 4 * w + 2) * QS + hq], acc);
 #pragma unroll
         for (int g = 0; g < 2; ++g) RX[(R_Y0 + 4 * w + 2 * g) * QS + hq] = relu4(quad_of(acc, g));
     }
@@ -329,56 +456,50 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
 
     // ---- P4: block 1 (16 -> 32): dw k5 over the 4 columns (VALU, in registers) -> pw, + proj(y) ---------
     {
-        int o = (int)P.sect[w][S_L1];
-        asm volatile("" : "+s"(o));
-        f32x16 acc = acc_of(WL(o + 1), WL(o + 2), WL(o + 3), WL(o + 4));
+        f32x16 acc = acc_of(p4w[0], p4w[1], p4w[2], p4w[3]);
         f32x4 d[2], y[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int q = 2 * j + h;
-            d[j] = ldt(wrs, q * 6 + 5, o);
+            d[j] = p4t[6 * j + 5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 const int tc = w + k - 2;
-                if (tc >= 0 && tc < 4) d[j] = fma4(ldt(wrs, q * 6 + k, o), RX[(R_Y0 + 4 * tc + 2 * j) * QS + hq], d[j]);
+                if (tc >= 0 && tc < 4) d[j] = fma4(p4t[6 * j + k], RX[(R_Y0 + 4 * tc + 2 * j) * QS + hq], d[j]);
             }
             d[j] = relu4(d[j]);
             y[j] = RX[(R_Y0 + 4 * w + 2 * j) * QS + hq];
         }
-        TG_MMA(acc, WL(o + 5), WL(o + 6), WL(o + 7), WL(o + 8), d[0], d[1], y[0], y[1])
+        TG_MMA(acc, p4w[4], p4w[5], p4w[6], p4w[7], d[0], d[1], y[0], y[1])
         store_tile_relu(RX, R_Y1 + 8 * w, m, h, acc);
     }
     __syncthreads();
 
     // ---- P5: s1 1x1 32 -> 32, stride 2: columns 0 and 2; waves 0,1 -------------------------------------
+    PRE_C
+    SB();
     if (w < 2) {
-        int o = (int)P.sect[w][S_S1];
-        asm volatile("" : "+s"(o));
-        f32x16 acc = acc_of(WL(o), WL(o + 1), WL(o + 2), WL(o + 3));
+        f32x16 acc = acc_of(p5w[0], p5w[1], p5w[2], p5w[3]);
         const int r = R_Y1 + 8 * (2 * w);
-        TG_MMA(acc, WL(o + 4), WL(o + 5), WL(o + 6), WL(o + 7), RX[(r + 0) * QS + hq], RX[(r + 2) * QS + hq], RX[(r + 4) * QS + hq], RX[(r + 6) * QS + hq])
+        TG_MMA(acc, p5w[4], p5w[5], p5w[6], p5w[7], RX[(r + 0) * QS + hq], RX[(r + 2) * QS + hq], RX[(r + 4) * QS + hq], RX[(r + 6) * QS + hq])
         store_tile_relu(RX, R_Y2 + 8 * w, m, h, acc);
     }
     __syncthreads();
 
     // ---- P6: block 2 (32 -> 32, identity residual) on 2 columns; waves 0,1 ------------------------------
     if (w < 2) {
-        int o = (int)P.sect[w][S_L2];
-        asm volatile("" : "+s"(o));
-        f32x16 acc = acc_of(WL(o + 1), WL(o + 2), WL(o + 3), WL(o + 4));
+        f32x16 acc = acc_of(p6w[0], p6w[1], p6w[2], p6w[3]);
         f32x4 d[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int q = 2 * j + h;
-            d[j] = ldt(wrs, q * 6 + 5, o);
+            d[j] = p6t[6 * j + 5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 const int tc = w + k - 2;
-                if (tc >= 0 && tc < 2) d[j] = fma4(ldt(wrs, q * 6 + k, o), RX[(R_Y2 + 8 * tc + 2 * j) * QS + hq], d[j]);
+                if (tc >= 0 && tc < 2) d[j] = fma4(p6t[6 * j + k], RX[(R_Y2 + 8 * tc + 2 * j) * QS + hq], d[j]);
             }
             d[j] = relu4(d[j]);
         }
-        TG_MMA(acc, WL(o + 5), WL(o + 6), WL(o + 7), WL(o + 8), d[0], d[1], d[2], d[3])
+        TG_MMA(acc, p6w[4], p6w[5], p6w[6], p6w[7], d[0], d[1], d[2], d[3])
         // + identity residual: lane (m,h) register 4g+i is channel 8g+4h+i = quad 2g+h of the input
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -389,61 +510,51 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
     __syncthreads();
 
     // ---- P7: s2 1x1 32 -> 32, stride 2: column 0; wave 0 -------------------------------------------------
+    PRE_L(0)
+    SB();
     if (w == 0) {
-        int o = (int)P.sect[w][S_S2];
-        asm volatile("" : "+s"(o));
-        f32x16 acc = acc_of(WL(o), WL(o + 1), WL(o + 2), WL(o + 3));
-        TG_MMA(acc, WL(o + 4), WL(o + 5), WL(o + 6), WL(o + 7), RX[(R_Y3 + 0) * QS + hq], RX[(R_Y3 + 2) * QS + hq], RX[(R_Y3 + 4) * QS + hq], RX[(R_Y3 + 6) * QS + hq])
+        f32x16 acc = acc_of(p7w[0], p7w[1], p7w[2], p7w[3]);
+        TG_MMA(acc, p7w[4], p7w[5], p7w[6], p7w[7], RX[(R_Y3 + 0) * QS + hq], RX[(R_Y3 + 2) * QS + hq], RX[(R_Y3 + 4) * QS + hq], RX[(R_Y3 + 6) * QS + hq])
         store_tile_relu(RX, R_Y4, m, h, acc);
     }
     __syncthreads();
 
     // ---- P8: block 3 (32 -> 64) on the single column (dw: centre tap only); waves 0,1 = output tile -----
     if (w < 2) {
-        int o = (int)P.sect[w][S_L3];
-        asm volatile("" : "+s"(o));
-        const int ob = o + 1 + 12 * w;
-        f32x16 acc = acc_of(WL(ob), WL(ob + 1), WL(ob + 2), WL(ob + 3));
+        f32x16 acc = acc_of(p8w[0], p8w[1], p8w[2], p8w[3]);
         f32x4 d[4], y[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int q = 2 * j + h;
             y[j] = RX[(R_Y4 + 2 * j) * QS + hq];
-            d[j] = relu4(fma4(ldt(wrs, q * 6 + 2, o), y[j], ldt(wrs, q * 6 + 5, o)));
+            d[j] = relu4(fma4(p8t[2 * j], y[j], p8t[2 * j + 1]));
         }
-        TG_MMA(acc, WL(ob + 4), WL(ob + 5), WL(ob + 6), WL(ob + 7), d[0], d[1], d[2], d[3])
-        TG_MMA(acc, WL(ob + 8), WL(ob + 9), WL(ob + 10), WL(ob + 11), y[0], y[1], y[2], y[3])
+        TG_MMA(acc, p8w[4], p8w[5], p8w[6], p8w[7], d[0], d[1], d[2], d[3])
+        TG_MMA(acc, p8w[8], p8w[9], p8w[10], p8w[11], y[0], y[1], y[2], y[3])
         store_tile_relu(RX, R_Y5 + 8 * w, m, h, acc);
     }
     __syncthreads();
 
     // ---- P9: s3 1x1 64 -> 64; waves 0,1 = output tile ---------------------------------------------------
     if (w < 2) {
-        int o = (int)P.sect[w][S_S3];
-        asm volatile("" : "+s"(o));
-        const int ob = o + 12 * w;
-        f32x16 acc = acc_of(WL(ob), WL(ob + 1), WL(ob + 2), WL(ob + 3));
-        TG_MMA(acc, WL(ob + 4), WL(ob + 5), WL(ob + 6), WL(ob + 7), RX[(R_Y5 + 0) * QS + hq], RX[(R_Y5 + 2) * QS + hq], RX[(R_Y5 + 4) * QS + hq], RX[(R_Y5 + 6) * QS + hq])
-        TG_MMA(acc, WL(ob + 8), WL(ob + 9), WL(ob + 10), WL(ob + 11), RX[(R_Y5 + 8) * QS + hq], RX[(R_Y5 + 10) * QS + hq], RX[(R_Y5 + 12) * QS + hq], RX[(R_Y5 + 14) * QS + hq])
+        f32x16 acc = acc_of(p9w[0], p9w[1], p9w[2], p9w[3]);
+        TG_MMA(acc, p9w[4], p9w[5], p9w[6], p9w[7], RX[(R_Y5 + 0) * QS + hq], RX[(R_Y5 + 2) * QS + hq], RX[(R_Y5 + 4) * QS + hq], RX[(R_Y5 + 6) * QS + hq])
+        TG_MMA(acc, p9w[8], p9w[9], p9w[10], p9w[11], RX[(R_Y5 + 8) * QS + hq], RX[(R_Y5 + 10) * QS + hq], RX[(R_Y5 + 12) * QS + hq], RX[(R_Y5 + 14) * QS + hq])
         store_tile_relu(RX, R_Y6 + 8 * w, m, h, acc);
     }
     __syncthreads();
 
     // ---- P10/P11: two stacked LSTM(64) cells.  wave w: unit half u = w&1; waves 0,1 contract the layer
     //      input (+bias), waves 2,3 contract h_{t-1}; partial gates meet in LDS, waves 0,1 finish the cell
-    const int u = w & 1, kh = w >> 1;
     float part = 0.f;
-#pragma unroll 1
+#pragma unroll
     for (int layer = 0; layer < 2; ++layer) {
-        int o = (int)P.sect[w][layer == 0 ? S_LSTM0 : S_LSTM1];
-        asm volatile("" : "+s"(o));
-        const int ob = o + 80 * u;
+        const int ob = (int)P.sect[w][layer == 0 ? S_LSTM0 : S_LSTM1] + 80 * u;
         f32x16 g4[4];
         int ws;
         const f32x4 *src;
         if (kh == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) g4[q] = acc_of(WL(ob + 4 * q), WL(ob + 4 * q + 1), WL(ob + 4 * q + 2), WL(ob + 4 * q + 3));
+            for (int q = 0; q < 4; ++q) g4[q] = acc_of(lb[4 * q], lb[4 * q + 1], lb[4 * q + 2], lb[4 * q + 3]);
             ws = ob + 16;
             src = RX + (layer == 0 ? R_Y6 : R_H0N) * QS + hq;
         } else {
@@ -452,9 +563,10 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
             ws = ob + 48;
             src = RX + (layer == 0 ? R_H0 : R_H1) * QS + hq;
         }
-        f32x4 Aw0 = WL(ws), Aw1 = WL(ws + 1), Aw2 = WL(ws + 2), Aw3 = WL(ws + 3), Aa = src[0], Bw0, Bw1, Bw2, Bw3, Ba;
+        f32x4 Aw0 = lw[0], Aw1 = lw[1], Aw2 = lw[2], Aw3 = lw[3], Aa = src[0], Bw0, Bw1, Bw2, Bw3, Ba;
 #define LS_LD(S, it) S##w0 = WL(ws + 4 * (it)); S##w1 = WL(ws + 4 * (it) + 1); S##w2 = WL(ws + 4 * (it) + 2); S##w3 = WL(ws + 4 * (it) + 3); S##a = src[(2 * (it)) * QS];
 #define LS_MMA(S) g4[0] = mfma4(S##w0, S##a, g4[0]); g4[1] = mfma4(S##w1, S##a, g4[1]); g4[2] = mfma4(S##w2, S##a, g4[2]); g4[3] = mfma4(S##w3, S##a, g4[3]);
+#pragma unroll
         for (int it = 0; it < 8; it += 2) {
             LS_LD(B, it + 1) SB();
             LS_MMA(A) SB();
@@ -464,6 +576,10 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
         }
 #undef LS_LD
 #undef LS_MMA
+        if (layer == 0) {
+            PRE_L(1)         // the second layer's biases and first weights fly during the first layer's cell update
+            SB();
+        }
         if (kh == 1) {
             float *gp = gpart + (size_t)u * 64 * 64 + lane;
 #pragma unroll
@@ -478,15 +594,12 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) g4[q][r] += gp[(q * 16 + r) * 64];
-            int oh = (int)P.sect[w][S_HEADB];
-            asm volatile("" : "+s"(oh));
             float *st = P.state + (size_t)slot * 256;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 i4 = quad_of(g4[0], g), f4 = quad_of(g4[1], g), c4g = quad_of(g4[2], g), o4 = quad_of(g4[3], g);
                 const int unit = 32 * u + 8 * g + 4 * h;
-                f32x4 cp = zero4;
-                if (live) cp = *reinterpret_cast<const f32x4 *>(st + 128 + 64 * layer + unit);
+                const f32x4 cp = cprev[layer][g];
                 f32x4 cn, hn;
 #define CELL(k)                                                             \
     cn.k = sigmoidf_(f4.k) * cp.k + sigmoidf_(i4.k) * tanhf_(c4g.k);      \
@@ -500,13 +613,17 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
                 if (layer == 0) {
                     RX[(R_H0N + 8 * u + 2 * g) * QS + hq] = hn;
                 } else {
-                    const f32x4 hw = WL(oh + 1 + 4 * u + g);
+                    const f32x4 hw = hwq[g];
                     part += hw.x * fmaxf(hn.x, 0.f) + hw.y * fmaxf(hn.y, 0.f) + hw.z * fmaxf(hn.z, 0.f) + hw.w * fmaxf(hn.w, 0.f);
                 }
             }
         }
         __syncthreads();
     }
+#undef PRE_A
+#undef PRE_B
+#undef PRE_C
+#undef PRE_L
     if (kh == 0) {
         part += __shfl_xor(part, 32);
         if (h == 0) headp[u * 32 + m] = part;
@@ -514,12 +631,10 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
     __syncthreads();
 
     // ---- head + state machine ------------------------------------------------------------------------
-    if (tid < MT && tile0 + tid < P.n) {
-        const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];
+    if (sm_thread) {
         const float p = fminf(sigmoidf_(hb + headp[tid] + headp[32 + tid]), 1.0f);
-        const int sm_slot = P.slots ? P.slots[tile0 + tid] : tile0 + tid;
         P.probs[(size_t)(tile0 + tid) * T + tframe] = p;
-        SmSlot sm = P.sm[sm_slot];
+        SmSlot sm = smL[tid];
         int seg = 0;
         const int ev = sm_step(sm, p, &seg);
         P.sm[sm_slot] = sm;

@@ -75,7 +75,7 @@ constexpr int LDS_BYTES = LDS_F4 * 16;
 //   silero_v4_tail : log-spectrum + adaptive normalisation, 4 separable blocks, 2 x LSTM(64), head, state machine
 namespace v4 {
 enum Section {
-    S_STFT = 0, S_NYQ,            // as V5 (the DFT basis is identical)
+    S_STFT = 0, S_NYQ,            // as V5 (the DFT basis is identical): folded-DFT tables, window table
     S_DW0,                        // first-layer depthwise taps+bias per channel quad (VALU table)
     S_L0,                         // first layer: pw(relu(dw(x1))) + proj(x1), 16 outputs (rows 16..31 of the tile are zero)
     S_S0, S_L1, S_S1, S_L2, S_S2, S_L3, S_S3, S_LSTM0, S_LSTM1, S_HEADB, S_COUNT
@@ -83,17 +83,18 @@ enum Section {
 constexpr int MAG_Q = 33;                      // quads per STFT column: 128 bins + Nyquist (+3 pad channels)
 constexpr int MAG_ROWS = 8 * MAG_Q;            // 264 rows per tile, row = 33 t + q
 constexpr int SCRATCH_F4_PER_TILE = MAG_ROWS * 32;   // global scratch uses 32 float4 per row (no padding)
-// silero_v4_stft LDS: raw frame [32][512] f32 + u/v of two columns (128 quad rows) + Nyquist magnitudes
+// silero_v4_stft LDS: raw frame [32][512] f32 + the 4-way fold of two columns (2 x 64 quad rows: pe, po, qe, qo as in
+// V5) + Nyquist magnitudes [2][32] + fold corrections [2][3][32]
 constexpr int K1_XS_F4 = 32 * 128;
 constexpr int K1_UV_ROWS = 128;
-constexpr int K1_LDS_F4 = K1_XS_F4 + K1_UV_ROWS * QS + 16;
+constexpr int K1_LDS_F4 = K1_XS_F4 + K1_UV_ROWS * QS + 16 + 48;
 // silero_v4_tail LDS rows
 constexpr int R_A16 = MAG_ROWS;                // first-layer output: 264 + 4 t' + quad
 constexpr int K2_ROWS = MAG_ROWS + 16;
 constexpr int R_Y0 = 0, R_Y1 = 16, R_Y2 = 48, R_Y3 = 64, R_Y4 = 80, R_Y5 = 88, R_Y6 = 104;
 constexpr int R_H0 = 120, R_H1 = 136, R_H0N = 152, R_GP = 168;   // gate partials: 2 x 64 regs x 64 lanes floats from row 168
 constexpr int K2_MISC_FLOATS = 32 + 8 * 32 + 64;   // mm[32], colmean[8][32], head partials [2][32]
-constexpr int K2_LDS_F4 = K2_ROWS * QS + K2_MISC_FLOATS / 4;
+constexpr int K2_LDS_F4 = K2_ROWS * QS + K2_MISC_FLOATS / 4 + 192;   // + the tile's 32 state machines (96 B each)
 }  // namespace v4
 
 // per-slot hysteresis state (VADProcessor fields, core/silero_model.py:596-639), 96 bytes.

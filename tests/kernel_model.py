@@ -228,30 +228,42 @@ def v4_step(W, sect, x, hc, gate=0.01):
     # ---- launch 1: reflect pad, fold, STFT, magnitudes -> scratch rows 33 t + q
     xp = np.pad(x, ((0, 0), (96, 96)), mode="reflect")                    # [32, 704]
     scratch = np.zeros((264, 32, 4))
-    nq = W[sect[0][S["S_NYQ"]]].reshape(-1)[:128].astype(np.float64)
-    n = np.arange(1, 129)
+    wtab = W[sect[0][S["S_NYQ"]]].reshape(-1)[:256].astype(np.float64)    # w[n], the k = 0 row of the stored basis
+    n = np.arange(64)
+    sgn = np.where(np.arange(32) % 2 == 0, 1.0, -1.0)[:, None]             # (-1)^r per tile row
     for grp in range(4):
         UV = np.zeros((128, 32, 4))
+        fcor = np.zeros((2, 3, 32))
         for cp in range(2):
             t = 2 * grp + cp
-            col = xp[:, 64 * t:64 * t + 256]
-            mir = np.where(n < 128, 256 - n, 0)
-            xm = np.where(n[None, :] < 128, col[:, mir], 0.0)
-            u = col[:, n] + xm
-            v = np.where(n[None, :] < 128, col[:, n] - xm, 0.0)
-            UV[64 * cp:64 * cp + 32] = u.reshape(32, 32, 4).transpose(1, 0, 2)
-            UV[64 * cp + 32:64 * cp + 64] = v.reshape(32, 32, 4).transpose(1, 0, 2)
-            scratch[33 * t + 32, :, 0] = np.abs(u @ nq)
+            y = xp[:, 64 * t:64 * t + 256] * wtab[None, :]
+            y1, y2, y3, y4 = y[:, n], y[:, 128 - n], y[:, 128 + n], y[:, (256 - n) % 256]
+            pe, po = y1 + y4 + y2 + y3, y1 + y4 - y2 - y3
+            qe, qo = y1 - y4 - y2 + y3, y1 - y4 + y2 - y3
+            for k, arr in enumerate((pe, po, qe, qo)):
+                arr = arr.copy()
+                arr[:, 0] = 0.0                                             # n = 0 is not part of the folded sums
+                UV[64 * cp + 16 * k:64 * cp + 16 * k + 16] = arr.reshape(32, 16, 4).transpose(1, 0, 2)
+            fcor[cp, 0], fcor[cp, 1], fcor[cp, 2] = y[:, 128], y[:, 64] + y[:, 192], y[:, 64] - y[:, 192]
+            pe4 = UV[64 * cp:64 * cp + 16]
+            alt = (pe4[:, :, 0] - pe4[:, :, 1] + pe4[:, :, 2] - pe4[:, :, 3]).sum(0)
+            scratch[33 * t + 32, :, 0] = np.abs(alt + fcor[cp, 0] + fcor[cp, 1])
         for w in range(4):
             ws = sect[w][S["S_STFT"]]
+            rR, rI = (0, 32) if w < 2 else (16, 48)
             are = [np.zeros((32, 32)) for _ in range(2)]
             aim = [np.zeros((32, 32)) for _ in range(2)]
-            for j in range(16):
+            for j in range(8):
                 for cp in range(2):
-                    are[cp] += _mfma4(W[ws + 2 * j], _rows(UV, 64 * cp + 2 * j, 64 * cp + 2 * j + 1))
-                    aim[cp] += _mfma4(W[ws + 2 * j + 1], _rows(UV, 64 * cp + 32 + 2 * j, 64 * cp + 32 + 2 * j + 1))
+                    are[cp] += _mfma4(W[ws + 2 * j], _rows(UV, 64 * cp + rR + 2 * j, 64 * cp + rR + 2 * j + 1))
+                    aim[cp] += _mfma4(W[ws + 2 * j + 1], _rows(UV, 64 * cp + rI + 2 * j, 64 * cp + rI + 2 * j + 1))
             for cp in range(2):
-                _store_tile(scratch, 33 * (2 * grp + cp) + 8 * w, np.sqrt(are[cp] ** 2 + aim[cp] ** 2), relu=False)
+                y128, a64, b64 = fcor[cp, 0][None, :], fcor[cp, 1][None, :], fcor[cp, 2][None, :]
+                if w < 2:
+                    re, im = are[cp] + y128 + sgn * a64, aim[cp]
+                else:
+                    re, im = are[cp] - y128, aim[cp] - sgn * b64
+                _store_tile(scratch, 33 * (2 * grp + cp) + 8 * w, np.sqrt(re ** 2 + im ** 2), relu=False)
     # ---- launch 2
     RX = np.zeros((280, 32, 4))
     RX[:264] = scratch
