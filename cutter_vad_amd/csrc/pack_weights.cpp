@@ -200,7 +200,8 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
                     sb.weight_block([&](int np, int c) { return convw(1, 32 * nt + np, c, tap); }, j);
             }
         }
-        // enc2 (waves 0,1): n-tile w, taps 1,2 on input columns 0,1
+        // enc2: n-tile w&1, taps 1,2 on input columns 0,1; waves 2,3 contract the second K half (column 1) of the
+        // SAME streams (their section offsets alias waves 0,1 below)
         out.sect[w][S_ENC2] = sb.blocks();
         if (w < 2) {
             sb.vector_blocks([&](int c) { return eb[2][32 * w + c]; });
@@ -224,6 +225,8 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
                 sb.weight_block([&](int np, int c) { return w_hh[(size_t)(q * 128 + 32 * w + np) * 128 + c]; }, j);
         sb.vector_blocks([&](int c) { return head_w[32 * w + c]; });
     }
+    out.sect[2][S_ENC2] = out.sect[0][S_ENC2];
+    out.sect[3][S_ENC2] = out.sect[1][S_ENC2];
     const uint32_t hb = sb.blocks();
     sb.new_block()[0] = head_b[0];
     // bin 128 of the folded STFT (VALU): floats 0..127 = C[128][1..128]; its sine row is exactly zero

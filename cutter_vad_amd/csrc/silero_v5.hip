@@ -388,11 +388,10 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
                 G_MMA(A) SB();
                 const int gn = g4 + 2 < 8 ? g4 + 2 : 6;
                 G_LDW(A, ws, gn) E1_LDA(A, gn) SB();
-                if (g4 == 6) {   // last pass: request enc2's (waves 0,1) and enc3's first blocks
-                    if (w < 2) {
-                        e2b0 = WL(ws_e2); e2b1 = WL(ws_e2 + 1); e2b2 = WL(ws_e2 + 2); e2b3 = WL(ws_e2 + 3);
-                        E2w0 = WL(ws_e2 + 4); E2w1 = WL(ws_e2 + 5); E2w2 = WL(ws_e2 + 6); E2w3 = WL(ws_e2 + 7);
-                    }
+                if (g4 == 6) {   // last pass: request enc2's (bias: K half 0 only) and enc3's first blocks
+                    const int ge = 4 + 8 * (w >> 1);           // this wave's K half: weight groups 2 (w>>1), 2 (w>>1) + 1
+                    e2b0 = WL(ws_e2); e2b1 = WL(ws_e2 + 1); e2b2 = WL(ws_e2 + 2); e2b3 = WL(ws_e2 + 3);
+                    E2w0 = WL(ws_e2 + ge); E2w1 = WL(ws_e2 + ge + 1); E2w2 = WL(ws_e2 + ge + 2); E2w3 = WL(ws_e2 + ge + 3);
                     e3b0 = WL(ws_e3); e3b1 = WL(ws_e3 + 1); e3b2 = WL(ws_e3 + 2); e3b3 = WL(ws_e3 + 3);
                     E3w0 = WL(ws_e3 + 4); E3w1 = WL(ws_e3 + 5); E3w2 = WL(ws_e3 + 6); E3w3 = WL(ws_e3 + 7);
                     SB();
@@ -407,10 +406,14 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
         __syncthreads();   // (4) enc1 out in B; region A free
         STAMP(8);
 
-        // ---- enc2: 64 -> 64 ch, k3 s2 p1, 2 -> 1 column (taps 1,2 on columns 0,1); waves 0,1 ----
-        if (w < 2) {
+        // ---- enc2: 64 -> 64 ch, k3 s2 p1, 2 -> 1 column (taps 1,2 on columns 0,1) ----
+        // split-K over the 4 waves: wave w = output tile w&1, K half w>>1 (= input column w>>1).  The two partial
+        // tiles (bias in half 0) go to rows 16 (w>>1) + 8 (w&1) un-activated; enc3 adds them and applies the ReLU
+        // as it reads its input - no extra barrier.
+        {
+            const int kh2 = w >> 1;
             const int ws = ws_e2 + 4;
-            f32x16 acc = acc_of(e2b0, e2b1, e2b2, e2b3);
+            f32x16 acc = kh2 == 0 ? acc_of(e2b0, e2b1, e2b2, e2b3) : (f32x16)(0.f);
             // iteration it in 0..15: column it>>3, quad pair it&7
 #define E2_ROW(it) (((it) >> 3) * 16 + 2 * ((it) & 7))
 #define E2_LDA(S, g4)                                                                      \
@@ -418,17 +421,14 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
     S##a2 = RX[E2_ROW(4 * (g4) + 2) * QS + hq]; S##a3 = RX[E2_ROW(4 * (g4) + 3) * QS + hq];
             f32x4 Aw0 = E2w0, Aw1 = E2w1, Aw2 = E2w2, Aw3 = E2w3, Bw0, Bw1, Bw2, Bw3;
             f32x4 Aa0, Aa1, Aa2, Aa3, Ba0, Ba1, Ba2, Ba3;
-            E2_LDA(A, 0)
-            for (int g4 = 0; g4 < 4; g4 += 2) {
-                G_LDW(B, ws, g4 + 1) E2_LDA(B, g4 + 1) SB();
-                G_MMA(A) SB();
-                const int gn = g4 + 2 < 4 ? g4 + 2 : 2;
-                G_LDW(A, ws, gn) E2_LDA(A, gn) SB();
-                G_MMA(B) SB();
-            }
+            E2_LDA(A, 2 * kh2)
+            G_LDW(B, ws, 2 * kh2 + 1) E2_LDA(B, 2 * kh2 + 1) SB();
+            G_MMA(A) SB();
+            G_MMA(B) SB();
 #undef E2_ROW
 #undef E2_LDA
-            store_tile_relu(RE, 8 * w, m, h, acc);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) RE[(16 * kh2 + 8 * (w & 1) + 2 * g) * QS + hq] = quad_of(acc, g);
         }
         STAMP(9);
         __syncthreads();   // (5) enc2 out in A
@@ -440,9 +440,14 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             const int ws = ws_e3 + 4;
             f32x16 acc = acc_of(e3b0, e3b1, e3b2, e3b3);
             f32x4 Aw0 = E3w0, Aw1 = E3w1, Aw2 = E3w2, Aw3 = E3w3, Bw0, Bw1, Bw2, Bw3;
-            f32x4 Aa0 = RE[0 * QS + hq], Aa1 = RE[2 * QS + hq], Aa2 = RE[4 * QS + hq], Aa3 = RE[6 * QS + hq];
+            // input quad r = relu(enc2 partial of K half 0 (row r) + K half 1 (row 16 + r))
+            auto e2q = [&](int r) -> f32x4 {
+                const f32x4 a = RE[r * QS + hq], b2 = RE[(16 + r) * QS + hq];
+                return relu4(f32x4{a.x + b2.x, a.y + b2.y, a.z + b2.z, a.w + b2.w});
+            };
+            f32x4 Aa0 = e2q(0), Aa1 = e2q(2), Aa2 = e2q(4), Aa3 = e2q(6);
             G_LDW(B, ws, 1)
-            const f32x4 Ba0 = RE[8 * QS + hq], Ba1 = RE[10 * QS + hq], Ba2 = RE[12 * QS + hq], Ba3 = RE[14 * QS + hq];
+            const f32x4 Ba0 = e2q(8), Ba1 = e2q(10), Ba2 = e2q(12), Ba3 = e2q(14);
             // the first weight blocks of the LSTM's input half
             Lw0 = WL(ws_l + 16); Lw1 = WL(ws_l + 17); Lw2 = WL(ws_l + 18); Lw3 = WL(ws_l + 19);
             SB();

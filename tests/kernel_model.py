@@ -153,18 +153,21 @@ def v5_step(W, sect, x, hc, gate=0.01):
     for w in range(4):
         _store_tile(RX, (w >> 1) * 16 + 8 * (w & 1), E1[w])
     # enc2
+    # split-K over the 4 waves: wave w = tile w&1, K half w>>1; partial tiles un-activated in rows 16 (w>>1) + 8 (w&1)
     E2 = {}
-    for w in range(2):
+    for w in range(4):
         ws = sect[w][S_ENC2]
-        acc = np.repeat(_vec(W[ws:ws + 4])[:, None], 32, 1)
+        kh = w >> 1
+        acc = np.repeat(_vec(W[ws:ws + 4])[:, None], 32, 1) if kh == 0 else np.zeros((32, 32))
         ws += 4
-        for it in range(16):
+        for it in range(8 * kh, 8 * kh + 8):
             ti, j = it >> 3, it & 7
             r = ti * 16 + 2 * j
             acc += _mfma4(W[ws + it], _rows(RX, r, r + 1))
         E2[w] = acc
-    for w in range(2):
-        _store_tile(RE, 8 * w, E2[w])
+    for w in range(4):
+        _store_tile(RE, 16 * (w >> 1) + 8 * (w & 1), E2[w], relu=False)
+    RE[0:16] = np.maximum(RE[0:16] + RE[16:32], 0.0)          # enc3 reads relu(half 0 + half 1)
     # enc3
     E3 = {}
     for w in range(4):
