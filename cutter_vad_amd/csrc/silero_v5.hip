@@ -125,7 +125,13 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
     if (sm_thread) smL[tid] = P.sm[sm_slot];
     const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];    // head bias
 
-    __syncthreads();   // h_{t-1} visible: the recurrent gate half starts before the first frame barrier
+    // every kernel argument the frame loop needs, fetched NOW (scalar loads from the kernarg segment cost a round
+    // trip when they are left to the point of first use, after the barrier)
+    {
+        const void *a0 = P.state, *a1 = P.sm, *a2 = P.probs, *a3 = P.events, *a4 = P.frames;
+        const int a5 = __builtin_bit_cast(int, P.thresh), a6 = P.fmt;
+        asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6));
+    }
     STAMP(0);
     for (int t = 0; t < T; ++t) {
         // section offsets, made opaque per frame: otherwise every block offset of the kernel (~300 SGPR
@@ -138,10 +144,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
         // any column requested in the same group, so waiting for a weight block never waits for the frame.
         // Fold: output (column c, stream ms, quad q), n = 4q..4q+3, from the column's quads q (y[n]), 32+q (y[128+n]),
         // 32-q / 31-q (y[128-n], reversed) and 64-q / 63-q (y[256-n], reversed); 16 lanes run over q.
-        f32x16 gi = acc_of(WL(ws_l), WL(ws_l + 1), WL(ws_l + 2), WL(ws_l + 3));
-        f32x16 gfo = acc_of(WL(ws_l + 4), WL(ws_l + 5), WL(ws_l + 6), WL(ws_l + 7));
-        f32x16 gg = acc_of(WL(ws_l + 8), WL(ws_l + 9), WL(ws_l + 10), WL(ws_l + 11));
-        f32x16 go = acc_of(WL(ws_l + 12), WL(ws_l + 13), WL(ws_l + 14), WL(ws_l + 15));
+        f32x16 gi, gfo, gg, go;
         {
             const int wh = ws_l + 16 + 64;                 // W_hh blocks: iteration it at wh + 4 it
             // The recurrent half runs as 8 groups of 2 k-iterations (32 MFMAs, W_hh blocks ping-ponged one group
@@ -217,9 +220,21 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
         __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                                                     \
     }
             f32x4 wA[8], wB[8];                            // W_hh blocks of a group of 2 k-iterations, ping-pong
+            f32x4 nb[16];                                  // gate biases = the accumulators' initial values
+#pragma unroll
+            for (int k = 0; k < 16; ++k) nb[k] = WL(ws_l + k);
             H_LDW(wA, 0)
             SB();
-            H_LDW(wB, 1) X_ISSUE(0, xa_, t) SB(); H_MMA(wA, 0) SB(); STAMP(20);
+            H_LDW(wB, 1) X_ISSUE(0, xa_, t) SB();
+            // (0) h_{t-1} visible.  The barrier sits INSIDE the loop, behind the first requests: the loop-invariant
+            // address arithmetic the compiler hoists into the preheader and the weight / frame requests above then run
+            // while the state loads of the prologue are still in flight.  For t > 0 it follows barrier (8) and costs nothing.
+            __syncthreads();
+            gi = acc_of(nb[0], nb[1], nb[2], nb[3]);
+            gfo = acc_of(nb[4], nb[5], nb[6], nb[7]);
+            gg = acc_of(nb[8], nb[9], nb[10], nb[11]);
+            go = acc_of(nb[12], nb[13], nb[14], nb[15]);
+            H_MMA(wA, 0) SB(); STAMP(20);
             H_LDW(wA, 2) X_ISSUE(1, xb_, t) SB(); H_MMA(wB, 1) SB(); STAMP(21);
             H_LDW(wB, 3) SB(); H_MMA(wA, 2) X_FOLD1(0, 0, xa_) H_MIX(6) SB(); STAMP(22);
             H_LDW(wA, 4) SB(); H_MMA(wB, 3) X_FOLD1(0, 1, xa_) H_MIX(6) SB(); STAMP(23);
