@@ -19,8 +19,8 @@ from typing import Any, Deque, Dict, List, Optional
 import numpy as np
 from pydantic import BaseModel, ConfigDict, Field, field_validator, model_validator
 
-from .. import _ffi
-from ..pool import EnginePool, default_pool, resolve_model_path
+from .. import _ffi, weights_io
+from ..pool import _VERSION_INT, EnginePool, default_pool, resolve_model_path
 from ..utils.audio import AudioUtils
 from ..utils.wav_writer import WAVWriter
 from .config import SileroModelVersion, VADConfig
@@ -122,20 +122,42 @@ class SileroVADModel:
         self._slot: Optional[int] = None
         self._pool = pool or default_pool()
         self._device_id = device_id
+        # the reference's session holds both sub-models of the graph and picks one per call from ``sr``; here each is
+        # an engine of its own: {is_8k: (session, slot)}, the 8 kHz one (V4 only) is created on first use
+        self._variants: Dict[bool, tuple] = {}
+        self._k8 = False
         self._load_model()
         self._reset_states()
 
     # -- silero_model.py:303-334
-    def _load_model(self) -> None:
+    def _load_model(self, sample_rate: int = 16000) -> None:
         try:
-            eng = self._pool.engine_for(self.config.model_path, self.config.model_version, self._device_id)
-            self.session = _Session(eng)
-            self._slot = eng.open_stream()
+            k8 = weights_io.is_8k_variant(_VERSION_INT[self.config.model_version], sample_rate)
+            eng = self._pool.engine_for(self.config.model_path, self.config.model_version, self._device_id,
+                                        sample_rate=sample_rate)
+            self._variants[k8] = (_Session(eng), eng.open_stream())
+            self.session, self._slot = self._variants[k8]
+            self._k8 = k8
         except (ModelNotFoundError, ModelInitializationError):
             raise
         except Exception as e:
             raise ModelInitializationError(self.config.model_version.value,
                                            f"Failed to load model from {self.config.model_path}: {e}")
+
+    def select_rate(self, sample_rate: int) -> None:
+        """What ``Equal(sr, 16000)`` does inside the graph: choose the sub-model for this call.  The recurrent state
+        is the graph's ``h`` / ``c`` inputs, shared by both branches, so it moves with the switch."""
+        self._check_rate(sample_rate, self.config.model_version)
+        k8 = weights_io.is_8k_variant(_VERSION_INT[self.config.model_version], sample_rate)
+        if k8 == self._k8:
+            return
+        hc = self.engine.get_state(self._slot)
+        if k8 in self._variants:
+            self.session, self._slot = self._variants[k8]
+            self._k8 = k8
+        else:
+            self._load_model(sample_rate)
+        self.engine.set_state(self._slot, hc)
 
     @property
     def engine(self):
@@ -149,8 +171,8 @@ class SileroVADModel:
 
     # -- silero_model.py:384-401
     def _reset_states(self) -> None:
-        if self.session is not None and self._slot is not None:
-            self.engine.reset([self._slot])
+        for sess, slot in self._variants.values():
+            sess.engine.reset([slot])
 
     @property
     def model_state(self) -> ModelState:
@@ -165,7 +187,7 @@ class SileroVADModel:
             if self.session is None:
                 raise ModelInitializationError(self.config.model_version.value, "Model not loaded")
             frame = self._prepare_audio_input(audio_chunk)
-            self._check_rate(sample_rate)
+            self.select_rate(sample_rate)
             p = float(self.engine.step([self._slot], frame, denoise=None)[0])
             p = self._extract_probability(p)
             self.prediction_count += 1
@@ -176,10 +198,12 @@ class SileroVADModel:
             raise AudioProcessingError(f"Model prediction failed: {e}")
 
     @staticmethod
-    def _check_rate(sample_rate: int) -> None:
-        # the graphs select the 16 kHz weights only for sr == 16000; the other branch cannot take
-        # the reference's 512-sample frames on V5 and is not built here for V4 either
-        if int(sample_rate) != 16000:
+    def _check_rate(sample_rate: int, model_version: SileroModelVersion = SileroModelVersion.V5) -> None:
+        # The graphs select the 16 kHz weights only for sr == 16000.  V4's other branch (its 8 kHz sub-model, taken for
+        # 8 / 24 / 48 kHz alike) is built; V5's cannot take the reference's 512-sample frames - a 3-D tensor reaches its
+        # LSTM-cell subgraph and onnxruntime refuses (reproduced by oracle/onnx_interp.py) - so it raises
+        # here as it does there.
+        if int(sample_rate) != 16000 and model_version == SileroModelVersion.V5:
             raise AudioProcessingError(
                 f"Model prediction failed: sample rate {sample_rate} selects the 8 kHz graph branch, "
                 "which is not available for 512-sample frames; resample to 16 kHz first")
@@ -209,11 +233,12 @@ class SileroVADModel:
         self._reset_states()
 
     def close(self) -> None:
-        if self.session is not None and self._slot is not None:
+        for sess, slot in self._variants.values():
             try:
-                self.engine.close_stream(self._slot)
+                sess.engine.close_stream(slot)
             except Exception:
                 pass
+        self._variants = {}
         self._slot = None
         self.session = None
 
@@ -381,7 +406,7 @@ class VADProcessor:
                 raise ModelInitializationError(self.config.model_version.value, "Model not loaded")
             kept = self._preprocess_audio_frame(audio_frame)
             self._sync_thresholds()
-            SileroVADModel._check_rate(self.config.sample_rate)
+            self.model.select_rate(int(self.config.sample_rate))
             frame = SileroVADModel._prepare_audio_input(np.asarray(audio_frame))
             thr = 0.01 if self.config.enable_denoising else None
             try:
@@ -428,7 +453,7 @@ class VADProcessor:
         if F:
             try:
                 self._sync_thresholds()
-                SileroVADModel._check_rate(self.config.sample_rate)
+                self.model.select_rate(int(self.config.sample_rate))
                 x = np.stack([SileroVADModel._prepare_audio_input(np.asarray(f))[0] for f in frames[:F]])[None]
                 thr = 0.01 if self.config.enable_denoising else None
                 eng, slot = self.model.engine, self.model.slot

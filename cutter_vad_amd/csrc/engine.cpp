@@ -273,6 +273,7 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
     e->base.wstream = e->d_wstream;
     e->base.wstream_bytes = (uint32_t)e->wbytes;
     std::memcpy(e->base.sect, pw.sect, sizeof pw.sect);
+    e->base.variant = pw.variant;
     e->base.state = e->d_state;
     e->base.sm = e->d_sm;
     e->open.assign((size_t)e->max_streams, 0);

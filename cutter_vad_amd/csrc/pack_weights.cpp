@@ -320,6 +320,14 @@ bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::strin
     }
     const float *head_w = B.get("head.w", 64), *head_b = B.get("head.b", 1);
     if (!err.empty()) return false;
+    {   // optional: meta.variant = 8000 marks the graph's else-branch (weights_io._extract_v4)
+        std::string none;
+        std::string *keep = B.err;
+        B.err = &none;
+        const float *var = B.get("meta.variant", 1);
+        B.err = keep;
+        out.variant = (var && var[0] == 8000.0f) ? 1 : 0;
+    }
     if (!check_stft_symmetry(stft, err)) return false;
     if (!check_windowed_dft(stft, err)) return false;
     // the STFT kernel emits its 128 regular bins in the even/odd order of the 4-way folded DFT (v5::bin_of_channel);

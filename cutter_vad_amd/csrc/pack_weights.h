@@ -13,6 +13,7 @@ namespace vadk {
 struct PackedWeights {
     std::vector<float> data;        // concatenated per-wave streams, multiple of BLK_FLOATS
     uint32_t sect[NWAVES][16] = {};  // block offset of every section
+    int32_t variant = 0;             // V4: 1 = the graph's 8 kHz sub-model (two time steps reach the LSTMs)
 };
 
 // blob: SVW container (cutter_vad_amd/weights_io.py).  On failure returns false and sets err

@@ -227,7 +227,11 @@ __device__ __forceinline__ float lognorm(float mag, float mm) { return log1p20(m
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P, const int tframe) {
+// K8: the graph's 8 kHz sub-model (else-branch, taken for every sr != 16000): identical up to block 2, then
+// the third stride conv has stride 1 (Conv_632), so TWO columns go through block 3 and the last 1x1 conv, the LSTMs run
+// two sequential time steps and the probability is the mean of the two sigmoids (ReduceMean over T).
+template <bool K8>
+__global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P, const int tframe) {
     using namespace vadk::v4;
     __shared__ f32x4 lds[K2_LDS_F4];
     f32x4 *const RX = lds;
@@ -509,42 +513,63 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
     }
     __syncthreads();
 
-    // ---- P7: s2 1x1 32 -> 32, stride 2: column 0; wave 0 -------------------------------------------------
+    // ---- P7: s2 1x1 32 -> 32.  16 kHz: stride 2 -> column 0, wave 0.  8 kHz: stride 1 -> column w, waves 0,1 ----
     PRE_L(0)
     SB();
-    if (w == 0) {
+    if (K8 ? w < 2 : w == 0) {
+        const int rin = R_Y3 + (K8 ? 8 * w : 0), rout = K8 ? R8_Y4 + 8 * w : R_Y4;
         f32x16 acc = acc_of(p7w[0], p7w[1], p7w[2], p7w[3]);
-        TG_MMA(acc, p7w[4], p7w[5], p7w[6], p7w[7], RX[(R_Y3 + 0) * QS + hq], RX[(R_Y3 + 2) * QS + hq], RX[(R_Y3 + 4) * QS + hq], RX[(R_Y3 + 6) * QS + hq])
-        store_tile_relu(RX, R_Y4, m, h, acc);
+        TG_MMA(acc, p7w[4], p7w[5], p7w[6], p7w[7], RX[(rin + 0) * QS + hq], RX[(rin + 2) * QS + hq], RX[(rin + 4) * QS + hq], RX[(rin + 6) * QS + hq])
+        store_tile_relu(RX, rout, m, h, acc);
     }
     __syncthreads();
 
-    // ---- P8: block 3 (32 -> 64) on the single column (dw: centre tap only); waves 0,1 = output tile -----
-    if (w < 2) {
+    // ---- P8: block 3 (32 -> 64).  16 kHz: one column (dw: centre tap only), waves 0,1 = output tile.
+    //      8 kHz: two columns, wave w = (output tile w&1, column w>>1); dw taps 2,3 on column 0 and 1,2 on column 1 ----
+    if (K8 || w < 2) {
         f32x16 acc = acc_of(p8w[0], p8w[1], p8w[2], p8w[3]);
         f32x4 d[4], y[4];
+        if (K8) {
+            int o_ = (int)P.sect[w][S_L3];
+            asm volatile("" : "+s"(o_));
+            const int col = w >> 1, oth = 1 - col;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            y[j] = RX[(R_Y4 + 2 * j) * QS + hq];
-            d[j] = relu4(fma4(p8t[2 * j], y[j], p8t[2 * j + 1]));
+            for (int j = 0; j < 4; ++j) {
+                const int q = 2 * j + h;
+                y[j] = RX[(R8_Y4 + 8 * col + 2 * j) * QS + hq];
+                const f32x4 yo = RX[(R8_Y4 + 8 * oth + 2 * j) * QS + hq];
+                // out[col] = b + w[2] in[col] + w[2 + (oth - col)] in[oth]
+                d[j] = relu4(fma4(ldt(wrs, q * 6 + 2 + (oth - col), o_), yo, fma4(p8t[2 * j], y[j], p8t[2 * j + 1])));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                y[j] = RX[(R_Y4 + 2 * j) * QS + hq];
+                d[j] = relu4(fma4(p8t[2 * j], y[j], p8t[2 * j + 1]));
+            }
         }
         TG_MMA(acc, p8w[4], p8w[5], p8w[6], p8w[7], d[0], d[1], d[2], d[3])
         TG_MMA(acc, p8w[8], p8w[9], p8w[10], p8w[11], y[0], y[1], y[2], y[3])
-        store_tile_relu(RX, R_Y5 + 8 * w, m, h, acc);
+        store_tile_relu(RX, K8 ? R8_Y5 + 16 * (w >> 1) + 8 * (w & 1) : R_Y5 + 8 * w, m, h, acc);
     }
     __syncthreads();
 
-    // ---- P9: s3 1x1 64 -> 64; waves 0,1 = output tile ---------------------------------------------------
-    if (w < 2) {
+    // ---- P9: s3 1x1 64 -> 64; 16 kHz: waves 0,1 = output tile; 8 kHz: wave w = (tile w&1, column w>>1) -----------
+    if (K8 || w < 2) {
+        const int rin = K8 ? R8_Y5 + 16 * (w >> 1) : R_Y5;
         f32x16 acc = acc_of(p9w[0], p9w[1], p9w[2], p9w[3]);
-        TG_MMA(acc, p9w[4], p9w[5], p9w[6], p9w[7], RX[(R_Y5 + 0) * QS + hq], RX[(R_Y5 + 2) * QS + hq], RX[(R_Y5 + 4) * QS + hq], RX[(R_Y5 + 6) * QS + hq])
-        TG_MMA(acc, p9w[8], p9w[9], p9w[10], p9w[11], RX[(R_Y5 + 8) * QS + hq], RX[(R_Y5 + 10) * QS + hq], RX[(R_Y5 + 12) * QS + hq], RX[(R_Y5 + 14) * QS + hq])
-        store_tile_relu(RX, R_Y6 + 8 * w, m, h, acc);
+        TG_MMA(acc, p9w[4], p9w[5], p9w[6], p9w[7], RX[(rin + 0) * QS + hq], RX[(rin + 2) * QS + hq], RX[(rin + 4) * QS + hq], RX[(rin + 6) * QS + hq])
+        TG_MMA(acc, p9w[8], p9w[9], p9w[10], p9w[11], RX[(rin + 8) * QS + hq], RX[(rin + 10) * QS + hq], RX[(rin + 12) * QS + hq], RX[(rin + 14) * QS + hq])
+        store_tile_relu(RX, K8 ? R8_Y6 + 16 * (w >> 1) + 8 * (w & 1) : R_Y6 + 8 * w, m, h, acc);
     }
     __syncthreads();
 
-    // ---- P10/P11: two stacked LSTM(64) cells.  wave w: unit half u = w&1; waves 0,1 contract the layer
-    //      input (+bias), waves 2,3 contract h_{t-1}; partial gates meet in LDS, waves 0,1 finish the cell
+    // ---- P10/P11: two stacked LSTM(64) cells, T3 time steps (1, or 2 for the 8 kHz sub-model).  wave w: unit half
+    //      u = w&1; waves 0,1 contract the layer input (+bias), waves 2,3 contract h_{t-1}; partial gates meet in
+    //      LDS, waves 0,1 finish the cell.  Between steps h lives in LDS (R_H0N / R_H1N) and c in registers.
+    constexpr int T3 = K8 ? 2 : 1;
+#pragma unroll
+    for (int step = 0; step < T3; ++step) {
     float part = 0.f;
 #pragma unroll
     for (int layer = 0; layer < 2; ++layer) {
@@ -556,12 +581,12 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
 #pragma unroll
             for (int q = 0; q < 4; ++q) g4[q] = acc_of(lb[4 * q], lb[4 * q + 1], lb[4 * q + 2], lb[4 * q + 3]);
             ws = ob + 16;
-            src = RX + (layer == 0 ? R_Y6 : R_H0N) * QS + hq;
+            src = RX + (layer == 0 ? (K8 ? R8_Y6 + 16 * step : R_Y6) : R_H0N) * QS + hq;
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) g4[q] = (f32x16)(0.f);
             ws = ob + 48;
-            src = RX + (layer == 0 ? R_H0 : R_H1) * QS + hq;
+            src = RX + (layer == 0 ? (step == 0 ? R_H0 : R_H0N) : (step == 0 ? R_H1 : R_H1N)) * QS + hq;
         }
         f32x4 Aw0 = lw[0], Aw1 = lw[1], Aw2 = lw[2], Aw3 = lw[3], Aa = src[0], Bw0, Bw1, Bw2, Bw3, Ba;
 #define LS_LD(S, it) S##w0 = WL(ws + 4 * (it)); S##w1 = WL(ws + 4 * (it) + 1); S##w2 = WL(ws + 4 * (it) + 2); S##w3 = WL(ws + 4 * (it) + 3); S##a = src[(2 * (it)) * QS];
@@ -576,8 +601,12 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
         }
 #undef LS_LD
 #undef LS_MMA
+        // the next cell's biases and first weights fly during this cell's update
         if (layer == 0) {
-            PRE_L(1)         // the second layer's biases and first weights fly during the first layer's cell update
+            PRE_L(1)
+            SB();
+        } else if (step + 1 < T3) {
+            PRE_L(0)
             SB();
         }
         if (kh == 1) {
@@ -606,13 +635,15 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
     hn.k = sigmoidf_(o4.k) * tanhf_(cn.k);
                 CELL(x) CELL(y) CELL(z) CELL(w)
 #undef CELL
-                if (live) {
+                cprev[layer][g] = cn;
+                if (step == T3 - 1 && live) {
                     *reinterpret_cast<f32x4 *>(st + 128 + 64 * layer + unit) = cn;
                     *reinterpret_cast<f32x4 *>(st + 64 * layer + unit) = hn;
                 }
                 if (layer == 0) {
                     RX[(R_H0N + 8 * u + 2 * g) * QS + hq] = hn;
                 } else {
+                    if (step + 1 < T3) RX[(R_H1N + 8 * u + 2 * g) * QS + hq] = hn;
                     const f32x4 hw = hwq[g];
                     part += hw.x * fmaxf(hn.x, 0.f) + hw.y * fmaxf(hn.y, 0.f) + hw.z * fmaxf(hn.z, 0.f) + hw.w * fmaxf(hn.w, 0.f);
                 }
@@ -620,19 +651,22 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const S
         }
         __syncthreads();
     }
+    if (kh == 0) {
+        part += __shfl_xor(part, 32);
+        if (h == 0) headp[step * 64 + u * 32 + m] = part;
+    }
+    }
 #undef PRE_A
 #undef PRE_B
 #undef PRE_C
 #undef PRE_L
-    if (kh == 0) {
-        part += __shfl_xor(part, 32);
-        if (h == 0) headp[u * 32 + m] = part;
-    }
     __syncthreads();
 
     // ---- head + state machine ------------------------------------------------------------------------
     if (sm_thread) {
-        const float p = fminf(sigmoidf_(hb + headp[tid] + headp[32 + tid]), 1.0f);
+        float p = sigmoidf_(hb + headp[tid] + headp[32 + tid]);
+        if (K8) p = (p + sigmoidf_(hb + headp[64 + tid] + headp[96 + tid])) * 0.5f;     // ReduceMean over the two time steps
+        p = fminf(p, 1.0f);
         P.probs[(size_t)(tile0 + tid) * T + tframe] = p;
         SmSlot sm = smL[tid];
         int seg = 0;
@@ -652,7 +686,10 @@ extern "C" hipError_t vadk_launch_silero_v4(const vadk::StepParams *p, hipStream
     if (tiles <= 0) return hipSuccess;
     for (int t = 0; t < p->T; ++t) {
         hipLaunchKernelGGL(silero_v4_stft, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, t);
-        hipLaunchKernelGGL(silero_v4_tail, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, t);
+        if (p->variant == 1)
+            hipLaunchKernelGGL(silero_v4_tail<true>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, t);
+        else
+            hipLaunchKernelGGL(silero_v4_tail<false>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, t);
     }
     return hipGetLastError();
 }

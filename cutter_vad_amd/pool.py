@@ -41,19 +41,24 @@ class EnginePool:
 
     def __init__(self) -> None:
         self._lock = threading.Lock()
-        self._engines: Dict[Tuple[str, int], Engine] = {}
+        self._engines: Dict[Tuple[str, int, bool], Engine] = {}
 
     def engine_for(self, model_path: str, version: SileroModelVersion, device_id: Optional[int] = None,
-                   max_streams: Optional[int] = None) -> Engine:
+                   max_streams: Optional[int] = None, sample_rate: int = 16000) -> Engine:
+        """``sample_rate`` picks the sub-model the graph would run: V4 has a second set of weights for every rate
+        but 16 000; it is a separate engine (own packed weights, same kernels + the 2-step LSTM tail)."""
         dev = default_device() if device_id is None else device_id
-        key = (os.path.abspath(model_path), dev)
+        k8 = weights_io.is_8k_variant(_VERSION_INT[version], sample_rate)
+        if k8 and model_path.endswith("_16k.svw"):
+            model_path = model_path[:-len("_16k.svw")] + "_8k.svw"
+        key = (os.path.abspath(model_path), dev, k8)
         with self._lock:
             eng = self._engines.get(key)
             if eng is None or not eng.handle:
                 if not os.path.exists(model_path):
                     raise ModelNotFoundError(model_path)
                 try:
-                    blob = weights_io.load_weight_blob(model_path, _VERSION_INT[version])
+                    blob = weights_io.load_weight_blob(model_path, _VERSION_INT[version], sample_rate)
                 except weights_io.WeightFormatError as e:
                     # same wording as the reference's signature check, silero_model.py:378-382
                     msg = str(e)
@@ -118,7 +123,7 @@ class StreamBatch:
         self.config = config or VADConfig()
         self._pool = pool or default_pool()
         self.engine = self._pool.engine_for(resolve_model_path(self.config), self.config.model_version, device_id,
-                                            max_streams)
+                                            max_streams, int(self.config.sample_rate))
         self.slots: List[int] = []
 
     def add(self, n: int = 1, config: Optional[VADConfig] = None) -> np.ndarray:

@@ -29,7 +29,7 @@ from typing import Callable, Deque, Dict, List, Optional
 
 import numpy as np
 
-from .. import _ffi
+from .. import _ffi, weights_io
 from ..core.config import SileroModelVersion, VADConfig
 from ..core.exceptions import AudioProcessingError, CallbackError
 from ..core.silero_model import SileroVADModel
@@ -96,10 +96,13 @@ class PooledSession:
 class SharedStreamPool:
     def __init__(self, model_version: SileroModelVersion = SileroModelVersion.V5, device_id: Optional[int] = None,
                  max_streams: Optional[int] = None, pool: Optional[EnginePool] = None,
-                 tick_interval: float = 0.010) -> None:
-        self._base = VADConfig(model_version=model_version)
+                 tick_interval: float = 0.010, sample_rate: int = 16000) -> None:
+        SileroVADModel._check_rate(sample_rate, model_version)
+        self._base = VADConfig(model_version=model_version, sample_rate=sample_rate)
+        self._k8 = weights_io.is_8k_variant(4 if model_version == SileroModelVersion.V4 else 5, sample_rate)
         self._pool = pool or default_pool()
-        self.engine = self._pool.engine_for(resolve_model_path(self._base), model_version, device_id, max_streams)
+        self.engine = self._pool.engine_for(resolve_model_path(self._base), model_version, device_id, max_streams,
+                                            sample_rate)
         self.tick_interval = tick_interval
         self._lock = threading.Lock()              # sessions / pending queues
         self._tick_lock = threading.Lock()         # one tick at a time
@@ -144,7 +147,7 @@ class SharedStreamPool:
         cfg = config or self._base
         if cfg.model_version != self._base.model_version:
             raise AudioProcessingError(f"this pool serves Silero {self._base.model_version.value} streams")
-        SileroVADModel._check_rate(cfg.sample_rate)        # same error as the reference's 8 kHz graph branch
+        self._check_session_rate(cfg)
         slot = int(self.engine.open_stream())
         try:
             self.engine.set_thresholds(slot, cfg.vad_start_probability, cfg.vad_end_probability, cfg.voice_start_ratio,
@@ -157,6 +160,14 @@ class SharedStreamPool:
             self._init_slot(slot, cfg)
             self._sessions[slot] = s
         return s
+
+    def _check_session_rate(self, cfg: VADConfig) -> None:
+        # V5 + a rate other than 16 kHz: the reference's graph fails on every frame; V4: the pool's engine is
+        # one of the graph's two sub-models, a session must ask for the same one
+        SileroVADModel._check_rate(cfg.sample_rate, cfg.model_version)
+        if weights_io.is_8k_variant(4 if cfg.model_version == SileroModelVersion.V4 else 5, cfg.sample_rate) != self._k8:
+            raise AudioProcessingError(f"Model prediction failed: this pool runs the {'8' if self._k8 else '16'} kHz "
+                                       f"sub-model, the session asks for sample rate {int(cfg.sample_rate)}")
 
     def close_session(self, s: PooledSession) -> None:
         with self._tick_lock:                      # never under a running launch
@@ -172,7 +183,7 @@ class SharedStreamPool:
     def reconfigure(self, s: PooledSession, config: VADConfig) -> None:
         """New thresholds / frame length for a live session; like ``ClientState.update_config`` rebuilding its
         wrapper (vad_websocket_server.py:300-318) the stream starts from a clean state."""
-        SileroVADModel._check_rate(config.sample_rate)
+        self._check_session_rate(config)
         with self._tick_lock:
             with self._lock:
                 s.pending.clear()

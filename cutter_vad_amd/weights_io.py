@@ -93,9 +93,15 @@ def _extract_v5(model: onnx_lite.Model) -> Dict[str, np.ndarray]:
     return t
 
 
-def _extract_v4(model: onnx_lite.Model) -> Dict[str, np.ndarray]:
-    top = model.graph.initializers
-    _, g = _find_branch(model, "then_branch")
+def _extract_v4(model: onnx_lite.Model, sample_rate: int = 16000) -> Dict[str, np.ndarray]:
+    """16 kHz sub-model (then-branch, ``model.*``) or the 8 kHz one (else-branch, ``model_8k.*``) that the graph
+    takes for EVERY ``sr != 16000``.  Same tensor names either way; the 8 kHz blob carries
+    ``meta.variant = 8000`` (its third stride conv has stride 1, which the engines must know)."""
+    k8 = sample_rate != 16000
+    pre = "model_8k" if k8 else "model"
+    top = {(("model" + k[len(pre):]) if k.startswith(pre + ".") else k): v for k, v in model.graph.initializers.items()
+           if not (k.startswith("model_8k.") and not k8)}
+    _, g = _find_branch(model, "else_branch" if k8 else "then_branch")
     # the two stacked LSTMs live in the "state supplied" sub-branch of the inner If
     lstm_inits = None
     for node in g.nodes:
@@ -140,12 +146,14 @@ def _extract_v4(model: onnx_lite.Model) -> Dict[str, np.ndarray]:
             t[f"lstm{li}.w_hh"] = _iofc_to_ifgo(R, H)
             t[f"lstm{li}.b_ih"] = _iofc_to_ifgo(B[:4 * H], H)
             t[f"lstm{li}.b_hh"] = _iofc_to_ifgo(B[4 * H:], H)
+        if k8:
+            t["meta.variant"] = np.array([8000.0], np.float32)
     except KeyError as e:  # pragma: no cover - wrong file
         raise WeightFormatError(f"not a Silero V4 graph: missing tensor {e}") from e
     return t
 
 
-def extract_from_onnx(path: str, version: int) -> Dict[str, np.ndarray]:
+def extract_from_onnx(path: str, version: int, sample_rate: int = 16000) -> Dict[str, np.ndarray]:
     model = onnx_lite.load_model(path)
     n_in, n_out = len(model.graph.inputs), len(model.graph.outputs)
     # same arity rule as the reference's _validate_model_signature (silero_model.py:369-376)
@@ -154,7 +162,7 @@ def extract_from_onnx(path: str, version: int) -> Dict[str, np.ndarray]:
         raise WeightFormatError(f"Expected {exp_in} inputs, got {n_in}")
     if n_out != exp_out:
         raise WeightFormatError(f"Expected {exp_out} outputs, got {n_out}")
-    t = _extract_v5(model) if version == 5 else _extract_v4(model)
+    t = _extract_v5(model) if version == 5 else _extract_v4(model, sample_rate)
     return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in t.items()}
 
 
@@ -202,19 +210,29 @@ def unpack_svw(blob: bytes) -> Tuple[int, Dict[str, np.ndarray]]:
     return version, out
 
 
-def packaged_blob_path(version: int) -> str:
+def is_8k_variant(version: int, sample_rate: int) -> bool:
+    """V4's graph runs its 8 kHz sub-model for every rate but 16 000 (``Equal(sr, 16000)``); V5's 8 kHz branch
+    cannot take the reference's 512-sample frames and is not built."""
+    return version == 4 and int(sample_rate) != 16000
+
+
+def packaged_blob_path(version: int, sample_rate: int = 16000) -> str:
     here = os.path.dirname(os.path.abspath(__file__))
-    return os.path.join(here, "weights", f"silero_v{version}_16k.svw")
+    tag = "8k" if is_8k_variant(version, sample_rate) else "16k"
+    return os.path.join(here, "weights", f"silero_v{version}_{tag}.svw")
 
 
-def load_weight_blob(model_path: str, version: int) -> bytes:
+def load_weight_blob(model_path: str, version: int, sample_rate: int = 16000) -> bytes:
     """Return the SVW blob for ``model_path`` — an ``.onnx`` file (converted on the fly,
     like the reference's ``_load_model``) or an ``.svw`` blob."""
     if model_path.endswith(".svw"):
         with open(model_path, "rb") as f:
             blob = f.read()
-        v, _ = unpack_svw(blob)
+        v, t = unpack_svw(blob)
         if v != version:
             raise WeightFormatError(f"weight blob is for Silero v{v}, requested v{version}")
+        if ("meta.variant" in t) != is_8k_variant(version, sample_rate):
+            raise WeightFormatError(f"weight blob is the {'8' if 'meta.variant' in t else '16'} kHz sub-model, "
+                                    f"requested sample rate {sample_rate}")
         return blob
-    return pack_svw(version, extract_from_onnx(model_path, version))
+    return pack_svw(version, extract_from_onnx(model_path, version, sample_rate if version == 4 else 16000))

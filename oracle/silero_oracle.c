@@ -76,6 +76,7 @@ typedef struct svo_model {
     const float *filt;
     const float *dw_w[4], *dw_b[4], *pw_w[4], *pw_b[4], *pj_w[4], *pj_b[4], *s_w[4], *s_b[4];
     const float *l_wih[2], *l_whh[2], *l_bih[2], *l_bhh[2];
+    int v4_8k;   /* the graph's else-branch (sr != 16000): third stride conv has stride 1 -> 2 time steps reach the LSTMs */
 } svo_model;
 
 static const float *svw_find(const svo_model *m, const char *name, uint64_t expect) {
@@ -155,6 +156,10 @@ SVO_API svo_model *svo_load(const void *blob, size_t len, char *err, size_t errl
         }
         NEED(m->head_w, "head.w", 64);
         NEED(m->head_b, "head.b", 1);
+        {
+            const float *var = svw_find(m, "meta.variant", 1);
+            m->v4_8k = var && var[0] == 8000.0f;
+        }
     } else {
         snprintf(err, errlen, "weight blob: unknown model version %d", m->version);
         goto fail;
@@ -298,7 +303,7 @@ static void v4_stride(const svo_model *m, int i, const float *in, int C, int Tin
 }
 
 static void step_v4(const svo_model *m, const float *x /*[512]*/, float *state /*[h0|h1|c0|c1] x64*/, float *prob) {
-    float xp[704], x1[258 * 8], a[16 * 8], b[32 * 4], c2[32 * 2], c3[64], t0[64 * 4];
+    float xp[704], x1[258 * 8], a[16 * 8], b[32 * 4], c2[32 * 2], c3[64 * 2], t0[64 * 4], xt[64];
     float *mag = x1, *norm = x1 + 129 * 8;
     /* 1. reflect pad 96 each side (numpy 'reflect': edge sample not repeated) */
     for (int i = 0; i < 96; ++i) xp[i] = x[96 - i];
@@ -332,17 +337,26 @@ static void step_v4(const svo_model *m, const float *x /*[512]*/, float *state /
     v4_block(m, 1, t0, 16, 32, 4, b);
     v4_stride(m, 1, b, 32, 4, 2, t0, 2);
     v4_block(m, 2, t0, 32, 32, 2, c2);
-    v4_stride(m, 2, c2, 32, 2, 2, t0, 1);
-    v4_block(m, 3, t0, 32, 64, 1, c3);
-    v4_stride(m, 3, c3, 64, 1, 1, t0, 1);
-    /* 13. two stacked LSTM(64): state = h[2][64] then c[2][64] (ONNX inputs h, c) */
-    lstm_cell(t0, 64, 64, m->l_wih[0], m->l_whh[0], m->l_bih[0], m->l_bhh[0], state, state + 128);
-    lstm_cell(state, 64, 64, m->l_wih[1], m->l_whh[1], m->l_bih[1], m->l_bhh[1], state + 64, state + 192);
-    /* 14. head */
-    acc_t s = (acc_t)m->head_b[0];
-    for (int j = 0; j < 64; ++j)
-        if (state[64 + j] > 0.f) s += (acc_t)m->head_w[j] * (acc_t)state[64 + j];
-    *prob = (float)sigmoid_a(s);
+    /* 16 kHz branch: stride 2 -> one time step.  8 kHz branch (torch_jit10, taken for every sr != 16000): the third
+     * stride conv has stride 1 (Conv_632), so T = 2 time steps go through block 3, the last 1x1 conv, both LSTMs
+     * (sequentially) and the head; the output is the mean of the two sigmoids (ReduceMean over T). */
+    const int T3 = m->v4_8k ? 2 : 1;
+    v4_stride(m, 2, c2, 32, 2, m->v4_8k ? 1 : 2, t0, T3);
+    v4_block(m, 3, t0, 32, 64, T3, c3);
+    v4_stride(m, 3, c3, 64, T3, 1, t0, T3);
+    acc_t psum = 0;
+    for (int t = 0; t < T3; ++t) {
+        for (int j = 0; j < 64; ++j) xt[j] = t0[j * T3 + t];
+        /* 13. two stacked LSTM(64): state = h[2][64] then c[2][64] (ONNX inputs h, c) */
+        lstm_cell(xt, 64, 64, m->l_wih[0], m->l_whh[0], m->l_bih[0], m->l_bhh[0], state, state + 128);
+        lstm_cell(state, 64, 64, m->l_wih[1], m->l_whh[1], m->l_bih[1], m->l_bhh[1], state + 64, state + 192);
+        /* 14. head */
+        acc_t s = (acc_t)m->head_b[0];
+        for (int j = 0; j < 64; ++j)
+            if (state[64 + j] > 0.f) s += (acc_t)m->head_w[j] * (acc_t)state[64 + j];
+        psum += (acc_t)(float)sigmoid_a(s);
+    }
+    *prob = (float)(psum / T3);
 }
 
 /* One frame, one stream.  state: 256 floats, ONNX tensor order

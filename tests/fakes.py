@@ -119,5 +119,6 @@ class FakePool:
     def __init__(self, engine: FakeEngine):
         self.engine = engine
 
-    def engine_for(self, model_path, version, device_id=None, max_streams=None):
+    def engine_for(self, model_path, version, device_id=None, max_streams=None, sample_rate=16000):
+        self.requested = getattr(self, "requested", []) + [(str(model_path), int(sample_rate))]
         return self.engine

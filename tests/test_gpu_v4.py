@@ -142,3 +142,62 @@ def test_wrapper_with_v4(engine):
         st = w.processor.model.model_state
         assert st.hidden_state.shape == (2, 1, 64) and st.cell_state.shape == (2, 1, 64)
         assert w.get_statistics()["total_frames_processed"] == 7
+
+
+# ------------------------------------------------------------------ a9: the 8 kHz sub-model (every sr != 16000)
+@pytest.fixture(scope="module")
+def setup8k():
+    from cutter_vad_amd.engine import Engine
+    from oracle import oracle
+    with open(weights_io.packaged_blob_path(4, 8000), "rb") as f:
+        blob = f.read()
+    e = Engine(blob, model_version=4, max_streams=512)
+    yield e, oracle.OracleModel(blob, "f64")
+    e.close()
+
+
+@pytest.mark.parametrize("n", [1, 33, 200])
+def test_8k_submodel_matches_oracle(setup8k, n):
+    eng, om8 = setup8k
+    T = 10
+    frames = make_streams(n, T, seed=800 + n)
+    slots = eng.open_streams(n)
+    try:
+        ref_p, ref_s = _oracle_run(om8, frames, 0.01)
+        cond = conditioning(om8, frames, 0.01, ref_p)
+        got = np.stack([eng.step(slots, frames[:, t]) for t in range(T)], axis=1)
+        assert (np.abs(got - ref_p) <= TOL_P + COND_K * cond).all(), float(np.abs(got - ref_p).max())
+        assert np.median(np.abs(got - ref_p)) <= 1e-6
+        st = np.stack([eng.get_state(s) for s in slots])
+        assert np.abs(st - ref_s).max() <= TOL_S
+        # T frames in one call == T calls (2 T launches either way), events come from the same state machine
+        eng.reset(slots)
+        multi, _ = eng.step_multi(slots, frames)
+        assert np.array_equal(multi, got)
+    finally:
+        for s in slots:
+            eng.close_stream(s)
+
+
+def test_8k_golden_and_wrapper_rate_selection(setup8k):
+    """The interpreter's goldens for sr = 8000, and the host mirror choosing the sub-model from the configured rate
+    exactly like Equal(sr, 16000) in the graph (24 kHz / 48 kHz land on the same 8 kHz weights)."""
+    import os
+    from cutter_vad_amd import SampleRate, SileroModelVersion, VADConfig, VADWrapper
+    eng, _ = setup8k
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "model_v4_8k.npz"))
+    pcm = np.load(os.path.join(os.path.dirname(__file__), "golden", "speech16k_i16.npz"))["pcm"]
+    sp = (pcm.astype(np.float32) / np.float32(32767.0))[: 240 * 512].reshape(240, 512)
+    slot = eng.open_stream()
+    try:
+        got = np.array([eng.step([slot], sp[t:t + 1])[0] for t in range(240)])
+        assert np.abs(got - g["speech_gate.probs"]).max() <= TOL_P
+    finally:
+        eng.close_stream(slot)
+    for rate in (8000, 48000):
+        with VADWrapper(VADConfig(sample_rate=SampleRate(rate), model_version=SileroModelVersion.V4)) as w:
+            for t in range(40):
+                w.process_audio_data(sp[t])
+            p = np.array(w.processor.voice_probabilities)
+            assert np.abs(p - g["speech_gate.probs"][:40]).max() <= TOL_P, rate
+            assert w.processor.get_model_info()["state_shape"]["hidden_state"] == (2, 1, 64)

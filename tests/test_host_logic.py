@@ -130,9 +130,22 @@ def test_model_operator_surface():
     assert info["model_version"] == "v5" and info["state_shape"]["state"] == (2, 1, 128)
     with pytest.raises(ModelNotFoundError):
         SileroVADModel("/nonexistent/silero_vad_v5.onnx", SileroModelVersion.V5, pool=FakePool(eng))
-    m4 = SileroVADModel(weights_io.packaged_blob_path(4), SileroModelVersion.V4, pool=FakePool(eng))
+    pool4 = FakePool(eng)
+    m4 = SileroVADModel(weights_io.packaged_blob_path(4), SileroModelVersion.V4, pool=pool4)
     st = m4.model_state
     assert st.hidden_state.shape == (2, 1, 64) and st.cell_state.shape == (2, 1, 64) and st.state is None
+    # V4's graph has a second sub-model for every rate but 16 000: selected per call from `sr`, like
+    # Equal(sr, 16000) in the graph, and the recurrent state moves with the switch
+    eng.script([0.3, 0.4, 0.6])
+    eng.set_state(m4.slot, np.arange(256, dtype=np.float32))
+    slot16 = m4.slot
+    assert m4.predict(np.zeros(512, np.float32), 48000) == pytest.approx(0.3)
+    assert pool4.requested[-1][1] == 48000 and m4.slot != slot16
+    assert np.array_equal(eng.get_state(m4.slot), np.arange(256, dtype=np.float32))
+    assert m4.predict(np.zeros(512, np.float32), 8000) == pytest.approx(0.4) and len(pool4.requested) == 2
+    assert m4.predict(np.zeros(512, np.float32), 16000) == pytest.approx(0.6) and m4.slot == slot16
+    m4.close()
+    assert sorted(eng.closed[-2:]) == sorted([slot16, slot16 + 1])
 
 
 def test_processor_state_machine_timing_like_reference_tests():

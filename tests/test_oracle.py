@@ -63,6 +63,28 @@ def test_model_matches_interpreter_goldens(version, acc, tol, speech):
     assert np.abs(st - g["batch7.state"]).max() <= 200 * tol
 
 
+@pytest.mark.parametrize("acc,tol", [("f64", 2e-6), ("f32", 3e-5)])
+def test_v4_8k_submodel_matches_interpreter_goldens(acc, tol, speech):
+    """V4's graph runs its 8 kHz sub-model (else-branch) for every sr != 16000 - two LSTM time steps per
+    frame, mean of two sigmoids.  Goldens: oracle/onnx_interp.py on the reference's .onnx with sr = 8000."""
+    g = np.load(os.path.join(GOLD, "model_v4_8k.npz"))
+    with open(weights_io.packaged_blob_path(4, 8000), "rb") as f:
+        om = oracle.OracleModel(f.read(), acc)
+    cases = model_cases(speech)
+    for name in ("speech_gate", "noise_0.02", "noise_0.3", "harmonic", "zeros", "short400_padded"):
+        p, st = om.run_stream(cases[name]["frames"][:240])
+        assert np.abs(p - g[f"{name}.probs"]).max() <= tol, name
+        assert np.abs(st - g[f"{name}.state"]).max() <= 200 * tol, name
+    fb = gate(make_streams(7, 10, seed=77))
+    st = np.zeros((7, 256), np.float32)
+    for t in range(10):
+        p = om.step_batch(np.ascontiguousarray(fb[:, t]), st, nthreads=3)
+        assert np.abs(p - g["batch7.probs"][:, t]).max() <= tol
+    # the 16 kHz weights on the same audio give something else entirely: the two sub-models are really distinct
+    p16, _ = oracle.OracleModel(_blob(4), acc).run_stream(cases["speech_gate"]["frames"][:240])
+    assert np.abs(p16 - g["speech_gate.probs"]).max() > 0.05
+
+
 def test_state_machine_matches_reference_traces():
     with open(os.path.join(GOLD, "state_machine.json")) as f:
         scen = json.load(f)["scenarios"]

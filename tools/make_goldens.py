@@ -83,14 +83,15 @@ def load_speech_16k() -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------
-def run_model(version: int, frames: np.ndarray, batched: bool = False):
-    """frames [T,512] (one stream) or [B,T,512] (batched=True).  -> probs, final state [.,256]"""
+def run_model(version: int, frames: np.ndarray, batched: bool = False, sample_rate: int = 16000):
+    """frames [T,512] (one stream) or [B,T,512] (batched=True).  -> probs, final state [.,256].
+    ``sample_rate`` is the graph's ``sr`` input: anything but 16000 selects V4's 8 kHz sub-model."""
     path = os.path.join(MODELS, "silero_vad_v5.onnx" if version == 5 else "silero_vad.onnx")
     sess = SileroOnnxSession(path, np.float64)
     if not batched:
         frames = frames[None]
     Bn, T, _ = frames.shape
-    sr = np.array([16000], np.int64)
+    sr = np.array([sample_rate], np.int64)
     probs = np.empty((Bn, T), np.float32)
     if version == 5:
         st = np.zeros((2, Bn, 128), np.float32)
@@ -126,6 +127,30 @@ def make_model_goldens(speech_i16):
         meta["batch7"] = "gate(tests.signals.make_streams(7,10,seed=77)), one batched run per frame"
         out["_meta"] = np.frombuffer(json.dumps({"source": "onnx_interp float64", "cases": meta}).encode(), np.uint8)
         np.savez_compressed(os.path.join(OUT, f"model_v{version}.npz"), **out)
+
+
+def make_v4_8k_goldens(speech_i16):
+    """V4's else-branch (sr != 16000), fed the same 512-sample frames the reference would feed it."""
+    cases = model_cases(speech_i16)
+    out, meta = {}, {}
+    for name in ("speech_gate", "noise_0.02", "noise_0.3", "harmonic", "zeros", "short400_padded"):
+        fr = cases[name]["frames"][:240]
+        p, s = run_model(4, fr, sample_rate=8000)
+        out[f"{name}.probs"], out[f"{name}.state"] = p, s
+        meta[name] = cases[name]["regen"] + " (first 240 frames), sr = 8000"
+        print(f"  v4-8k {name}: T={len(p)} p[min,max]=({p.min():.4f},{p.max():.4f})")
+    # 24 kHz and 48 kHz take the same branch: identical outputs
+    fr = cases["harmonic"]["frames"]
+    for sr in (24000, 48000):
+        p, s = run_model(4, fr, sample_rate=sr)
+        assert np.array_equal(p, out["harmonic.probs"]) and np.array_equal(s, out["harmonic.state"]), sr
+    fb = gate(make_streams(7, 10, seed=77))
+    p, s = run_model(4, fb, batched=True, sample_rate=8000)
+    out["batch7.probs"], out["batch7.state"] = p, s
+    meta["batch7"] = "gate(tests.signals.make_streams(7,10,seed=77)), one batched run per frame, sr = 8000"
+    out["_meta"] = np.frombuffer(json.dumps({"source": "onnx_interp float64, sr = 8000 (24000 / 48000 verified identical)",
+                                             "cases": meta}).encode(), np.uint8)
+    np.savez_compressed(os.path.join(OUT, "model_v4_8k.npz"), **out)
 
 
 # --------------------------------------------------------------------------------------
@@ -258,12 +283,16 @@ def make_util_goldens(rtv):
 def main():
     os.makedirs(OUT, exist_ok=True)
     speech = load_speech_16k()
+    if "--only-v4-8k" in sys.argv:
+        make_v4_8k_goldens(speech)
+        return
     np.savez_compressed(os.path.join(OUT, "speech16k_i16.npz"), pcm=speech,
                         _meta=np.frombuffer(b"examples/audios/SampleVoiceMono.wav [::3] (48 kHz -> 16 kHz), int16", np.uint8))
     print(f"speech: {speech.size} samples @16k")
     rtv = import_reference()
     print("model goldens (onnx_interp):")
     make_model_goldens(speech)
+    make_v4_8k_goldens(speech)
     print("state machine goldens (reference VADProcessor):")
     make_state_machine_goldens(rtv)
     print("end-to-end golden (reference VADWrapper over onnx_interp):")
