@@ -2,7 +2,7 @@
 """Export the summaries the profiles/ directory keeps from rocprofv3's rocpd (sqlite) output.
 
     rocpd_export.py stats   <results.db>            -> kernel stats CSV on stdout (rocprofv3 --stats columns)
-    rocpd_export.py pmc     <dir with *_results.db> -> pmc_traffic JSON on stdout (same maths as parse_pmc.py)
+    rocpd_export.py pmc     <dir with *_results.db> -> pmc_traffic JSON on stdout (HBM bytes per launch, corrected as MI355X_MICROARCH.md prescribes for gfx950)
     rocpd_export.py pmc-csv <results.db>            -> per-dispatch counter CSV on stdout
 """
 import csv
