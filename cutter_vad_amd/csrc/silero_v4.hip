@@ -21,19 +21,17 @@
 using namespace vadk;
 using namespace vadk::dev;
 
-namespace {
+// -DVADK_STAMPS (tools/kbench4.cpp): s_memtime at phase boundaries, [block][wave][32]; stft uses 0..15, tail 16..31
+#ifdef VADK_STAMPS
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        if (lane == 0) P.stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + (k)] = clock64();          \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
-// xp = reflect-pad(x, 96, 96) (numpy 'reflect'), as aligned quads: xp[4Q .. 4Q+3], Q in 0..175, from
-// the raw frame xs[0..127] (quads of x[512]):  xp[i] = x[96-i] (i<96), x[i-96] (i<608), x[1118-i] (else)
-__device__ __forceinline__ f32x4 xp_quad(const f32x4 *xs, int Q) {
-    if (Q >= 24 && Q < 152) return xs[Q - 24];
-    if (Q < 24) {
-        const f32x4 lo = xs[24 - Q], hi = xs[23 - Q];          // x[96-4Q] | x[95-4Q], x[94-4Q], x[93-4Q]
-        return f32x4{lo.x, hi.w, hi.z, hi.y};
-    }
-    const f32x4 p = xs[279 - Q], pm = xs[278 - Q];              // x[1118-4Q] = quad (279-Q) comp 2
-    return f32x4{p.z, p.y, p.x, pm.w};
-}
+namespace {
 
 }  // namespace
 
@@ -43,8 +41,12 @@ __device__ __forceinline__ f32x4 xp_quad(const f32x4 *xs, int Q) {
 extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const StepParams P, const int tframe) {
     using namespace vadk::v4;
     __shared__ f32x4 lds[K1_LDS_F4];
-    f32x4 *const XS = lds;                          // raw frame, [32 streams][128 quads]
-    f32x4 *const UV = lds + K1_XS_F4;               // u/v of the two columns in flight: rows 64c' + q | 64c' + 32 + q
+    // xp = reflect-pad(x, 96, 96) (numpy 'reflect'), materialised once per frame: [32 streams][176 quads].  x sits at
+    // quads 24..151 (aligned: 96 = 4 * 24); the two 24-quad edges are mirrored from it after the load.  The fold then
+    // reads plain quads (a branchy on-the-fly reflection serialised ~100 dependent LDS reads per group).
+    f32x4 *const XP = lds;
+    f32x4 *const UV = lds + K1_XS_F4;
+    constexpr int XPQ = K1_XP_QUADS;               // u/v of the two columns in flight: rows 64c' + q | 64c' + 32 + q
     float *const nyqv = reinterpret_cast<float *>(UV + K1_UV_ROWS * QS);   // [2][32]
     float *const fcor = nyqv + 64;                  // [2 columns][y128, a64, b64][32 streams]
 
@@ -60,6 +62,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
     const int o_stft = (int)P.sect[w][S_STFT];
     f32x4 *const scratch = reinterpret_cast<f32x4 *>(P.scratch) + (size_t)blockIdx.x * SCRATCH_F4_PER_TILE;
 
+    STAMP(0);
     // ---- raw frame -> LDS (gate + int16 scaling fused), lanes run along the frame ---------------
     {
         const float thr = P.thresh;
@@ -75,7 +78,10 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
                     if (g2 < P.n) xv[it] = reinterpret_cast<const f32x4 *>(P.frames)[((size_t)g2 * T + tframe) * 128 + (idx & 127)];
                 }
 #pragma unroll
-                for (int it = 0; it < 8; ++it) XS[(half * 8 + it) * NTHREADS + tid] = gate4(xv[it], thr);
+                for (int it = 0; it < 8; ++it) {
+                    const int idx = (half * 8 + it) * NTHREADS + tid;
+                    XP[(idx >> 7) * XPQ + 24 + (idx & 127)] = gate4(xv[it], thr);
+                }
             } else {
                 const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
 #pragma unroll 1
@@ -84,12 +90,31 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
                     const int g2 = tile0 + (idx >> 7);
                     i16x4 s = i16x4{0, 0, 0, 0};
                     if (g2 < P.n) s = reinterpret_cast<const i16x4 *>(P.frames)[((size_t)g2 * T + tframe) * 128 + (idx & 127)];
-                    XS[idx] = gate4(f32x4{(float)s.x / sc, (float)s.y / sc, (float)s.z / sc, (float)s.w / sc}, thr);
+                    XP[(idx >> 7) * XPQ + 24 + (idx & 127)] = gate4(f32x4{(float)s.x / sc, (float)s.y / sc, (float)s.z / sc, (float)s.w / sc}, thr);
                 }
             }
         }
     }
     __syncthreads();
+    // mirrored edges: xp[i] = x[96 - i] (i < 96) and xp[608 + i] = x[510 - i]; in xp coordinates x[k] = xp[96 + k].
+    //   left  quad Q  < 24 : {x[96-4Q], x[95-4Q], x[94-4Q], x[93-4Q]} = {lo.x, hi.w, hi.z, hi.y}, lo = xp quad 48-Q, hi = 47-Q
+    //   right quad Q >= 152: x[1118-4Q-j], j = 0..3                    = {p.z, p.y, p.x, pm.w},  p  = xp quad 303-Q, pm = 302-Q
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int idx = it * NTHREADS + tid;          // 32 streams x 48 edge quads
+        const int ms = idx / 48, k = idx - ms * 48;
+        f32x4 *row = XP + ms * XPQ;
+        if (k < 24) {
+            const f32x4 lo = row[48 - k], hi = row[47 - k];
+            row[k] = f32x4{lo.x, hi.w, hi.z, hi.y};
+        } else {
+            const int Q = 128 + k;
+            const f32x4 p = row[303 - Q], pm = row[302 - Q];
+            row[Q] = f32x4{p.z, p.y, p.x, pm.w};
+        }
+    }
+    __syncthreads();
+    STAMP(1);
 
     // window of the stored basis (its k = 0 cosine row): w[n] and w[128 + n] = w[128 - n] for this lane's n = 4q .. 4q + 3
     const int fq = tid & 15;
@@ -110,10 +135,10 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
                 const int o = rr * 16 + (tid >> 4);      // (column c', stream): o = c' * 32 + stream
                 const int cp = o >> 5, ms = o & 31;
                 const int Q0 = 16 * (2 * grp + cp);      // first xp quad of the column
-                const f32x4 *xs = XS + ms * 128;
-                const f32x4 xA = xp_quad(xs, Q0 + fq), xC = xp_quad(xs, Q0 + 32 + fq);
-                const f32x4 r1a = xp_quad(xs, Q0 + 32 - fq), r1b = xp_quad(xs, Q0 + 31 - fq);
-                const f32x4 r2a = xp_quad(xs, fq == 0 ? Q0 + 63 : Q0 + 64 - fq), r2b = xp_quad(xs, Q0 + 63 - fq);   // quad 64 of the last column does not exist; its only use (n = 0) is masked
+                const f32x4 *xs = XP + ms * XPQ + Q0;
+                const f32x4 xA = xs[fq], xC = xs[32 + fq];
+                const f32x4 r1a = xs[32 - fq], r1b = xs[31 - fq];
+                const f32x4 r2a = xs[fq == 0 ? 63 : 64 - fq], r2b = xs[63 - fq];   // quad 64 of the last column does not exist; its only use (n = 0) is masked
                 const f32x4 y1 = f32x4{xA.x * W1.x, xA.y * W1.y, xA.z * W1.z, xA.w * W1.w};
                 const f32x4 y3 = f32x4{xC.x * W3.x, xC.y * W3.y, xC.z * W3.z, xC.w * W3.w};
                 const f32x4 y2 = f32x4{r1a.x * W3.x, r1b.w * W3.y, r1b.z * W3.z, r1b.y * W3.w};
@@ -128,7 +153,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
                 f32x4 qo = f32x4{d14.x + d23.x, d14.y + d23.y, d14.z + d23.z, d14.w + d23.w};
                 if (fq == 0) {
                     pe.x = po.x = qe.x = qo.x = 0.f;
-                    const float y64 = xp_quad(xs, Q0 + 16).x * w64, y192 = xp_quad(xs, Q0 + 48).x * w64;
+                    const float y64 = xs[16].x * w64, y192 = xs[48].x * w64;
                     fcor[(cp * 3 + 0) * 32 + ms] = y3.x;           // y[128]
                     fcor[(cp * 3 + 1) * 32 + ms] = y64 + y192;     // a64
                     fcor[(cp * 3 + 2) * 32 + ms] = y64 - y192;     // b64
@@ -141,7 +166,9 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
         }
         f32x4 Are = ldw(wrs, lane16, ws), Aim = ldw(wrs, lane16, ws + 1);
         SB();
+        if (grp == 0) STAMP(2);
         __syncthreads();
+        if (grp == 0) STAMP(3);
         // ---- bin 128 on the VALU: re = sum_n pe[n] (-1)^n + y128 + a64, im == 0; 64 (column, stream) pairs, 4 lanes each
         {
             const int pair = tid >> 2, part = tid & 3;
@@ -181,6 +208,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
 #undef K1_LD
 #undef K1_MMA
         }
+        if (grp == 0) STAMP(4);
         // ---- rank-1 terms, magnitudes -> global scratch, row (33 t + quad), 32 float4 per row.
         //      Register 4g+i holds tile row r = 8g + 4h + i: (-1)^r = (-1)^i
 #pragma unroll
@@ -197,7 +225,10 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
                     f32x4{mag_(r.x + rp, i.x + ip), mag_(r.y + rm, i.y + im_), mag_(r.z + rp, i.z + ip), mag_(r.w + rm, i.w + im_)};
             }
         }
+        if (grp == 0) STAMP(5);
         __syncthreads();       // nyqv complete; every wave done with UV / fcor before the next fold overwrites them
+        if (grp == 0) STAMP(6);
+        if (grp == 3) STAMP(7);
         if (tid < 64) scratch[(size_t)(MAG_Q * (2 * grp + h) + 32) * 32 + m] = f32x4{nyqv[h * 32 + m], 0.f, 0.f, 0.f};
     }
 }
@@ -257,6 +288,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 *const scratch = reinterpret_cast<const f32x4 *>(P.scratch) + (size_t)blockIdx.x * SCRATCH_F4_PER_TILE;
 
+    STAMP(16);
     // ---- early requests: everything that comes from HBM and is needed late is asked for now, under the 135 KB
     //      magnitude load: the slot's state machine (-> LDS), c_{t-1} of both LSTM layers (registers), head weights
     SmSlot *const smL = reinterpret_cast<SmSlot *>(misc + K2_MISC_FLOATS);
@@ -289,6 +321,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
     }
     __syncthreads();
 
+    STAMP(17);
     // ---- P1: adaptive normalisation scalar: mean over bins per column, reflect-padded 7-tap smoothing, mean over columns
     {
         const int ms = tid & 31, tc = tid >> 5;       // one (column, stream) per thread
@@ -371,6 +404,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
         _Pragma("unroll") for (int k = 0; k < 4; ++k) lw[k] = WL(ob_ + (kh == 0 ? 16 : 48) + k);  \
     }
 
+    STAMP(18);
     // ---- P2: first layer; wave w produces output column t' = w (input column t = 2w), 16 channels ---------
     {
         const int tcol = 2 * w;
@@ -395,42 +429,50 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
         P2_TABLES(tb, 0)
         // weights of the next phases (P3, P4, P5): they do not depend on LDS and land during this loop
         PRE_A
+        // one k-iteration: channel quad q = 2 j + h of the 34 (129 channels + 7 of padding; the padding's table rows and
+        // weight columns are zero, its activations are read from quad 32 so that they are finite)
+#define P2_ITER(TB, NT, jj)                                                                          \
+    {                                                                                                \
+        const int j_ = (jj), jn_ = j_ < 16 ? j_ + 1 : 16;                                             \
+        const int qr = min(2 * j_ + h, 32);                                                           \
+        P2_TABLES(NT, jn_)                                                                            \
+        const f32x4 nWa = WL(ws + 4 * jn_), nWb = WL(ws + 4 * jn_ + 1), nWc = WL(ws + 4 * jn_ + 2), nWd = WL(ws + 4 * jn_ + 3); \
+        SB();                                                                                         \
+        /* depthwise k5 p2 over the 8 columns, magnitude part and normalised part, + the undelayed x1 quads */ \
+        f32x4 dm = TB[0], dn = TB[1];            /* biases */                                         \
+        f32x4 xm = zero4, xn = zero4;                                                                 \
+        _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                               \
+            const int tc = tcol + k - 2;                                                              \
+            if (tc >= 0 && tc < 8) {             /* wave-uniform */                                   \
+                const f32x4 mg = RX[(MAG_Q * tc + qr) * QS + m];                                      \
+                const f32x4 sp = f32x4{lognorm(mg.x, mm), lognorm(mg.y, mm), lognorm(mg.z, mm), lognorm(mg.w, mm)}; \
+                dm = fma4(TB[2 + 2 * k], mg, dm);                                                     \
+                dn = fma4(TB[3 + 2 * k], sp, dn);                                                     \
+                if (k == 2) { xm = mg; xn = sp; }                                                     \
+            }                                                                                         \
+        }                                                                                             \
+        dm = relu4(dm);                                                                               \
+        dn = relu4(dn);                                                                               \
+        SB();                                                                                         \
+        TG_MMA(acc, Wa, Wb, Wc, Wd, dm, xm, dn, xn)      /* pw|mag . dm + proj|mag . xm + pw|norm . dn + proj|norm . xn */ \
+        SB();                                                                                         \
+        Wa = nWa; Wb = nWb; Wc = nWc; Wd = nWd;                                                       \
+    }
 #pragma unroll 1
-        for (int j = 0; j < 17; ++j) {
-            const int q = 2 * j + h;                 // this lane's channel quad (33 -> all zero)
-            const int jn = j < 16 ? j + 1 : 16;
-            P2_TABLES(nt, jn)
-            const f32x4 nWa = WL(ws + 4 * jn), nWb = WL(ws + 4 * jn + 1), nWc = WL(ws + 4 * jn + 2), nWd = WL(ws + 4 * jn + 3);
-            SB();
-            // depthwise k5 p2 over the 8 columns, magnitude part and normalised part, + the undelayed x1 quads
-            f32x4 dm = tb[0], dn = tb[1];            // biases
-            f32x4 xm = zero4, xn = zero4;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int tc = tcol + k - 2;
-                if (tc >= 0 && tc < 8 && q < 33) {
-                    const f32x4 mg = RX[(MAG_Q * tc + q) * QS + m];
-                    const f32x4 sp = f32x4{lognorm(mg.x, mm), lognorm(mg.y, mm), lognorm(mg.z, mm), lognorm(mg.w, mm)};
-                    dm = fma4(tb[2 + 2 * k], mg, dm);
-                    dn = fma4(tb[3 + 2 * k], sp, dn);
-                    if (k == 2) { xm = mg; xn = sp; }
-                }
-            }
-            dm = relu4(dm);
-            dn = relu4(dn);
-            SB();
-            TG_MMA(acc, Wa, Wb, Wc, Wd, dm, xm, dn, xn)      // pw|mag . dm + proj|mag . xm + pw|norm . dn + proj|norm . xn
-            SB();
-            Wa = nWa; Wb = nWb; Wc = nWc; Wd = nWd;
-#pragma unroll
-            for (int k = 0; k < 12; ++k) tb[k] = nt[k];
+        for (int j = 0; j < 16; j += 2) {            // two iterations per trip: the table rows ping-pong between tb and nt
+            P2_ITER(tb, nt, j)
+            P2_ITER(nt, tb, j + 1)
         }
+        P2_ITER(tb, nt, 16)
+#undef P2_ITER
 #undef P2_TABLES
         // rows 0..15 of the tile are the 16 channels: registers of g = 0,1
 #pragma unroll
         for (int g = 0; g < 2; ++g) RX[(R_A16 + 4 * w + 2 * g) * QS + hq] = relu4(quad_of(acc, g));
     }
+    STAMP(19);
     __syncthreads();   // the magnitude rows are free from here on
+    STAMP(20);
 
     // previous h of both LSTM layers -> rows R_H0.. (32 quads per stream), requested now, used much later
     {
@@ -478,6 +520,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
     }
     __syncthreads();
 
+    STAMP(21);
     // ---- P5: s1 1x1 32 -> 32, stride 2: columns 0 and 2; waves 0,1 -------------------------------------
     PRE_C
     SB();
@@ -513,6 +556,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
     }
     __syncthreads();
 
+    STAMP(22);
     // ---- P7: s2 1x1 32 -> 32.  16 kHz: stride 2 -> column 0, wave 0.  8 kHz: stride 1 -> column w, waves 0,1 ----
     PRE_L(0)
     SB();
@@ -564,6 +608,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
     }
     __syncthreads();
 
+    STAMP(23);
     // ---- P10/P11: two stacked LSTM(64) cells, T3 time steps (1, or 2 for the 8 kHz sub-model).  wave w: unit half
     //      u = w&1; waves 0,1 contract the layer input (+bias), waves 2,3 contract h_{t-1}; partial gates meet in
     //      LDS, waves 0,1 finish the cell.  Between steps h lives in LDS (R_H0N / R_H1N) and c in registers.
@@ -660,6 +705,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
 #undef PRE_B
 #undef PRE_C
 #undef PRE_L
+    STAMP(24);
     __syncthreads();
 
     // ---- head + state machine ------------------------------------------------------------------------

@@ -83,9 +83,10 @@ enum Section {
 constexpr int MAG_Q = 33;                      // quads per STFT column: 128 bins + Nyquist (+3 pad channels)
 constexpr int MAG_ROWS = 8 * MAG_Q;            // 264 rows per tile, row = 33 t + q
 constexpr int SCRATCH_F4_PER_TILE = MAG_ROWS * 32;   // global scratch uses 32 float4 per row (no padding)
-// silero_v4_stft LDS: raw frame [32][512] f32 + the 4-way fold of two columns (2 x 64 quad rows: pe, po, qe, qo as in
+// silero_v4_stft LDS: reflect-padded frame [32][704] f32 + the 4-way fold of two columns (2 x 64 quad rows: pe, po, qe, qo as in
 // V5) + Nyquist magnitudes [2][32] + fold corrections [2][3][32]
-constexpr int K1_XS_F4 = 32 * 128;
+constexpr int K1_XP_QUADS = 176;               // reflect-padded frame: 704 samples per stream
+constexpr int K1_XS_F4 = 32 * K1_XP_QUADS;
 constexpr int K1_UV_ROWS = 128;
 constexpr int K1_LDS_F4 = K1_XS_F4 + K1_UV_ROWS * QS + 16 + 48;
 // silero_v4_tail LDS rows

@@ -29,9 +29,9 @@ __device__ __forceinline__ f32x16 acc_from(const f32x4 *ws) {
     return a;
 }
 
-__device__ __forceinline__ f32x4 relu4(f32x4 v) {
-    return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
-}
+// ReLU as ONE v_med3_f32 (median of v, 0, +inf): fmaxf() costs two v_max_f32 each, the first only to quiet signalling NaNs
+__device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)}; }
 
 __device__ __forceinline__ f32x4 quad_of(const f32x16 &a, int g) {
     switch (g) {
