@@ -64,34 +64,39 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
 
     STAMP(0);
     // ---- raw frame -> LDS (gate + int16 scaling fused), lanes run along the frame ---------------
+    // All 16 quads of a thread are requested before the first is used (one HBM round trip, not one per batch); the
+    // buffer descriptor's range check zero-fills the streams past n.
     {
         const float thr = P.thresh;
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            if (P.fmt == 0) {
-                f32x4 xv[8];
+        const bool f32in = P.fmt == 0;
+        const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
+        if (f32in) {
+            u32x4 xv[16];
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int idx = (half * 8 + it) * NTHREADS + tid;
-                    const int g2 = tile0 + (idx >> 7);
-                    xv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (g2 < P.n) xv[it] = reinterpret_cast<const f32x4 *>(P.frames)[((size_t)g2 * T + tframe) * 128 + (idx & 127)];
-                }
+            for (int it = 0; it < 16; ++it) {
+                const int idx = it * NTHREADS + tid;
+                xv[it] = __builtin_amdgcn_raw_buffer_load_b128(frs, (((tile0 + (idx >> 7)) * T + tframe) * 128 + (idx & 127)) * 16, 0, 0);
+            }
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int idx = (half * 8 + it) * NTHREADS + tid;
-                    XP[(idx >> 7) * XPQ + 24 + (idx & 127)] = gate4(xv[it], thr);
-                }
-            } else {
-                const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
-#pragma unroll 1
-                for (int it = 0; it < 8; ++it) {
-                    const int idx = (half * 8 + it) * NTHREADS + tid;
-                    const int g2 = tile0 + (idx >> 7);
-                    i16x4 s = i16x4{0, 0, 0, 0};
-                    if (g2 < P.n) s = reinterpret_cast<const i16x4 *>(P.frames)[((size_t)g2 * T + tframe) * 128 + (idx & 127)];
-                    XP[(idx >> 7) * XPQ + 24 + (idx & 127)] = gate4(f32x4{(float)s.x / sc, (float)s.y / sc, (float)s.z / sc, (float)s.w / sc}, thr);
-                }
+            for (int it = 0; it < 16; ++it) {
+                const int idx = it * NTHREADS + tid;
+                XP[(idx >> 7) * XPQ + 24 + (idx & 127)] = gate4(__builtin_bit_cast(f32x4, xv[it]), thr);
+            }
+        } else {
+            const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
+            u32x2 sv[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int idx = it * NTHREADS + tid;
+                sv[it] = __builtin_amdgcn_raw_buffer_load_b64(frs, (((tile0 + (idx >> 7)) * T + tframe) * 128 + (idx & 127)) * 8, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int idx = it * NTHREADS + tid;
+                const int s0 = (int)(short)(sv[it].x & 0xffffu), s1 = (int)(short)(sv[it].x >> 16);
+                const int s2 = (int)(short)(sv[it].y & 0xffffu), s3 = (int)(short)(sv[it].y >> 16);
+                XP[(idx >> 7) * XPQ + 24 + (idx & 127)] = gate4(f32x4{(float)s0 / sc, (float)s1 / sc, (float)s2 / sc, (float)s3 / sc}, thr);
             }
         }
     }
@@ -311,29 +316,38 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
 #pragma unroll
         for (int g = 0; g < 4; ++g) hwq[g] = WL(oh + 1 + 4 * u + g);
     }
+    f32x4 hprev[4];                                // h_{t-1} of both layers, stream tid & 31, quads 4 (tid >> 5) .. + 3
+    {
+        const int g2 = tile0 + (tid & 31);
+        const bool ok = g2 < P.n;
+        const int s2 = ok ? (P.slots ? P.slots[g2] : g2) : 0;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const f32x4 v = reinterpret_cast<const f32x4 *>(P.state + (size_t)s2 * 256)[(tid >> 5) * 4 + qq];
+            hprev[qq] = ok ? v : zero4;
+        }
+    }
     const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];
 
-    // ---- P0: magnitudes scratch -> LDS rows (33 t + q) ------------------------------------------------
-#pragma unroll 3
-    for (int it = 0; it < 33; ++it) {
-        const int idx = it * NTHREADS + tid;          // 264 rows x 32
-        RX[(idx >> 5) * QS + (idx & 31)] = scratch[idx];
-    }
-    __syncthreads();
-
-    STAMP(17);
-    // ---- P1: adaptive normalisation scalar: mean over bins per column, reflect-padded 7-tap smoothing, mean over columns
+    // ---- P0 + P1: magnitudes scratch -> LDS rows (33 t + q), and the per-column mean of the log-spectrum on the way:
+    //      thread = (column tc, stream ms) requests its 33 quads at once and takes the logs as they arrive - the hand-off
+    //      is HBM-bandwidth-bound (34.6 MB per step for 8 192 streams), the quarter-rate v_log_f32 work hides under it
     {
-        const int ms = tid & 31, tc = tid >> 5;       // one (column, stream) per thread
+        const int ms = tid & 31, tc = tid >> 5;
+        f32x4 mv[33];
+#pragma unroll
+        for (int q = 0; q < 33; ++q) mv[q] = scratch[(MAG_Q * tc + q) * 32 + ms];
         float s = 0.f;
-#pragma unroll 4
+#pragma unroll
         for (int q = 0; q < 32; ++q) {
-            const f32x4 v = RX[(MAG_Q * tc + q) * QS + ms];
-            s += (log1p20(v.x) + log1p20(v.y)) + (log1p20(v.z) + log1p20(v.w));
+            RX[(MAG_Q * tc + q) * QS + ms] = mv[q];
+            s += (log1p20(mv[q].x) + log1p20(mv[q].y)) + (log1p20(mv[q].z) + log1p20(mv[q].w));
         }
-        s += log1p20(RX[(MAG_Q * tc + 32) * QS + ms].x);
+        RX[(MAG_Q * tc + 32) * QS + ms] = mv[32];
+        s += log1p20(mv[32].x);
         colmean[tc * 32 + ms] = s * (1.0f / 129.0f);
     }
+    STAMP(17);
     __syncthreads();
     if (tid < 32) {
         const int o_dw0 = (int)P.sect[0][S_DW0];
@@ -474,19 +488,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
     __syncthreads();   // the magnitude rows are free from here on
     STAMP(20);
 
-    // previous h of both LSTM layers -> rows R_H0.. (32 quads per stream), requested now, used much later
-    {
-        const int fm = tid & 31, part = tid >> 5;
-        const int g2 = tile0 + fm;
-        const int s2 = g2 < P.n ? (P.slots ? P.slots[g2] : g2) : -1;
+    // previous h of both LSTM layers (requested at kernel start) -> rows R_H0.. (32 quads per stream)
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const int q = part * 4 + qq;
-            f32x4 v = zero4;
-            if (s2 >= 0) v = reinterpret_cast<const f32x4 *>(P.state + (size_t)s2 * 256)[q];
-            RX[(R_H0 + q) * QS + fm] = v;
-        }
-    }
+    for (int qq = 0; qq < 4; ++qq) RX[(R_H0 + (tid >> 5) * 4 + qq) * QS + (tid & 31)] = hprev[qq];
 
     // ---- P3: s0 1x1 16 -> 16 on the 4 kept columns (stride 2 already applied: t = 0,2,4,6) -------------
     {

@@ -73,6 +73,7 @@ __device__ __forceinline__ f32x16 acc_of(f32x4 b0, f32x4 b1, f32x4 b2, f32x4 b3)
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // one 1 KiB weight block: 16 bytes per lane at byte offset voff = lane*16, block index in SGPRs
 __device__ __forceinline__ f32x4 ldw(__amdgpu_buffer_rsrc_t rs, int voff, int blk) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, blk * 1024, 0));
