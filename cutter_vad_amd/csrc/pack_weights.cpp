@@ -411,20 +411,23 @@ bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::strin
         sb.vector_blocks([&](int c) { return sbias[3][32 * nt + c]; });
         for (int j = 0; j < 8; ++j) sb.weight_block([&](int np, int c) { return sw[3][(size_t)(32 * nt + np) * 64 + c]; }, j);
     }
-    // S_LSTM{0,1}: per unit half u: bias (4 gates x 4 blocks), W_ih (8 it x 4 gates), W_hh (8 it x 4 gates); gate order i,f,g,o
-    for (int l = 0; l < 2; ++l) {
-        sec[l == 0 ? S_LSTM0 : S_LSTM1] = sb.blocks();
-        for (int u = 0; u < 2; ++u) {
-            for (int q = 0; q < 4; ++q)
-                sb.vector_blocks([&](int c) { const int r = q * 64 + 32 * u + c; return lbi[l][r] + lbh[l][r]; });
-            for (int j = 0; j < 8; ++j)
-                for (int q = 0; q < 4; ++q)
-                    sb.weight_block([&](int np, int c) { return lwi[l][(size_t)(q * 64 + 32 * u + np) * 64 + c]; }, j);
-            for (int j = 0; j < 8; ++j)
-                for (int q = 0; q < 4; ++q)
-                    sb.weight_block([&](int np, int c) { return lwh[l][(size_t)(q * 64 + 32 * u + np) * 64 + c]; }, j);
+    // S_LSTM{0,1}: per wave w = hidden units 16w .. 16w+15, all four gates, full K (no partial sums to exchange):
+    //   tile A rows 0..15 = gate i, rows 16..31 = gate f;  tile B rows = gates g | o   (PyTorch row order i,f,g,o)
+    //   stream: bias A (4 blocks), bias B (4), then 16 k-iterations x {A, B}: iterations 0..7 contract the layer input
+    //   (W_ih), 8..15 contract h_{t-1} (W_hh).  The MFMA D layout then puts i, f, g, o of a unit into the same lane.
+    uint32_t lstm_sec[2][NWAVES];
+    for (int l = 0; l < 2; ++l)
+        for (int w = 0; w < NWAVES; ++w) {
+            lstm_sec[l][w] = sb.blocks();
+            auto grow = [&](int tile, int np) { return (2 * tile + (np >> 4)) * 64 + 16 * w + (np & 15); };   // gate row in [256]
+            for (int tile = 0; tile < 2; ++tile)
+                sb.vector_blocks([&](int c) { const int r = grow(tile, c); return lbi[l][r] + lbh[l][r]; });
+            for (int j = 0; j < 16; ++j)
+                for (int tile = 0; tile < 2; ++tile) {
+                    const float *wsrc = j < 8 ? lwi[l] : lwh[l];
+                    sb.weight_block([&](int np, int c) { return wsrc[(size_t)grow(tile, np) * 64 + c]; }, j & 7);
+                }
         }
-    }
     // S_HEADB: block 0 float 0 = head bias; then head weights per unit half (4 vector blocks each)
     sec[S_HEADB] = sb.blocks();
     sb.new_block()[0] = head_b[0];
@@ -434,6 +437,8 @@ bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::strin
     std::memcpy(sb.new_block(), stft, 256 * sizeof(float));
     for (int w = 0; w < NWAVES; ++w) {
         for (int k = 0; k < S_COUNT; ++k) out.sect[w][k] = sec[k];
+        out.sect[w][S_LSTM0] = lstm_sec[0][w];
+        out.sect[w][S_LSTM1] = lstm_sec[1][w];
         out.sect[w][S_STFT] = sb.blocks();
         pack_dft4_wave(sb, w);
     }

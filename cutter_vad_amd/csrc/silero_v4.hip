@@ -275,7 +275,6 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
     float *const mmv = misc;                 // [32]  mean_mean per stream
     float *const colmean = misc + 32;        // [8][32]
     float *const headp = misc + 32 + 256;    // [2][32]
-    float *const gpart = reinterpret_cast<float *>(RX + R_GP * QS);   // [2][64 regs][64 lanes]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -300,8 +299,8 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
     const bool sm_thread = tid < MT && tile0 + tid < P.n;
     const int sm_slot = sm_thread ? (P.slots ? P.slots[tile0 + tid] : tile0 + tid) : 0;
     if (sm_thread) smL[tid] = P.sm[sm_slot];
-    const int u = w & 1, kh = w >> 1;              // LSTM roles: unit half u; waves 0,1 contract the input, 2,3 h_{t-1}
-    f32x4 cprev[2][4], hwq[4];
+    const int u = w & 1;                           // output tile of the 64-channel phases P8 / P9
+    f32x4 cprev[2][2], hwq[2];                     // LSTM: wave w owns units 16w .. 16w+15; a lane holds 8 of them (2 quads)
     {
         const float *st = P.state + (size_t)slot * 256;
         int oh = (int)P.sect[w][S_HEADB];
@@ -309,12 +308,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
 #pragma unroll
         for (int layer = 0; layer < 2; ++layer)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(st + 128 + 64 * layer + 32 * u + 8 * g + 4 * h);
-                cprev[layer][g] = live ? v : zero4;
+            for (int e = 0; e < 2; ++e) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(st + 128 + 64 * layer + 16 * w + 8 * e + 4 * h);
+                cprev[layer][e] = live ? v : zero4;
             }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) hwq[g] = WL(oh + 1 + 4 * u + g);
+        for (int e = 0; e < 2; ++e) hwq[e] = WL(oh + 1 + 4 * (w >> 1) + 2 * (w & 1) + e);
     }
     f32x4 hprev[4];                                // h_{t-1} of both layers, stream tid & 31, quads 4 (tid >> 5) .. + 3
     {
@@ -376,7 +375,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
     f32x4 p3w[6], p4w[8], p4t[12], p5w[8];       // set A: requested before the P2 loop
     f32x4 p6w[8], p6t[24], p7w[8];               // set B: requested at P3
     f32x4 p8w[12], p8t[8], p9w[12];              // set C: requested at P5
-    f32x4 lb[16], lw[4];                         // set L: LSTM gate biases (input waves) + first weight group, per layer
+    f32x4 lb[8], lw[4];                          // set L: LSTM gate biases (tiles A, B) + the first two k-iterations' weights, per layer
 #define PRE_A                                                                                     \
     {                                                                                             \
         int o_ = (int)P.sect[w][S_S0];                                                            \
@@ -408,17 +407,14 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
         o_ = (int)P.sect[w][S_S3];                                                                \
         _Pragma("unroll") for (int k = 0; k < 12; ++k) p9w[k] = WL(o_ + 12 * u + k);              \
     }
-    // LSTM layer `layer`: waves kh = 0 start from the bias and contract the layer input, waves kh = 1 contract h_{t-1}
+    // LSTM layer `layer`, this wave's 16 units: biases of tiles A (i|f) and B (g|o), weights of k-iterations 0 and 1
 #define PRE_L(layer)                                                                              \
     {                                                                                             \
-        const int ob_ = (int)P.sect[w][(layer) == 0 ? S_LSTM0 : S_LSTM1] + 80 * u;                \
-        if (kh == 0) {                                                                            \
-            _Pragma("unroll") for (int k = 0; k < 16; ++k) lb[k] = WL(ob_ + k);                   \
-        }                                                                                         \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) lw[k] = WL(ob_ + (kh == 0 ? 16 : 48) + k);  \
+        const int ob_ = (int)P.sect[w][(layer) == 0 ? S_LSTM0 : S_LSTM1];                         \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) lb[k] = WL(ob_ + k);                        \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) lw[k] = WL(ob_ + 8 + k);                    \
     }
 
-    STAMP(18);
     // ---- P2: first layer; wave w produces output column t' = w (input column t = 2w), 16 channels ---------
     {
         const int tcol = 2 * w;
@@ -613,41 +609,40 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
     __syncthreads();
 
     STAMP(23);
-    // ---- P10/P11: two stacked LSTM(64) cells, T3 time steps (1, or 2 for the 8 kHz sub-model).  wave w: unit half
-    //      u = w&1; waves 0,1 contract the layer input (+bias), waves 2,3 contract h_{t-1}; partial gates meet in
-    //      LDS, waves 0,1 finish the cell.  Between steps h lives in LDS (R_H0N / R_H1N) and c in registers.
+    // ---- P10/P11: two stacked LSTM(64) cells, T3 time steps (1, or 2 for the 8 kHz sub-model).  Wave w owns hidden
+    //      units 16w .. 16w+15 with all four gates and the full K = 128 (layer input | h_{t-1}): tile A rows = gates i|f,
+    //      tile B rows = gates g|o, so i, f, g, o of a unit land in the same lane and every wave finishes its own
+    //      cells - no partial sums to exchange, one barrier per cell.  Between steps h lives in LDS, c in registers.
     constexpr int T3 = K8 ? 2 : 1;
+    constexpr int R_H0M = R8_Y5;                    // 8 kHz only: layer 0's h after the SECOND step (R_H0N is still being read)
 #pragma unroll
     for (int step = 0; step < T3; ++step) {
     float part = 0.f;
 #pragma unroll
     for (int layer = 0; layer < 2; ++layer) {
-        const int ob = (int)P.sect[w][layer == 0 ? S_LSTM0 : S_LSTM1] + 80 * u;
-        f32x16 g4[4];
-        int ws;
-        const f32x4 *src;
-        if (kh == 0) {
+        const int ob = (int)P.sect[w][layer == 0 ? S_LSTM0 : S_LSTM1];
+        f32x16 gA = acc_of(lb[0], lb[1], lb[2], lb[3]), gB = acc_of(lb[4], lb[5], lb[6], lb[7]);
+        const int rx = layer == 0 ? (K8 ? R8_Y6 + 16 * step : R_Y6) : (step == 0 ? R_H0N : R_H0M);
+        const int rh = layer == 0 ? (step == 0 ? R_H0 : R_H0N) : (step == 0 ? R_H1 : R_H1N);
+        const f32x4 *const xsrc = RX + rx * QS + hq, *const hsrc = RX + rh * QS + hq;
+        // stage s = k-iterations 2s, 2s+1 (16 MFMAs); iterations 0..7 contract the layer input, 8..15 h_{t-1}
+#define LS_ROW(it) (((it) < 8 ? xsrc : hsrc)[(2 * ((it) & 7)) * QS])
+#define LS_LD(S, st)                                                                              \
+    S##w0 = WL(ob + 8 + 4 * (st)); S##w1 = WL(ob + 9 + 4 * (st)); S##w2 = WL(ob + 10 + 4 * (st)); S##w3 = WL(ob + 11 + 4 * (st)); \
+    S##a0 = LS_ROW(2 * (st)); S##a1 = LS_ROW(2 * (st) + 1);
+#define LS_MMA(S)                                                                                 \
+    gA = mfma4(S##w0, S##a0, gA); gB = mfma4(S##w1, S##a0, gB); gA = mfma4(S##w2, S##a1, gA); gB = mfma4(S##w3, S##a1, gB);
+        f32x4 Aw0 = lw[0], Aw1 = lw[1], Aw2 = lw[2], Aw3 = lw[3], Aa0 = LS_ROW(0), Aa1 = LS_ROW(1);
+        f32x4 Bw0, Bw1, Bw2, Bw3, Ba0, Ba1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) g4[q] = acc_of(lb[4 * q], lb[4 * q + 1], lb[4 * q + 2], lb[4 * q + 3]);
-            ws = ob + 16;
-            src = RX + (layer == 0 ? (K8 ? R8_Y6 + 16 * step : R_Y6) : R_H0N) * QS + hq;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) g4[q] = (f32x16)(0.f);
-            ws = ob + 48;
-            src = RX + (layer == 0 ? (step == 0 ? R_H0 : R_H0N) : (step == 0 ? R_H1 : R_H1N)) * QS + hq;
-        }
-        f32x4 Aw0 = lw[0], Aw1 = lw[1], Aw2 = lw[2], Aw3 = lw[3], Aa = src[0], Bw0, Bw1, Bw2, Bw3, Ba;
-#define LS_LD(S, it) S##w0 = WL(ws + 4 * (it)); S##w1 = WL(ws + 4 * (it) + 1); S##w2 = WL(ws + 4 * (it) + 2); S##w3 = WL(ws + 4 * (it) + 3); S##a = src[(2 * (it)) * QS];
-#define LS_MMA(S) g4[0] = mfma4(S##w0, S##a, g4[0]); g4[1] = mfma4(S##w1, S##a, g4[1]); g4[2] = mfma4(S##w2, S##a, g4[2]); g4[3] = mfma4(S##w3, S##a, g4[3]);
-#pragma unroll
-        for (int it = 0; it < 8; it += 2) {
-            LS_LD(B, it + 1) SB();
+        for (int st = 0; st < 8; st += 2) {
+            LS_LD(B, st + 1) SB();
             LS_MMA(A) SB();
-            const int itn = it + 2 < 8 ? it + 2 : 6;
-            LS_LD(A, itn) SB();
+            const int stn = st + 2 < 8 ? st + 2 : 6;
+            LS_LD(A, stn) SB();
             LS_MMA(B) SB();
         }
+#undef LS_ROW
 #undef LS_LD
 #undef LS_MMA
         // the next cell's biases and first weights fly during this cell's update
@@ -658,52 +653,38 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
             PRE_L(0)
             SB();
         }
-        if (kh == 1) {
-            float *gp = gpart + (size_t)u * 64 * 64 + lane;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gp[(q * 16 + r) * 64] = g4[q][r];
-        }
-        __syncthreads();
-        if (kh == 0) {
-            const float *gp = gpart + (size_t)u * 64 * 64 + lane;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) g4[q][r] += gp[(q * 16 + r) * 64];
+        {
             float *st = P.state + (size_t)slot * 256;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 i4 = quad_of(g4[0], g), f4 = quad_of(g4[1], g), c4g = quad_of(g4[2], g), o4 = quad_of(g4[3], g);
-                const int unit = 32 * u + 8 * g + 4 * h;
-                const f32x4 cp = cprev[layer][g];
+            for (int e = 0; e < 2; ++e) {
+                // tile row 8 r' + 4 h + i is register 4 r' + i: rows 0..15 (r' = 0,1) = first gate, 16..31 = second gate
+                const f32x4 i4 = quad_of(gA, e), f4 = quad_of(gA, 2 + e), c4g = quad_of(gB, e), o4 = quad_of(gB, 2 + e);
+                const int unit = 16 * w + 8 * e + 4 * h;
+                const f32x4 cp = cprev[layer][e];
                 f32x4 cn, hn;
 #define CELL(k)                                                             \
     cn.k = sigmoidf_(f4.k) * cp.k + sigmoidf_(i4.k) * tanhf_(c4g.k);      \
     hn.k = sigmoidf_(o4.k) * tanhf_(cn.k);
                 CELL(x) CELL(y) CELL(z) CELL(w)
 #undef CELL
-                cprev[layer][g] = cn;
+                cprev[layer][e] = cn;
                 if (step == T3 - 1 && live) {
                     *reinterpret_cast<f32x4 *>(st + 128 + 64 * layer + unit) = cn;
                     *reinterpret_cast<f32x4 *>(st + 64 * layer + unit) = hn;
                 }
                 if (layer == 0) {
-                    RX[(R_H0N + 8 * u + 2 * g) * QS + hq] = hn;
+                    RX[((step == 0 ? R_H0N : R_H0M) + 4 * w + 2 * e) * QS + hq] = hn;
                 } else {
-                    if (step + 1 < T3) RX[(R_H1N + 8 * u + 2 * g) * QS + hq] = hn;
-                    const f32x4 hw = hwq[g];
+                    if (step + 1 < T3) RX[(R_H1N + 4 * w + 2 * e) * QS + hq] = hn;
+                    const f32x4 hw = hwq[e];
                     part += hw.x * fmaxf(hn.x, 0.f) + hw.y * fmaxf(hn.y, 0.f) + hw.z * fmaxf(hn.z, 0.f) + hw.w * fmaxf(hn.w, 0.f);
                 }
             }
         }
         __syncthreads();
     }
-    if (kh == 0) {
-        part += __shfl_xor(part, 32);
-        if (h == 0) headp[step * 64 + u * 32 + m] = part;
-    }
+    part += __shfl_xor(part, 32);
+    if (h == 0) headp[step * 128 + w * 32 + m] = part;
     }
 #undef PRE_A
 #undef PRE_B
@@ -714,8 +695,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
 
     // ---- head + state machine ------------------------------------------------------------------------
     if (sm_thread) {
-        float p = sigmoidf_(hb + headp[tid] + headp[32 + tid]);
-        if (K8) p = (p + sigmoidf_(hb + headp[64 + tid] + headp[96 + tid])) * 0.5f;     // ReduceMean over the two time steps
+        float p = sigmoidf_(hb + ((headp[tid] + headp[32 + tid]) + (headp[64 + tid] + headp[96 + tid])));
+        if (K8)     // ReduceMean over the two time steps
+            p = (p + sigmoidf_(hb + ((headp[128 + tid] + headp[160 + tid]) + (headp[192 + tid] + headp[224 + tid])))) * 0.5f;
         p = fminf(p, 1.0f);
         P.probs[(size_t)(tile0 + tid) * T + tframe] = p;
         SmSlot sm = smL[tid];

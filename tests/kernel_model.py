@@ -428,25 +428,27 @@ def v4_step(W, sect, x, hc, gate=0.01):
     z = np.zeros(32)
     oh = sect[0][S["S_HEADB"]]
     for layer in range(2):
-        o = sect[0][S["S_LSTM0" if layer == 0 else "S_LSTM1"]]
         xin = 104 if layer == 0 else 152
         hin = 120 if layer == 0 else 136
         hn_all = np.zeros((64, 32))
-        for u in range(2):
-            ob = o + 80 * u
-            g = [_bias_tile(W, ob + 4 * q) for q in range(4)]
-            for it in range(8):
-                for q in range(4):
-                    g[q] += _mfma4(W[ob + 16 + 4 * it + q], _rows(RX, xin + 2 * it, xin + 2 * it + 1))
-                    g[q] += _mfma4(W[ob + 48 + 4 * it + q], _rows(RX, hin + 2 * it, hin + 2 * it + 1))
-            cp = hc[:, 128 + 64 * layer + 32 * u:128 + 64 * layer + 32 * u + 32].astype(np.float64).T
-            cn = sig(g[1]) * cp + sig(g[0]) * np.tanh(g[2])
-            hn = sig(g[3]) * np.tanh(cn)
-            new[:, 128 + 64 * layer + 32 * u:128 + 64 * layer + 32 * u + 32] = cn.T
-            new[:, 64 * layer + 32 * u:64 * layer + 32 * u + 32] = hn.T
-            hn_all[32 * u:32 * u + 32] = hn
+        for w in range(4):                                   # wave w: units 16w..16w+15, tiles A = i|f, B = g|o
+            ob = sect[w][S["S_LSTM0" if layer == 0 else "S_LSTM1"]]
+            gA, gB = _bias_tile(W, ob), _bias_tile(W, ob + 4)
+            for it in range(16):
+                src = (xin if it < 8 else hin) + 2 * (it & 7)
+                gA += _mfma4(W[ob + 8 + 2 * it], _rows(RX, src, src + 1))
+                gB += _mfma4(W[ob + 8 + 2 * it + 1], _rows(RX, src, src + 1))
+            gi, gf, gg, go = gA[:16], gA[16:], gB[:16], gB[16:]
+            sl = slice(16 * w, 16 * w + 16)
+            cp = hc[:, 128 + 64 * layer:192 + 64 * layer].astype(np.float64).T[sl]
+            cn = sig(gf) * cp + sig(gi) * np.tanh(gg)
+            hn = sig(go) * np.tanh(cn)
+            new[:, 128 + 64 * layer + 16 * w:128 + 64 * layer + 16 * w + 16] = cn.T
+            new[:, 64 * layer + 16 * w:64 * layer + 16 * w + 16] = hn.T
+            hn_all[sl] = hn
             if layer == 1:
-                z += (_vec(W[oh + 1 + 4 * u:oh + 5 + 4 * u])[:, None] * np.maximum(hn, 0)).sum(0)
+                hw = _vec(W[oh + 1 + 4 * (w >> 1):oh + 5 + 4 * (w >> 1)])[16 * (w & 1):16 * (w & 1) + 16]
+                z += (hw[:, None] * np.maximum(hn, 0)).sum(0)
         if layer == 0:
             RX[152:168] = hn_all.T.reshape(32, 16, 4).transpose(1, 0, 2)
     prob = sig(z + W[oh][0, 0])

@@ -109,6 +109,41 @@ def v4_alone():
             "frac_of_fp32_peak_at_1.38_MFLOP_per_frame": 1.38e6 * B / dt / 157.3e12}
 
 
+def resampler_alone():
+    """vadk_resample_512 alone: 4096 chunks per launch, device-resident, per input rate."""
+    B = 4096
+    eng = Engine(blob(5), max_streams=64)
+    out = []
+    ts = torch.cuda.Stream()
+    y = torch.empty(B, 512, device="cuda")
+    for sr, n_in in ((8000, 256), (24000, 768), (48000, 1536)):
+        x = (0.1 * torch.randn(4, B, n_in, device="cuda")).contiguous()
+        lib = eng._lib
+
+        def step(i):
+            assert lib.vad_resample_device(eng.handle, x[i % 4].data_ptr(), B, n_in, sr, y.data_ptr(), ts.cuda_stream) == 0
+
+        dt = timed(step, [ts])
+        flop = 2.0 * 512 * n_in * B
+        out.append({"config": f"resampler alone: {B} chunks of {n_in} samples ({sr} Hz) -> 512", "us_per_launch": dt * 1e6,
+                    "chunks_per_s": B / dt, "TFLOP_s_dense_operator": flop / dt / 1e12,
+                    "frac_of_fp32_peak": flop / dt / 157.3e12})
+    eng.close()
+    return out
+
+
+def v4_8k():
+    B = 8192
+    eng = Engine(open(weights_io.packaged_blob_path(4, 8000), "rb").read(), model_version=4, max_streams=B)
+    eng.open_streams(B)
+    ring = (0.1 * torch.randn(16, B, 512, device="cuda")).contiguous()
+    probs = torch.empty(B, device="cuda")
+    ts = torch.cuda.Stream()
+    dt = timed(lambda i: eng.step_device(B, ring[i % 16].data_ptr(), probs.data_ptr(), stream=ts.cuda_stream), [ts])
+    eng.close()
+    return {"config": "batch=8192, V4 8 kHz sub-model (a9; two LSTM steps per frame)", "us_per_step": dt * 1e6, "frames_per_s": B / dt}
+
+
 def host_api():
     """PCIe-inclusive: vad_step with HOST pointers (pageable numpy arrays): H2D frames, kernel, D2H probs, sync."""
     import time
@@ -138,5 +173,7 @@ def host_api():
 if __name__ == "__main__":
     for r in host_api():
         print(json.dumps(r), flush=True)
-    for fn in (config1, config3, config4_per_gpu, v4_alone):
+    for r in resampler_alone():
+        print(json.dumps(r), flush=True)
+    for fn in (config1, config3, config4_per_gpu, v4_alone, v4_8k):
         print(json.dumps(fn()), flush=True)
