@@ -47,7 +47,11 @@ __device__ __forceinline__ f32x4 quad_of(const f32x16 &a, int g) {
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(NTHREADS, 1) vadk_resample_512(const vadk::ResampleParams P) {
+// NT = output tiles per wave.  NT = 4: one workgroup produces all 512 outputs of its 32 chunks.  NT = 2: two workgroups
+// (blockIdx.y) share a chunk tile, 256 outputs each - used when the call has too few chunk tiles to fill the 256 CUs
+// (the input is read twice, from L2, which costs less than idle CUs).
+template <int NT>
+__global__ void __launch_bounds__(NTHREADS, 1) vadk_resample_512(const vadk::ResampleParams P) {
     constexpr int CH_ROWS = 64;                       // one chunk = 256 samples = 64 quad rows
     __shared__ f32x4 lds[2 * CH_ROWS * QS];
     const int tid = threadIdx.x;
@@ -61,11 +65,14 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) vadk_resample_512(cons
     const __amdgpu_buffer_rsrc_t wrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wstream), 0, (int)P.wstream_bytes, 0x00020000);
     const int lane16 = lane * 16;
-    const int wbase = w * (int)P.wave_blocks;
+    // the packed operator: wave stream w' holds, per k-iteration, the blocks of output tiles 4w' .. 4w'+3.  With NT = 2 this
+    // wave owns tiles 8y + 2w + {0, 1}: stream w' = 2y + (w >> 1), blocks 2(w & 1) + {0, 1} of each iteration.
+    const int ot0 = NT == 4 ? 4 * w : 8 * (int)blockIdx.y + 2 * w;     // first output tile of this wave
+    const int wbase = (ot0 >> 2) * (int)P.wave_blocks + (ot0 & 3);
 
-    f32x16 acc[4];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = (f32x16)(0.f);
+    for (int k = 0; k < NT; ++k) acc[k] = (f32x16)(0.f);
 
     // chunk loader: 32 streams x 64 quads = 2048 float4, 8 per thread; lanes run over quads of one stream
     f32x4 xr[8];
@@ -95,14 +102,12 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) vadk_resample_512(cons
         if (c + 1 < nchunks) load_chunk(c + 1);          // global loads in flight under the MFMAs
         int ws = wbase + c * 128;                        // 32 k-iterations x 4 tiles per chunk
         asm volatile("" : "+s"(ws));
-        f32x4 Aw0 = ldw(wrs, lane16, ws), Aw1 = ldw(wrs, lane16, ws + 1), Aw2 = ldw(wrs, lane16, ws + 2),
-              Aw3 = ldw(wrs, lane16, ws + 3);
-        f32x4 Aa = X[hq], Bw0, Bw1, Bw2, Bw3, Ba;
+        f32x4 Aw[NT], Bw[NT], Aa, Ba;
 #define R_LD(S, j)                                                                              \
-    S##w0 = ldw(wrs, lane16, ws + 4 * (j)); S##w1 = ldw(wrs, lane16, ws + 4 * (j) + 1);         \
-    S##w2 = ldw(wrs, lane16, ws + 4 * (j) + 2); S##w3 = ldw(wrs, lane16, ws + 4 * (j) + 3);     \
+    _Pragma("unroll") for (int k = 0; k < NT; ++k) S##w[k] = ldw(wrs, lane16, ws + 4 * (j) + k); \
     S##a = X[(2 * (j)) * QS + hq];
-#define R_MMA(S) acc[0] = mfma4(S##w0, S##a, acc[0]); acc[1] = mfma4(S##w1, S##a, acc[1]); acc[2] = mfma4(S##w2, S##a, acc[2]); acc[3] = mfma4(S##w3, S##a, acc[3]);
+#define R_MMA(S) _Pragma("unroll") for (int k = 0; k < NT; ++k) acc[k] = mfma4(S##w[k], S##a, acc[k]);
+        R_LD(A, 0)
         for (int j = 0; j < 32; j += 2) {
             R_LD(B, j + 1) SB();
             R_MMA(A) SB();
@@ -115,12 +120,12 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) vadk_resample_512(cons
         if (c + 1 < nchunks) store_chunk((c + 1) & 1);   // the other buffer: last read two chunks ago
         __syncthreads();
     }
-    // epilogue: lane (m,h) holds outputs 32*(4w+k) + 8g + 4h + i
+    // epilogue: lane (m,h) holds outputs 32*(ot0+k) + 8g + 4h + i
     const int g2 = tile0 + m;
     if (g2 < P.n) {
-        float *o = P.out + (size_t)g2 * 512 + 128 * w + 4 * h;
+        float *o = P.out + (size_t)g2 * 512 + 32 * ot0 + 4 * h;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < NT; ++k)
 #pragma unroll
             for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(o + 32 * k + 8 * g) = quad_of(acc[k], g);
     }
@@ -129,6 +134,9 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) vadk_resample_512(cons
 extern "C" hipError_t vadk_launch_resample(const vadk::ResampleParams *p, hipStream_t stream) {
     const int tiles = (p->n + vadk::MT - 1) / vadk::MT;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(vadk_resample_512, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+    if (tiles <= 128)
+        hipLaunchKernelGGL(vadk_resample_512<2>, dim3(tiles, 2), dim3(vadk::NTHREADS), 0, stream, *p);
+    else
+        hipLaunchKernelGGL(vadk_resample_512<4>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
     return hipGetLastError();
 }

@@ -49,6 +49,20 @@ def test_oracle_agrees_and_linearity(engine):
         assert np.abs(const - 0.25).max() <= TOL                        # DC is preserved (fp32 operator rows)
 
 
+def test_both_launch_shapes_agree(engine):
+    """Calls of up to 128 chunk tiles split the 512 outputs over two workgroups per tile, larger calls use one: the two
+    shapes must give bit-identical rows (same operator blocks, same order of accumulation)."""
+    import scipy.signal
+    for sr, n_in in ((8000, 256), (48000, 1536)):
+        x = (0.4 * np.random.default_rng(sr + 1).standard_normal((4200, n_in))).astype(np.float32)   # 132 tiles
+        big = engine.resample(x, sr)
+        small = engine.resample(x[:100], sr)                                                         # 4 tiles, split
+        assert np.array_equal(big[:100], small)
+        pick = [0, 31, 32, 4127, 4199]
+        ref = np.stack([scipy.signal.resample(x[i], 512).astype(np.float32) for i in pick])
+        assert np.abs(big[pick] - ref).max() <= TOL
+
+
 def test_audio_utils_resample_goes_through_the_engine(engine):
     from cutter_vad_amd import AudioProcessingError, AudioUtils
     import scipy.signal
