@@ -148,6 +148,35 @@ def v4_8k():
     return {"config": "batch=8192, V4 8 kHz sub-model (a9; two LSTM steps per frame)", "us_per_step": dt * 1e6, "frames_per_s": B / dt}
 
 
+def single_stream_wrapper():
+    """configs[0]: ONE stream through the drop-in VADWrapper (host framing + one launch + sync + callbacks per chunk)."""
+    import time
+    import numpy as np
+    from cutter_vad_amd import VADConfig, VADWrapper
+    pcm = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                               "speech16k_i16.npz"))["pcm"]
+    x = pcm.astype(np.float32) / 32767.0
+    out = []
+    for chunk in (512, 480, 1024):
+        n = min(x.size // chunk, 600)
+        seg = [0]
+        with VADWrapper(VADConfig(vad_start_probability=0.4, vad_end_probability=0.3, voice_start_frame_count=6,
+                                  voice_end_frame_count=12, buffer_size=chunk if chunk < 512 else 512)) as w:
+            w.set_callbacks(None, lambda wav: seg.__setitem__(0, seg[0] + 1), None)
+            for i in range(20):
+                w.process_audio_data(x[i * chunk:(i + 1) * chunk])
+            w.reset()
+            t0 = time.perf_counter()
+            for i in range(n):
+                w.process_audio_data(x[i * chunk:(i + 1) * chunk])
+            dt = (time.perf_counter() - t0) / n
+            frames = w.get_statistics()["total_frames_processed"]
+        out.append({"config": f"configs[0]: single stream, VADWrapper.process_audio_data, {chunk}-sample chunks",
+                    "us_per_chunk": dt * 1e6, "frames_per_chunk": frames / n, "real_time_factor": (chunk / 16000) / dt,
+                    "segments": seg[0]})
+    return out
+
+
 def host_api():
     """PCIe-inclusive: vad_step with HOST pointers (pageable numpy arrays): H2D frames, kernel, D2H probs, sync."""
     import time
@@ -176,6 +205,8 @@ def host_api():
 
 if __name__ == "__main__":
     for r in host_api():
+        print(json.dumps(r), flush=True)
+    for r in single_stream_wrapper():
         print(json.dumps(r), flush=True)
     for r in resampler_alone():
         print(json.dumps(r), flush=True)
