@@ -167,27 +167,36 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
     auto convw = [&](int layer, int o, int c, int tap) -> float {
         return c < ci[layer] ? ew[layer][((size_t)o * ci[layer] + c) * 3 + tap] : 0.f;
     };
-    // enc0 reads the |STFT| channels in the kernel's even/odd bin order (vad_layout.h)
-    auto conv0 = [&](int o, int ch, int tap) -> float { return ew[0][((size_t)o * 129 + bin_of_channel(ch)) * 3 + tap]; };
     for (int w = 0; w < NWAVES; ++w) {
         // STFT on the folded input (vad_layout.h): bins 32w..32w+31, {re, im} per k-iteration;
         // k-iteration j contracts n = 8j+1 .. 8j+8 (quad 2j on the lower half-wave, 2j+1 on the upper)
         out.sect[w][S_STFT] = sb.blocks();
         pack_dft4_wave(sb, w);
-        // enc0: out channels 32w.., taps 0..2 per k-iteration, then the Nyquist input channel
+        // enc0 as a Toom-3 product (vad_layout.h): out channels 32w.., per k-iteration the five point-wise weight blocks
+        // V(0) = w2, V(1)/2, V(-1)/2, V(2), V(inf) = w0 of V(z) = w2 + w1 z + w0 z^2 (evaluated in double); then the
+        // Nyquist input channel: block A = points 0, 1, -1, 2 in the four components (lower half-wave), block B = inf
         out.sect[w][S_ENC0] = sb.blocks();
         sb.vector_blocks([&](int c) { return eb[0][32 * w + c]; });
+        auto toom = [&](int o, int c129, int p) -> float {
+            const double v0 = ew[0][((size_t)o * 129 + c129) * 3 + 2], v1 = ew[0][((size_t)o * 129 + c129) * 3 + 1],
+                         v2 = ew[0][((size_t)o * 129 + c129) * 3 + 0];
+            switch (p) {
+                case 0: return (float)v0;
+                case 1: return (float)(0.5 * (v0 + v1 + v2));
+                case 2: return (float)(0.5 * (v0 - v1 + v2));
+                case 3: return (float)(v0 + 2.0 * v1 + 4.0 * v2);
+                default: return (float)v2;
+            }
+        };
         for (int j = 0; j < 16; ++j)
-            for (int tap = 0; tap < 3; ++tap)
-                sb.weight_block([&](int np, int c) { return conv0(32 * w + np, c, tap); }, j);
-        for (int tout = 0; tout < 3; ++tout) {
-            // activation quad = (|X128| of column 0, 1, 2, 0) on the lower half-wave, zeros on the upper
-            float *b = sb.new_block();
+            for (int p = 0; p < 5; ++p)
+                sb.weight_block([&](int np, int c) { return toom(32 * w + np, bin_of_channel(c), p); }, j);
+        {
+            float *a = sb.new_block();
             for (int l = 0; l < 32; ++l)
-                for (int i = 0; i < 3; ++i) {
-                    const int tap = i - tout + 1;
-                    b[l * 4 + i] = (tap >= 0 && tap < 3) ? convw(0, 32 * w + l, 128, tap) : 0.f;
-                }
+                for (int p = 0; p < 4; ++p) a[l * 4 + p] = toom(32 * w + l, 128, p);
+            float *b = sb.new_block();
+            for (int l = 0; l < 32; ++l) b[l * 4] = toom(32 * w + l, 128, 4);
         }
         // enc1: n-tile w&1, output column w>>1; taps (1,2) for column 0, (0,1) for column 1
         out.sect[w][S_ENC1] = sb.blocks();

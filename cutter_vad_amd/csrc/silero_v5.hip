@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
 
         // ---- STFT: wave w owns the 32 bins bin_of_channel(32w + r): cos on pe|po, -sin on qe|qo, 3 columns ----
         // enc0's bias and first weights ride along (requested at the end of this phase)
-        f32x4 e0b0, e0b1, e0b2, e0b3, E0w0, E0w1, E0w2;
+        f32x4 e0b0, e0b1, e0b2, e0b3, E0w[5];
         {
             f32x16 are[3], aim[3];
 #pragma unroll
@@ -304,49 +304,69 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
 #undef STFT_MMA
             // request enc0's bias + first weights now: they land while the magnitudes are written
             e0b0 = WL(ws_e0); e0b1 = WL(ws_e0 + 1); e0b2 = WL(ws_e0 + 2); e0b3 = WL(ws_e0 + 3);
-            E0w0 = WL(ws_e0 + 4); E0w1 = WL(ws_e0 + 5); E0w2 = WL(ws_e0 + 6);
+#pragma unroll
+            for (int p = 0; p < 5; ++p) E0w[p] = WL(ws_e0 + 4 + p);
             SB();
             STAMP(16);
             __syncthreads();   // (1b) every wave is done reading u/v: the magnitudes may overwrite them
-            // rank-1 terms, then magnitude -> rows 32c + 8w + 2g + h.  Register 4g+i holds row r = 8g+4h+i: (-1)^r = (-1)^i
+            // rank-1 terms, then magnitudes.  Register 4g+i holds row r = 8g+4h+i: (-1)^r = (-1)^i.  The three columns
+            // m0, m1, m2 of a bin go to enc0 as the Toom-3 evaluations of m0 + m1 z + m2 z^2 (vad_layout.h):
+            // rows 32p + 8w + 2g + h, p = 0..4 for z = 0, 1, -1, 2, inf
+            float rp[3], rm[3], ip[3], im_[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float y128 = fcor[(c * 3 + 0) * 32 + m], a64 = fcor[(c * 3 + 1) * 32 + m], b64 = fcor[(c * 3 + 2) * 32 + m];
                 // even bins: re += y128 + a64 (-1)^r ; odd bins: re -= y128, im -= b64 (-1)^r
-                const float rp = w < 2 ? y128 + a64 : -y128, rm = w < 2 ? y128 - a64 : -y128;
-                const float ip = w < 2 ? 0.f : -b64, im_ = w < 2 ? 0.f : b64;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 r = quad_of(are[c], g), i = quad_of(aim[c], g);
-                    RX[(c * 32 + 8 * w + 2 * g) * QS + hq] = f32x4{mag_(r.x + rp, i.x + ip), mag_(r.y + rm, i.y + im_),
-                                                                  mag_(r.z + rp, i.z + ip), mag_(r.w + rm, i.w + im_)};
-                }
+                rp[c] = w < 2 ? y128 + a64 : -y128; rm[c] = w < 2 ? y128 - a64 : -y128;
+                ip[c] = w < 2 ? 0.f : -b64; im_[c] = w < 2 ? 0.f : b64;
             }
-            // row 96: (|X128| of column 0,1,2, 0) ; row 97: zeros (pairs with row 96 in the MFMA k-step)
-            if (tid < 64) RX[96 * QS + hq] = h == 0 ? f32x4{nyqv[m], nyqv[32 + m], nyqv[64 + m], 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 mg[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x4 r = quad_of(are[c], g), i = quad_of(aim[c], g);
+                    mg[c] = f32x4{mag_(r.x + rp[c], i.x + ip[c]), mag_(r.y + rm[c], i.y + im_[c]),
+                                  mag_(r.z + rp[c], i.z + ip[c]), mag_(r.w + rm[c], i.w + im_[c])};
+                }
+                const f32x4 s02 = f32x4{mg[0].x + mg[2].x, mg[0].y + mg[2].y, mg[0].z + mg[2].z, mg[0].w + mg[2].w};
+                f32x4 *o = RX + (8 * w + 2 * g) * QS + hq;
+                o[0] = mg[0];
+                o[32 * QS] = f32x4{s02.x + mg[1].x, s02.y + mg[1].y, s02.z + mg[1].z, s02.w + mg[1].w};
+                o[64 * QS] = f32x4{s02.x - mg[1].x, s02.y - mg[1].y, s02.z - mg[1].z, s02.w - mg[1].w};
+                o[96 * QS] = f32x4{fmaf(4.f, mg[2].x, fmaf(2.f, mg[1].x, mg[0].x)), fmaf(4.f, mg[2].y, fmaf(2.f, mg[1].y, mg[0].y)),
+                                   fmaf(4.f, mg[2].z, fmaf(2.f, mg[1].z, mg[0].z)), fmaf(4.f, mg[2].w, fmaf(2.f, mg[1].w, mg[0].w))};
+                o[128 * QS] = mg[2];
+            }
+            // |X128|: rows 160 / 161 = (points 0, 1, -1, 2) / zeros, rows 162 / 163 = (inf, 0, 0, 0) / zeros
+            if (tid < 64) {
+                const float n0 = nyqv[m], n1 = nyqv[32 + m], n2 = nyqv[64 + m];
+                const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                RX[ROW_NYQ * QS + hq] = h == 0 ? f32x4{n0, (n0 + n2) + n1, (n0 + n2) - n1, fmaf(4.f, n2, fmaf(2.f, n1, n0))} : z4;
+                RX[(ROW_NYQ + 2) * QS + hq] = h == 0 ? f32x4{n2, 0.f, 0.f, 0.f} : z4;
+            }
         }
         STAMP(3);
         __syncthreads();   // (2) magnitudes complete
         STAMP(4);
 
-        // ---- enc0: 129 -> 128 ch, k3 s1 p1, 3 -> 3 columns; wave w: channels 32w.. ---------
+        // ---- enc0: 129 -> 128 ch, k3 s1 p1, 3 -> 3 columns; wave w: channels 32w..  Toom-3: five point-wise
+        //      contractions over the 129 channels instead of seven (tap, column) ones, then the interpolation ---------
         f32x4 e1b0, e1b1, e1b2, e1b3, E1w0, E1w1, E1w2, E1w3;
         {
             const int ws = ws_e0 + 4;
-            f32x16 acc[3];
-            acc[0] = acc_of(e0b0, e0b1, e0b2, e0b3);
-            acc[1] = acc[0];
-            acc[2] = acc[0];
-            f32x4 Aw0 = E0w0, Aw1 = E0w1, Aw2 = E0w2, Bw0, Bw1, Bw2;
-            f32x4 Aa0 = RX[0 * QS + hq], Aa1 = RX[32 * QS + hq], Aa2 = RX[64 * QS + hq], Ba0, Ba1, Ba2;
+            f32x16 acc[5];
+#pragma unroll
+            for (int p = 0; p < 5; ++p) acc[p] = (f32x16)(0.f);
+            f32x4 Aw[5], Bw[5], Aa[5], Ba[5];
+#pragma unroll
+            for (int p = 0; p < 5; ++p) { Aw[p] = E0w[p]; Aa[p] = RX[(32 * p) * QS + hq]; }
 #define E0_LD(S, jj)                                                                       \
-    S##w0 = WL(ws + (3 * (jj))); S##w1 = WL(ws + (3 * (jj) + 1)); S##w2 = WL(ws + (3 * (jj) + 2)); \
-    S##a0 = RX[(2 * (jj)) * QS + hq]; S##a1 = RX[(32 + 2 * (jj)) * QS + hq]; S##a2 = RX[(64 + 2 * (jj)) * QS + hq];
-            // out[c] += W[tap] * in[c + tap - 1]
-#define E0_MMA(S)                                                                          \
-    acc[0] = mfma4(S##w1, S##a0, acc[0]); acc[1] = mfma4(S##w0, S##a0, acc[1]); acc[2] = mfma4(S##w0, S##a1, acc[2]); \
-    acc[0] = mfma4(S##w2, S##a1, acc[0]); acc[1] = mfma4(S##w1, S##a1, acc[1]); acc[2] = mfma4(S##w1, S##a2, acc[2]); \
-    acc[1] = mfma4(S##w2, S##a2, acc[1]);
+    _Pragma("unroll") for (int p = 0; p < 5; ++p) {                                        \
+        S##w[p] = WL(ws + 5 * (jj) + p);                                                   \
+        S##a[p] = RX[(32 * p + 2 * (jj)) * QS + hq];                                       \
+    }
+#define E0_MMA(S) _Pragma("unroll") for (int p = 0; p < 5; ++p) acc[p] = mfma4(S##w[p], S##a[p], acc[p]);
             for (int j = 0; j < 16; j += 2) {
                 E0_LD(B, j + 1) SB();
                 E0_MMA(A) SB();
@@ -357,16 +377,30 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
 #undef E0_LD
 #undef E0_MMA
             STAMP(17);
-            {   // input channel 128 (Nyquist bin): one k-iteration against per-column weight blocks
-                const f32x4 an = RX[96 * QS + hq];
-                const f32x4 wn0 = WL(ws + 48), wn1 = WL(ws + 49), wn2 = WL(ws + 50);
+            {   // input channel 128 (Nyquist bin): one MFMA per point (K = 2 with the upper half-wave at zero)
+                const f32x4 an = RX[ROW_NYQ * QS + hq], bn = RX[(ROW_NYQ + 2) * QS + hq];
+                const f32x4 wna = WL(ws + 80), wnb = WL(ws + 81);
                 // enc1's bias and first group of weights
                 e1b0 = WL(ws_e1); e1b1 = WL(ws_e1 + 1); e1b2 = WL(ws_e1 + 2); e1b3 = WL(ws_e1 + 3);
                 E1w0 = WL(ws_e1 + 4); E1w1 = WL(ws_e1 + 5); E1w2 = WL(ws_e1 + 6); E1w3 = WL(ws_e1 + 7);
                 SB();
-                acc[0] = mfma4(wn0, an, acc[0]);
-                acc[1] = mfma4(wn1, an, acc[1]);
-                acc[2] = mfma4(wn2, an, acc[2]);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wna.x, an.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wna.y, an.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wna.z, an.z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wna.w, an.w, acc[3], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(wnb.x, bn.x, acc[4], 0, 0, 0);
+            }
+            // interpolation (P(1), P(-1) arrive halved: the 1/2 sits in the weights) + bias
+            {
+                const f32x16 bias = acc_of(e0b0, e0b1, e0b2, e0b3);
+                const f32x16 y0 = acc[0], y4 = acc[4];
+                const f32x16 bb = acc[1] - acc[2];
+                const f32x16 y2 = (acc[1] + acc[2]) - y0 - y4;
+                const f32x16 t2 = (acc[3] - y0) - 4.0f * y2 - 16.0f * y4;          // = 2 (y1 + 4 y3)
+                const f32x16 y3 = t2 * (1.0f / 6.0f) - bb * (1.0f / 3.0f);
+                acc[0] = (bb - y3) + bias;
+                acc[1] = y2 + bias;
+                acc[2] = y3 + bias;
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) store_tile_relu(RE, c * 32 + 8 * w, m, h, acc[c]);

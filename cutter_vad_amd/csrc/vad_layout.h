@@ -46,7 +46,7 @@ namespace v5 {
 // weight-stream sections, in blocks, per wave
 constexpr int STFT_BLOCKS = 16;            // 8 k-iterations x {cos, -sin}
 constexpr int NYQ_BLOCKS = 1;              // shared table: floats 0..255 = w[n] (the Hann window of the stored basis)
-constexpr int ENC0_BLOCKS = 4 + 16 * 3 + 3;  // bias, 16 k-iterations x 3 taps, Nyquist channel x 3 t_out
+constexpr int ENC0_BLOCKS = 4 + 16 * 5 + 2;  // bias, 16 k-iterations x 5 Toom-3 points, Nyquist channel (points 0,1,-1,2 | inf)
 constexpr int ENC1_BLOCKS = 4 + 2 * 16;
 constexpr int ENC2_BLOCKS = 4 + 2 * 8;     // waves 0,1 only
 constexpr int ENC3_BLOCKS = 4 + 8;
@@ -58,11 +58,19 @@ __host__ __device__ constexpr int bin_of_channel(int ch) {
 
 // LDS, in quad rows.  One activation region X, reused by every layer:
 //   loader : column c: pe -> rows 64c + q, po -> 64c + 16 + q, qe -> 64c + 32 + q, qo -> 64c + 48 + q   (q = 0..15, n = 4q..4q+3)
-//   |STFT| : rows 32c + ch/4 (c = 0..2), row 96 = (|X128| of columns 0,1,2, 0), row 97 = 0
-//   enc0   : rows 98 + 32c + ch/4          enc1 : rows 16c + ch/4
-//   enc2   : rows 98 + ch/4                enc3 : rows ch/4 (LSTM input)
-constexpr int ROWS_X = 194;
-constexpr int ROW_E = 98;                  // first row of the upper half (enc0 / enc2 outputs)
+//   |STFT| : the three columns x0, x1, x2 of a channel enter enc0 as the Toom-3 evaluations of x0 + x1 z + x2 z^2 at
+//            z = 0, 1, -1, 2, inf: rows 32p + ch/4 (p = 0..4); rows 160/161 = (the same for |X128|, points 0,1,-1,2) / 0,
+//            rows 162/163 = (|X128| at inf, 0, 0, 0) / 0
+//   enc0   : rows 164 + 32c + ch/4         enc1 : rows 16c + ch/4
+//   enc2   : rows 164 + ch/4 (two K halves) enc3 : rows ch/4 (LSTM input)
+// enc0 as a Toom-3 product: out(c) = sum_tap w[tap] x[c + tap - 1] are the coefficients y1, y2, y3 of
+// (w2 + w1 z + w0 z^2)(x0 + x1 z + x2 z^2); five point-wise products (one MFMA contraction over the channels each)
+// replace the seven (tap, column) contractions: y0 = P(0), y4 = P(inf), y2 = (P(1) + P(-1))/2 - y0 - y4,
+// b = (P(1) - P(-1))/2, y3 = ((P(2) - y0 - 4 y2 - 16 y4)/2 - b)/3, y1 = b - y3.  fp32 error 1.5-2.5 x that of the direct
+// sums on real spectra (tools note in DESIGN.md), 28 % fewer MFMAs in the kernel's largest phase.
+constexpr int ROWS_X = 260;
+constexpr int ROW_E = 164;                 // first row of the upper part (enc0 / enc2 outputs)
+constexpr int ROW_NYQ = 160;
 constexpr int ROWS_H = 32;                 // h_{t-1}
 constexpr int LDS_F4 = (ROWS_X + ROWS_H) * QS + 32 + 24 + 72 + 16 + 192;  // + head partials [4][32], |X128| [3][32], fold corrections [3][3][32], write sink [64], state machines [32] x 96 B
 constexpr int LDS_BYTES = LDS_F4 * 16;

@@ -67,9 +67,9 @@ def v5_step(W, sect, x, hc, gate=0.01):
     x = x.astype(np.float64)
     if gate is not None and gate >= 0:
         x = np.where(np.abs(x) > gate, x, 0.0)
-    RX = np.zeros((194, 32, 4))
+    RX = np.zeros((260, 32, 4))
     RH = np.zeros((32, 32, 4))
-    RE = RX[98:]
+    RE = RX[164:]
     # loader: window + 4-way fold of every column (vad_layout.h, v5): rows 64c + {0,16,32,48} + q hold pe, po, qe, qo
     wtab = W[sect[0][S_NYQ]].reshape(-1)[:256].astype(np.float64)         # w[n], the k = 0 row of the stored basis
     fcor = np.zeros((3, 3, 32))
@@ -113,28 +113,37 @@ def v5_step(W, sect, x, hc, gate=0.01):
             else:
                 re, im = are[c] - y128, aim[c] - sgn * b64
             mags[w].append(np.sqrt(re ** 2 + im ** 2))
+    # enc0 input: Toom-3 evaluations of m0 + m1 z + m2 z^2 at z = 0, 1, -1, 2, inf -> rows 32 p + ch/4
     for w in range(4):
-        for c in range(3):
-            _store_tile(RX, c * 32 + 8 * w, mags[w][c], relu=False)
-    RX[96] = np.concatenate([nyq.T, np.zeros((32, 1))], axis=1)
-    RX[97] = 0
-    # enc0
+        m0, m1, m2 = mags[w]
+        for p, v in enumerate((m0, (m0 + m2) + m1, (m0 + m2) - m1, m0 + 2 * m1 + 4 * m2, m2)):
+            _store_tile(RX, 32 * p + 8 * w, v, relu=False)
+    n0, n1, n2 = nyq
+    RX[160] = np.stack([n0, (n0 + n2) + n1, (n0 + n2) - n1, n0 + 2 * n1 + 4 * n2], axis=1)
+    RX[162] = np.stack([n2, np.zeros(32), np.zeros(32), np.zeros(32)], axis=1)
+    RX[161] = 0
+    RX[163] = 0
+    # enc0: five point-wise contractions, then the interpolation (vad_layout.h)
     E0 = {}
     for w in range(4):
         ws = sect[w][S_ENC0]
-        bias = _vec(W[ws:ws + 4])
-        acc = [np.repeat(bias[:, None], 32, 1) for _ in range(3)]
+        bias = np.repeat(_vec(W[ws:ws + 4])[:, None], 32, 1)
+        P = [np.zeros((32, 32)) for _ in range(5)]
         ws += 4
         for j in range(16):
-            wt = [W[ws + 3 * j + t] for t in range(3)]
-            a = [_rows(RX, 32 * c + 2 * j, 32 * c + 2 * j + 1) for c in range(3)]
-            acc[0] += _mfma4(wt[1], a[0]) + _mfma4(wt[2], a[1])
-            acc[1] += _mfma4(wt[0], a[0]) + _mfma4(wt[1], a[1]) + _mfma4(wt[2], a[2])
-            acc[2] += _mfma4(wt[0], a[1]) + _mfma4(wt[1], a[2])
-        an = _rows(RX, 96, 97)
-        for c in range(3):
-            acc[c] += _mfma4(W[ws + 48 + c], an)
-        E0[w] = acc
+            for p in range(5):
+                P[p] += _mfma4(W[ws + 5 * j + p], _rows(RX, 32 * p + 2 * j, 32 * p + 2 * j + 1))
+        an, bn = _rows(RX, 160, 161), _rows(RX, 162, 163)
+        wa, wb = W[ws + 80].astype(np.float64).reshape(2, 32, 4), W[ws + 81].astype(np.float64).reshape(2, 32, 4)
+        for p in range(4):     # one K = 2 MFMA per point: component p of block A against component p of the activation quad
+            P[p] += np.einsum("hn,hm->nm", wa[:, :, p], an.reshape(2, 32, 4)[:, :, p])
+        P[4] += np.einsum("hn,hm->nm", wb[:, :, 0], bn.reshape(2, 32, 4)[:, :, 0])
+        y0, y4 = P[0], P[4]
+        bb = P[1] - P[2]
+        y2 = (P[1] + P[2]) - y0 - y4
+        t2 = (P[3] - y0) - 4 * y2 - 16 * y4
+        y3 = t2 / 6 - bb / 3
+        E0[w] = [(bb - y3) + bias, y2 + bias, y3 + bias]
     for w in range(4):
         for c in range(3):
             _store_tile(RE, c * 32 + 8 * w, E0[w][c])
