@@ -213,11 +213,14 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
         gi = mfma4(WS[0], av0, gi); gfo = mfma4(WS[1], av0, gfo); gg = mfma4(WS[2], av0, gg); go = mfma4(WS[3], av0, go); \
         gi = mfma4(WS[4], av1, gi); gfo = mfma4(WS[5], av1, gfo); gg = mfma4(WS[6], av1, gg); go = mfma4(WS[7], av1, go); \
     }
-            // 32 x { 1 MFMA, up to NV VALU } in program order for the group that ends here
+            // program order of the group that ends here: 4 x { 8 MFMA, up to 40 VALU }.  The fold's VALU work does not hide
+            // under the MFMAs (same pipe) - the interleave only lets its LDS writes and the next requests overlap them -
+            // and every MFMA <-> VALU alternation costs ~14 cycles (tools/ubench/mfma_valu.hip), so the pieces are coarse:
+            // measured 50.0 us vs 50.4 (1 : 6 interleave) vs 50.2 (no interleave)
 #define H_MIX(NV)                                                                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < 32; ++i_) {                                                         \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                      \
-        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x002, 40, 0);                                                     \
     }
             f32x4 wA[8], wB[8];                            // W_hh blocks of a group of 2 k-iterations, ping-pong
             f32x4 nb[16];                                  // gate biases = the accumulators' initial values
