@@ -189,8 +189,18 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
             if (part == 0) nyqv[cp * 32 + ms] = fabsf(a + fcor[(cp * 3 + 0) * 32 + ms] + fcor[(cp * 3 + 1) * 32 + ms]);
         }
         // ---- MFMA: wave w = bins bin_of_channel(32 w + r): cos on pe | po, -sin on qe | qo (even | odd bins), two columns, K = 64
+        // the accumulators start from the rank-1 terms of n = 0, 64, 128 (register 4g+i holds tile row r = 8g+4h+i: (-1)^r = (-1)^i)
+        //   even bins: re += y128 + a64 (-1)^r ; odd bins: re -= y128, im -= b64 (-1)^r
         f32x16 are[2], aim[2];
-        are[0] = are[1] = aim[0] = aim[1] = (f32x16)(0.f);
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            const float y128 = fcor[(cp * 3 + 0) * 32 + m], a64 = fcor[(cp * 3 + 1) * 32 + m], b64 = fcor[(cp * 3 + 2) * 32 + m];
+            const float rp = w < 2 ? y128 + a64 : -y128, rm = w < 2 ? y128 - a64 : -y128;
+            const float ip = w < 2 ? 0.f : -b64, im_ = w < 2 ? 0.f : b64;
+            const f32x4 qr = f32x4{rp, rm, rp, rm}, qi = f32x4{ip, im_, ip, im_};
+            are[cp] = acc_of(qr, qr, qr, qr);
+            aim[cp] = acc_of(qi, qi, qi, qi);
+        }
         {
             const int rR = w < 2 ? 0 : 16, rI = w < 2 ? 32 : 48;
             const f32x4 *const XR = UV + rR * QS + hq, *const XI = UV + rI * QS + hq;
@@ -214,20 +224,15 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
 #undef K1_MMA
         }
         if (grp == 0) STAMP(4);
-        // ---- rank-1 terms, magnitudes -> global scratch, row (33 t + quad), 32 float4 per row.
-        //      Register 4g+i holds tile row r = 8g + 4h + i: (-1)^r = (-1)^i
+        // ---- magnitudes -> global scratch, row (33 t + quad), 32 float4 per row
 #pragma unroll
         for (int cp = 0; cp < 2; ++cp) {
             const int tcol = 2 * grp + cp;
-            const float y128 = fcor[(cp * 3 + 0) * 32 + m], a64 = fcor[(cp * 3 + 1) * 32 + m], b64 = fcor[(cp * 3 + 2) * 32 + m];
-            // even bins: re += y128 + a64 (-1)^r ; odd bins: re -= y128, im -= b64 (-1)^r
-            const float rp = w < 2 ? y128 + a64 : -y128, rm = w < 2 ? y128 - a64 : -y128;
-            const float ip = w < 2 ? 0.f : -b64, im_ = w < 2 ? 0.f : b64;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 r = quad_of(are[cp], g), i = quad_of(aim[cp], g);
                 scratch[(size_t)(MAG_Q * tcol + 8 * w + 2 * g + h) * 32 + m] =
-                    f32x4{mag_(r.x + rp, i.x + ip), mag_(r.y + rm, i.y + im_), mag_(r.z + rp, i.z + ip), mag_(r.w + rm, i.w + im_)};
+                    f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
             }
         }
         if (grp == 0) STAMP(5);

@@ -278,11 +278,18 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
         // enc0's bias and first weights ride along (requested at the end of this phase)
         f32x4 e0b0, e0b1, e0b2, e0b3, E0w[5];
         {
+            // The accumulators START from the rank-1 terms of n = 0, 64, 128 (the samples the fold cannot pair), so the
+            // epilogue only takes magnitudes.  Register 4g+i holds tile row r = 8g+4h+i: (-1)^r = (-1)^i.
+            //   even bins: re += y128 + a64 (-1)^r ; odd bins: re -= y128, im -= b64 (-1)^r
             f32x16 are[3], aim[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                are[c] = (f32x16)(0.f);
-                aim[c] = (f32x16)(0.f);
+                const float y128 = fcor[(c * 3 + 0) * 32 + m], a64 = fcor[(c * 3 + 1) * 32 + m], b64 = fcor[(c * 3 + 2) * 32 + m];
+                const float rp = w < 2 ? y128 + a64 : -y128, rm = w < 2 ? y128 - a64 : -y128;
+                const float ip = w < 2 ? 0.f : -b64, im_ = w < 2 ? 0.f : b64;
+                const f32x4 qr = f32x4{rp, rm, rp, rm}, qi = f32x4{ip, im_, ip, im_};
+                are[c] = acc_of(qr, qr, qr, qr);
+                aim[c] = acc_of(qi, qi, qi, qi);
             }
             const int rR = w < 2 ? 0 : 16, rI = w < 2 ? 32 : 48;     // even bins read pe / qe, odd bins po / qo
             const f32x4 *const XR = RX + rR * QS + hq, *const XI = RX + rI * QS + hq;
@@ -312,25 +319,16 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             SB();
             STAMP(16);
             __syncthreads();   // (1b) every wave is done reading u/v: the magnitudes may overwrite them
-            // rank-1 terms, then magnitudes.  Register 4g+i holds row r = 8g+4h+i: (-1)^r = (-1)^i.  The three columns
+            // magnitudes.  The three columns
             // m0, m1, m2 of a bin go to enc0 as the Toom-3 evaluations of m0 + m1 z + m2 z^2 (vad_layout.h):
             // rows 32p + 8w + 2g + h, p = 0..4 for z = 0, 1, -1, 2, inf
-            float rp[3], rm[3], ip[3], im_[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float y128 = fcor[(c * 3 + 0) * 32 + m], a64 = fcor[(c * 3 + 1) * 32 + m], b64 = fcor[(c * 3 + 2) * 32 + m];
-                // even bins: re += y128 + a64 (-1)^r ; odd bins: re -= y128, im -= b64 (-1)^r
-                rp[c] = w < 2 ? y128 + a64 : -y128; rm[c] = w < 2 ? y128 - a64 : -y128;
-                ip[c] = w < 2 ? 0.f : -b64; im_[c] = w < 2 ? 0.f : b64;
-            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 mg[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const f32x4 r = quad_of(are[c], g), i = quad_of(aim[c], g);
-                    mg[c] = f32x4{mag_(r.x + rp[c], i.x + ip[c]), mag_(r.y + rm[c], i.y + im_[c]),
-                                  mag_(r.z + rp[c], i.z + ip[c]), mag_(r.w + rm[c], i.w + im_[c])};
+                    mg[c] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
                 }
                 const f32x4 s02 = f32x4{mg[0].x + mg[2].x, mg[0].y + mg[2].y, mg[0].z + mg[2].z, mg[0].w + mg[2].w};
                 f32x4 *o = RX + (8 * w + 2 * g) * QS + hq;
