@@ -7,5 +7,5 @@ while [ $# -gt 0 ] && [ "$1" != "--" ]; do FLAGS+=("$1"); shift; done
 OUT=${KBENCH_OUT:-/tmp/kbench4_$$}
 BLOB=cutter_vad_amd/weights/silero_v4_16k.svw
 [ "$3" == "8k" ] && BLOB=cutter_vad_amd/weights/silero_v4_8k.svw
-hipcc --offload-arch=gfx950 -O3 -std=c++17 "${FLAGS[@]}" -o "$OUT" tools/kbench4.cpp cutter_vad_amd/csrc/silero_v4.hip cutter_vad_amd/csrc/pack_weights.cpp 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form "${FLAGS[@]}" -o "$OUT" tools/kbench4.cpp cutter_vad_amd/csrc/silero_v4.hip cutter_vad_amd/csrc/pack_weights.cpp 2>/dev/null
 "$OUT" $BLOB "$1" "$2"
