@@ -165,8 +165,14 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             };
             // reversed reads come from the other lanes of the row: row_mirror hands lane q the value of lane 15 - q
             // (quad 31 - q of B, 63 - q of D); one more row_shr:1 gives quad 32 - q / 64 - q (lane 0 keeps `edge`)
-            auto mirror = [](float v) -> float {
-                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+            auto mirror = [](float v) -> float {      // every lane of a row has a source: no `old` value to materialise
+                return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+            };
+            auto st2 = [](f32x4 *dst, f32x4 v) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 *d = reinterpret_cast<f32x2 *>(dst);
+                d[0] = f32x2{v.x, v.y};
+                d[1] = f32x2{v.z, v.w};
             };
             auto shr1 = [](float edge, float v) -> float {
                 return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
@@ -201,10 +207,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             fcor[fo + (q0 ? 32 : 0)] = y64 + y192;  /* a64 */                                                    \
             fcor[fo + (q0 ? 64 : 0)] = y64 - y192;  /* b64 */                                                    \
         }                                                                                                       \
-        RX[(64 * (c) + q) * QS + ms] = pe;                                                                      \
-        RX[(64 * (c) + 16 + q) * QS + ms] = po;                                                                 \
-        RX[(64 * (c) + 32 + q) * QS + ms] = qe;                                                                 \
-        RX[(64 * (c) + 48 + q) * QS + ms] = qo;                                                                 \
+        /* stored as two 8-byte halves each: the sums come out of the packed adds as register PAIRS, a 16-byte store      \
+           would first copy them into four consecutive registers */                                            \
+        st2(&RX[(64 * (c) + q) * QS + ms], pe);                                                                 \
+        st2(&RX[(64 * (c) + 16 + q) * QS + ms], po);                                                            \
+        st2(&RX[(64 * (c) + 32 + q) * QS + ms], qe);                                                            \
+        st2(&RX[(64 * (c) + 48 + q) * QS + ms], qo);                                                            \
     }
 #define H_LDW(WS, g) _Pragma("unroll") for (int k = 0; k < 8; ++k) WS[k] = WL(wh + 8 * (g) + k);
 #define H_MMA(WS, g)                                                                                            \
