@@ -168,12 +168,6 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             auto mirror = [](float v) -> float {      // every lane of a row has a source: no `old` value to materialise
                 return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
             };
-            auto st2 = [](f32x4 *dst, f32x4 v) {
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                f32x2 *d = reinterpret_cast<f32x2 *>(dst);
-                d[0] = f32x2{v.x, v.y};
-                d[1] = f32x2{v.z, v.w};
-            };
             auto shr1 = [](float edge, float v) -> float {
                 return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
             };
@@ -340,12 +334,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
                 }
                 const f32x4 s02 = f32x4{mg[0].x + mg[2].x, mg[0].y + mg[2].y, mg[0].z + mg[2].z, mg[0].w + mg[2].w};
                 f32x4 *o = RX + (8 * w + 2 * g) * QS + hq;
-                o[0] = mg[0];
-                o[32 * QS] = f32x4{s02.x + mg[1].x, s02.y + mg[1].y, s02.z + mg[1].z, s02.w + mg[1].w};
-                o[64 * QS] = f32x4{s02.x - mg[1].x, s02.y - mg[1].y, s02.z - mg[1].z, s02.w - mg[1].w};
-                o[96 * QS] = f32x4{fmaf(4.f, mg[2].x, fmaf(2.f, mg[1].x, mg[0].x)), fmaf(4.f, mg[2].y, fmaf(2.f, mg[1].y, mg[0].y)),
-                                   fmaf(4.f, mg[2].z, fmaf(2.f, mg[1].z, mg[0].z)), fmaf(4.f, mg[2].w, fmaf(2.f, mg[1].w, mg[0].w))};
-                o[128 * QS] = mg[2];
+                st2(o, mg[0]);
+                st2(o + 32 * QS, f32x4{s02.x + mg[1].x, s02.y + mg[1].y, s02.z + mg[1].z, s02.w + mg[1].w});
+                st2(o + 64 * QS, f32x4{s02.x - mg[1].x, s02.y - mg[1].y, s02.z - mg[1].z, s02.w - mg[1].w});
+                st2(o + 96 * QS, f32x4{fmaf(4.f, mg[2].x, fmaf(2.f, mg[1].x, mg[0].x)), fmaf(4.f, mg[2].y, fmaf(2.f, mg[1].y, mg[0].y)),
+                                       fmaf(4.f, mg[2].z, fmaf(2.f, mg[1].z, mg[0].z)), fmaf(4.f, mg[2].w, fmaf(2.f, mg[1].w, mg[0].w))});
+                st2(o + 128 * QS, mg[2]);
             }
             // |X128|: rows 160 / 161 = (points 0, 1, -1, 2) / zeros, rows 162 / 163 = (inf, 0, 0, 0) / zeros
             if (tid < 64) {

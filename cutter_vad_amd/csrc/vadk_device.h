@@ -29,6 +29,15 @@ __device__ __forceinline__ f32x16 acc_from(const f32x4 *ws) {
     return a;
 }
 
+// A quad stored as two 8-byte halves: values that come out of packed (pair) arithmetic or of scalar ops need not be copied
+// into four consecutive registers first (the compiler merges the two halves into one ds_write2_b64)
+__device__ __forceinline__ void st2(f32x4 *dst, f32x4 v) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 *d = reinterpret_cast<f32x2 *>(dst);
+    d[0] = f32x2{v.x, v.y};
+    d[1] = f32x2{v.z, v.w};
+}
+
 // ReLU as ONE v_med3_f32 (median of v, 0, +inf): fmaxf() costs two v_max_f32 each, the first only to quiet signalling NaNs
 __device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)}; }
@@ -56,7 +65,9 @@ __device__ __forceinline__ float sigmoidf_(float v) {
 __device__ __forceinline__ float tanhf_(float v) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * v));
 }
-__device__ __forceinline__ float mag_(float re, float im) { return __builtin_amdgcn_sqrtf(re * re + im * im); }
+// one v_mul + one v_fma (written as an explicit fma: left as re*re + im*im the vectoriser pairs the two products into a
+// v_pk_mul_f32 and pays three register copies per magnitude to line the operands up)
+__device__ __forceinline__ float mag_(float re, float im) { return __builtin_amdgcn_sqrtf(__builtin_fmaf(re, re, im * im)); }
 
 __device__ __forceinline__ f32x16 acc_of(f32x4 b0, f32x4 b1, f32x4 b2, f32x4 b3) {
     f32x16 a;
