@@ -163,10 +163,10 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
                     fcor[(cp * 3 + 1) * 32 + ms] = y64 + y192;     // a64
                     fcor[(cp * 3 + 2) * 32 + ms] = y64 - y192;     // b64
                 }
-                UV[(64 * cp + fq) * QS + ms] = pe;
-                UV[(64 * cp + 16 + fq) * QS + ms] = po;
-                UV[(64 * cp + 32 + fq) * QS + ms] = qe;
-                UV[(64 * cp + 48 + fq) * QS + ms] = qo;
+                st2(&UV[(64 * cp + fq) * QS + ms], pe);
+                st2(&UV[(64 * cp + 16 + fq) * QS + ms], po);
+                st2(&UV[(64 * cp + 32 + fq) * QS + ms], qe);
+                st2(&UV[(64 * cp + 48 + fq) * QS + ms], qo);
             }
         }
         f32x4 Are = ldw(wrs, lane16, ws), Aim = ldw(wrs, lane16, ws + 1);
