@@ -95,6 +95,8 @@ SIGNATURES = {
     "vad_step_multi": (C.c_int, [_vp, _i64p, C.c_int64, C.c_int32, _vp, C.c_int, C.c_float, _f32p, _u8p]),
     "vad_step_device": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, C.c_float, _vp, _vp, _vp, _vp]),
     "vad_resample": (C.c_int, [_vp, _f32p, C.c_int64, C.c_int32, C.c_int32, _f32p]),
+    "vad_resample_multi_device": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_void_p), _i64p, C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_void_p), _vp]),
     "vad_resample_device": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_int32, _vp, _vp]),
     "vad_debug_pack_weights": (C.c_int, [C.c_int32, _vp, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_uint32)]),

@@ -550,7 +550,8 @@ int get_resample_op(vad_engine *e, int n_in, vad_engine::ResampleOp **out) {
     return VAD_OK;
 }
 
-int resample_launch(vad_engine *e, const float *d_in, int64_t n, int32_t n_in, int32_t sr_in, float *d_out, hipStream_t s) {
+// fills one segment descriptor (validates the chunk convention, builds / finds the operator)
+int resample_segment(vad_engine *e, const float *d_in, int64_t n, int32_t n_in, int32_t sr_in, float *d_out, vadk::ResampleSeg &sg) {
     const int want = resample_chunk_len(sr_in);
     if (want == 0)
         return e->fail(VAD_ERR_UNSUPPORTED, "Failed to resample audio from %dHz to 16000Hz: supported input rates are 8000, 24000, 48000", sr_in);
@@ -558,14 +559,22 @@ int resample_launch(vad_engine *e, const float *d_in, int64_t n, int32_t n_in, i
         return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio from %dHz to 16000Hz: a chunk must hold %d samples, got %d", sr_in, want, n_in);
     vad_engine::ResampleOp *op = nullptr;
     if (int rc = get_resample_op(e, n_in, &op)) return rc;
+    sg.wstream = op->d_w;
+    sg.wstream_bytes = (uint32_t)op->bytes;
+    sg.wave_blocks = op->wave_blocks;
+    sg.in = d_in;
+    sg.out = d_out;
+    sg.n = (int32_t)n;
+    sg.n_in = n_in;
+    return VAD_OK;
+}
+
+int resample_launch(vad_engine *e, const float *d_in, int64_t n, int32_t n_in, int32_t sr_in, float *d_out, hipStream_t s) {
     vadk::ResampleParams p{};
-    p.wstream = op->d_w;
-    p.wstream_bytes = (uint32_t)op->bytes;
-    p.wave_blocks = op->wave_blocks;
-    p.in = d_in;
-    p.out = d_out;
-    p.n = (int32_t)n;
-    p.n_in = n_in;
+    if (int rc = resample_segment(e, d_in, n, n_in, sr_in, d_out, p.seg[0])) return rc;
+    p.nseg = 1;
+    p.tile_start[0] = 0;
+    p.tile_start[1] = (int32_t)((n + vadk::MT - 1) / vadk::MT);
     hipError_t r = vadk_launch_resample(&p, s);
     if (r != hipSuccess) return e->hip_fail(r, "resample kernel launch");
     return VAD_OK;
@@ -599,6 +608,29 @@ int vad_resample_device(vad_engine *e, const float *d_in, int64_t n, int32_t n_i
     if (n == 0) return VAD_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     return resample_launch(e, d_in, n, n_in, sr_in, d_out, stream ? static_cast<hipStream_t>(stream) : e->stream);
+}
+
+int vad_resample_multi_device(vad_engine *e, int32_t nseg, const float *const *d_in, const int64_t *n, const int32_t *n_in,
+                              const int32_t *sr_in, float *const *d_out, void *stream) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (nseg < 1 || nseg > vadk::RESAMPLE_MAX_SEGS || !d_in || !n || !n_in || !sr_in || !d_out)
+        return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio: 1..%d segments, non-null tables", vadk::RESAMPLE_MAX_SEGS);
+    HIP_TRY(e, hipSetDevice(e->device));
+    vadk::ResampleParams p{};
+    int32_t tiles = 0;
+    for (int k = 0; k < nseg; ++k) {
+        if (n[k] < 0 || (n[k] > 0 && (!d_in[k] || !d_out[k])))
+            return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio: null buffer or bad count in segment %d", k);
+        if (int rc = resample_segment(e, d_in[k], n[k], n_in[k], sr_in[k], d_out[k], p.seg[k])) return rc;
+        p.tile_start[k] = tiles;
+        tiles += (int32_t)((n[k] + vadk::MT - 1) / vadk::MT);
+    }
+    p.nseg = nseg;
+    p.tile_start[nseg] = tiles;
+    hipError_t r = vadk_launch_resample(&p, stream ? static_cast<hipStream_t>(stream) : e->stream);
+    if (r != hipSuccess) return e->hip_fail(r, "resample kernel launch");
+    return VAD_OK;
 }
 
 int vad_debug_resample_operator(int32_t n_in, float *R, size_t r_floats) {

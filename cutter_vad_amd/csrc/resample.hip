@@ -51,15 +51,22 @@ __device__ __forceinline__ f32x4 quad_of(const f32x16 &a, int g) {
 // (blockIdx.y) share a chunk tile, 256 outputs each - used when the call has too few chunk tiles to fill the 256 CUs
 // (the input is read twice, from L2, which costs less than idle CUs).
 template <int NT>
-__global__ void __launch_bounds__(NTHREADS, 1) vadk_resample_512(const vadk::ResampleParams P) {
+__global__ void __launch_bounds__(NTHREADS, 1) vadk_resample_512(const vadk::ResampleParams PP) {
     constexpr int CH_ROWS = 64;                       // one chunk = 256 samples = 64 quad rows
+    // which segment does this workgroup serve?  (block-uniform: scalar compares on kernel arguments)
+    int sidx = 0;
+#pragma unroll
+    for (int k = 1; k < RESAMPLE_MAX_SEGS; ++k)
+        if (k < PP.nseg && (int)blockIdx.x >= PP.tile_start[k]) sidx = k;
+    const vadk::ResampleSeg P = PP.seg[sidx];
+    const int tile_in_seg = (int)blockIdx.x - PP.tile_start[sidx];
     __shared__ f32x4 lds[2 * CH_ROWS * QS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31, h = lane >> 5;
     const int hq = h * QS + m;
-    const int tile0 = blockIdx.x * MT;
+    const int tile0 = tile_in_seg * MT;
     const int nchunks = P.n_in >> 8;
     const int quads_per_stream = P.n_in >> 2;
     const __amdgpu_buffer_rsrc_t wrs =
@@ -132,9 +139,11 @@ __global__ void __launch_bounds__(NTHREADS, 1) vadk_resample_512(const vadk::Res
 }
 
 extern "C" hipError_t vadk_launch_resample(const vadk::ResampleParams *p, hipStream_t stream) {
-    const int tiles = (p->n + vadk::MT - 1) / vadk::MT;
+    const int tiles = p->tile_start[p->nseg];
     if (tiles <= 0) return hipSuccess;
-    if (tiles <= 128)
+    // up to 256 chunk tiles: two workgroups per tile (finer grain also evens out mixed-rate launches, whose 48 kHz tiles run
+    // six times longer than their 8 kHz ones)
+    if (tiles <= 256)
         hipLaunchKernelGGL(vadk_resample_512<2>, dim3(tiles, 2), dim3(vadk::NTHREADS), 0, stream, *p);
     else
         hipLaunchKernelGGL(vadk_resample_512<4>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);

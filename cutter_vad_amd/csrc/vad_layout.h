@@ -147,7 +147,7 @@ struct StepParams {
 };
 
 // resampler launch parameters (csrc/resample.hip)
-struct ResampleParams {
+struct ResampleSeg {
     const float *wstream;     // packed operator R[512][n_in]: per wave, per 256-sample chunk, per k-iteration: 4 tile blocks
     uint32_t wstream_bytes;
     uint32_t wave_blocks;     // blocks per wave = (n_in / 8) * 4
@@ -155,6 +155,14 @@ struct ResampleParams {
     float *out;               // [n][512]
     int32_t n;
     int32_t n_in;             // multiple of 256
+};
+// one launch resamples up to 4 segments (e.g. the 8 / 24 / 48 kHz clients of a tick): workgroups
+// tile_start[s] .. tile_start[s+1]-1 serve segment s
+constexpr int RESAMPLE_MAX_SEGS = 4;
+struct ResampleParams {
+    ResampleSeg seg[RESAMPLE_MAX_SEGS];
+    int32_t nseg;
+    int32_t tile_start[RESAMPLE_MAX_SEGS + 1];
 };
 
 }  // namespace vadk

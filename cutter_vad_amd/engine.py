@@ -198,6 +198,16 @@ class Engine:
         self._check(self._lib.vad_step_device(self._h, d_slots or None, n, d_frames, fmt, thr, d_probs,
                                               d_events or None, d_seg or None, stream or None))
 
+    def resample_multi_device(self, segments, stream: int = 0) -> None:
+        """One launch for up to 4 segments ``(d_in, n, n_in, sr_in, d_out)`` of device pointers (integers)."""
+        k = len(segments)
+        d_in = (C.c_void_p * k)(*[int(s[0]) for s in segments])
+        n = (C.c_int64 * k)(*[int(s[1]) for s in segments])
+        n_in = (C.c_int32 * k)(*[int(s[2]) for s in segments])
+        sr = (C.c_int32 * k)(*[int(s[3]) for s in segments])
+        d_out = (C.c_void_p * k)(*[int(s[4]) for s in segments])
+        self._check(self._lib.vad_resample_multi_device(self._h, k, d_in, n, n_in, sr, d_out, stream or None))
+
     # ------------------------------------------------------------------ resampler (a11)
     def resample(self, chunks, sr_in: int) -> np.ndarray:
         """chunks [n, n_in] float32 at ``sr_in`` -> [n, 512] at 16 kHz (``vad_resample``)."""

@@ -190,6 +190,11 @@ VAD_API int vad_step_device(vad_engine *e, const int32_t *d_slots, int64_t n, co
 VAD_API int vad_resample(vad_engine *e, const float *in, int64_t n, int32_t n_in, int32_t sr_in, float *out);
 VAD_API int vad_resample_device(vad_engine *e, const float *d_in, int64_t n, int32_t n_in, int32_t sr_in, float *d_out,
                         void *stream);
+/* the same for up to 4 segments of different input rates in ONE launch (a tick's 8 / 24 / 48 kHz clients): segment k is
+ * d_in[k] [n[k]][n_in[k]] at sr_in[k] -> d_out[k] [n[k]][512]; the tables are host arrays, the buffers device pointers */
+#define VAD_RESAMPLE_MAX_SEGMENTS 4
+VAD_API int vad_resample_multi_device(vad_engine *e, int32_t nseg, const float *const *d_in, const int64_t *n,
+                                      const int32_t *n_in, const int32_t *sr_in, float *const *d_out, void *stream);
 
 /*
  * Diagnostic (no GPU needed): run the host-side weight packer and return the per-wave MFMA

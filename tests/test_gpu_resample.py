@@ -50,17 +50,37 @@ def test_oracle_agrees_and_linearity(engine):
 
 
 def test_both_launch_shapes_agree(engine):
-    """Calls of up to 128 chunk tiles split the 512 outputs over two workgroups per tile, larger calls use one: the two
+    """Calls of up to 256 chunk tiles split the 512 outputs over two workgroups per tile, larger calls use one: the two
     shapes must give bit-identical rows (same operator blocks, same order of accumulation)."""
     import scipy.signal
     for sr, n_in in ((8000, 256), (48000, 1536)):
-        x = (0.4 * np.random.default_rng(sr + 1).standard_normal((4200, n_in))).astype(np.float32)   # 132 tiles
+        x = (0.4 * np.random.default_rng(sr + 1).standard_normal((8300, n_in))).astype(np.float32)   # 260 tiles
         big = engine.resample(x, sr)
         small = engine.resample(x[:100], sr)                                                         # 4 tiles, split
         assert np.array_equal(big[:100], small)
-        pick = [0, 31, 32, 4127, 4199]
+        pick = [0, 31, 32, 4127, 8299]
         ref = np.stack([scipy.signal.resample(x[i], 512).astype(np.float32) for i in pick])
         assert np.abs(big[pick] - ref).max() <= TOL
+
+
+def test_mixed_rates_in_one_launch(engine):
+    """vad_resample_multi_device: the 8 / 24 / 48 kHz chunks of a tick in ONE launch == three single-rate calls, bit for bit."""
+    import torch
+    rng = np.random.default_rng(5)
+    xs = [(0.3 * rng.standard_normal((n, n_in))).astype(np.float32) for n, (_, n_in) in zip((70, 33, 201), RATES)]
+    ref = [engine.resample(x, sr) for x, (sr, _) in zip(xs, RATES)]
+    d_in = [torch.from_numpy(x).cuda() for x in xs]
+    d_out = [torch.full((x.shape[0], 512), float("nan"), device="cuda") for x in xs]
+    segs = [(a.data_ptr(), a.shape[0], a.shape[1], sr, o.data_ptr()) for a, o, (sr, _) in zip(d_in, d_out, RATES)]
+    engine.resample_multi_device(segs)
+    engine.synchronize()
+    for o, r in zip(d_out, ref):
+        assert np.array_equal(o.cpu().numpy(), r)
+    from cutter_vad_amd import AudioProcessingError
+    with pytest.raises(AudioProcessingError):
+        engine.resample_multi_device([(d_in[0].data_ptr(), 70, 256, 44100, d_out[0].data_ptr())])
+    with pytest.raises(AudioProcessingError):
+        engine.resample_multi_device(segs + segs)                      # more than 4 segments
 
 
 def test_audio_utils_resample_goes_through_the_engine(engine):
