@@ -206,9 +206,12 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
         g_create_error = "Failed to load model: model_version must be 4 or 5";
         return VAD_ERR_INVALID_ARG;
     }
-    if (desc->sample_rate != 16000) {
-        // the graphs' sr != 16000 branch cannot run on 512-sample frames
-        g_create_error = "Failed to load model: only the 16 kHz branch is implemented (resample first)";
+    // `sample_rate` is the graph's `sr` input (core/silero_model.py:491): 16000 selects the 16 kHz sub-model, every other
+    // value the graph's else-branch.  V5's else-branch cannot run on 512-sample frames; V4's is the 8 kHz
+    // sub-model and needs the blob that holds ITS weights (meta.variant = 8000).
+    const bool want_8k = desc->sample_rate != 16000;
+    if (want_8k && desc->model_version == 5) {
+        g_create_error = "Failed to load model: Silero V5 runs 512-sample frames only through its 16 kHz branch (resample first)";
         return VAD_ERR_UNSUPPORTED;
     }
     if (desc->max_streams < 1) {
@@ -221,6 +224,11 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
                                              : vadk::pack_silero_v4(desc->weights, desc->weights_len, pw, perr);
     if (!ok) {
         g_create_error = perr;
+        return VAD_ERR_BAD_WEIGHTS;
+    }
+    if (want_8k != (pw.variant == 1)) {
+        g_create_error = want_8k ? "Failed to load model: sample_rate selects Silero V4's 8 kHz sub-model but the weight blob holds the 16 kHz one"
+                                 : "Failed to load model: sample_rate 16000 but the weight blob holds Silero V4's 8 kHz sub-model";
         return VAD_ERR_BAD_WEIGHTS;
     }
     int ndev = 0;

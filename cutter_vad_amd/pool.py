@@ -66,7 +66,7 @@ class EnginePool:
                         msg = f"Model signature validation failed: {msg}"
                     raise ModelInitializationError(version.value, f"Failed to load model from {model_path}: {msg}")
                 eng = Engine(blob, model_version=_VERSION_INT[version], device_id=dev,
-                             max_streams=max_streams or default_max_streams())
+                             max_streams=max_streams or default_max_streams(), sample_rate=8000 if k8 else 16000)
                 self._engines[key] = eng
             return eng
 

@@ -54,7 +54,7 @@ typedef enum vad_status {
     VAD_ERR_HIP = -4,           /* a HIP runtime call failed -> AudioProcessingError("Model prediction failed: ...") :444-447 */
     VAD_ERR_NO_SLOT = -5,       /* stream pool exhausted */
     VAD_ERR_BAD_SLOT = -6,      /* slot not open / out of range / duplicated within one step */
-    VAD_ERR_UNSUPPORTED = -7    /* e.g. sample_rate != 16000 (the reference's 8 kHz graph branch) */
+    VAD_ERR_UNSUPPORTED = -7    /* e.g. Silero V5 with sample_rate != 16000 (its 8 kHz graph branch cannot take 512-sample frames) */
 } vad_status;
 
 typedef enum vad_frame_format {
@@ -76,7 +76,8 @@ typedef struct vad_engine_desc {
     size_t weights_len;
     int32_t device_id;          /* HIP device ordinal; one engine drives one GPU */
     int32_t max_streams;        /* capacity of the per-GPU stream pool (slots) */
-    int32_t sample_rate;        /* must be 16000 (core/silero_model.py:491) */
+    int32_t sample_rate;        /* the graph's `sr` input (core/silero_model.py:491): 16000, or - Silero V4 only, with the blob of its 8 kHz
+                                   sub-model - 8000 / 24000 / 48000 */
     uint32_t flags;             /* reserved, 0 */
 } vad_engine_desc;
 

@@ -151,7 +151,7 @@ def setup8k():
     from oracle import oracle
     with open(weights_io.packaged_blob_path(4, 8000), "rb") as f:
         blob = f.read()
-    e = Engine(blob, model_version=4, max_streams=512)
+    e = Engine(blob, model_version=4, max_streams=512, sample_rate=8000)
     yield e, oracle.OracleModel(blob, "f64")
     e.close()
 
@@ -177,6 +177,20 @@ def test_8k_submodel_matches_oracle(setup8k, n):
     finally:
         for s in slots:
             eng.close_stream(s)
+
+
+def test_engine_refuses_a_blob_of_the_other_branch(blob):
+    from cutter_vad_amd import ModelInitializationError
+    from cutter_vad_amd.engine import Engine
+    with open(weights_io.packaged_blob_path(4, 8000), "rb") as f:
+        blob8 = f.read()
+    for b, sr in ((blob, 8000), (blob8, 16000), (blob, 48000)):
+        with pytest.raises(ModelInitializationError, match="sub-model"):
+            Engine(b, model_version=4, max_streams=8, sample_rate=sr)
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        with pytest.raises(ModelInitializationError, match="16 kHz branch"):
+            Engine(f.read(), model_version=5, max_streams=8, sample_rate=8000)
+    Engine(blob8, model_version=4, max_streams=8, sample_rate=24000).close()       # 24 kHz selects the same sub-model
 
 
 def test_8k_golden_and_wrapper_rate_selection(setup8k):

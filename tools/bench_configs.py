@@ -132,7 +132,8 @@ def resampler_alone():
 
 def v4_8k():
     B = 8192
-    eng = Engine(open(weights_io.packaged_blob_path(4, 8000), "rb").read(), model_version=4, max_streams=B)
+    eng = Engine(open(weights_io.packaged_blob_path(4, 8000), "rb").read(), model_version=4, max_streams=B,
+                 sample_rate=8000)
     eng.open_streams(B)
     ring = (0.1 * torch.randn(16, B, 512, device="cuda")).contiguous()
     probs = torch.empty(B, device="cuda")
