@@ -61,6 +61,10 @@ struct vad_engine {
     uint8_t *d_events = nullptr; size_t d_events_cap = 0;
     int32_t *d_seg = nullptr;  size_t d_seg_cap = 0;
     int32_t *d_slots = nullptr; size_t d_slots_cap = 0;
+    // small calls (a few streams: the one-wrapper-per-client pattern): ONE pinned block in, ONE pinned block out
+    static constexpr size_t SMALL_BYTES = 256u << 10;
+    uint8_t *h_small_in = nullptr, *h_small_out = nullptr;   // hipHostMalloc
+    uint8_t *d_small_in = nullptr, *d_small_out = nullptr;
     vadk::StepParams base{};
     struct ResampleOp {
         int n_in = 0;
@@ -159,6 +163,42 @@ int step_host(vad_engine *e, const int64_t *slots, int64_t n, int32_t T, const v
     if (int rc = check_slots(e, slots, n)) return rc;
     HIP_TRY(e, hipSetDevice(e->device));
     const size_t fb = frame_bytes(fmt) * (size_t)n * T;
+    // ---- small calls: frames + slots travel as one pinned block, probs + seg + events come back as one; one
+    //      synchronisation.  (The general path below issues 2 pageable H2D copies, waits, launches, 3 D2H copies, waits.)
+    {
+        auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        const size_t o_slots = up16(fb), in_bytes = o_slots + sizeof(int32_t) * n;
+        const size_t o_seg = up16(sizeof(float) * n * T), o_ev = o_seg + up16(sizeof(int32_t) * n), out_bytes = o_ev + (size_t)n * T;
+        if (in_bytes <= vad_engine::SMALL_BYTES && out_bytes <= vad_engine::SMALL_BYTES) {
+            if (!e->h_small_in) {
+                HIP_TRY(e, hipHostMalloc((void **)&e->h_small_in, vad_engine::SMALL_BYTES, hipHostMallocDefault));
+                HIP_TRY(e, hipHostMalloc((void **)&e->h_small_out, vad_engine::SMALL_BYTES, hipHostMallocDefault));
+                HIP_TRY(e, hipMalloc((void **)&e->d_small_in, vad_engine::SMALL_BYTES));
+                HIP_TRY(e, hipMalloc((void **)&e->d_small_out, vad_engine::SMALL_BYTES));
+            }
+            std::memcpy(e->h_small_in, frames, fb);
+            int32_t *hs = reinterpret_cast<int32_t *>(e->h_small_in + o_slots);
+            for (int64_t i = 0; i < n; ++i) hs[i] = (int32_t)slots[i];
+            HIP_TRY(e, hipMemcpyAsync(e->d_small_in, e->h_small_in, in_bytes, hipMemcpyHostToDevice, e->stream));
+            vadk::StepParams p = e->base;
+            p.slots = reinterpret_cast<const int32_t *>(e->d_small_in + o_slots);
+            p.frames = e->d_small_in;
+            p.probs = reinterpret_cast<float *>(e->d_small_out);
+            p.seg_frames = reinterpret_cast<int32_t *>(e->d_small_out + o_seg);
+            p.events = e->d_small_out + o_ev;
+            p.n = (int32_t)n;
+            p.T = T;
+            p.fmt = fmt;
+            p.thresh = thr;
+            if (int rc = launch(e, p, e->stream)) return rc;
+            HIP_TRY(e, hipMemcpyAsync(e->h_small_out, e->d_small_out, out_bytes, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
+            std::memcpy(probs, e->h_small_out, sizeof(float) * n * T);
+            if (seg) std::memcpy(seg, e->h_small_out + o_seg, sizeof(int32_t) * n);
+            if (events) std::memcpy(events, e->h_small_out + o_ev, (size_t)n * T);
+            return VAD_OK;
+        }
+    }
     if (int rc = ensure(e, e->d_frames, e->d_frames_cap, fb)) return rc;
     if (int rc = ensure(e, e->d_probs, e->d_probs_cap, sizeof(float) * n * T)) return rc;
     if (int rc = ensure(e, e->d_events, e->d_events_cap, (size_t)n * T)) return rc;
@@ -297,9 +337,11 @@ void vad_engine_destroy(vad_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void *bufs[] = {e->d_wstream, e->d_state, e->d_sm, e->d_scratch, e->d_frames, e->d_probs, e->d_events, e->d_seg, e->d_slots,
-                    e->d_rs_in, e->d_rs_out};
+                    e->d_rs_in, e->d_rs_out, e->d_small_in, e->d_small_out};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    if (e->h_small_in) (void)hipHostFree(e->h_small_in);
+    if (e->h_small_out) (void)hipHostFree(e->h_small_out);
     for (auto &op : e->resample_ops)
         if (op.d_w) (void)hipFree(op.d_w);
     if (e->stream) (void)hipStreamDestroy(e->stream);
