@@ -8,11 +8,14 @@
 // (core/silero_model.py:790-949).
 //
 // One workgroup (4 waves) carries a tile of 32 streams through the WHOLE network:
-//   load+gate -> STFT (windowed DFT as MFMA GEMM) -> |.| -> enc0..enc3 (+ReLU) -> LSTM cell
-//   -> head -> sigmoid -> state machine.
+//   recurrent gate half W_hh.h while the frame is loaded, gated, windowed and 4-way folded -> STFT as a folded DFT
+//   (K = 64) -> |.| -> enc0 as a Toom-3 product (5 point-wise contractions) -> enc1 -> enc2 (split-K) -> enc3 ->
+//   input gate half W_ih.x -> LSTM cell -> head -> sigmoid -> state machine.
 // Activations never leave the CU (LDS quads, see vad_layout.h); weights stream from L2 into
 // VGPRs in packed per-wave order; all contractions are v_mfma_f32_32x32x2_f32 (exact fp32).
 // T > 1 frames per stream are processed in-kernel with h in LDS and c in registers.
+// fp32 MFMAs and VALU instructions of a wave do NOT overlap on this chip (tools/ubench/mfma_valu.hip): the kernel's
+// cost is MFMA cycles plus VALU cycles, which is why the algebra (folds, Toom-3) and the instruction counts matter.
 #include <hip/hip_runtime.h>
 #include "vad_layout.h"
 #include "sm_device.h"

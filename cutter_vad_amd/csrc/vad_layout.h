@@ -48,7 +48,7 @@ constexpr int STFT_BLOCKS = 16;            // 8 k-iterations x {cos, -sin}
 constexpr int NYQ_BLOCKS = 1;              // shared table: floats 0..255 = w[n] (the Hann window of the stored basis)
 constexpr int ENC0_BLOCKS = 4 + 16 * 5 + 2;  // bias, 16 k-iterations x 5 Toom-3 points, Nyquist channel (points 0,1,-1,2 | inf)
 constexpr int ENC1_BLOCKS = 4 + 2 * 16;
-constexpr int ENC2_BLOCKS = 4 + 2 * 8;     // waves 0,1 only
+constexpr int ENC2_BLOCKS = 4 + 2 * 8;     // packed for waves 0,1; waves 2,3 read the second K half of the same streams
 constexpr int ENC3_BLOCKS = 4 + 8;
 constexpr int LSTM_BLOCKS = 16 + 64 + 64 + 4;  // bias(4 gates), W_ih, W_hh, head weights
 enum Section { S_STFT = 0, S_NYQ, S_ENC0, S_ENC1, S_ENC2, S_ENC3, S_LSTM, S_HEADB, S_COUNT };  // S_HEADB: 1 block, float 0 = head bias
