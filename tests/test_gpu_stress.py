@@ -1,0 +1,90 @@
+"""Randomised end-to-end stress of the C ABI on the GPU: open / close / reset / step / step_multi / save / restore in
+random order, random slot subsets and call sizes (both staging paths of the host-pointer entry points), both frame
+formats - every probability checked against a per-stream oracle replay."""
+
+import numpy as np
+import pytest
+
+from cutter_vad_amd import weights_io
+from tests.signals import make_streams
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("version", [5, 4])
+def test_random_api_sequence_matches_per_stream_oracle(version):
+    from cutter_vad_amd import VADError
+    from cutter_vad_amd.engine import Engine
+    from oracle import oracle
+    with open(weights_io.packaged_blob_path(version), "rb") as f:
+        blob = f.read()
+    om = oracle.OracleModel(blob, "f64")
+    rng = np.random.default_rng(1000 + version)
+    POOL = 300
+    audio = make_streams(POOL, 64, seed=31 + version)            # every logical stream has 64 frames to play
+    tol = 2e-5 if version == 5 else 1e-4                            # V4: tests/test_gpu_v4.py on its conditioning
+    with Engine(blob, model_version=version, max_streams=POOL) as eng:
+        slot_of, pos, state, saved = {}, {}, {}, {}
+        worst, checked = 0.0, 0
+        for it in range(260):
+            op = rng.choice(["open", "step", "step", "step", "multi", "close", "reset", "save", "restore"])
+            live = sorted(slot_of)
+            if op == "open" or len(live) < 8:
+                free = [i for i in range(POOL) if i not in slot_of]
+                for i in rng.choice(free, size=min(len(free), int(rng.integers(1, 40))), replace=False):
+                    slot_of[int(i)] = int(eng.open_stream())
+                    pos[int(i)], state[int(i)] = 0, np.zeros((1, 256), np.float32)
+            elif op in ("step", "multi"):
+                k = int(rng.integers(1, len(live) + 1))
+                ids = [int(i) for i in rng.choice(live, size=k, replace=False)]
+                T = 1 if op == "step" else int(rng.integers(2, 4))
+                ids = [i for i in ids if pos[i] + T <= 64]
+                if not ids:
+                    continue
+                fr = np.stack([audio[i, pos[i]:pos[i] + T] for i in ids])                      # [k, T, 512]
+                use_i16 = bool(rng.integers(0, 2))
+                if use_i16:
+                    q = np.clip(np.round(fr * 32767.0), -32768, 32767).astype(np.int16)
+                    fr_ref = (q.astype(np.float32) / np.float32(32767.0)).astype(np.float32)
+                    send = q
+                else:
+                    fr_ref, send = fr, fr
+                slots = [slot_of[i] for i in ids]
+                if T == 1:
+                    got = eng.step(slots, send[:, 0])[:, None]
+                else:
+                    got, _ = eng.step_multi(slots, send)
+                for r, i in enumerate(ids):
+                    for t in range(T):
+                        ref = om.step_batch(oracle.denoise(fr_ref[r, t]).reshape(1, 512), state[i], nthreads=1)[0]
+                        worst = max(worst, abs(float(got[r, t]) - float(ref)))
+                        checked += 1
+                    pos[i] += T
+            elif op == "close" and len(live) > 8:
+                for i in rng.choice(live, size=int(rng.integers(1, 6)), replace=False):
+                    eng.close_stream(slot_of.pop(int(i)))
+                    saved.pop(int(i), None)
+            elif op == "reset":
+                ids = [int(i) for i in rng.choice(live, size=int(rng.integers(1, 5)), replace=False)]
+                eng.reset([slot_of[i] for i in ids])
+                for i in ids:
+                    state[i] = np.zeros((1, 256), np.float32)
+            elif op == "save":
+                i = int(rng.choice(live))
+                saved[i] = (eng.save_stream(slot_of[i]), pos[i], state[i].copy())
+            elif op == "restore" and saved:
+                i = int(rng.choice(sorted(saved)))
+                blob_i, p_i, st_i = saved[i]
+                eng.restore_stream(slot_of[i], blob_i)
+                pos[i], state[i] = p_i, st_i.copy()
+        assert checked > 1500 and worst <= tol, (checked, worst)
+        # bookkeeping survived: a slot cannot be stepped twice in one call, closed slots are refused
+        s = slot_of[sorted(slot_of)[0]]
+        with pytest.raises(Exception):
+            eng.step([s, s], np.zeros((2, 512), np.float32))
+        last = sorted(slot_of)[-1]
+        gone = slot_of.pop(last)
+        eng.close_stream(gone)
+        with pytest.raises((VADError, Exception)):
+            eng.step([gone], np.zeros((1, 512), np.float32))
+        assert eng.info()["open_streams"] == len(slot_of)
