@@ -170,12 +170,11 @@ int step_host(vad_engine *e, const int64_t *slots, int64_t n, int32_t T, const v
         const size_t o_slots = up16(fb), in_bytes = o_slots + sizeof(int32_t) * n;
         const size_t o_seg = up16(sizeof(float) * n * T), o_ev = o_seg + up16(sizeof(int32_t) * n), out_bytes = o_ev + (size_t)n * T;
         if (in_bytes <= vad_engine::SMALL_BYTES && out_bytes <= vad_engine::SMALL_BYTES) {
-            if (!e->h_small_in) {
-                HIP_TRY(e, hipHostMalloc((void **)&e->h_small_in, vad_engine::SMALL_BYTES, hipHostMallocDefault));
-                HIP_TRY(e, hipHostMalloc((void **)&e->h_small_out, vad_engine::SMALL_BYTES, hipHostMallocDefault));
-                HIP_TRY(e, hipMalloc((void **)&e->d_small_in, vad_engine::SMALL_BYTES));
-                HIP_TRY(e, hipMalloc((void **)&e->d_small_out, vad_engine::SMALL_BYTES));
-            }
+            // allocated on first use, each buffer on its own so that a failed attempt can be repeated
+            if (!e->h_small_in) HIP_TRY(e, hipHostMalloc((void **)&e->h_small_in, vad_engine::SMALL_BYTES, hipHostMallocDefault));
+            if (!e->h_small_out) HIP_TRY(e, hipHostMalloc((void **)&e->h_small_out, vad_engine::SMALL_BYTES, hipHostMallocDefault));
+            if (!e->d_small_in) HIP_TRY(e, hipMalloc((void **)&e->d_small_in, vad_engine::SMALL_BYTES));
+            if (!e->d_small_out) HIP_TRY(e, hipMalloc((void **)&e->d_small_out, vad_engine::SMALL_BYTES));
             std::memcpy(e->h_small_in, frames, fb);
             int32_t *hs = reinterpret_cast<int32_t *>(e->h_small_in + o_slots);
             for (int64_t i = 0; i < n; ++i) hs[i] = (int32_t)slots[i];
