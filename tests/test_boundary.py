@@ -109,6 +109,31 @@ def test_weights_blob_roundtrip_and_reference_arity_rule(tmp_path):
         weights_io.load_weight_blob(str(p), 4)
 
 
+def test_v4_blobs_name_their_graph_branch(tmp_path):
+    """V4 ships two sub-models; a blob is tied to its branch by `meta.variant` and the loader refuses the
+    wrong one; when the reference's .onnx is at hand the packaged blobs must equal a fresh extraction."""
+    import os
+    b16 = open(weights_io.packaged_blob_path(4), "rb").read()
+    b8 = open(weights_io.packaged_blob_path(4, 48000), "rb").read()
+    assert weights_io.packaged_blob_path(4, 8000) == weights_io.packaged_blob_path(4, 24000) != weights_io.packaged_blob_path(4)
+    assert weights_io.packaged_blob_path(5, 8000) == weights_io.packaged_blob_path(5)      # V5 has no second blob
+    t16, t8 = weights_io.unpack_svw(b16)[1], weights_io.unpack_svw(b8)[1]
+    assert "meta.variant" not in t16 and float(t8["meta.variant"][0]) == 8000.0
+    assert set(t8) - {"meta.variant"} == set(t16) and not np.array_equal(t8["l0.pw.w"], t16["l0.pw.w"])
+    assert np.array_equal(t8["stft.basis"], t16["stft.basis"])          # the DFT basis is shared by the two sub-models
+    p16, p8 = tmp_path / "a_16k.svw", tmp_path / "a_8k.svw"
+    p16.write_bytes(b16)
+    p8.write_bytes(b8)
+    assert weights_io.load_weight_blob(str(p8), 4, 24000) == b8
+    for path, sr in ((p16, 8000), (p8, 16000)):
+        with pytest.raises(weights_io.WeightFormatError, match="sub-model"):
+            weights_io.load_weight_blob(str(path), 4, sr)
+    onnx = "/root/reference/src/real_time_vad/models/silero_vad.onnx"
+    if os.path.exists(onnx):                                             # not on the GPU box
+        assert weights_io.load_weight_blob(onnx, 4, 16000) == b16
+        assert weights_io.load_weight_blob(onnx, 4, 8000) == b8
+
+
 def test_resample_operator_matches_scipy_and_reference_fixture():
     """R[512][n_in] applied on the host == scipy.signal.resample == AudioUtils.resample_audio fixture."""
     import scipy.signal
