@@ -51,10 +51,12 @@ class AudioUtils:
         the reference."""
         hop = frame_size // 2 if hop_size is None else hop_size
         count = (len(audio_data) - frame_size) // hop + 1
-        frames = np.zeros((count, frame_size), dtype=audio_data.dtype)
-        if count > 0:
-            idx = np.arange(count)[:, None] * hop + np.arange(frame_size)[None, :]
-            frames[:] = audio_data[idx]
+        frames = np.zeros((count, frame_size), dtype=audio_data.dtype)      # count < 0 raises here, like the reference
+        if 0 < count <= 32:                       # the usual chunk: one to a few frames, plain row copies are fastest
+            for i in range(count):
+                frames[i] = audio_data[i * hop:i * hop + frame_size]
+        elif count > 0:
+            frames[:] = np.lib.stride_tricks.sliding_window_view(audio_data, frame_size)[::hop][:count]
         return frames
 
     @staticmethod
