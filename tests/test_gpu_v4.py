@@ -215,3 +215,57 @@ def test_8k_golden_and_wrapper_rate_selection(setup8k):
             p = np.array(w.processor.voice_probabilities)
             assert np.abs(p - g["speech_gate.probs"][:40]).max() <= TOL_P, rate
             assert w.processor.get_model_info()["state_shape"]["hidden_state"] == (2, 1, 64)
+
+
+def test_rate_switch_mid_stream_carries_the_state(blob):
+    """The graph's h / c inputs are shared by its two branches: a V4 stream that changes `sr` between calls continues
+    with the same recurrent state in the other sub-model (SileroVADModel.select_rate moves it between the engines)."""
+    from cutter_vad_amd import SileroModelVersion
+    from cutter_vad_amd.core.silero_model import SileroVADModel
+    from oracle import oracle
+    with open(weights_io.packaged_blob_path(4, 8000), "rb") as f:
+        om8 = oracle.OracleModel(f.read(), "f64")
+    om16 = oracle.OracleModel(blob, "f64")
+    x = make_streams(1, 12, seed=4321)[0]
+    rates = [16000] * 3 + [8000] * 4 + [16000] * 2 + [48000] * 3
+    m = SileroVADModel(weights_io.packaged_blob_path(4), SileroModelVersion.V4)
+    try:
+        st = np.zeros((1, 256), np.float32)
+        for t, sr in enumerate(rates):
+            got = m.predict(x[t], sr)                                    # no gate on this entry point
+            ref = (om16 if sr == 16000 else om8).step_batch(x[t].reshape(1, 512), st, nthreads=1)[0]
+            assert abs(got - float(ref)) <= TOL_P, (t, sr)
+        hc = np.concatenate([m.model_state.hidden_state.ravel(), m.model_state.cell_state.ravel()])
+        assert np.abs(hc - st.ravel()).max() <= TOL_S
+        assert m.prediction_count == len(rates)
+    finally:
+        m.close()
+
+
+def test_shared_pool_on_the_8k_submodel_with_int16_wire_frames():
+    from cutter_vad_amd import SampleRate, SileroModelVersion, VADConfig
+    from cutter_vad_amd.core.exceptions import AudioProcessingError
+    from cutter_vad_amd.server import SharedStreamPool
+    from oracle import oracle
+    with open(weights_io.packaged_blob_path(4, 8000), "rb") as f:
+        om8 = oracle.OracleModel(f.read(), "f64")
+    pool = SharedStreamPool(model_version=SileroModelVersion.V4, sample_rate=8000)
+    try:
+        cfg = VADConfig(model_version=SileroModelVersion.V4, sample_rate=SampleRate(8000), buffer_size=512)
+        n, T = 20, 8
+        sessions = [pool.open_session(cfg) for _ in range(n)]
+        with pytest.raises(AudioProcessingError, match="sub-model"):
+            pool.open_session(VADConfig(model_version=SileroModelVersion.V4, sample_rate=SampleRate(16000)))
+        x = make_streams(n, T, seed=99)
+        q = np.clip(np.round(x * 32767.0), -32768, 32767).astype("<i2")
+        st = np.zeros((n, 256), np.float32)
+        for t in range(T):
+            for k, s in enumerate(sessions):
+                s.submit_pcm16(q[k, t].tobytes())
+            assert pool.tick() == n
+            xf = (q[:, t].astype(np.float32) / np.float32(32767.0)).astype(np.float32)
+            ref = om8.step_batch(oracle.denoise(xf).reshape(n, 512), st, nthreads=4)
+            got = np.array([s.last_probability for s in sessions])
+            assert np.abs(got - ref).max() <= TOL_P, t
+    finally:
+        pool.close()
