@@ -1,6 +1,6 @@
 """ASGI application with the reference server's wire protocol on the shared stream pool.
 
-Protocol (websocket_service/server/vad_websocket_server.py): ``GET /`` health (:751-759); websocket ``/vad`` with
+Protocol (websocket_service/server/vad_websocket_server.py): ``GET /`` / ``/health`` / ``/clients`` (:751-788); websocket ``/vad`` with
 query parameters mode / sample_rate / channels / sample_width / frame_duration_ms / start_probability /
 end_probability / start_frame_count / end_frame_count / start_ratio / end_ratio / timeout (:532-548, :551-611);
 binary messages = one PCM frame of exactly ``sample_rate * frame_duration_ms/1000 * channels * sample_width``
@@ -110,6 +110,7 @@ class ClientSession:
         self.cfg = cfg
         self.pool = pool
         self.loop = loop
+        self.start_time = time.time()
         self.segment_index = 0
         self.voice_start_time: Optional[float] = None
         self.last_voice_time: Optional[float] = None
@@ -265,6 +266,16 @@ def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0
     async def root():
         return {"message": "VAD WebSocket Server", "status": "running", "connected_clients": len(state["clients"]),
                 "timestamp": now_ms()}
+
+    @app.get("/health")
+    async def health():
+        return {"status": "healthy", "connected_clients": len(state["clients"]), "timestamp": now_ms()}
+
+    @app.get("/clients")
+    async def list_clients():
+        info = {cid: {"connected_at": c.start_time, "config": c.cfg, "segment_index": c.segment_index}
+                for cid, c in state["clients"].items()}
+        return {"connected_clients": len(info), "clients": info, "timestamp": now_ms()}
 
     @app.get("/stats")
     async def stats():

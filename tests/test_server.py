@@ -147,6 +147,11 @@ def test_wire_protocol_over_asgi():
             hello = json.loads(ws.receive_text())
             assert hello["event"] == "INFO" and hello["message"] == "VAD WebSocket server ready" and "timestamp_ms" in hello
             assert client.get("/").json()["connected_clients"] == 1
+            assert client.get("/health").json()["status"] == "healthy"
+            info = client.get("/clients").json()
+            assert info["connected_clients"] == 1
+            (only,) = info["clients"].values()
+            assert only["segment_index"] == 0 and only["config"]["vad"]["start_frame_count"] == 2
             ws.send_text(json.dumps({"type": "HEARTBEAT"}))
             assert json.loads(ws.receive_text())["message"] == "Heartbeat received"
             ws.send_bytes(b"\0" * 100)
