@@ -71,6 +71,7 @@ struct vad_engine {
         float *d_w = nullptr;
         size_t bytes = 0;
         uint32_t wave_blocks = 0;
+        uint32_t row256_block = 0;
     };
     std::vector<ResampleOp> resample_ops;   // built lazily, one per input rate
     float *d_rs_in = nullptr;  size_t d_rs_in_cap = 0;
@@ -581,11 +582,12 @@ int get_resample_op(vad_engine *e, int n_in, vad_engine::ResampleOp **out) {
             *out = &op;
             return VAD_OK;
         }
-    std::vector<float> R, packed;
-    vadk::build_resample_operator(n_in, R);
+    std::vector<float> packed;
+    std::string perr;
     vad_engine::ResampleOp op;
     op.n_in = n_in;
-    op.wave_blocks = vadk::pack_resample_operator(R, n_in, packed);
+    op.wave_blocks = vadk::pack_resample_operator(n_in, packed, &op.row256_block, perr);
+    if (op.wave_blocks == 0) return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio: %s", perr.c_str());
     op.bytes = packed.size() * sizeof(float);
     hipError_t r = hipMalloc((void **)&op.d_w, op.bytes);
     if (r != hipSuccess) return e->hip_fail(r, "hipMalloc(resample operator)");
@@ -611,6 +613,7 @@ int resample_segment(vad_engine *e, const float *d_in, int64_t n, int32_t n_in, 
     sg.wstream = op->d_w;
     sg.wstream_bytes = (uint32_t)op->bytes;
     sg.wave_blocks = op->wave_blocks;
+    sg.row256_block = op->row256_block;
     sg.in = d_in;
     sg.out = d_out;
     sg.n = (int32_t)n;

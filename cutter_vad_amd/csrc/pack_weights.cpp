@@ -250,7 +250,19 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
     return true;
 }
 
+namespace {
+void build_resample_operator_d(int n_in, std::vector<double> &R);
+}
+
 void build_resample_operator(int n_in, std::vector<float> &R) {
+    std::vector<double> Rd;
+    build_resample_operator_d(n_in, Rd);
+    R.resize(Rd.size());
+    for (size_t i = 0; i < Rd.size(); ++i) R[i] = (float)Rd[i];
+}
+
+namespace {
+void build_resample_operator_d(int n_in, std::vector<double> &R) {
     // scipy.signal.resample, real input, window=None:
     //   X = rfft(x); Y[0:N/2+1] = X[0:N/2+1] with N = min(n_in, n_out); if N is even the bin N/2 is
     //   doubled when down-sampling and halved when up-sampling; y = irfft(Y, n_out) * n_out / n_in.
@@ -261,7 +273,7 @@ void build_resample_operator(int n_in, std::vector<float> &R) {
     const int M = (N % 2 == 0) ? N / 2 - 1 : (N - 1) / 2;
     const double two_pi = 6.283185307179586476925286766559;
     const long long period = (long long)n_in * n_out;
-    R.assign((size_t)n_out * n_in, 0.f);
+    R.assign((size_t)n_out * n_in, 0.0);
     for (int o = 0; o < n_out; ++o) {
         for (int i = 0; i < n_in; ++i) {
             long long p = ((long long)o * n_in - (long long)i * n_out) % period;   // exact phase reduction
@@ -277,20 +289,50 @@ void build_resample_operator(int n_in, std::vector<float> &R) {
                 // up  : Y[kq] = X[kq] / 2 (X[kq] is the real input Nyquist bin), a regular output bin (weight 2)
                 v += (n_out < n_in) ? 2.0 * ci * co : ci * co;
             }
-            R[(size_t)o * n_in + i] = (float)(v / (double)n_in);
+            R[(size_t)o * n_in + i] = v / (double)n_in;
         }
     }
 }
+}  // namespace
 
-uint32_t pack_resample_operator(const std::vector<float> &R, int n_in, std::vector<float> &out) {
-    const int nchunks = n_in / 256;
+// The operator is mirror-symmetric, R[o][i] == R[512 - o][n_in - i] (indices mod 512 / mod n_in; checked below), so with
+//   u[j] = x[j] + x[n_in - j], v[j] = x[j] - x[n_in - j]  (0 < j < n_in/2),  u[0] = x[0], v[0] = 0
+//   Sh[o] = sum_{j < n_in/2} GS[o][j] u[j] + R[o][n_in/2] x[n_in/2],   Ah[o] = sum_j GA[o][j] v[j]
+//   GS[o][j] = (R[o][j] + R[o][n_in-j]) / 2 (GS[o][0] = R[o][0]),      GA[o][j] = (R[o][j] - R[o][n_in-j]) / 2
+// the outputs are y[o] = Sh[o] + Ah[o] and y[512 - o] = Sh[o] - Ah[o] for o = 0..255 and y[256] = Sh[256]: 512 rows of
+// K = n_in / 2 instead of 512 rows of K = n_in - half the MFMAs.
+// Packed layout: wave stream w' (4 of them) = output rows o = 64 w' .. 64 w' + 63 as two 32-row tiles t = 0, 1:
+//   8 vector blocks R[o][n_in/2] (tile 0, tile 1), then per k-iteration (8 values of j) the blocks S t0, S t1, A t0, A t1;
+// after the four streams: row 256 of GS (n_in/2 floats) followed by R[256][n_in/2].
+uint32_t pack_resample_operator(int n_in, std::vector<float> &out, uint32_t *row256_block, std::string &err) {
+    std::vector<double> R;
+    build_resample_operator_d(n_in, R);
+    const int K = n_in / 2;
+    double worst = 0;
+    for (int o = 0; o < 512; ++o)
+        for (int i = 0; i < n_in; ++i)
+            worst = std::max(worst, std::fabs(R[(size_t)o * n_in + i] - R[(size_t)((512 - o) % 512) * n_in + (n_in - i) % n_in]));
+    if (worst > 1e-12) {
+        err = "resample operator is not mirror-symmetric";
+        return 0;
+    }
+    auto Rv = [&](int o, int i) { return R[(size_t)o * n_in + i]; };
+    auto GS = [&](int o, int j) -> float { return j == 0 ? (float)Rv(o, 0) : (float)(0.5 * (Rv(o, j) + Rv(o, n_in - j))); };
+    auto GA = [&](int o, int j) -> float { return j == 0 ? 0.f : (float)(0.5 * (Rv(o, j) - Rv(o, n_in - j))); };
     StreamBuilder sb;
-    for (int w = 0; w < NWAVES; ++w)
-        for (int c = 0; c < nchunks; ++c)
-            for (int j = 0; j < 32; ++j)
-                for (int tt = 0; tt < 4; ++tt)
-                    sb.weight_block([&](int np, int k) { return R[(size_t)(32 * (4 * w + tt) + np) * n_in + 256 * c + k]; }, j);
+    for (int w = 0; w < NWAVES; ++w) {
+        for (int t = 0; t < 2; ++t) sb.vector_blocks([&](int c) { return (float)Rv(64 * w + 32 * t + c, K); });
+        for (int j = 0; j < K / 8; ++j) {
+            for (int t = 0; t < 2; ++t) sb.weight_block([&](int np, int k) { return GS(64 * w + 32 * t + np, k); }, j);
+            for (int t = 0; t < 2; ++t) sb.weight_block([&](int np, int k) { return GA(64 * w + 32 * t + np, k); }, j);
+        }
+    }
     const uint32_t per_wave = sb.blocks() / NWAVES;
+    *row256_block = sb.blocks();
+    for (int j0 = 0; j0 <= K; j0 += BLK_FLOATS) {
+        float *b = sb.new_block();
+        for (int j = j0; j < j0 + BLK_FLOATS && j <= K; ++j) b[j - j0] = j < K ? GS(256, j) : (float)Rv(256, K);
+    }
     out = std::move(sb.data);
     return per_wave;
 }

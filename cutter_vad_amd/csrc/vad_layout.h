@@ -148,9 +148,10 @@ struct StepParams {
 
 // resampler launch parameters (csrc/resample.hip)
 struct ResampleSeg {
-    const float *wstream;     // packed operator R[512][n_in]: per wave, per 256-sample chunk, per k-iteration: 4 tile blocks
+    const float *wstream;     // mirror-folded operator (pack_weights.cpp: pack_resample_operator)
     uint32_t wstream_bytes;
-    uint32_t wave_blocks;     // blocks per wave = (n_in / 8) * 4
+    uint32_t wave_blocks;     // blocks per wave stream = 8 + (n_in / 16) * 4
+    uint32_t row256_block;    // first block of the extra output row 256
     const float *in;          // [n][n_in]
     float *out;               // [n][512]
     int32_t n;
