@@ -70,8 +70,8 @@ struct vad_engine {
         int n_in = 0;
         float *d_w = nullptr;
         size_t bytes = 0;
-        uint32_t wave_blocks = 0;
-        uint32_t row256_block = 0;
+        uint32_t tile_blocks = 0;
+        uint32_t row128_block = 0;
     };
     std::vector<ResampleOp> resample_ops;   // built lazily, one per input rate
     float *d_rs_in = nullptr;  size_t d_rs_in_cap = 0;
@@ -586,8 +586,8 @@ int get_resample_op(vad_engine *e, int n_in, vad_engine::ResampleOp **out) {
     std::string perr;
     vad_engine::ResampleOp op;
     op.n_in = n_in;
-    op.wave_blocks = vadk::pack_resample_operator(n_in, packed, &op.row256_block, perr);
-    if (op.wave_blocks == 0) return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio: %s", perr.c_str());
+    op.tile_blocks = vadk::pack_resample_operator(n_in, packed, &op.row128_block, perr);
+    if (op.tile_blocks == 0) return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio: %s", perr.c_str());
     op.bytes = packed.size() * sizeof(float);
     hipError_t r = hipMalloc((void **)&op.d_w, op.bytes);
     if (r != hipSuccess) return e->hip_fail(r, "hipMalloc(resample operator)");
@@ -612,8 +612,8 @@ int resample_segment(vad_engine *e, const float *d_in, int64_t n, int32_t n_in, 
     if (int rc = get_resample_op(e, n_in, &op)) return rc;
     sg.wstream = op->d_w;
     sg.wstream_bytes = (uint32_t)op->bytes;
-    sg.wave_blocks = op->wave_blocks;
-    sg.row256_block = op->row256_block;
+    sg.tile_blocks = op->tile_blocks;
+    sg.row128_block = op->row128_block;
     sg.in = d_in;
     sg.out = d_out;
     sg.n = (int32_t)n;

@@ -295,46 +295,74 @@ void build_resample_operator_d(int n_in, std::vector<double> &R) {
 }
 }  // namespace
 
-// The operator is mirror-symmetric, R[o][i] == R[512 - o][n_in - i] (indices mod 512 / mod n_in; checked below), so with
-//   u[j] = x[j] + x[n_in - j], v[j] = x[j] - x[n_in - j]  (0 < j < n_in/2),  u[0] = x[0], v[0] = 0
-//   Sh[o] = sum_{j < n_in/2} GS[o][j] u[j] + R[o][n_in/2] x[n_in/2],   Ah[o] = sum_j GA[o][j] v[j]
-//   GS[o][j] = (R[o][j] + R[o][n_in-j]) / 2 (GS[o][0] = R[o][0]),      GA[o][j] = (R[o][j] - R[o][n_in-j]) / 2
-// the outputs are y[o] = Sh[o] + Ah[o] and y[512 - o] = Sh[o] - Ah[o] for o = 0..255 and y[256] = Sh[256]: 512 rows of
-// K = n_in / 2 instead of 512 rows of K = n_in - half the MFMAs.
-// Packed layout: wave stream w' (4 of them) = output rows o = 64 w' .. 64 w' + 63 as two 32-row tiles t = 0, 1:
-//   8 vector blocks R[o][n_in/2] (tile 0, tile 1), then per k-iteration (8 values of j) the blocks S t0, S t1, A t0, A t1;
-// after the four streams: row 256 of GS (n_in/2 floats) followed by R[256][n_in/2].
-uint32_t pack_resample_operator(int n_in, std::vector<float> &out, uint32_t *row256_block, std::string &err) {
+// The operator has two exact symmetries (both checked below; indices mod 512 / mod n):
+//   half-period shift  R[o + 256][i + n/2] == R[o][i]      (a radix-2 step: even / odd harmonics separate)
+//   mirror             R[512 - o][n - i]   == R[o][i]
+// With H = n/2, Q = n/4, xe[i] = x[i] + x[i+H], xo[i] = x[i] - x[i+H], RE[o][i] = R[o][i] + R[o][i+H], RO = R - R(shifted):
+//   y[o] + y[o+256] = sum_{i<H} RE[o][i] xe[i],   y[o] - y[o+256] = sum_{i<H} RO[o][i] xo[i]          (o < 256)
+// and each of the two half-size products folds about its own midpoint (RO and xo are anti-periodic in H, which moves the
+// unpaired j = 0 term from the symmetric to the antisymmetric part):
+//   ue[j] = xe[j] + xe[H-j], ve[j] = xe[j] - xe[H-j], uo[j] = xo[j] + xo[H-j], vo[j] = xo[j] - xo[H-j]   (0 < j < Q)
+//   ue[0] = xe[0], ve[0] = 0, uo[0] = 0, vo[0] = xo[0]
+//   se[o] = GSE[o].ue + RE[o][Q] xe[Q] / 2,  ae[o] = GAE[o].ve,  so[o] = GSO[o].uo + RO[o][Q] xo[Q] / 2,  ao[o] = GAO[o].vo
+//   G{S,A}{E,O}[o][j] = (R{E,O}[o][j] +/- R{E,O}[o][H-j]) / 4  (j > 0),  GSE[o][0] = RE[o][0] / 2,  GAO[o][0] = RO[o][0] / 2
+//   y[o] = se+ae+so+ao,  y[o+256] = se+ae-so-ao,  y[256-o] = se-ae+so-ao,  y[512-o] = se-ae-so+ao        (o = 0..127)
+//   y[128] = se[128] + so[128],  y[384] = se[128] - so[128]
+// 4 x 128 rows of K = n/4 instead of 512 rows of K = n: a quarter of the dense MFMAs.
+// Packed layout: row tile t (4 of them) = rows o = 32 t .. 32 t + 31:
+//   4 vector blocks RE[o][Q] / 2, 4 vector blocks RO[o][Q] / 2, then per k-iteration (8 values of j) the blocks SE, AE, SO, AO;
+// after the four tiles: GSE[128][0..Q), GSO[128][0..Q), RE[128][Q] / 2, RO[128][Q] / 2 as plain floats.
+uint32_t pack_resample_operator(int n_in, std::vector<float> &out, uint32_t *row128_block, std::string &err) {
     std::vector<double> R;
     build_resample_operator_d(n_in, R);
-    const int K = n_in / 2;
-    double worst = 0;
-    for (int o = 0; o < 512; ++o)
-        for (int i = 0; i < n_in; ++i)
-            worst = std::max(worst, std::fabs(R[(size_t)o * n_in + i] - R[(size_t)((512 - o) % 512) * n_in + (n_in - i) % n_in]));
-    if (worst > 1e-12) {
-        err = "resample operator is not mirror-symmetric";
+    const int n = n_in, H = n / 2, Q = n / 4;
+    if (n % 256) {
+        err = "resample chunk length must be a multiple of 256 samples";
         return 0;
     }
-    auto Rv = [&](int o, int i) { return R[(size_t)o * n_in + i]; };
-    auto GS = [&](int o, int j) -> float { return j == 0 ? (float)Rv(o, 0) : (float)(0.5 * (Rv(o, j) + Rv(o, n_in - j))); };
-    auto GA = [&](int o, int j) -> float { return j == 0 ? 0.f : (float)(0.5 * (Rv(o, j) - Rv(o, n_in - j))); };
+    auto Rv = [&](int o, int i) { return R[(size_t)(o & 511) * n + (i % n)]; };
+    double worst = 0;
+    for (int o = 0; o < 512; ++o)
+        for (int i = 0; i < n; ++i) {
+            worst = std::max(worst, std::fabs(Rv(o, i) - Rv(512 - o, n - i)));
+            worst = std::max(worst, std::fabs(Rv(o, i) - Rv(o + 256, i + H)));
+        }
+    if (worst > 1e-12) {
+        err = "resample operator lacks the symmetries the folded kernel relies on";
+        return 0;
+    }
+    auto RE = [&](int o, int i) { return Rv(o, i) + Rv(o, i + H); };
+    auto RO = [&](int o, int i) { return Rv(o, i) - Rv(o, i + H); };
+    auto GSE = [&](int o, int j) -> float { return (float)(j == 0 ? 0.5 * RE(o, 0) : 0.25 * (RE(o, j) + RE(o, H - j))); };
+    auto GAE = [&](int o, int j) -> float { return (float)(j == 0 ? 0.0 : 0.25 * (RE(o, j) - RE(o, H - j))); };
+    auto GSO = [&](int o, int j) -> float { return (float)(j == 0 ? 0.0 : 0.25 * (RO(o, j) + RO(o, H - j))); };
+    auto GAO = [&](int o, int j) -> float { return (float)(j == 0 ? 0.5 * RO(o, 0) : 0.25 * (RO(o, j) - RO(o, H - j))); };
     StreamBuilder sb;
-    for (int w = 0; w < NWAVES; ++w) {
-        for (int t = 0; t < 2; ++t) sb.vector_blocks([&](int c) { return (float)Rv(64 * w + 32 * t + c, K); });
-        for (int j = 0; j < K / 8; ++j) {
-            for (int t = 0; t < 2; ++t) sb.weight_block([&](int np, int k) { return GS(64 * w + 32 * t + np, k); }, j);
-            for (int t = 0; t < 2; ++t) sb.weight_block([&](int np, int k) { return GA(64 * w + 32 * t + np, k); }, j);
+    for (int t = 0; t < 4; ++t) {
+        sb.vector_blocks([&](int c) { return (float)(0.5 * RE(32 * t + c, Q)); });
+        sb.vector_blocks([&](int c) { return (float)(0.5 * RO(32 * t + c, Q)); });
+        for (int j = 0; j < Q / 8; ++j) {
+            sb.weight_block([&](int np, int k) { return GSE(32 * t + np, k); }, j);
+            sb.weight_block([&](int np, int k) { return GAE(32 * t + np, k); }, j);
+            sb.weight_block([&](int np, int k) { return GSO(32 * t + np, k); }, j);
+            sb.weight_block([&](int np, int k) { return GAO(32 * t + np, k); }, j);
         }
     }
-    const uint32_t per_wave = sb.blocks() / NWAVES;
-    *row256_block = sb.blocks();
-    for (int j0 = 0; j0 <= K; j0 += BLK_FLOATS) {
+    const uint32_t per_tile = sb.blocks() / 4;
+    *row128_block = sb.blocks();
+    std::vector<float> row(2 * (size_t)Q + 2);
+    for (int j = 0; j < Q; ++j) {
+        row[j] = GSE(128, j);
+        row[Q + j] = GSO(128, j);
+    }
+    row[2 * Q] = (float)(0.5 * RE(128, Q));
+    row[2 * Q + 1] = (float)(0.5 * RO(128, Q));
+    for (size_t j0 = 0; j0 < row.size(); j0 += BLK_FLOATS) {
         float *b = sb.new_block();
-        for (int j = j0; j < j0 + BLK_FLOATS && j <= K; ++j) b[j - j0] = j < K ? GS(256, j) : (float)Rv(256, K);
+        for (size_t j = j0; j < j0 + BLK_FLOATS && j < row.size(); ++j) b[j - j0] = row[j];
     }
     out = std::move(sb.data);
-    return per_wave;
+    return per_tile;
 }
 
 bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::string &err) {

@@ -25,7 +25,7 @@ bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::strin
 // scipy.signal.resample(x, 512) for len(x) == n_in as a dense operator R[512][n_in] (row-major),
 // built in double precision from the closed form of the Fourier method (utils/audio.py:46-49).
 void build_resample_operator(int n_in, std::vector<float> &R);
-// mirror-folded packing of that operator (pack_weights.cpp); returns the blocks per wave stream, 0 on failure
-uint32_t pack_resample_operator(int n_in, std::vector<float> &out, uint32_t *row256_block, std::string &err);
+// radix-2 + mirror-folded packing of that operator (pack_weights.cpp); returns the blocks per row tile, 0 on failure
+uint32_t pack_resample_operator(int n_in, std::vector<float> &out, uint32_t *row128_block, std::string &err);
 
 }  // namespace vadk

@@ -47,18 +47,23 @@ __device__ __forceinline__ f32x4 quad_of(const f32x16 &a, int g) {
 
 }  // namespace
 
-// The operator is mirror-symmetric (R[o][i] == R[512-o][n_in-i]), so the kernel contracts the folded input
-//   u[j] = x[j] + x[n_in-j],  v[j] = x[j] - x[n_in-j]   (j < n_in/2; u[0] = x[0], v[0] = 0)
-// against the half-width operators GS / GA (pack_weights.cpp): Sh[o] = GS[o].u + R[o][n_in/2] x[n_in/2], Ah[o] = GA[o].v,
-// y[o] = Sh + Ah, y[512-o] = Sh - Ah (o = 0..255), y[256] = Sh[256] - half the MFMAs of the dense product.
-// NT = (S, A) tile pairs per wave.  NT = 2: one workgroup produces all 512 outputs of its 32 chunks (wave w: rows
-// o = 64w..64w+63).  NT = 1: two workgroups (blockIdx.y) share a chunk tile (wave (y, w): o = 32 (4y + w)..+31) - used
-// when the call has too few chunk tiles to fill the 256 CUs (the input is read twice, from L2).
+// The operator has a half-period shift symmetry and a mirror symmetry (pack_weights.cpp: pack_resample_operator spells
+// out the algebra), so the kernel contracts four folded inputs of length Q = n_in / 4
+//   ue / ve = (x[j] + x[j+H]) +/- (x[H-j] + x[n-j]),   uo / vo = (x[j] - x[j+H]) +/- (x[H-j] - x[n-j])      (H = n_in / 2)
+// against four 128-row operators (se, ae, so, ao) and recombines
+//   y[o] = se+ae+so+ao, y[o+256] = se+ae-so-ao, y[256-o] = se-ae+so-ao, y[512-o] = se-ae-so+ao   (o < 128; 128, 384 on the VALU)
+// - a quarter of the dense product's MFMAs.
+// NT = 2: one workgroup per chunk tile, wave w = row tile w (o = 32w..32w+31) with all four parts.
+// NT = 1: two workgroups (blockIdx.y) share a chunk tile: wave (y, w) = row tile 2y + (w >> 1), parts (se, ae) or (so, ao)
+// by w & 1, partner waves swap their sums through LDS at the end - used when the call has too few chunk tiles to fill the
+// 256 CUs (the input is read twice, from L2).
 template <int NT>
 __global__ void __launch_bounds__(NTHREADS, 1) vadk_resample_512(const vadk::ResampleParams PP) {
-    constexpr int CH_ROWS = 32;                       // one K chunk = 128 folded samples = 32 quad rows of u + 32 of v
-    __shared__ f32x4 lds[2 * 2 * CH_ROWS * QS + 64];
-    float *const red = reinterpret_cast<float *>(lds + 2 * 2 * CH_ROWS * QS);      // [8 parts][32 streams]: row 256
+    constexpr int CH_ROWS = 16;                       // one K chunk = 64 folded samples = 16 quad rows of each of ue, ve, uo, vo
+    constexpr int NP = 2 * NT;                        // accumulators per wave
+    constexpr int BUF = 4 * CH_ROWS * QS;
+    __shared__ f32x4 lds[2 * BUF + 64];
+    float *const red = reinterpret_cast<float *>(lds + 2 * BUF);                    // [8 parts][32 streams]: rows 128 / 384
     // which segment does this workgroup serve?  (block-uniform: scalar compares on kernel arguments)
     int sidx = 0;
 #pragma unroll
@@ -72,137 +77,192 @@ __global__ void __launch_bounds__(NTHREADS, 1) vadk_resample_512(const vadk::Res
     const int m = lane & 31, h = lane >> 5;
     const int hq = h * QS + m;
     const int tile0 = tile_in_seg * MT;
-    const int K = P.n_in >> 1;                        // folded length
-    const int nchunks = K >> 7;
-    const int Q = P.n_in >> 2;                        // quads per input chunk
+    const int Q = P.n_in >> 2;                        // folded length in samples = quads per input chunk
+    const int nchunks = Q >> 6;
     const __amdgpu_buffer_rsrc_t wrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wstream), 0, (int)P.wstream_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.in), 0, (int)((unsigned)P.n * (unsigned)P.n_in * 4u), 0x00020000);
     const int lane16 = lane * 16;
-    // this wave's rows: stream w' of the packed operator, first tile pair tp0 inside it
-    const int ot0 = NT == 2 ? 2 * w : 4 * (int)blockIdx.y + w;       // first 32-row output tile (0..7)
-    const int wbase = (ot0 >> 1) * (int)P.wave_blocks;
-    const int tsel = ot0 & 1;                                         // NT = 1: which of the stream's two tiles
+    const int rt = NT == 2 ? w : 2 * (int)blockIdx.y + (w >> 1);     // this wave's 32-row output tile (0..3)
+    const int po = NT == 2 ? 0 : (w & 1);                            // NT = 1: 0 = the (se, ae) pair, 1 = (so, ao)
+    const int wbase = rt * (int)P.tile_blocks;
 
-    // accumulators start from the rank-1 term of x[n_in/2] (the one sample the fold cannot pair): R[o][n_in/2] x[n_in/2]
-    f32x16 accS[NT], accA[NT];
+    // the one sample each half-size product cannot pair, x[Q] +/- x[Q + H], enters as a rank-1 term: accumulator init
+    f32x16 acc[NP];
     {
         const int g2 = tile0 + m;
-        const float xmid = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (g2 * P.n_in + K) * 4, 0, 0));
+        const float xa_ = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (g2 * P.n_in + Q) * 4, 0, 0));
+        const float xb_ = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (g2 * P.n_in + 3 * Q) * 4, 0, 0));
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int tb = wbase + 4 * (NT == 2 ? t : tsel);
+            const int tb = wbase + 4 * (NT == 2 ? t : po);
+            const float xmid = (NT == 2 ? t : po) == 0 ? xa_ + xb_ : xa_ - xb_;
             const f32x4 r0 = ldw(wrs, lane16, tb), r1 = ldw(wrs, lane16, tb + 1), r2 = ldw(wrs, lane16, tb + 2), r3 = ldw(wrs, lane16, tb + 3);
-            accS[t] = f32x16{r0.x * xmid, r0.y * xmid, r0.z * xmid, r0.w * xmid, r1.x * xmid, r1.y * xmid, r1.z * xmid, r1.w * xmid,
-                             r2.x * xmid, r2.y * xmid, r2.z * xmid, r2.w * xmid, r3.x * xmid, r3.y * xmid, r3.z * xmid, r3.w * xmid};
-            accA[t] = (f32x16)(0.f);
+            acc[2 * t] = f32x16{r0.x * xmid, r0.y * xmid, r0.z * xmid, r0.w * xmid, r1.x * xmid, r1.y * xmid, r1.z * xmid, r1.w * xmid,
+                                r2.x * xmid, r2.y * xmid, r2.z * xmid, r2.w * xmid, r3.x * xmid, r3.y * xmid, r3.z * xmid, r3.w * xmid};
+            acc[2 * t + 1] = (f32x16)(0.f);
         }
     }
 
-    // chunk loader: 32 streams x 32 folded quads, 4 per thread; the three input quads of a folded quad are
-    // x quad q (forward), quad Q - q (element 0) and quad Q - q - 1 (elements 3, 2, 1: x[n_in - 4q - e])
-    u32x4 xa[4], xb[4], xc[4];
+    // chunk loader: 32 streams x 16 folded quads, 2 per thread.  Folded quad q (j = 4q..4q+3) needs x[j] (quad q), x[j+H]
+    // (quad q + Q/2), x[H-j] (quad Q/2 - q element 0, quad Q/2 - q - 1 elements 3, 2, 1) and x[n-j] (likewise from Q - q)
+    u32x4 xl[2][6];
     auto load_chunk = [&](int c) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < 2; ++it) {
             const int idx = it * NTHREADS + tid;
-            const int ms = idx >> 5, q = (idx & 31) + 32 * c;
+            const int ms = idx >> 4, q = (idx & 15) + 16 * c;
             const int base = (tile0 + ms) * Q;                       // streams past n: out of range -> zeros
-            xa[it] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + q) * 16, 0, 0);
-            xb[it] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (q == 0 ? 0 : Q - q)) * 16, 0, 0);
-            xc[it] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + Q - q - 1) * 16, 0, 0);
+            xl[it][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + q) * 16, 0, 0);
+            xl[it][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + q + (Q >> 1)) * 16, 0, 0);
+            xl[it][2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (Q >> 1) - q) * 16, 0, 0);
+            xl[it][3] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (Q >> 1) - q - 1) * 16, 0, 0);
+            xl[it][4] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (q == 0 ? 0 : Q - q)) * 16, 0, 0);
+            xl[it][5] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + Q - q - 1) * 16, 0, 0);
         }
     };
     auto store_chunk = [&](int c, int buf) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < 2; ++it) {
             const int idx = it * NTHREADS + tid;
-            const int ms = idx >> 5, ql = idx & 31;
-            const f32x4 a = __builtin_bit_cast(f32x4, xa[it]), b = __builtin_bit_cast(f32x4, xb[it]), cc = __builtin_bit_cast(f32x4, xc[it]);
-            f32x4 u = f32x4{a.x + b.x, a.y + cc.w, a.z + cc.z, a.w + cc.y};
-            f32x4 v = f32x4{a.x - b.x, a.y - cc.w, a.z - cc.z, a.w - cc.y};
-            if (ql + 32 * c == 0) { u.x = a.x; v.x = 0.f; }          // j = 0 has no partner
-            lds[(buf * 2 * CH_ROWS + ql) * QS + ms] = u;
-            lds[(buf * 2 * CH_ROWS + CH_ROWS + ql) * QS + ms] = v;
+            const int ms = idx >> 4, ql = idx & 15;
+            const f32x4 a = __builtin_bit_cast(f32x4, xl[it][0]), cc = __builtin_bit_cast(f32x4, xl[it][1]);
+            const f32x4 b0 = __builtin_bit_cast(f32x4, xl[it][2]), b1 = __builtin_bit_cast(f32x4, xl[it][3]);
+            const f32x4 d0 = __builtin_bit_cast(f32x4, xl[it][4]), d1 = __builtin_bit_cast(f32x4, xl[it][5]);
+            const f32x4 b = f32x4{b0.x, b1.w, b1.z, b1.y}, d = f32x4{d0.x, d1.w, d1.z, d1.y};
+            const f32x4 pe = a + cc, me = a - cc, qe = b + d, qo = b - d;
+            f32x4 ue = pe + qe, ve = pe - qe, uo = me + qo, vo = me - qo;
+            if (ql + 16 * c == 0) { ue.x = pe.x; ve.x = 0.f; uo.x = 0.f; vo.x = me.x; }     // j = 0 has no partner
+            f32x4 *dst = lds + buf * BUF + ql * QS + ms;
+            dst[0] = ue;
+            dst[CH_ROWS * QS] = ve;
+            dst[2 * CH_ROWS * QS] = uo;
+            dst[3 * CH_ROWS * QS] = vo;
         }
     };
 
-    // output row 256 on the VALU: thread = (stream tid & 31, part tid >> 5) sums 4 quads of every chunk
-    float r256 = 0.f;
-    const bool do256 = NT == 2 || blockIdx.y == 0;
+    // output rows 128 / 384 on the VALU: thread = (stream tid & 31, part tid >> 5); parts 0..3 dot ue with GSE[128], 4..7 uo
+    // with GSO[128], four quads of every chunk each
+    float r128 = 0.f;
+    const bool do128 = NT == 2 || blockIdx.y == 0;
+    const int part = tid >> 5, pr = part & 3, psel = part >> 2;
 
+    // The operator stream does not depend on LDS, so its loads run D k-iterations (about 4 k cycles of MFMA) ahead,
+    // across chunk boundaries.  That depth is what hides the next chunk's input loads: loads complete in order, so the
+    // first operator block issued after them cannot be consumed before they have come back from HBM.
+    constexpr int D = NT == 1 ? 8 : 4;
+    f32x4 wq[D][NP], xq[2][NP];
+    int ws = wbase + 8 + (NT == 2 ? 0 : 2 * po);           // 8 k-iterations x {SE, AE, SO, AO} per chunk
+    const int xrow0 = (NT == 2 ? 0 : 2 * po) * CH_ROWS * QS + hq;
+#define R_LDW(slot, j)                                                                          \
+    _Pragma("unroll") for (int k = 0; k < NP; ++k) wq[slot][k] = ldw(wrs, lane16, ws + 4 * (j) + k);
+#define R_LDX(slot, j)                                                                          \
+    _Pragma("unroll") for (int k = 0; k < NP; ++k) xq[slot][k] = X[xrow0 + (k * CH_ROWS + 2 * (j)) * QS];
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) { R_LDW(d, d) }
     load_chunk(0);
     store_chunk(0, 0);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
-        const f32x4 *U = lds + (c & 1) * 2 * CH_ROWS * QS, *V = U + CH_ROWS * QS;
-        if (c + 1 < nchunks) load_chunk(c + 1);          // global loads in flight under the MFMAs
-        int ws = wbase + 8 + c * 64 + (NT == 2 ? 0 : tsel);    // 16 k-iterations x {S t0, S t1, A t0, A t1} per chunk
+        const f32x4 *X = lds + (c & 1) * BUF;
         asm volatile("" : "+s"(ws));
-        if (do256) {
-            const int ms = tid & 31, part = tid >> 5;
+        R_LDX(0, 0)
+        f32x4 g128[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            R_LDW((j + D - 1) % D, j + D - 1)            // past j = 7: the next chunk's blocks (the stream is contiguous)
+            if (j == 0) {
+                if (c + 1 < nchunks) load_chunk(c + 1);  // global loads in flight under the MFMAs
+                if (do128) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        g128[i] = ldw(wrs, (psel * (Q >> 2) + 16 * c + 4 * pr + i) * 16, (int)P.row128_block);
+                }
+            }
+            if (j + 1 < 8) { R_LDX((j + 1) & 1, j + 1) }
+            SB();
+#pragma unroll
+            for (int k = 0; k < NP; ++k) acc[k] = mfma4(wq[j % D][k], xq[j & 1][k], acc[k]);
+            SB();
+        }
+        ws += 32;
+        if (do128) {
+            const int ms = tid & 31;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int ql = part * 4 + i;
-                const f32x4 g = ldw(wrs, (32 * c + ql) * 16, (int)P.row256_block);
-                const f32x4 uu = U[ql * QS + ms];
-                r256 += g.x * uu.x + g.y * uu.y + g.z * uu.z + g.w * uu.w;
+                const f32x4 uu = X[(psel * 2 * CH_ROWS + 4 * pr + i) * QS + ms];
+                r128 += g128[i].x * uu.x + g128[i].y * uu.y + g128[i].z * uu.z + g128[i].w * uu.w;
             }
         }
-        f32x4 AwS[NT], AwA[NT], BwS[NT], BwA[NT], Au, Av, Bu, Bv;
-#define R_LD(S, j)                                                                              \
-    _Pragma("unroll") for (int k = 0; k < NT; ++k) {                                            \
-        S##wS[k] = ldw(wrs, lane16, ws + 4 * (j) + k);                                          \
-        S##wA[k] = ldw(wrs, lane16, ws + 4 * (j) + 2 + k);                                      \
-    }                                                                                           \
-    S##u = U[(2 * (j)) * QS + hq]; S##v = V[(2 * (j)) * QS + hq];
-#define R_MMA(S)                                                                                \
-    _Pragma("unroll") for (int k = 0; k < NT; ++k) {                                            \
-        accS[k] = mfma4(S##wS[k], S##u, accS[k]);                                               \
-        accA[k] = mfma4(S##wA[k], S##v, accA[k]);                                               \
-    }
-        R_LD(A, 0)
-        for (int j = 0; j < 16; j += 2) {
-            R_LD(B, j + 1) SB();
-            R_MMA(A) SB();
-            const int jn = j + 2 < 16 ? j + 2 : 14;
-            R_LD(A, jn) SB();
-            R_MMA(B) SB();
-        }
-#undef R_LD
-#undef R_MMA
         if (c + 1 < nchunks) store_chunk(c + 1, (c + 1) & 1);   // the other buffer: last read two chunks ago
         __syncthreads();
     }
-    // epilogue: lane (m, h) holds rows o = 32 (ot0 + t) + 8g + 4h + i of Sh and Ah
+#undef R_LDW
+#undef R_LDX
+    // epilogue: lane (m, h) holds rows o = 32 rt + 8g + 4h + i of its parts
     const int g2 = tile0 + m;
-    if (g2 < P.n) {
-        float *o = P.out + (size_t)g2 * 512;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
+    float *const o = P.out + (size_t)g2 * 512;
+    if constexpr (NT == 2) {
+        if (g2 < P.n) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int row = 32 * (ot0 + t) + 8 * g + 4 * h;
-                const f32x4 sh = quad_of(accS[t], g), ah = quad_of(accA[t], g);
-                *reinterpret_cast<f32x4 *>(o + row) = f32x4{sh.x + ah.x, sh.y + ah.y, sh.z + ah.z, sh.w + ah.w};
-                if (row != 0) o[512 - row] = sh.x - ah.x;            // y[512 - o] = Sh - Ah; o = 0 is its own mirror
-                o[511 - row] = sh.y - ah.y;
-                o[510 - row] = sh.z - ah.z;
-                o[509 - row] = sh.w - ah.w;
+                const int row = 32 * rt + 8 * g + 4 * h;
+                const f32x4 se = quad_of(acc[0], g), ae = quad_of(acc[1], g), so = quad_of(acc[2], g), ao = quad_of(acc[3], g);
+                const f32x4 pe = se + ae, me = se - ae, pO = so + ao, mO = so - ao;
+                *reinterpret_cast<f32x4 *>(o + row) = pe + pO;
+                *reinterpret_cast<f32x4 *>(o + 256 + row) = pe - pO;
+                const f32x4 lo = me + mO, hi = me - mO;
+                if (row != 0) { o[256 - row] = lo.x; o[512 - row] = hi.x; }     // o = 0: rows 256 and 512 = 0 are written above
+                o[255 - row] = lo.y; o[511 - row] = hi.y;
+                o[254 - row] = lo.z; o[510 - row] = hi.z;
+                o[253 - row] = lo.w; o[509 - row] = hi.w;
             }
+        }
+    } else {
+        // partner waves (w ^ 1: the other pair of the same row tile) swap s + a and s - a through the now idle staging area
+        f32x4 *const ex = lds;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 s_ = quad_of(acc[0], g), a_ = quad_of(acc[1], g);
+            ex[(w * 8 + g) * 64 + lane] = s_ + a_;
+            ex[(w * 8 + 4 + g) * 64 + lane] = s_ - a_;
+        }
+        __syncthreads();
+        if (g2 < P.n) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = 32 * rt + 8 * g + 4 * h;
+                const f32x4 s_ = quad_of(acc[0], g), a_ = quad_of(acc[1], g);
+                const f32x4 pp = ex[((w ^ 1) * 8 + g) * 64 + lane], pm = ex[((w ^ 1) * 8 + 4 + g) * 64 + lane];
+                if (po == 0) {          // this wave: (se, ae); partner: (so, ao) -> y[o], y[256 - o]
+                    *reinterpret_cast<f32x4 *>(o + row) = (s_ + a_) + pp;
+                    const f32x4 lo = (s_ - a_) + pm;
+                    if (row != 0) o[256 - row] = lo.x;
+                    o[255 - row] = lo.y; o[254 - row] = lo.z; o[253 - row] = lo.w;
+                } else {                // this wave: (so, ao); partner: (se, ae) -> y[o + 256], y[512 - o]
+                    *reinterpret_cast<f32x4 *>(o + 256 + row) = pp - (s_ + a_);
+                    const f32x4 hi = pm - (s_ - a_);
+                    if (row != 0) o[512 - row] = hi.x;
+                    o[511 - row] = hi.y; o[510 - row] = hi.z; o[509 - row] = hi.w;
+                }
+            }
+        }
     }
-    if (do256) {
-        const int ms = tid & 31, part = tid >> 5;
-        red[part * 32 + ms] = r256;
+    if (do128) {
+        const int ms = tid & 31;
+        red[part * 32 + ms] = r128;
         __syncthreads();
         if (tid < 32 && tile0 + tid < P.n) {
-            float s = 0.f;
+            float e = 0.f, od = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s += red[k * 32 + tid];
-            const float xmid = P.in[(size_t)(tile0 + tid) * P.n_in + K];
-            const float r = ldw(wrs, (K >> 2) * 16, (int)P.row256_block).x;     // K is a multiple of 128
-            P.out[(size_t)(tile0 + tid) * 512 + 256] = s + r * xmid;
+            for (int k = 0; k < 4; ++k) { e += red[k * 32 + tid]; od += red[(4 + k) * 32 + tid]; }
+            const float *x = P.in + (size_t)(tile0 + tid) * P.n_in;
+            const f32x4 mid = ldw(wrs, (Q >> 1) * 16, (int)P.row128_block);       // floats 2Q, 2Q + 1: RE[128][Q] / 2, RO[128][Q] / 2
+            e += mid.x * (x[Q] + x[3 * Q]);
+            od += mid.y * (x[Q] - x[3 * Q]);
+            P.out[(size_t)(tile0 + tid) * 512 + 128] = e + od;
+            P.out[(size_t)(tile0 + tid) * 512 + 384] = e - od;
         }
     }
 }

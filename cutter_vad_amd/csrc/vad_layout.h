@@ -148,10 +148,10 @@ struct StepParams {
 
 // resampler launch parameters (csrc/resample.hip)
 struct ResampleSeg {
-    const float *wstream;     // mirror-folded operator (pack_weights.cpp: pack_resample_operator)
+    const float *wstream;     // folded operator (pack_weights.cpp: pack_resample_operator)
     uint32_t wstream_bytes;
-    uint32_t wave_blocks;     // blocks per wave stream = 8 + (n_in / 16) * 4
-    uint32_t row256_block;    // first block of the extra output row 256
+    uint32_t tile_blocks;     // blocks per 32-row tile = 8 + (n_in / 32) * 4
+    uint32_t row128_block;    // first block of the VALU row's coefficients (outputs 128 / 384)
     const float *in;          // [n][n_in]
     float *out;               // [n][512]
     int32_t n;

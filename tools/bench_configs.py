@@ -74,6 +74,40 @@ def config3():
             "frames_per_s": 3 * per / dt}
 
 
+def config3_pipelined():
+    """configs[3] with the caller's software pipeline: the resample launch of tick t+1 runs on a second HIP stream beside
+    the model step of tick t (4 095 streams leave half the CUs free, and the resample workgroups fit beside nothing else of
+    the model kernel's).  Every tick is still resampled and then stepped in order; two 16 kHz buffers alternate."""
+    B = 4096
+    per = B // 3
+    eng = Engine(blob(5), max_streams=B)
+    eng.open_streams(B)
+    rates = ((8000, 256), (24000, 768), (48000, 1536))
+    rings = [(0.1 * torch.randn(8, per, n_in, device="cuda")).contiguous() for _, n_in in rates]
+    f16 = [torch.empty(3 * per, 512, device="cuda") for _ in range(2)]
+    probs = torch.empty(3 * per, device="cuda")
+    sr_, sm_ = torch.cuda.Stream(), torch.cuda.Stream()
+    resampled = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+    for ev in consumed:
+        ev.record(sm_)
+
+    def step(i):
+        b = i & 1
+        sr_.wait_event(consumed[b])                    # the model step two ticks back has read this buffer
+        eng.resample_multi_device([(rings[k][i % 8].data_ptr(), per, n_in, sr, f16[b][k * per:(k + 1) * per].data_ptr())
+                                   for k, (sr, n_in) in enumerate(rates)], stream=sr_.cuda_stream)
+        resampled[b].record(sr_)
+        sm_.wait_event(resampled[b])
+        eng.step_device(3 * per, f16[b].data_ptr(), probs.data_ptr(), stream=sm_.cuda_stream)
+        consumed[b].record(sm_)
+
+    dt = timed(step, [sm_, sr_])
+    eng.close()
+    return {"config": "configs[3], resample of tick t+1 on a second HIP stream beside the model step of tick t",
+            "us_per_step": dt * 1e6, "frames_per_s": 3 * per / dt}
+
+
 def config4_per_gpu():
     B = 4096
     e5, e4 = Engine(blob(5), max_streams=B), Engine(blob(4), model_version=4, max_streams=B)
@@ -199,11 +233,18 @@ def host_api():
 
 
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1:                      # e.g. `bench_configs.py config3 config3_pipelined`
+        for name in sys.argv[1:]:
+            r = globals()[name]()
+            for row in (r if isinstance(r, list) else [r]):
+                print(json.dumps(row), flush=True)
+        sys.exit(0)
     for r in host_api():
         print(json.dumps(r), flush=True)
     for r in single_stream_wrapper():
         print(json.dumps(r), flush=True)
     for r in resampler_alone():
         print(json.dumps(r), flush=True)
-    for fn in (config1, config3, config4_per_gpu, v4_alone, v4_8k):
+    for fn in (config1, config3, config3_pipelined, config4_per_gpu, v4_alone, v4_8k):
         print(json.dumps(fn()), flush=True)
