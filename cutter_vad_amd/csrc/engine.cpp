@@ -697,6 +697,31 @@ int vad_debug_resample_operator(int32_t n_in, float *R, size_t r_floats) {
     return VAD_OK;
 }
 
+int vad_debug_pack_resample(int32_t n_in, float *out, size_t out_floats, size_t *n_floats, uint32_t *tile_blocks,
+                            uint32_t *row128_block) {
+    g_create_error.clear();
+    if (n_in < 256 || n_in % 256 || !n_floats || !tile_blocks || !row128_block) {
+        g_create_error = "vad_debug_pack_resample: n_in must be a positive multiple of 256";
+        return VAD_ERR_INVALID_ARG;
+    }
+    std::vector<float> packed;
+    std::string perr;
+    *tile_blocks = vadk::pack_resample_operator(n_in, packed, row128_block, perr);
+    if (*tile_blocks == 0) {
+        g_create_error = perr;
+        return VAD_ERR_INVALID_ARG;
+    }
+    *n_floats = packed.size();
+    if (out) {
+        if (out_floats < packed.size()) {
+            g_create_error = "vad_debug_pack_resample: output buffer too small";
+            return VAD_ERR_INVALID_ARG;
+        }
+        std::memcpy(out, packed.data(), packed.size() * sizeof(float));
+    }
+    return VAD_OK;
+}
+
 int vad_debug_pack_weights(int32_t model_version, const void *weights, size_t weights_len, float *out,
                            size_t out_floats, size_t *n_floats, uint32_t *sect_out) {
     g_create_error.clear();

@@ -213,6 +213,14 @@ VAD_API int vad_debug_pack_weights(int32_t model_version, const void *weights, s
 VAD_API int vad_debug_resample_operator(int32_t n_in, float *R, size_t r_floats);
 
 /*
+ * Diagnostic (no GPU needed): the folded, MFMA-packed form of that operator exactly as the kernel
+ * streams it (csrc/pack_weights.cpp: pack_resample_operator).  out may be NULL to query n_floats.
+ * tile_blocks = 1 KiB blocks per 32-row tile, row128_block = first block of the VALU row.
+ */
+VAD_API int vad_debug_pack_resample(int32_t n_in, float *out, size_t out_floats, size_t *n_floats,
+                                    uint32_t *tile_blocks, uint32_t *row128_block);
+
+/*
  * Diagnostic: replay a scripted probability sequence through ONE slot's device-side state
  * machine (the code path vad_step_events runs after the model).  probs [n] -> events_out [n],
  * seg_frames_out [n] (segment length in frames on END, else 0).  Lets the GPU test-suite check

@@ -462,3 +462,51 @@ def v4_step(W, sect, x, hc, gate=0.01):
             RX[152:168] = hn_all.T.reshape(32, 16, 4).transpose(1, 0, 2)
     prob = sig(z + W[oh][0, 0])
     return prob.astype(np.float32), new.astype(np.float32)
+
+
+def resample_512(x):
+    """NumPy model of ``vadk_resample_512`` (csrc/resample.hip): the four folded inputs, the packed operator stream read
+    block by block as the waves read it, the rank-1 accumulator init, the VALU row and the epilogue's recombination.
+    x [n <= 32, n_in] -> y [n, 512] (float64 arithmetic)."""
+    lib = _ffi.lib()
+    n, n_in = x.shape
+    nf, tb, r128 = C.c_size_t(), C.c_uint32(), C.c_uint32()
+    assert lib.vad_debug_pack_resample(n_in, None, 0, C.byref(nf), C.byref(tb), C.byref(r128)) == 0
+    flat = np.empty(nf.value, np.float32)
+    assert lib.vad_debug_pack_resample(n_in, flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size, C.byref(nf), C.byref(tb),
+                                       C.byref(r128)) == 0
+    W = flat.reshape(-1, 64, 4)
+    tb, r128 = tb.value, r128.value
+    Q, H = n_in // 4, n_in // 2
+    xs = np.zeros((MT, n_in))
+    xs[:n] = x
+    # store_chunk: folded quads, j = 4q + e
+    j = np.arange(Q)
+    a, c = xs[:, j], xs[:, j + H]
+    b, d = xs[:, (H - j) % n_in], xs[:, (n_in - j) % n_in]
+    pe, me, qe, qo = a + c, a - c, b + d, b - d
+    ops = [pe + qe, pe - qe, me + qo, me - qo]                  # ue, ve, uo, vo  [32, Q]
+    ops[0][:, 0], ops[1][:, 0], ops[2][:, 0], ops[3][:, 0] = pe[:, 0], 0.0, 0.0, me[:, 0]
+    quads = [o.reshape(MT, Q // 4, 4).transpose(1, 0, 2) for o in ops]      # [quad row][m][4]
+    mids = [xs[:, Q] + xs[:, 3 * Q], xs[:, Q] - xs[:, 3 * Q]]
+    y = np.zeros((MT, 512))
+    for rt in range(4):
+        base = rt * tb
+        acc = [np.outer(_vec(W[base:base + 4]), mids[0]), np.zeros((32, MT)),
+               np.outer(_vec(W[base + 4:base + 8]), mids[1]), np.zeros((32, MT))]
+        for kj in range(Q // 8):
+            for p in range(4):
+                acc[p] += _mfma4(W[base + 8 + 4 * kj + p], _rows(quads[p], 2 * kj, 2 * kj + 1))
+        se, ae, so, ao = acc
+        for r in range(32):
+            o = 32 * rt + r
+            y[:, o] = se[r] + ae[r] + so[r] + ao[r]
+            y[:, o + 256] = se[r] + ae[r] - so[r] - ao[r]
+            if o:
+                y[:, 256 - o] = se[r] - ae[r] + so[r] - ao[r]
+                y[:, 512 - o] = se[r] - ae[r] - so[r] + ao[r]
+    row = W[r128:].reshape(-1)
+    e = ops[0] @ row[:Q].astype(np.float64) + row[2 * Q] * mids[0]
+    od = ops[2] @ row[Q:2 * Q].astype(np.float64) + row[2 * Q + 1] * mids[1]
+    y[:, 128], y[:, 384] = e + od, e - od
+    return y[:n]

@@ -150,6 +150,20 @@ def test_resample_operator_matches_scipy_and_reference_fixture():
     assert lib.vad_debug_resample_operator(100, None, 0) == _ffi.VAD_ERR_INVALID_ARG
 
 
+def test_folded_resample_stream_reproduces_scipy():
+    """The kernel's folded contraction, evaluated in NumPy from the packed operator stream alone (tests/kernel_model.py),
+    equals scipy.signal.resample: guards the packer's layout and the fold algebra without a GPU."""
+    import scipy.signal
+    from tests import kernel_model
+    for n_in in (256, 768, 1536):
+        x = (0.5 * np.random.default_rng(n_in).standard_normal((7, n_in))).astype(np.float32)
+        got = kernel_model.resample_512(x.astype(np.float64))
+        ref = scipy.signal.resample(x.astype(np.float64), 512, axis=1)
+        assert np.abs(got - ref).max() <= 1e-6, n_in
+    nf, tb, r128 = C.c_size_t(), C.c_uint32(), C.c_uint32()
+    assert _ffi.lib().vad_debug_pack_resample(100, None, 0, C.byref(nf), C.byref(tb), C.byref(r128)) == _ffi.VAD_ERR_INVALID_ARG
+
+
 def test_packed_layout_reproduces_the_oracle_v4():
     """NumPy model of the two V4 launches over the packed streams == oracle."""
     from oracle import oracle
