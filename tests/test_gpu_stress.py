@@ -88,3 +88,55 @@ def test_random_api_sequence_matches_per_stream_oracle(version):
         with pytest.raises((VADError, Exception)):
             eng.step([gone], np.zeros((1, 512), np.float32))
         assert eng.info()["open_streams"] == len(slot_of)
+
+
+@pytest.mark.parametrize("version", [5, 4])
+def test_concurrent_callers_on_one_engine_match_a_serial_run(version):
+    """SURVEY §8b threading: the entry points are thread-safe per engine, a slot is stepped by one caller at a time.
+    Six threads step disjoint slot groups of ONE engine (host-pointer API, both staging paths by group size) while a
+    seventh keeps resampling on the same engine; every group must reproduce, bit for bit, what a serial run produces."""
+    import threading
+    from cutter_vad_amd.engine import Engine
+    with open(weights_io.packaged_blob_path(version), "rb") as f:
+        blob = f.read()
+    sizes = [1, 7, 32, 33, 200, 700]
+    T = 12
+    audio = [make_streams(n, T, seed=50 + i) for i, n in enumerate(sizes)]
+    with Engine(blob, model_version=version, max_streams=sum(sizes)) as eng:
+        groups = [eng.open_streams(n) for n in sizes]
+        serial = [np.stack([eng.step(g, a[:, t]) for t in range(T)], axis=1) for g, a in zip(groups, audio)]
+        states = [eng.get_state(int(g[-1])) for g in groups]
+        for g in groups:
+            eng.reset(g)
+        got = [None] * len(sizes)
+        errors = []
+        stop = threading.Event()
+
+        def worker(i):
+            try:
+                got[i] = np.stack([eng.step(groups[i], audio[i][:, t]) for t in range(T)], axis=1)
+            except Exception as e:  # pragma: no cover
+                errors.append(e)
+
+        def resampler():
+            x = (0.1 * np.random.default_rng(9).standard_normal((40, 768))).astype(np.float32)
+            first = eng.resample(x, 24000)
+            try:
+                while not stop.is_set():
+                    assert np.array_equal(eng.resample(x, 24000), first)
+            except Exception as e:  # pragma: no cover
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(sizes))]
+        side = threading.Thread(target=resampler)
+        side.start()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        stop.set()
+        side.join()
+        assert not errors, errors
+        for i in range(len(sizes)):
+            assert np.array_equal(got[i], serial[i]), sizes[i]
+            assert np.array_equal(eng.get_state(int(groups[i][-1])), states[i])
