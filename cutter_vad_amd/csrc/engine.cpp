@@ -54,7 +54,6 @@ struct vad_engine {
     size_t wbytes = 0;
     float *d_state = nullptr;
     vadk::SmSlot *d_sm = nullptr;
-    float *d_scratch = nullptr;   // V4: |STFT| hand-off between the two launches of a frame
     // staging for the host-pointer entry points (grown on demand)
     void *d_frames = nullptr;  size_t d_frames_cap = 0;
     float *d_probs = nullptr;  size_t d_probs_cap = 0;
@@ -312,12 +311,6 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
         if ((r = hipMemcpy(e->d_sm, init.data(), sizeof(vadk::SmSlot) * init.size(), hipMemcpyHostToDevice)) != hipSuccess)
             return bail(r, "hipMemcpy(sm)");
     }
-    if (e->version == 4) {
-        const size_t tiles = ((size_t)e->max_streams + vadk::MT - 1) / vadk::MT;
-        if ((r = hipMalloc((void **)&e->d_scratch, tiles * vadk::v4::SCRATCH_F4_PER_TILE * 16)) != hipSuccess)
-            return bail(r, "hipMalloc(v4 scratch)");
-        e->base.scratch = e->d_scratch;
-    }
     e->base.wstream = e->d_wstream;
     e->base.wstream_bytes = (uint32_t)e->wbytes;
     std::memcpy(e->base.sect, pw.sect, sizeof pw.sect);
@@ -336,7 +329,7 @@ void vad_engine_destroy(vad_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void *bufs[] = {e->d_wstream, e->d_state, e->d_sm, e->d_scratch, e->d_frames, e->d_probs, e->d_events, e->d_seg, e->d_slots,
+    void *bufs[] = {e->d_wstream, e->d_state, e->d_sm, e->d_frames, e->d_probs, e->d_events, e->d_seg, e->d_slots,
                     e->d_rs_in, e->d_rs_out, e->d_small_in, e->d_small_out};
     for (void *b : bufs)
         if (b) (void)hipFree(b);

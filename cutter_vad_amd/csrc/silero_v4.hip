@@ -3,12 +3,14 @@
 // Replaces `session.run` on silero_vad.onnx's 16 kHz branch for a batch of independent streams
 // (reference call site: /root/reference/src/real_time_vad/core/silero_model.py:433 with the feeds
 // of :494-499; dataflow: SURVEY.md §8 a8), plus the per-frame pre-steps and the state machine, as
-// in silero_v5.hip.  Two launches per frame (vad_layout.h explains why):
+// in silero_v5.hip.  One launch per frame, two parts that time-share the CU's LDS (vad_layout.h has the two layouts):
 //
-//   silero_v4_stft : load + gate + reflect-pad(96,96) + window + 4-way fold -> 8-column DFT (MFMA, K = 64) -> |.|
-//                    -> global scratch [tile][8][33 quads][32 streams]
-//   silero_v4_tail : log(1 + |X| 2^20), adaptive normalisation, first layer (dw k5 + pw + proj),
-//                    1x1 stride convs, 3 separable blocks, LSTM(64) x 2, head, state machine
+//   STFT part : load + gate + reflect-pad(96,96) + window + 4-way fold -> 8-column DFT (MFMA, K = 64) -> |.|, kept in
+//               REGISTERS (128 per lane: the 258 x 8 first-layer input of 32 streams does not fit LDS next to the STFT
+//               operands, but one wave per SIMD owns 512 registers)
+//   tail      : the magnitudes move into LDS once the STFT operands are dead, then log(1 + |X| 2^20), adaptive
+//               normalisation, first layer (dw k5 + pw + proj), 1x1 stride convs, 3 separable blocks, LSTM(64) x 2,
+//               head, state machine
 //
 // Same conventions as the V5 kernel: 32 streams per workgroup, weights on the MFMA A operand,
 // activations as LDS quads on the B operand, packed per-wave weight streams read through one
@@ -21,7 +23,7 @@
 using namespace vadk;
 using namespace vadk::dev;
 
-// -DVADK_STAMPS (tools/kbench4.cpp): s_memtime at phase boundaries, [block][wave][32]; stft uses 0..15, tail 16..31
+// -DVADK_STAMPS (tools/kbench4.cpp): s_memtime at phase boundaries, [block][wave][32]; the STFT part uses 0..15, the tail 16..31
 #ifdef VADK_STAMPS
 #define STAMP(k)                                                                                   \
     do {                                                                                           \
@@ -33,14 +35,36 @@ using namespace vadk::dev;
 
 namespace {
 
+// one "thin" MFMA group: 4 k-iterations = 4 weight blocks x 4 activation quads -> 16 MFMAs on one accumulator
+#define TG_MMA(acc, w0, w1, w2, w3, a0, a1, a2, a3) \
+    acc = mfma4(w0, a0, acc); acc = mfma4(w1, a1, acc); acc = mfma4(w2, a2, acc); acc = mfma4(w3, a3, acc);
+
+__device__ __forceinline__ f32x4 ldt(__amdgpu_buffer_rsrc_t rs, int row, int blk) {   // table row (float4) of a VALU table
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, row * 16, blk * 1024, 0));
+}
+
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) {
+    return f32x4{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
+}
+
+__device__ __forceinline__ float log1p20(float mag) {   // log(1 + mag * 2^20): Mul, Add, Log of the graph
+    return __builtin_amdgcn_logf(1.0f + mag * 1048576.0f) * 0.69314718055994531f;
+}
+// the same minus the adaptive-normalisation mean: Sub of the graph
+__device__ __forceinline__ float lognorm(float mag, float mm) { return log1p20(mag) - mm; }
+
 }  // namespace
 
-// =====================================================================================================
-//  launch 1: STFT magnitudes
-// =====================================================================================================
-extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const StepParams P, const int tframe) {
+// K8: the graph's 8 kHz sub-model (else-branch, taken for every sr != 16000; SURVEY a9): identical up to block 2, then
+// the third stride conv has stride 1 (Conv_632), so TWO columns go through block 3 and the last 1x1 conv, the LSTMs run
+// two sequential time steps and the probability is the mean of the two sigmoids (ReduceMean over T).
+template <bool K8>
+__global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P, const int tframe) {
     using namespace vadk::v4;
-    __shared__ f32x4 lds[K1_LDS_F4];
+    __shared__ f32x4 lds[V4_LDS_F4];
+    // =================================================================================================
+    //  STFT part
+    // =================================================================================================
     // xp = reflect-pad(x, 96, 96) (numpy 'reflect'), materialised once per frame: [32 streams][176 quads].  x sits at
     // quads 24..151 (aligned: 96 = 4 * 24); the two 24-quad edges are mirrored from it after the load.  The fold then
     // reads plain quads (a branchy on-the-fly reflection serialised ~100 dependent LDS reads per group).
@@ -60,7 +84,19 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wstream), 0, (int)P.wstream_bytes, 0x00020000);
     const int lane16 = lane * 16;
     const int o_stft = (int)P.sect[w][S_STFT];
-    f32x4 *const scratch = reinterpret_cast<f32x4 *>(P.scratch) + (size_t)blockIdx.x * SCRATCH_F4_PER_TILE;
+
+    // the tail's view of the same LDS (second layout) and its per-lane constants
+    f32x4 *const RX = lds;
+    float *const misc = reinterpret_cast<float *>(lds + K2_ROWS * QS);
+    float *const mmv = misc;                 // [32]  mean_mean per stream
+    float *const colmean = misc + 32;        // [8][32]
+    float *const headp = misc + 32 + 256;    // [2][32]
+    float *const colpart = misc + K2_MISC_FLOATS;   // [4 waves][8 columns][32 streams]: partial log sums
+    const int gf = tile0 + m;
+    const bool live = gf < P.n;
+    const int slot = live ? (P.slots ? P.slots[gf] : gf) : 0;
+#define WL(blk) ldw(wrs, lane16, (blk))
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
     STAMP(0);
     // ---- raw frame -> LDS (gate + int16 scaling fused), lanes run along the frame ---------------
@@ -121,13 +157,52 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
     __syncthreads();
     STAMP(1);
 
+    // ---- early requests: everything that comes from HBM and is needed late is asked for now,
+    //      while the frame is being folded: the slot's state machine
+    //      (-> LDS, past both layouts), c_{t-1} of both LSTM layers (registers), head weights
+    SmSlot *const smL = reinterpret_cast<SmSlot *>(lds + V4_SM_F4);
+    const bool sm_thread = tid < MT && tile0 + tid < P.n;
+    const int sm_slot = sm_thread ? (P.slots ? P.slots[tile0 + tid] : tile0 + tid) : 0;
+    if (sm_thread) smL[tid] = P.sm[sm_slot];
+    const int u = w & 1;                           // output tile of the 64-channel phases P8 / P9
+    f32x4 cprev[2][2], hwq[2];                     // LSTM: wave w owns units 16w .. 16w+15; a lane holds 8 of them (2 quads)
+    {
+        const float *st = P.state + (size_t)slot * 256;
+        int oh = (int)P.sect[w][S_HEADB];
+        asm volatile("" : "+s"(oh));
+#pragma unroll
+        for (int layer = 0; layer < 2; ++layer)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(st + 128 + 64 * layer + 16 * w + 8 * e + 4 * h);
+                cprev[layer][e] = live ? v : zero4;
+            }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) hwq[e] = WL(oh + 1 + 4 * (w >> 1) + 2 * (w & 1) + e);
+    }
+    f32x4 hprev[4];                                // h_{t-1} of both layers, stream tid & 31, quads 4 (tid >> 5) .. + 3
+    {
+        const int g2 = tile0 + (tid & 31);
+        const bool ok = g2 < P.n;
+        const int s2 = ok ? (P.slots ? P.slots[g2] : g2) : 0;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const f32x4 v = reinterpret_cast<const f32x4 *>(P.state + (size_t)s2 * 256)[(tid >> 5) * 4 + qq];
+            hprev[qq] = ok ? v : zero4;
+        }
+    }
+    const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];
+
+
     // window of the stored basis (its k = 0 cosine row): w[n] and w[128 + n] = w[128 - n] for this lane's n = 4q .. 4q + 3
     const int fq = tid & 15;
     const int o_win = (int)P.sect[w][S_NYQ];
     const f32x4 W1 = ldw(wrs, fq * 16, o_win), W3 = ldw(wrs, (32 + fq) * 16, o_win);
     const float w64 = ldw(wrs, 16 * 16, o_win).x;                 // w[64] = w[192]
 
-#pragma unroll 1
+    f32x4 mg[8][4];                                  // |X| of this wave's 32 bins, 8 columns: register 4g+i = bin row 8g+4h+i
+    float nyq[4];                                    // threads < 64: |X[128]| of column 2 grp + h, stream m
+#pragma unroll
     for (int grp = 0; grp < 4; ++grp) {              // STFT columns 2 grp, 2 grp + 1 (hop 64 on the padded frame)
         int ws = o_stft;
         asm volatile("" : "+s"(ws));
@@ -224,131 +299,50 @@ extern "C" __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_stft(const S
 #undef K1_MMA
         }
         if (grp == 0) STAMP(4);
-        // ---- magnitudes -> global scratch, row (33 t + quad), 32 float4 per row
+        // ---- magnitudes: kept in registers until the STFT operands in LDS are dead
 #pragma unroll
         for (int cp = 0; cp < 2; ++cp) {
-            const int tcol = 2 * grp + cp;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 r = quad_of(are[cp], g), i = quad_of(aim[cp], g);
-                scratch[(size_t)(MAG_Q * tcol + 8 * w + 2 * g + h) * 32 + m] =
-                    f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
+                mg[2 * grp + cp][g] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
             }
         }
         if (grp == 0) STAMP(5);
         __syncthreads();       // nyqv complete; every wave done with UV / fcor before the next fold overwrites them
         if (grp == 0) STAMP(6);
         if (grp == 3) STAMP(7);
-        if (tid < 64) scratch[(size_t)(MAG_Q * (2 * grp + h) + 32) * 32 + m] = f32x4{nyqv[h * 32 + m], 0.f, 0.f, 0.f};
+        nyq[grp] = nyqv[(tid < 64 ? h : 0) * 32 + m];
     }
-}
 
-// =====================================================================================================
-//  launch 2: everything after the STFT
-// =====================================================================================================
-namespace {
 
-// one "thin" MFMA group: 4 k-iterations = 4 weight blocks x 4 activation quads -> 16 MFMAs on one accumulator
-#define TG_MMA(acc, w0, w1, w2, w3, a0, a1, a2, a3) \
-    acc = mfma4(w0, a0, acc); acc = mfma4(w1, a1, acc); acc = mfma4(w2, a2, acc); acc = mfma4(w3, a3, acc);
-
-__device__ __forceinline__ f32x4 ldt(__amdgpu_buffer_rsrc_t rs, int row, int blk) {   // table row (float4) of a VALU table
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, row * 16, blk * 1024, 0));
-}
-
-__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) {
-    return f32x4{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
-}
-
-__device__ __forceinline__ float log1p20(float mag) {   // log(1 + mag * 2^20): Mul, Add, Log of the graph
-    return __builtin_amdgcn_logf(1.0f + mag * 1048576.0f) * 0.69314718055994531f;
-}
-// the same minus the adaptive-normalisation mean: Sub of the graph
-__device__ __forceinline__ float lognorm(float mag, float mm) { return log1p20(mag) - mm; }
-
-}  // namespace
-
-// K8: the graph's 8 kHz sub-model (else-branch, taken for every sr != 16000; SURVEY a9): identical up to block 2, then
-// the third stride conv has stride 1 (Conv_632), so TWO columns go through block 3 and the last 1x1 conv, the LSTMs run
-// two sequential time steps and the probability is the mean of the two sigmoids (ReduceMean over T).
-template <bool K8>
-__global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P, const int tframe) {
-    using namespace vadk::v4;
-    __shared__ f32x4 lds[K2_LDS_F4];
-    f32x4 *const RX = lds;
-    float *const misc = reinterpret_cast<float *>(lds + K2_ROWS * QS);
-    float *const mmv = misc;                 // [32]  mean_mean per stream
-    float *const colmean = misc + 32;        // [8][32]
-    float *const headp = misc + 32 + 256;    // [2][32]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = lane & 31, h = lane >> 5;
-    const int hq = h * QS + m;
-    const int tile0 = blockIdx.x * MT;
-    const int gf = tile0 + m;
-    const bool live = gf < P.n;
-    const int slot = live ? (P.slots ? P.slots[gf] : gf) : 0;
-    const int T = P.T;
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wstream), 0, (int)P.wstream_bytes, 0x00020000);
-    const int lane16 = lane * 16;
-#define WL(blk) ldw(wrs, lane16, (blk))
-    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 *const scratch = reinterpret_cast<const f32x4 *>(P.scratch) + (size_t)blockIdx.x * SCRATCH_F4_PER_TILE;
-
+    // =================================================================================================
+    //  tail: the LDS is re-used with the second layout from here on (every wave is past the last group's barrier)
+    // =================================================================================================
     STAMP(16);
-    // ---- early requests: everything that comes from HBM and is needed late is asked for now, under the 135 KB
-    //      magnitude load: the slot's state machine (-> LDS), c_{t-1} of both LSTM layers (registers), head weights
-    SmSlot *const smL = reinterpret_cast<SmSlot *>(misc + K2_MISC_FLOATS);
-    const bool sm_thread = tid < MT && tile0 + tid < P.n;
-    const int sm_slot = sm_thread ? (P.slots ? P.slots[tile0 + tid] : tile0 + tid) : 0;
-    if (sm_thread) smL[tid] = P.sm[sm_slot];
-    const int u = w & 1;                           // output tile of the 64-channel phases P8 / P9
-    f32x4 cprev[2][2], hwq[2];                     // LSTM: wave w owns units 16w .. 16w+15; a lane holds 8 of them (2 quads)
-    {
-        const float *st = P.state + (size_t)slot * 256;
-        int oh = (int)P.sect[w][S_HEADB];
-        asm volatile("" : "+s"(oh));
+    // ---- P0 + P1: magnitudes registers -> LDS rows (33 t + q), and the per-column mean of the log-spectrum on the way:
+    //      a lane sums the logs of its 16 bins per column, the two half-waves meet in a shuffle, the four waves in LDS
 #pragma unroll
-        for (int layer = 0; layer < 2; ++layer)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(st + 128 + 64 * layer + 16 * w + 8 * e + 4 * h);
-                cprev[layer][e] = live ? v : zero4;
-            }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) hwq[e] = WL(oh + 1 + 4 * (w >> 1) + 2 * (w & 1) + e);
-    }
-    f32x4 hprev[4];                                // h_{t-1} of both layers, stream tid & 31, quads 4 (tid >> 5) .. + 3
-    {
-        const int g2 = tile0 + (tid & 31);
-        const bool ok = g2 < P.n;
-        const int s2 = ok ? (P.slots ? P.slots[g2] : g2) : 0;
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const f32x4 v = reinterpret_cast<const f32x4 *>(P.state + (size_t)s2 * 256)[(tid >> 5) * 4 + qq];
-            hprev[qq] = ok ? v : zero4;
-        }
-    }
-    const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];
-
-    // ---- P0 + P1: magnitudes scratch -> LDS rows (33 t + q), and the per-column mean of the log-spectrum on the way:
-    //      thread = (column tc, stream ms) requests its 33 quads at once and takes the logs as they arrive - the hand-off
-    //      is HBM-bandwidth-bound (34.6 MB per step for 8 192 streams), the quarter-rate v_log_f32 work hides under it
-    {
-        const int ms = tid & 31, tc = tid >> 5;
-        f32x4 mv[33];
-#pragma unroll
-        for (int q = 0; q < 33; ++q) mv[q] = scratch[(MAG_Q * tc + q) * 32 + ms];
+    for (int tc = 0; tc < 8; ++tc) {
         float s = 0.f;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            RX[(MAG_Q * tc + q) * QS + ms] = mv[q];
-            s += (log1p20(mv[q].x) + log1p20(mv[q].y)) + (log1p20(mv[q].z) + log1p20(mv[q].w));
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = mg[tc][g];
+            RX[(MAG_Q * tc + 8 * w + 2 * g + h) * QS + m] = v;
+            s += (log1p20(v.x) + log1p20(v.y)) + (log1p20(v.z) + log1p20(v.w));
         }
-        RX[(MAG_Q * tc + 32) * QS + ms] = mv[32];
-        s += log1p20(mv[32].x);
+        s += __shfl_xor(s, 32);
+        if (h == 0) colpart[(w * 8 + tc) * 32 + m] = s;
+    }
+    if (tid < 64) {
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) RX[(MAG_Q * (2 * grp + h) + 32) * QS + m] = f32x4{nyq[grp], 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    {
+        const int ms = tid & 31, tc = tid >> 5;
+        const float s = ((colpart[tc * 32 + ms] + colpart[(8 + tc) * 32 + ms]) + (colpart[(16 + tc) * 32 + ms] + colpart[(24 + tc) * 32 + ms])) +
+                        log1p20(RX[(MAG_Q * tc + 32) * QS + ms].x);
         colmean[tc * 32 + ms] = s * (1.0f / 129.0f);
     }
     STAMP(17);
@@ -717,16 +711,15 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_tail(const StepParams P
     }
 }
 
-// host-callable launcher: the T frames of a call run as 2 T launches on one stream (state lives in HBM between them)
+// host-callable launcher: the T frames of a call run as T launches on one stream (state lives in HBM between them)
 extern "C" hipError_t vadk_launch_silero_v4(const vadk::StepParams *p, hipStream_t stream) {
     const int tiles = (p->n + vadk::MT - 1) / vadk::MT;
     if (tiles <= 0) return hipSuccess;
     for (int t = 0; t < p->T; ++t) {
-        hipLaunchKernelGGL(silero_v4_stft, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, t);
         if (p->variant == 1)
-            hipLaunchKernelGGL(silero_v4_tail<true>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, t);
+            hipLaunchKernelGGL(silero_v4_step<true>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, t);
         else
-            hipLaunchKernelGGL(silero_v4_tail<false>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, t);
+            hipLaunchKernelGGL(silero_v4_step<false>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, t);
     }
     return hipGetLastError();
 }

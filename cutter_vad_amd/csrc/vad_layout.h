@@ -77,10 +77,10 @@ constexpr int LDS_BYTES = LDS_F4 * 16;
 }  // namespace v5
 
 // ---- Silero V4 (16 kHz branch) -------------------------------------------------------
-// Two launches per frame (the 258 x 8 first-layer input of 32 streams does not fit one CU's LDS next
-// to the STFT operands):
-//   silero_v4_stft : gate/int16 ingest, reflect pad 96+96, fold, 8-column STFT (MFMA), |.| -> scratch
-//   silero_v4_tail : log-spectrum + adaptive normalisation, 4 separable blocks, 2 x LSTM(64), head, state machine
+// One launch per frame, two LDS layouts in sequence (the 258 x 8 first-layer input of 32 streams does not fit one CU's
+// LDS next to the STFT operands, so the magnitudes wait in registers until those are dead):
+//   STFT part : gate/int16 ingest, reflect pad 96+96, fold, 8-column STFT (MFMA), |.| -> registers
+//   tail      : log-spectrum + adaptive normalisation, 4 separable blocks, 2 x LSTM(64), head, state machine
 namespace v4 {
 enum Section {
     S_STFT = 0, S_NYQ,            // as V5 (the DFT basis is identical): folded-DFT tables, window table
@@ -90,14 +90,13 @@ enum Section {
 };
 constexpr int MAG_Q = 33;                      // quads per STFT column: 128 bins + Nyquist (+3 pad channels)
 constexpr int MAG_ROWS = 8 * MAG_Q;            // 264 rows per tile, row = 33 t + q
-constexpr int SCRATCH_F4_PER_TILE = MAG_ROWS * 32;   // global scratch uses 32 float4 per row (no padding)
-// silero_v4_stft LDS: reflect-padded frame [32][704] f32 + the 4-way fold of two columns (2 x 64 quad rows: pe, po, qe, qo as in
+// STFT part, LDS: reflect-padded frame [32][704] f32 + the 4-way fold of two columns (2 x 64 quad rows: pe, po, qe, qo as in
 // V5) + Nyquist magnitudes [2][32] + fold corrections [2][3][32]
 constexpr int K1_XP_QUADS = 176;               // reflect-padded frame: 704 samples per stream
 constexpr int K1_XS_F4 = 32 * K1_XP_QUADS;
 constexpr int K1_UV_ROWS = 128;
 constexpr int K1_LDS_F4 = K1_XS_F4 + K1_UV_ROWS * QS + 16 + 48;
-// silero_v4_tail LDS rows
+// tail, LDS rows
 constexpr int R_A16 = MAG_ROWS;                // first-layer output: 264 + 4 t' + quad
 constexpr int K2_ROWS = MAG_ROWS + 16;
 constexpr int R_Y0 = 0, R_Y1 = 16, R_Y2 = 48, R_Y3 = 64, R_Y4 = 80, R_Y5 = 88, R_Y6 = 104;
@@ -105,7 +104,10 @@ constexpr int R_H0 = 120, R_H1 = 136, R_H0N = 152, R_GP = 168;   // gate partial
 constexpr int K2_MISC_FLOATS = 32 + 8 * 32 + 256;  // mm[32], colmean[8][32], head partials [2 steps][4 waves][32]
 // 8 kHz sub-model: two columns survive the third stride conv (stride 1); rows re-used from dead activations
 constexpr int R8_Y4 = 80, R8_Y5 = 0, R8_Y6 = 32, R_H1N = 96;
-constexpr int K2_LDS_F4 = K2_ROWS * QS + K2_MISC_FLOATS / 4 + 192;   // + the tile's 32 state machines (96 B each)
+constexpr int K2_LDS_F4 = K2_ROWS * QS + K2_MISC_FLOATS / 4 + 256;   // + partial log sums [4 waves][8 columns][32 streams]
+constexpr int V4_SM_F4 = K1_LDS_F4 > K2_LDS_F4 ? K1_LDS_F4 : K2_LDS_F4;   // the tile's 32 state machines (96 B each) sit past both layouts
+constexpr int V4_LDS_F4 = V4_SM_F4 + 192;
+static_assert(V4_LDS_F4 * 16 <= 160 * 1024, "V4 LDS layout exceeds one CU");
 }  // namespace v4
 
 // per-slot hysteresis state (VADProcessor fields, core/silero_model.py:596-639), 96 bytes.
@@ -140,7 +142,7 @@ struct StepParams {
     int32_t fmt;                   // vad_frame_format
     float thresh;                  // denoise gate, < 0 = off
     int32_t variant;               // V4 only: 1 = 8 kHz sub-model (pack_weights.h)
-    float *scratch;                // V4 only: |STFT| hand-off between the two launches, [tiles][264][32] float4
+    float *scratch;                // unused (was the V4 hand-off buffer); kept so that the struct layout is stable
 #ifdef VADK_STAMPS
     unsigned long long *stamps;    // diagnostic builds only (tools/kbench.cpp): [block][wave][16] s_memtime stamps
 #endif

@@ -42,13 +42,12 @@ int main(int argc, char **argv) {
     if (!vadk::pack_silero_v4(blob.data(), blob.size(), pw, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     const int tiles = (B + vadk::MT - 1) / vadk::MT;
     vadk::StepParams p{};
-    float *d_w, *d_state, *d_frames, *d_probs, *d_scratch;
+    float *d_w, *d_state, *d_frames, *d_probs;
     vadk::SmSlot *d_sm;
     CK(hipMalloc(&d_w, pw.data.size() * 4));
     CK(hipMemcpy(d_w, pw.data.data(), pw.data.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_state, (size_t)B * 256 * 4));
     CK(hipMemset(d_state, 0, (size_t)B * 256 * 4));
-    CK(hipMalloc(&d_scratch, (size_t)tiles * vadk::v4::SCRATCH_F4_PER_TILE * 16));
     std::vector<vadk::SmSlot> sm(B);
     for (auto &s : sm) { memset(&s, 0, sizeof s); s.start_prob = s.end_prob = 0.7; s.start_ratio = 0.8; s.end_ratio = 0.95; s.start_count = 10; s.end_count = 50; s.seg_frames = -1; }
     CK(hipMalloc(&d_sm, sizeof(vadk::SmSlot) * B));
@@ -66,7 +65,6 @@ int main(int argc, char **argv) {
     memcpy(p.sect, pw.sect, sizeof pw.sect);
     p.variant = pw.variant;
     p.state = d_state; p.sm = d_sm; p.slots = nullptr; p.probs = d_probs; p.events = nullptr; p.seg_frames = nullptr;
-    p.scratch = d_scratch;
     p.n = B; p.T = 1; p.fmt = 0; p.thresh = 0.01f;
 #ifdef VADK_STAMPS
     unsigned long long *d_st;
