@@ -414,15 +414,23 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P
         _Pragma("unroll") for (int k = 0; k < 4; ++k) lw[k] = WL(ob_ + 8 + k);                    \
     }
 
-    // ---- P2: first layer; wave w produces output column t' = w (input column t = 2w), 16 channels ---------
+    // ---- P2: first layer, all four kept output columns t' (input column t = 2 t') in every wave, K split over the waves:
+    //      wave w contracts the channel-quad pairs j = w, w + 4, ..  (17 k-iterations: wave 0 takes five, the others four).
+    //      The log-spectrum of a (channel quad, column) is evaluated once per k-iteration and serves the five taps of every
+    //      output column (a column split makes each wave re-evaluate its neighbours' columns: 340 quarter-rate logs per
+    //      lane instead of 160).  The four partial tiles per column meet in LDS once the magnitude rows are dead.
     {
-        const int tcol = 2 * w;
         int o_dw0 = (int)P.sect[w][S_DW0], o_l0 = (int)P.sect[w][S_L0];
         asm volatile("" : "+s"(o_dw0), "+s"(o_l0));
-        f32x16 acc = acc_of(WL(o_l0), WL(o_l0 + 1), WL(o_l0 + 2), WL(o_l0 + 3));
+        f32x16 acc[4];
+        {
+            const f32x4 b0 = WL(o_l0), b1 = WL(o_l0 + 1), b2 = WL(o_l0 + 2), b3 = WL(o_l0 + 3);
+            acc[0] = w == 0 ? acc_of(b0, b1, b2, b3) : acc_of(zero4, zero4, zero4, zero4);     // the bias enters once
+            acc[1] = acc[0]; acc[2] = acc[0]; acc[3] = acc[0];
+        }
         const int ws = o_l0 + 4;
         const float mm = mmv[m];
-        f32x4 Wa = WL(ws), Wb = WL(ws + 1), Wc = WL(ws + 2), Wd = WL(ws + 3);
+        f32x4 Wa = WL(ws + 4 * w), Wb = WL(ws + 4 * w + 1), Wc = WL(ws + 4 * w + 2), Wd = WL(ws + 4 * w + 3);
         // depthwise taps + bias of this lane's channel quad for one k-iteration: 12 table rows, requested one iteration
         // ahead (they come from L2: consumed in the iteration that asks for them they cost a round trip each time)
         f32x4 tb[12], nt[12];
@@ -435,49 +443,64 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P
             T[3 + 2 * k] = ldt(wrs, (34 + q_) * 6 + k, o_dw0);                             \
         }                                                                                  \
     }
-        P2_TABLES(tb, 0)
+        P2_TABLES(tb, w)
         // weights of the next phases (P3, P4, P5): they do not depend on LDS and land during this loop
         PRE_A
         // one k-iteration: channel quad q = 2 j + h of the 34 (129 channels + 7 of padding; the padding's table rows and
         // weight columns are zero, its activations are read from quad 32 so that they are finite)
 #define P2_ITER(TB, NT, jj)                                                                          \
     {                                                                                                \
-        const int j_ = (jj), jn_ = j_ < 16 ? j_ + 1 : 16;                                             \
+        const int j_ = (jj), jn_ = min(j_ + 4, 16);                                                   \
         const int qr = min(2 * j_ + h, 32);                                                           \
         P2_TABLES(NT, jn_)                                                                            \
         const f32x4 nWa = WL(ws + 4 * jn_), nWb = WL(ws + 4 * jn_ + 1), nWc = WL(ws + 4 * jn_ + 2), nWd = WL(ws + 4 * jn_ + 3); \
+        f32x4 mgc[8], spc[8];                                                                         \
+        _Pragma("unroll") for (int tc = 0; tc < 8; ++tc) mgc[tc] = RX[(MAG_Q * tc + qr) * QS + m];    \
         SB();                                                                                         \
-        /* depthwise k5 p2 over the 8 columns, magnitude part and normalised part, + the undelayed x1 quads */ \
-        f32x4 dm = TB[0], dn = TB[1];            /* biases */                                         \
-        f32x4 xm = zero4, xn = zero4;                                                                 \
-        _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                               \
-            const int tc = tcol + k - 2;                                                              \
-            if (tc >= 0 && tc < 8) {             /* wave-uniform */                                   \
-                const f32x4 mg = RX[(MAG_Q * tc + qr) * QS + m];                                      \
-                const f32x4 sp = f32x4{lognorm(mg.x, mm), lognorm(mg.y, mm), lognorm(mg.z, mm), lognorm(mg.w, mm)}; \
-                dm = fma4(TB[2 + 2 * k], mg, dm);                                                     \
-                dn = fma4(TB[3 + 2 * k], sp, dn);                                                     \
-                if (k == 2) { xm = mg; xn = sp; }                                                     \
+        _Pragma("unroll") for (int tc = 0; tc < 8; ++tc)                                              \
+            spc[tc] = f32x4{lognorm(mgc[tc].x, mm), lognorm(mgc[tc].y, mm), lognorm(mgc[tc].z, mm), lognorm(mgc[tc].w, mm)}; \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                               \
+            /* depthwise k5 p2 around input column 2c, magnitude part and normalised part */         \
+            f32x4 dm = TB[0], dn = TB[1];        /* biases */                                         \
+            _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                           \
+                const int tc = 2 * c + k - 2;                                                         \
+                if (tc >= 0 && tc < 8) {                                                              \
+                    dm = fma4(TB[2 + 2 * k], mgc[tc], dm);                                            \
+                    dn = fma4(TB[3 + 2 * k], spc[tc], dn);                                            \
+                }                                                                                     \
             }                                                                                         \
+            dm = relu4(dm);                                                                           \
+            dn = relu4(dn);                                                                           \
+            SB();                                                                                     \
+            /* pw|mag . dm + proj|mag . x1 + pw|norm . dn + proj|norm . x1 (x1 = the undelayed column 2c) */ \
+            TG_MMA(acc[c], Wa, Wb, Wc, Wd, dm, mgc[2 * c], dn, spc[2 * c])                            \
+            SB();                                                                                     \
         }                                                                                             \
-        dm = relu4(dm);                                                                               \
-        dn = relu4(dn);                                                                               \
-        SB();                                                                                         \
-        TG_MMA(acc, Wa, Wb, Wc, Wd, dm, xm, dn, xn)      /* pw|mag . dm + proj|mag . xm + pw|norm . dn + proj|norm . xn */ \
-        SB();                                                                                         \
         Wa = nWa; Wb = nWb; Wc = nWc; Wd = nWd;                                                       \
     }
 #pragma unroll 1
-        for (int j = 0; j < 16; j += 2) {            // two iterations per trip: the table rows ping-pong between tb and nt
+        for (int j = w; j < 16; j += 8) {            // two iterations per trip: the table rows ping-pong between tb and nt
             P2_ITER(tb, nt, j)
-            P2_ITER(nt, tb, j + 1)
+            P2_ITER(nt, tb, j + 4)
         }
-        P2_ITER(tb, nt, 16)
+        if (w == 0) P2_ITER(tb, nt, 16)
 #undef P2_ITER
 #undef P2_TABLES
-        // rows 0..15 of the tile are the 16 channels: registers of g = 0,1
+        STAMP(18);
+        __syncthreads();   // every wave is done with the magnitude rows: they now carry the partial tiles
+        // rows 0..15 of a tile are the 16 channels (registers of g = 0,1): PART[wave][column][channel quad][stream]
 #pragma unroll
-        for (int g = 0; g < 2; ++g) RX[(R_A16 + 4 * w + 2 * g) * QS + hq] = relu4(quad_of(acc, g));
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) RX[((w * 4 + c) * 4 + 2 * g) * QS + hq] = quad_of(acc[c], g);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * NTHREADS + tid;      // (column, channel quad, stream)
+            const int cq = idx >> 5, ms = idx & 31;
+            const f32x4 p0 = RX[cq * QS + ms], p1 = RX[(16 + cq) * QS + ms], p2 = RX[(32 + cq) * QS + ms], p3 = RX[(48 + cq) * QS + ms];
+            RX[(R_A16 + cq) * QS + ms] = relu4((p0 + p1) + (p2 + p3));
+        }
     }
     STAMP(19);
     __syncthreads();   // the magnitude rows are free from here on

@@ -1,7 +1,7 @@
 // Developer micro-benchmark for the V4 kernel pair (not part of the product, not a test).
 //   tools/kbench4.sh [-DVADK_STAMPS] -- <B> <steps> [8k]
 // Times back-to-back steps (2 launches each) with hipEvents; with -DVADK_STAMPS both kernels record s_memtime at their
-// phase boundaries (stft: slots 0..15, tail: slots 16..31) and this program prints the per-phase cycle budget.
+// phase boundaries (STFT part: slots 0..15, tail: slots 16..31) and this program prints the per-phase cycle budget.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -94,18 +94,20 @@ int main(int argc, char **argv) {
     std::vector<unsigned long long> st((size_t)tiles * 4 * 32);
     CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
     auto S = [&](int b, int w, int k) { return st[((size_t)b * 4 + w) * 32 + k]; };
+    // cycles between consecutive stamps that exist (a stamp index that the kernel does not write is skipped)
     for (int w = 0; w < 4; ++w) {
-        printf("wave %d stft:", w);
-        for (int k = 1; k < 16; ++k) {
-            double acc = 0; int cnt = 0;
-            for (int b = 0; b < tiles; ++b) if (S(b, w, k) && S(b, w, k - 1)) { acc += (double)(S(b, w, k) - S(b, w, k - 1)); ++cnt; }
-            if (cnt) printf(" s%d=%.0f", k, acc / cnt);
-        }
-        printf("\nwave %d tail:", w);
-        for (int k = 17; k < 32; ++k) {
-            double acc = 0; int cnt = 0;
-            for (int b = 0; b < tiles; ++b) if (S(b, w, k) && S(b, w, k - 1)) { acc += (double)(S(b, w, k) - S(b, w, k - 1)); ++cnt; }
-            if (cnt) printf(" t%d=%.0f", k - 16, acc / cnt);
+        printf("wave %d:", w);
+        int prev = -1;
+        for (int k = 0; k < 32; ++k) {
+            int have = 0;
+            for (int b = 0; b < tiles; ++b) have += S(b, w, k) != 0;
+            if (!have) continue;
+            if (prev >= 0) {
+                double acc = 0; int cnt = 0;
+                for (int b = 0; b < tiles; ++b) if (S(b, w, k) && S(b, w, prev)) { acc += (double)(S(b, w, k) - S(b, w, prev)); ++cnt; }
+                if (cnt) printf(" %d>%d=%.0f", prev, k, acc / cnt);
+            }
+            prev = k;
         }
         printf("\n");
     }
