@@ -79,6 +79,20 @@ class StreamBuilder {
             for (int i = 0; i < 4; ++i) b[l * 4 + i] = value(np, 8 * j + 4 * hh + i);
         }
     }
+    // 16-row tile for v_mfma_f32_16x16x4_f32: lane l = (row l & 15, k group l >> 4), component i = input channel 16 j + 4 (l >> 4) + i
+    template <class F>
+    void weight_block16(F &&value /* (row r < 16, channel c) -> float */, int j) {
+        float *b = new_block();
+        for (int l = 0; l < 64; ++l)
+            for (int i = 0; i < 4; ++i) b[l * 4 + i] = value(l & 15, 16 * j + 4 * (l >> 4) + i);
+    }
+    // a per-output-channel vector in that tile's D layout: lane (column l & 15, l >> 4) holds channels 4 (l >> 4) .. + 3
+    template <class F>
+    void vector_block16(F &&value /* (channel < 16) -> float */) {
+        float *b = new_block();
+        for (int l = 0; l < 64; ++l)
+            for (int i = 0; i < 4; ++i) b[l * 4 + i] = value(4 * (l >> 4) + i);
+    }
     // 4 lane-expanded blocks holding a per-output-channel vector for one 32-channel tile
     template <class F>
     void vector_blocks(F &&value /* (channel within tile) -> float */) {
@@ -448,13 +462,18 @@ bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::strin
             std::memcpy(blk, tab.data() + off, sizeof(float) * std::min<size_t>(BLK_FLOATS, tab.size() - off));
         }
     }
-    // S_L0: 16 outputs on rows 0..15 of the tile; per k-iteration: pw|mag, proj|mag, pw|norm, proj|norm
+    // S_L0: 16 outputs as 16x16x4 tiles.  Bias block, then the Nyquist channel's four weight columns (pw|mag, proj|mag,
+    // pw|norm, proj|norm; that channel is contracted on the VALU), then per k-iteration of 16 channels the same four operands
     sec[S_L0] = sb.blocks();
-    sb.vector_blocks([&](int c) { return c < 16 ? pwb[0][c] + pjb[0][c] : 0.f; });
-    for (int j = 0; j < 17; ++j)
+    sb.vector_block16([&](int r) { return pwb[0][r] + pjb[0][r]; });
+    for (int p = 0; p < 2; ++p) {
+        sb.vector_block16([&](int r) { return pww[0][(size_t)r * 258 + 129 * p + bin(128)]; });
+        sb.vector_block16([&](int r) { return pjw[0][(size_t)r * 258 + 129 * p + bin(128)]; });
+    }
+    for (int j = 0; j < 8; ++j)
         for (int p = 0; p < 2; ++p) {
-            sb.weight_block([&](int np, int c) { return (np < 16 && c < 129) ? pww[0][(size_t)np * 258 + 129 * p + bin(c)] : 0.f; }, j);
-            sb.weight_block([&](int np, int c) { return (np < 16 && c < 129) ? pjw[0][(size_t)np * 258 + 129 * p + bin(c)] : 0.f; }, j);
+            sb.weight_block16([&](int r, int c) { return pww[0][(size_t)r * 258 + 129 * p + bin(c)]; }, j);
+            sb.weight_block16([&](int r, int c) { return pjw[0][(size_t)r * 258 + 129 * p + bin(c)]; }, j);
         }
     // S_S0: 16 -> 16 (rows 0..15)
     sec[S_S0] = sb.blocks();

@@ -43,6 +43,15 @@ __device__ __forceinline__ f32x4 ldt(__amdgpu_buffer_rsrc_t rs, int row, int blk
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, row * 16, blk * 1024, 0));
 }
 
+// 16 output rows x 16 streams x 16 channels: four v_mfma_f32_16x16x4_f32 (component i = channels 4 kq + i of the lane groups kq)
+__device__ __forceinline__ f32x4 mfma16(f32x4 w, f32x4 a, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a.w, acc, 0, 0, 0);
+    return acc;
+}
+
 __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) {
     return f32x4{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
 }
@@ -414,85 +423,118 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P
         _Pragma("unroll") for (int k = 0; k < 4; ++k) lw[k] = WL(ob_ + 8 + k);                    \
     }
 
-    // ---- P2: first layer, all four kept output columns t' (input column t = 2 t') in every wave, K split over the waves:
-    //      wave w contracts the channel-quad pairs j = w, w + 4, ..  (17 k-iterations: wave 0 takes five, the others four).
-    //      The log-spectrum of a (channel quad, column) is evaluated once per k-iteration and serves the five taps of every
-    //      output column (a column split makes each wave re-evaluate its neighbours' columns: 340 quarter-rate logs per
-    //      lane instead of 160).  The four partial tiles per column meet in LDS once the magnitude rows are dead.
+    // ---- P2: first layer (258 -> 16 channels), all four kept output columns t' (input column t = 2 t') in every wave, K
+    //      split over the waves: wave w contracts the channel quads 16 j + 4 kq of j = w and w + 4 (128 bins; the Nyquist
+    //      channel is a rank-1 term on the VALU, output column w in wave w).  The log-spectrum of a (channel quad, column)
+    //      is evaluated once and serves the five taps of every output column (a column split makes each wave re-evaluate
+    //      its neighbours' columns).  16 output channels = v_mfma_f32_16x16x4_f32 tiles (a 32-row tile wastes half of every
+    //      MFMA): lane (n, kq) = (stream n | n + 16 by half sg, channel quad 4 j + kq); D: lane (n, rq) = output quad rq.
+    //      The four partial tiles per column meet in LDS once the magnitude rows are dead.
     {
+        const int n16 = lane & 15, kq = lane >> 4;
         int o_dw0 = (int)P.sect[w][S_DW0], o_l0 = (int)P.sect[w][S_L0];
         asm volatile("" : "+s"(o_dw0), "+s"(o_l0));
-        f32x16 acc[4];
+        f32x4 acc[4][2];
         {
-            const f32x4 b0 = WL(o_l0), b1 = WL(o_l0 + 1), b2 = WL(o_l0 + 2), b3 = WL(o_l0 + 3);
-            acc[0] = w == 0 ? acc_of(b0, b1, b2, b3) : acc_of(zero4, zero4, zero4, zero4);     // the bias enters once
-            acc[1] = acc[0]; acc[2] = acc[0]; acc[3] = acc[0];
+            const f32x4 b0 = WL(o_l0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c][0] = acc[c][1] = w == 0 ? b0 : zero4;       // the bias enters once
         }
-        const int ws = o_l0 + 4;
-        const float mm = mmv[m];
-        f32x4 Wa = WL(ws + 4 * w), Wb = WL(ws + 4 * w + 1), Wc = WL(ws + 4 * w + 2), Wd = WL(ws + 4 * w + 3);
-        // depthwise taps + bias of this lane's channel quad for one k-iteration: 12 table rows, requested one iteration
-        // ahead (they come from L2: consumed in the iteration that asks for them they cost a round trip each time)
-        f32x4 tb[12], nt[12];
-#define P2_TABLES(T, jj)                                                                   \
-    {                                                                                      \
-        const int q_ = 2 * (jj) + h;                                                       \
-        T[0] = ldt(wrs, q_ * 6 + 5, o_dw0); T[1] = ldt(wrs, (34 + q_) * 6 + 5, o_dw0);     \
-        _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                    \
-            T[2 + 2 * k] = ldt(wrs, q_ * 6 + k, o_dw0);                                    \
-            T[3 + 2 * k] = ldt(wrs, (34 + q_) * 6 + k, o_dw0);                             \
-        }                                                                                  \
-    }
-        P2_TABLES(tb, w)
+        const int ws = o_l0 + 5;
+        const float mm2[2] = {mmv[n16], mmv[16 + n16]};
+        // depthwise taps + bias of this lane's channel quad: 12 table rows per k-iteration, both iterations requested now
+        f32x4 tb[2][12], wq[2][4];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int q_ = 4 * (w + 4 * it) + kq;
+            tb[it][0] = ldt(wrs, q_ * 6 + 5, o_dw0); tb[it][1] = ldt(wrs, (34 + q_) * 6 + 5, o_dw0);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                tb[it][2 + 2 * k] = ldt(wrs, q_ * 6 + k, o_dw0);
+                tb[it][3 + 2 * k] = ldt(wrs, (34 + q_) * 6 + k, o_dw0);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wq[it][k] = WL(ws + 4 * (w + 4 * it) + k);
+        }
+        // Nyquist channel: quad 32 of the tables (component 0), its four weight columns in the D layout
+        f32x4 tn[12], wn[4];
+        tn[0] = ldt(wrs, 32 * 6 + 5, o_dw0); tn[1] = ldt(wrs, (34 + 32) * 6 + 5, o_dw0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { tn[2 + 2 * k] = ldt(wrs, 32 * 6 + k, o_dw0); tn[3 + 2 * k] = ldt(wrs, (34 + 32) * 6 + k, o_dw0); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wn[k] = WL(o_l0 + 1 + k);
         // weights of the next phases (P3, P4, P5): they do not depend on LDS and land during this loop
         PRE_A
-        // one k-iteration: channel quad q = 2 j + h of the 34 (129 channels + 7 of padding; the padding's table rows and
-        // weight columns are zero, its activations are read from quad 32 so that they are finite)
-#define P2_ITER(TB, NT, jj)                                                                          \
-    {                                                                                                \
-        const int j_ = (jj), jn_ = min(j_ + 4, 16);                                                   \
-        const int qr = min(2 * j_ + h, 32);                                                           \
-        P2_TABLES(NT, jn_)                                                                            \
-        const f32x4 nWa = WL(ws + 4 * jn_), nWb = WL(ws + 4 * jn_ + 1), nWc = WL(ws + 4 * jn_ + 2), nWd = WL(ws + 4 * jn_ + 3); \
-        f32x4 mgc[8], spc[8];                                                                         \
-        _Pragma("unroll") for (int tc = 0; tc < 8; ++tc) mgc[tc] = RX[(MAG_Q * tc + qr) * QS + m];    \
-        SB();                                                                                         \
-        _Pragma("unroll") for (int tc = 0; tc < 8; ++tc)                                              \
-            spc[tc] = f32x4{lognorm(mgc[tc].x, mm), lognorm(mgc[tc].y, mm), lognorm(mgc[tc].z, mm), lognorm(mgc[tc].w, mm)}; \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                               \
-            /* depthwise k5 p2 around input column 2c, magnitude part and normalised part */         \
-            f32x4 dm = TB[0], dn = TB[1];        /* biases */                                         \
-            _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                           \
-                const int tc = 2 * c + k - 2;                                                         \
-                if (tc >= 0 && tc < 8) {                                                              \
-                    dm = fma4(TB[2 + 2 * k], mgc[tc], dm);                                            \
-                    dn = fma4(TB[3 + 2 * k], spc[tc], dn);                                            \
-                }                                                                                     \
-            }                                                                                         \
-            dm = relu4(dm);                                                                           \
-            dn = relu4(dn);                                                                           \
-            SB();                                                                                     \
-            /* pw|mag . dm + proj|mag . x1 + pw|norm . dn + proj|norm . x1 (x1 = the undelayed column 2c) */ \
-            TG_MMA(acc[c], Wa, Wb, Wc, Wd, dm, mgc[2 * c], dn, spc[2 * c])                            \
-            SB();                                                                                     \
-        }                                                                                             \
-        Wa = nWa; Wb = nWb; Wc = nWc; Wd = nWd;                                                       \
-    }
-#pragma unroll 1
-        for (int j = w; j < 16; j += 8) {            // two iterations per trip: the table rows ping-pong between tb and nt
-            P2_ITER(tb, nt, j)
-            P2_ITER(nt, tb, j + 4)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+                const int ms = n16 + 16 * sg;
+                const float mm = mm2[sg];
+                f32x4 mgc[8], spc[8];
+#pragma unroll
+                for (int tc = 0; tc < 8; ++tc) mgc[tc] = RX[(MAG_Q * tc + 4 * (w + 4 * it) + kq) * QS + ms];
+                SB();
+#pragma unroll
+                for (int tc = 0; tc < 8; ++tc)
+                    spc[tc] = f32x4{lognorm(mgc[tc].x, mm), lognorm(mgc[tc].y, mm), lognorm(mgc[tc].z, mm), lognorm(mgc[tc].w, mm)};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // depthwise k5 p2 around input column 2c, magnitude part and normalised part
+                    f32x4 dm = tb[it][0], dn = tb[it][1];        // biases
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        const int tc = 2 * c + k - 2;
+                        if (tc >= 0 && tc < 8) {
+                            dm = fma4(tb[it][2 + 2 * k], mgc[tc], dm);
+                            dn = fma4(tb[it][3 + 2 * k], spc[tc], dn);
+                        }
+                    }
+                    dm = relu4(dm);
+                    dn = relu4(dn);
+                    SB();
+                    // pw|mag . dm + proj|mag . x1 + pw|norm . dn + proj|norm . x1 (x1 = the undelayed column 2c)
+                    f32x4 a_ = acc[c][sg];
+                    a_ = mfma16(wq[it][0], dm, a_);
+                    a_ = mfma16(wq[it][1], mgc[2 * c], a_);
+                    a_ = mfma16(wq[it][2], dn, a_);
+                    a_ = mfma16(wq[it][3], spc[2 * c], a_);
+                    acc[c][sg] = a_;
+                    SB();
+                }
+            }
         }
-        if (w == 0) P2_ITER(tb, nt, 16)
-#undef P2_ITER
-#undef P2_TABLES
+        // Nyquist channel of output column w (input column 2w): scalars per stream, rank-1 into this lane's output quad
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+            const int ms = n16 + 16 * sg;
+            const float mm = mm2[sg];
+            float dm = tn[0].x, dn = tn[1].x, xm = 0.f, xn = 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int tc = 2 * w + k - 2;
+                if (tc >= 0 && tc < 8) {             // wave-uniform
+                    const float mg = RX[(MAG_Q * tc + 32) * QS + ms].x;
+                    const float sp = lognorm(mg, mm);
+                    dm = fmaf(tn[2 + 2 * k].x, mg, dm);
+                    dn = fmaf(tn[3 + 2 * k].x, sp, dn);
+                    if (k == 2) { xm = mg; xn = sp; }
+                }
+            }
+            dm = fmaxf(dm, 0.f);
+            dn = fmaxf(dn, 0.f);
+            const f32x4 r1 = wn[0] * dm + wn[1] * xm + wn[2] * dn + wn[3] * xn;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c == w) acc[c][sg] = acc[c][sg] + r1;
+        }
         STAMP(18);
         __syncthreads();   // every wave is done with the magnitude rows: they now carry the partial tiles
-        // rows 0..15 of a tile are the 16 channels (registers of g = 0,1): PART[wave][column][channel quad][stream]
+        // PART[wave][column][output quad][stream]: the D layout of a 16x16 tile is exactly an LDS quad per lane
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) RX[((w * 4 + c) * 4 + 2 * g) * QS + hq] = quad_of(acc[c], g);
+            for (int sg = 0; sg < 2; ++sg) RX[((w * 4 + c) * 4 + kq) * QS + n16 + 16 * sg] = acc[c][sg];
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < 2; ++it) {

@@ -289,40 +289,60 @@ def v4_step(W, sect, x, hc, gate=0.01):
     filt = np.concatenate([f0, f1[:3]])
     mp = np.concatenate([colmean[[3, 2, 1]], colmean, colmean[[6, 5, 4]]])  # [14, 32]
     mm = np.mean([sum(filt[k] * mp[t + k] for k in range(7)) for t in range(8)], axis=0)   # [32]
-    # P2 first layer
+    # P2 first layer: 16x16x4 tiles, K split over the waves (j = w, w + 4), Nyquist channel as a rank-1 term of wave w
     o_l0 = sect[0][S["S_L0"]]
-    A16 = {}
+    ws = o_l0 + 5
+
+    def vec16(blk):                               # vector_block16: lane (n, rq) holds channels 4 rq .. + 3
+        return np.concatenate([W[blk][16 * rq].astype(np.float64) for rq in range(4)])
+
+    def mfma16(wblk, a):                          # wblk lane (r, kq), a lane (n, kq): D[r][n]
+        return np.einsum("kri,kni->rn", wblk.astype(np.float64).reshape(4, 16, 4), a.reshape(4, 16, 4))
+
+    part = np.zeros((4, 4, 16, 32))               # [wave][column][channel][stream]
+    part[0] += vec16(o_l0)[None, :, None]
+    wn = [vec16(o_l0 + 1 + k) for k in range(4)]
     for w in range(4):
-        tcol = 2 * w
-        acc = _bias_tile(W, o_l0)
-        ws = o_l0 + 4
-        for j in range(17):
-            frag = {k: np.zeros((64, 4)) for k in ("dm", "xm", "dn", "xn")}
-            for h in range(2):
-                q = 2 * j + h
-                dm = np.repeat(_table_row(W, o_dw0, q * 6 + 5)[None], 32, 0)
-                dn = np.repeat(_table_row(W, o_dw0, (34 + q) * 6 + 5)[None], 32, 0)
-                xm = np.zeros((32, 4))
-                xn = np.zeros((32, 4))
-                for k in range(5):
-                    tc = tcol + k - 2
-                    if 0 <= tc < 8 and q < 33:
-                        mg = RX[33 * tc + q]
-                        sp = lg(mg) - mm[:, None]
-                        dm = dm + _table_row(W, o_dw0, q * 6 + k)[None] * mg
-                        dn = dn + _table_row(W, o_dw0, (34 + q) * 6 + k)[None] * sp
-                        if k == 2:
-                            xm, xn = mg, sp
-                sl = slice(32 * h, 32 * h + 32)
-                frag["dm"][sl], frag["xm"][sl] = np.maximum(dm, 0), xm
-                frag["dn"][sl], frag["xn"][sl] = np.maximum(dn, 0), xn
-            for i, k in enumerate(("dm", "xm", "dn", "xn")):
-                acc += _mfma4(W[ws + 4 * j + i], frag[k])
-        A16[w] = np.maximum(acc, 0)
-    for w in range(4):
-        for g in range(2):
-            for h in range(2):
-                RX[264 + 4 * w + 2 * g + h] = A16[w][8 * g + 4 * h:8 * g + 4 * h + 4].T
+        for it in range(2):
+            j = w + 4 * it
+            for sg in range(2):
+                st = slice(16 * sg, 16 * sg + 16)
+                for c in range(4):
+                    frag = {k: np.zeros((64, 4)) for k in ("dm", "xm", "dn", "xn")}
+                    for kq in range(4):
+                        q = 4 * j + kq
+                        dm = np.repeat(_table_row(W, o_dw0, q * 6 + 5)[None], 16, 0)
+                        dn = np.repeat(_table_row(W, o_dw0, (34 + q) * 6 + 5)[None], 16, 0)
+                        for k in range(5):
+                            tc = 2 * c + k - 2
+                            if 0 <= tc < 8:
+                                mg = RX[33 * tc + q][st]
+                                sp = lg(mg) - mm[st, None]
+                                dm = dm + _table_row(W, o_dw0, q * 6 + k)[None] * mg
+                                dn = dn + _table_row(W, o_dw0, (34 + q) * 6 + k)[None] * sp
+                        sl = slice(16 * kq, 16 * kq + 16)
+                        mg0 = RX[33 * 2 * c + q][st]
+                        frag["dm"][sl], frag["xm"][sl] = np.maximum(dm, 0), mg0
+                        frag["dn"][sl], frag["xn"][sl] = np.maximum(dn, 0), lg(mg0) - mm[st, None]
+                    for i, k in enumerate(("dm", "xm", "dn", "xn")):
+                        part[w, c, :, st] += mfma16(W[ws + 4 * j + i], frag[k])
+        # Nyquist channel (table quad 32, component 0) of output column w
+        dm = np.full(32, _table_row(W, o_dw0, 32 * 6 + 5)[0])
+        dn = np.full(32, _table_row(W, o_dw0, (34 + 32) * 6 + 5)[0])
+        for k in range(5):
+            tc = 2 * w + k - 2
+            if 0 <= tc < 8:
+                mg = RX[33 * tc + 32][:, 0]
+                dm = dm + _table_row(W, o_dw0, 32 * 6 + k)[0] * mg
+                dn = dn + _table_row(W, o_dw0, (34 + 32) * 6 + k)[0] * (lg(mg) - mm)
+        xm = RX[33 * 2 * w + 32][:, 0]
+        xn = lg(xm) - mm
+        part[w, w] += (np.outer(wn[0], np.maximum(dm, 0)) + np.outer(wn[1], xm) + np.outer(wn[2], np.maximum(dn, 0)) +
+                       np.outer(wn[3], xn))
+    first = np.maximum(part.sum(axis=0), 0)       # [column][16 channels][32 streams]
+    for c in range(4):
+        for q in range(4):
+            RX[264 + 4 * c + q] = first[c, 4 * q:4 * q + 4].T
     hprev = hc[:, :128].astype(np.float64)
     RX[120:152] = hprev.reshape(32, 32, 4).transpose(1, 0, 2)
 
