@@ -63,6 +63,7 @@ struct vad_engine {
     // small calls (a few streams: the one-wrapper-per-client pattern): ONE pinned block in, ONE pinned block out
     static constexpr size_t SMALL_BYTES = 256u << 10;
     uint8_t *h_small_in = nullptr, *h_small_out = nullptr;   // hipHostMalloc
+    std::vector<void *> host_blocks;                         // vad_host_alloc: freed with the engine
     uint8_t *d_small_in = nullptr, *d_small_out = nullptr;
     vadk::StepParams base{};
     struct ResampleOp {
@@ -335,6 +336,7 @@ void vad_engine_destroy(vad_engine *e) {
         if (b) (void)hipFree(b);
     if (e->h_small_in) (void)hipHostFree(e->h_small_in);
     if (e->h_small_out) (void)hipHostFree(e->h_small_out);
+    for (void *b : e->host_blocks) (void)hipHostFree(b);
     for (auto &op : e->resample_ops)
         if (op.d_w) (void)hipFree(op.d_w);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -755,6 +757,29 @@ int vad_debug_sm_replay(vad_engine *e, int64_t slot, const float *probs, int64_t
     HIP_TRY(e, hipMemcpyAsync(events_out, e->d_events, (size_t)n, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(seg_frames_out, e->d_seg, sizeof(int32_t) * n, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return VAD_OK;
+}
+
+int vad_host_alloc(vad_engine *e, size_t bytes, void **out) {
+    if (!e || !out || bytes == 0) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    void *p = nullptr;
+    HIP_TRY(e, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    e->host_blocks.push_back(p);
+    *out = p;
+    return VAD_OK;
+}
+
+int vad_host_free(vad_engine *e, void *p) {
+    if (!e || !p) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    auto it = std::find(e->host_blocks.begin(), e->host_blocks.end(), p);
+    if (it == e->host_blocks.end()) return e->fail(VAD_ERR_INVALID_ARG, "vad_host_free: not a block of this engine");
+    e->host_blocks.erase(it);
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));      // no copy of ours may still be reading it
+    HIP_TRY(e, hipHostFree(p));
     return VAD_OK;
 }
 

@@ -87,6 +87,17 @@ class Engine:
     def synchronize(self) -> None:
         self._check(self._lib.vad_engine_synchronize(self._h))
 
+    def pinned_array(self, shape, dtype=np.float32) -> np.ndarray:
+        """A numpy array over page-locked host memory (``vad_host_alloc``): frame and result buffers handed to the
+        host-pointer entry points from it are DMA'd without a staging copy.  The memory belongs to the engine and is
+        released by ``close()``: do not use the array after that."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        self._check(self._lib.vad_host_alloc(self._h, max(1, n * dt.itemsize), C.byref(p)))
+        buf = (C.c_char * (n * dt.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
     # ------------------------------------------------------------------ streams
     def open_stream(self) -> int:
         s = C.c_int64()

@@ -233,6 +233,17 @@ VAD_API int vad_debug_sm_replay(vad_engine *e, int64_t slot, const float *probs,
 /* block until everything enqueued on the engine's own stream has finished */
 VAD_API int vad_engine_synchronize(vad_engine *e);
 
+/*
+ * Page-locked host memory for the caller's frame / result buffers.  The host-pointer entry points
+ * (vad_step, vad_step_events, vad_step_multi, vad_resample) accept ANY host pointer; buffers from
+ * this allocator are DMA'd directly (no runtime staging copy), which is what bounds a large batch:
+ * 8 192 f32 frames are 16.8 MB per step.  The reference has no counterpart (numpy arrays handed to
+ * onnxruntime, silero_model.py:471-499); the Python mirror exposes it as Engine.pinned_array().
+ * Memory stays valid until vad_host_free or vad_engine_destroy.
+ */
+VAD_API int vad_host_alloc(vad_engine *e, size_t bytes, void **out);
+VAD_API int vad_host_free(vad_engine *e, void *p);
+
 #ifdef __cplusplus
 }
 #endif

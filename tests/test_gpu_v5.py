@@ -212,3 +212,33 @@ def test_stream_save_restore(engine):
     finally:
         for s in slots:
             engine.close_stream(int(s))
+
+
+def test_page_locked_buffers_give_the_same_results_and_die_with_the_engine():
+    """vad_host_alloc / Engine.pinned_array: frames handed over from page-locked memory take the direct DMA path; results
+    are bit-identical to the pageable path, foreign pointers are refused by vad_host_free."""
+    import ctypes as C
+    from cutter_vad_amd import _ffi
+    from cutter_vad_amd.engine import Engine
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        blob = f.read()
+    n = 700
+    x = make_streams(n, 3, seed=77)
+    with Engine(blob, model_version=5, max_streams=n) as eng:
+        slots = eng.open_streams(n)
+        ref = np.stack([eng.step(slots, x[:, t]) for t in range(3)], axis=1)
+        eng.reset(slots)
+        px = eng.pinned_array((3, n, 512), np.float32)
+        px[:] = x.transpose(1, 0, 2)
+        got = np.stack([eng.step(slots, px[t]) for t in range(3)], axis=1)
+        assert np.array_equal(got, ref)
+        q = eng.pinned_array((n, 512), np.int16)
+        q[:] = np.clip(np.round(x[:, 0] * 32767.0), -32768, 32767).astype(np.int16)
+        eng.reset(slots)
+        a = eng.step(slots, q)
+        eng.reset(slots)
+        assert np.array_equal(a, eng.step(slots, np.array(q)))
+        lib = eng._lib
+        assert lib.vad_host_free(eng.handle, C.c_void_p(x.ctypes.data)) == _ffi.VAD_ERR_INVALID_ARG
+        assert lib.vad_host_free(eng.handle, C.c_void_p(q.ctypes.data)) == 0
+        del q

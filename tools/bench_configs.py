@@ -217,7 +217,10 @@ def host_api():
     rng = np.random.default_rng(0)
     x32 = (0.1 * rng.standard_normal((4, B, 512))).astype(np.float32)
     x16 = np.clip(x32 * 32767.0, -32768, 32767).astype(np.int16)
-    for name, x in (("f32", x32), ("int16", x16)):
+    p32, p16 = eng.pinned_array(x32.shape, np.float32), eng.pinned_array(x16.shape, np.int16)
+    p32[:], p16[:] = x32, x16
+    for name, x in (("f32", x32), ("int16", x16), ("f32 (page-locked: Engine.pinned_array)", p32),
+                    ("int16 (page-locked: Engine.pinned_array)", p16)):
         for i in range(5):
             eng.step(slots, x[i % 4])
         t0 = time.perf_counter()
@@ -225,7 +228,8 @@ def host_api():
         for i in range(n):
             eng.step(slots, x[i % 4])
         dt = (time.perf_counter() - t0) / n
-        out.append({"config": f"batch=8192, V5, host-pointer API (vad_step, {name} frames in pageable host memory, "
+        where = "" if "page-locked" in name else " in pageable host memory"
+        out.append({"config": f"batch=8192, V5, host-pointer API (vad_step, {name} frames{where}, "
                               "H2D + kernel + D2H + sync per step)", "us_per_step": dt * 1e6, "frames_per_s": B / dt,
                     "h2d_GBps": x[0].nbytes / dt / 1e9})
     eng.close()
