@@ -100,7 +100,7 @@ constexpr int K1_LDS_F4 = K1_XS_F4 + K1_UV_ROWS * QS + 16 + 48;
 constexpr int R_A16 = MAG_ROWS;                // first-layer output: 264 + 4 t' + quad
 constexpr int K2_ROWS = MAG_ROWS + 16;
 constexpr int R_Y0 = 0, R_Y1 = 16, R_Y2 = 48, R_Y3 = 64, R_Y4 = 80, R_Y5 = 88, R_Y6 = 104;
-constexpr int R_H0 = 120, R_H1 = 136, R_H0N = 152, R_GP = 168;   // gate partials: 2 x 64 regs x 64 lanes floats from row 168
+constexpr int R_H0 = 120, R_H1 = 136, R_H0N = 152;   // h_{t-1} of LSTM layers 0 / 1, layer 0's new h
 constexpr int K2_MISC_FLOATS = 32 + 8 * 32 + 256;  // mm[32], colmean[8][32], head partials [2 steps][4 waves][32]
 // 8 kHz sub-model: two columns survive the third stride conv (stride 1); rows re-used from dead activations
 constexpr int R8_Y4 = 80, R8_Y5 = 0, R8_Y6 = 32, R_H1N = 96;
@@ -142,7 +142,6 @@ struct StepParams {
     int32_t fmt;                   // vad_frame_format
     float thresh;                  // denoise gate, < 0 = off
     int32_t variant;               // V4 only: 1 = 8 kHz sub-model (pack_weights.h)
-    float *scratch;                // unused (was the V4 hand-off buffer); kept so that the struct layout is stable
 #ifdef VADK_STAMPS
     unsigned long long *stamps;    // diagnostic builds only (tools/kbench.cpp): [block][wave][16] s_memtime stamps
 #endif
