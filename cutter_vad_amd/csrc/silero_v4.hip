@@ -170,9 +170,14 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P
     //      while the frame is being folded: the slot's state machine
     //      (-> LDS, past both layouts), c_{t-1} of both LSTM layers (registers), head weights
     SmSlot *const smL = reinterpret_cast<SmSlot *>(lds + V4_SM_F4);
-    const bool sm_thread = tid < MT && tile0 + tid < P.n;
-    const int sm_slot = sm_thread ? (P.slots ? P.slots[tile0 + tid] : tile0 + tid) : 0;
-    if (sm_thread) smL[tid] = P.sm[sm_slot];
+    // (tid & 31 == m: ONE slot lookup serves h, c and the state machine.  The 96 B are requested here by every thread for
+    // the stream tid & 31 and stored to LDS by threads < 32 at the start of the tail: stored right here, the wait for them
+    // was a memory round trip in front of the first fold.)
+    const bool sm_thread = tid < MT && live;
+    const int sm_slot = slot;
+    f32x4 smq[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) smq[k] = reinterpret_cast<const f32x4 *>(P.sm + slot)[k];
     const int u = w & 1;                           // output tile of the 64-channel phases P8 / P9
     f32x4 cprev[2][2], hwq[2];                     // LSTM: wave w owns units 16w .. 16w+15; a lane holds 8 of them (2 quads)
     {
@@ -191,13 +196,10 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P
     }
     f32x4 hprev[4];                                // h_{t-1} of both layers, stream tid & 31, quads 4 (tid >> 5) .. + 3
     {
-        const int g2 = tile0 + (tid & 31);
-        const bool ok = g2 < P.n;
-        const int s2 = ok ? (P.slots ? P.slots[g2] : g2) : 0;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            const f32x4 v = reinterpret_cast<const f32x4 *>(P.state + (size_t)s2 * 256)[(tid >> 5) * 4 + qq];
-            hprev[qq] = ok ? v : zero4;
+            const f32x4 v = reinterpret_cast<const f32x4 *>(P.state + (size_t)slot * 256)[(tid >> 5) * 4 + qq];
+            hprev[qq] = live ? v : zero4;
         }
     }
     const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];
@@ -329,6 +331,10 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P
     //  tail: the LDS is re-used with the second layout from here on (every wave is past the last group's barrier)
     // =================================================================================================
     STAMP(16);
+    if (tid < MT) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) reinterpret_cast<f32x4 *>(smL + tid)[k] = smq[k];
+    }
     // ---- P0 + P1: magnitudes registers -> LDS rows (33 t + q), and the per-column mean of the log-spectrum on the way:
     //      a lane sums the logs of its 16 bins per column, the two half-waves meet in a shuffle, the four waves in LDS
 #pragma unroll

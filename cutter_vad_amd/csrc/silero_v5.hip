@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
     const int m = lane & 31;
     const int h = lane >> 5;
     const int tile0 = blockIdx.x * MT;
+    STAMP(19);                                    // kernel entry
     const int gf = tile0 + m;                     // this lane's stream index within the call
     const bool live = gf < P.n;
     const int slot = live ? (P.slots ? P.slots[gf] : gf) : 0;
@@ -96,13 +97,11 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
     f32x4 hv[4];
     const int fm = tid & 31, part = tid >> 5;
     {
-        const int g2 = tile0 + fm;
-        const bool ok = g2 < P.n;
-        const int s2 = ok ? (P.slots ? P.slots[g2] : g2) : 0;
+        // fm == m (a wave is 64 lanes): the stream this thread loads h for is the stream of its MFMA column -> ONE slot lookup
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            const f32x4 v = reinterpret_cast<const f32x4 *>(P.state + (size_t)s2 * 256)[part * 4 + qq];
-            hv[qq] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 v = reinterpret_cast<const f32x4 *>(P.state + (size_t)slot * 256)[part * 4 + qq];
+            hv[qq] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     const f32x4 W1 = ldw(wrs, q * 16, o_nyq), W3 = ldw(wrs, (32 + q) * 16, o_nyq);   // window w[n], w[128+n] = w[128-n]
@@ -117,15 +116,23 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
         }
         cst = acc_of(c4[0], c4[1], c4[2], c4[3]);
     }
+    // the slot's state machine (96 B in HBM between calls) is fetched now, lives in LDS for the call and goes back with
+    // the last frame: its HBM latency is off the tail of the kernel.  It is REQUESTED with h and c (every thread asks for
+    // the slot of stream tid & 31 - the same lookup again - threads < 32 keep it) and stored to LDS after h: asked for
+    // behind the h store it was a second memory round trip before the frame loop.
+    const bool sm_thread = (tid < MT) && live;
+    const int sm_slot = slot;
+    f32x4 smq[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) smq[k] = reinterpret_cast<const f32x4 *>(P.sm + slot)[k];
     SB();
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) RH[(part * 4 + qq) * QS + fm] = hv[qq];
     int seg_last = 0;
-    const bool sm_thread = (tid < MT) && (tile0 + tid < P.n);
-    const int sm_slot = sm_thread ? (P.slots ? P.slots[tile0 + tid] : tile0 + tid) : 0;
-    // the slot's state machine (96 B in HBM between calls) is fetched now, lives in LDS for the call and goes back
-    // with the last frame: its HBM latency is off the tail of the kernel
-    if (sm_thread) smL[tid] = P.sm[sm_slot];
+    if (tid < MT) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) reinterpret_cast<f32x4 *>(smL + tid)[k] = smq[k];
+    }
     const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];    // head bias
 
     // every kernel argument the frame loop needs, fetched NOW (scalar loads from the kernarg segment cost a round

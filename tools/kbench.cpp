@@ -130,7 +130,9 @@ int main(int argc, char **argv) {
             for (int b = 0; b < tiles; ++b) acc += (double)(S(b, w, k) - S(b, w, 0));
             printf(" g%d=%.0f", k - 20, acc / tiles);
         }
-        printf("\n");
+        double pro = 0;
+        for (int b = 0; b < tiles; ++b) pro += (double)(S(b, w, 0) - S(b, w, 19));
+        printf("   prologue (kernel entry -> frame loop) = %.0f\n", pro / tiles);
     }
 #endif
     return 0;
