@@ -216,7 +216,7 @@ def v5_step(W, sect, x, hc, gate=0.01):
 
 
 # ======================================================================================
-#  Silero V4: model of silero_v4_stft + silero_v4_tail over the packed streams
+#  Silero V4: model of silero_v4_step (STFT part + tail) over the packed streams
 # ======================================================================================
 V4 = dict(S_STFT=0, S_NYQ=1, S_DW0=2, S_L0=3, S_S0=4, S_L1=5, S_S1=6, S_L2=7, S_S2=8, S_L3=9, S_S3=10, S_LSTM0=11,
           S_LSTM1=12, S_HEADB=13)
@@ -237,9 +237,9 @@ def v4_step(W, sect, x, hc, gate=0.01):
     if gate is not None and gate >= 0:
         x = np.where(np.abs(x) > gate, x, 0.0)
     S = V4
-    # ---- launch 1: reflect pad, fold, STFT, magnitudes -> scratch rows 33 t + q
+    # ---- STFT part: reflect pad, fold, STFT, magnitudes (registers in the kernel) -> rows 33 t + q of the tail's LDS layout
     xp = np.pad(x, ((0, 0), (96, 96)), mode="reflect")                    # [32, 704]
-    scratch = np.zeros((264, 32, 4))
+    mags = np.zeros((264, 32, 4))
     wtab = W[sect[0][S["S_NYQ"]]].reshape(-1)[:256].astype(np.float64)    # w[n], the k = 0 row of the stored basis
     n = np.arange(64)
     sgn = np.where(np.arange(32) % 2 == 0, 1.0, -1.0)[:, None]             # (-1)^r per tile row
@@ -259,7 +259,7 @@ def v4_step(W, sect, x, hc, gate=0.01):
             fcor[cp, 0], fcor[cp, 1], fcor[cp, 2] = y[:, 128], y[:, 64] + y[:, 192], y[:, 64] - y[:, 192]
             pe4 = UV[64 * cp:64 * cp + 16]
             alt = (pe4[:, :, 0] - pe4[:, :, 1] + pe4[:, :, 2] - pe4[:, :, 3]).sum(0)
-            scratch[33 * t + 32, :, 0] = np.abs(alt + fcor[cp, 0] + fcor[cp, 1])
+            mags[33 * t + 32, :, 0] = np.abs(alt + fcor[cp, 0] + fcor[cp, 1])
         for w in range(4):
             ws = sect[w][S["S_STFT"]]
             rR, rI = (0, 32) if w < 2 else (16, 48)
@@ -275,10 +275,10 @@ def v4_step(W, sect, x, hc, gate=0.01):
                     re, im = are[cp] + y128 + sgn * a64, aim[cp]
                 else:
                     re, im = are[cp] - y128, aim[cp] - sgn * b64
-                _store_tile(scratch, 33 * (2 * grp + cp) + 8 * w, np.sqrt(re ** 2 + im ** 2), relu=False)
-    # ---- launch 2
+                _store_tile(mags, 33 * (2 * grp + cp) + 8 * w, np.sqrt(re ** 2 + im ** 2), relu=False)
+    # ---- tail
     RX = np.zeros((280, 32, 4))
-    RX[:264] = scratch
+    RX[:264] = mags
     lg = lambda mg: np.log(1.0 + mg * 1048576.0)
     o_dw0 = sect[0][S["S_DW0"]]
     colmean = np.zeros((8, 32))

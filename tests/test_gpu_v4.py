@@ -1,4 +1,4 @@
-"""GPU parity of the Silero V4 path (a8): silero_v4_stft + silero_v4_tail through the C ABI vs the oracle."""
+"""GPU parity of the Silero V4 path (a8): silero_v4_step through the C ABI vs the oracle."""
 
 import numpy as np
 import pytest
