@@ -150,6 +150,28 @@ def test_resample_operator_matches_scipy_and_reference_fixture():
     assert lib.vad_debug_resample_operator(100, None, 0) == _ffi.VAD_ERR_INVALID_ARG
 
 
+def _build_c_example(tmp_path):
+    import subprocess
+    pkg = os.path.join(ROOT, "cutter_vad_amd")
+    exe = str(tmp_path / "c_abi_min")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_abi_min.c"), "-L", pkg, "-lvad_engine", f"-Wl,-rpath,{pkg}", "-o", exe])
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_caller_fails_loudly_without_gpu(tmp_path):
+    """include/vad_engine.h compiles as pedantic C99, a C program links against the library through it alone, and -
+    in this GPU-less container - vad_engine_create refuses with VAD_ERR_NO_DEVICE instead of computing anything."""
+    import subprocess
+    import torch
+    exe = _build_c_example(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the run itself is covered by tests/test_gpu_v5.py")
+    r = subprocess.run([exe, weights_io.packaged_blob_path(5)], capture_output=True, text=True)
+    assert r.returncode == 1
+    assert "no HIP device" in r.stderr and "no CPU fallback" in r.stderr
+
+
 def test_folded_resample_stream_reproduces_scipy():
     """The kernel's folded contraction, evaluated in NumPy from the packed operator stream alone (tests/kernel_model.py),
     equals scipy.signal.resample: guards the packer's layout and the fold algebra without a GPU."""

@@ -242,3 +242,21 @@ def test_page_locked_buffers_give_the_same_results_and_die_with_the_engine():
         assert lib.vad_host_free(eng.handle, C.c_void_p(x.ctypes.data)) == _ffi.VAD_ERR_INVALID_ARG
         assert lib.vad_host_free(eng.handle, C.c_void_p(q.ctypes.data)) == 0
         del q
+
+
+def test_c_caller_gets_the_same_probabilities(tmp_path):
+    """examples/c_abi_min.c (C99, only include/vad_engine.h) against the Python mirror on the same frames."""
+    import re
+    import subprocess
+    from cutter_vad_amd.engine import Engine
+    from tests.test_boundary import _build_c_example
+    exe = _build_c_example(tmp_path)
+    path = weights_io.packaged_blob_path(5)
+    r = subprocess.run([exe, path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.array([float(x) for x in re.findall(r"p = ([0-9.]+)", r.stdout)], np.float32)
+    k = np.arange(512)
+    frames = np.stack([np.float32(0.1) * ((k * (i + 3)) % 17 - 8).astype(np.float32) / np.float32(8.0) for i in range(3)])   # the C expression, in float
+    with open(path, "rb") as f, Engine(f.read(), model_version=5, max_streams=8) as eng:
+        ref = eng.step(eng.open_streams(3), frames)
+    assert got.shape == (3,) and np.abs(got - ref).max() <= 1e-6      # printed with 6 decimals
