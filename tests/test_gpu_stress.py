@@ -11,21 +11,35 @@ from tests.signals import make_streams
 pytestmark = pytest.mark.gpu
 
 
+import os
+
+# VAD_STRESS_SEEDS=N runs N differently seeded sequences per model (soak runs; the default suite runs one)
+_SEEDS = list(range(int(os.environ.get("VAD_STRESS_SEEDS", "1"))))
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
 @pytest.mark.parametrize("version", [5, 4])
-def test_random_api_sequence_matches_per_stream_oracle(version):
+def test_random_api_sequence_matches_per_stream_oracle(version, seed):
     from cutter_vad_amd import VADError
     from cutter_vad_amd.engine import Engine
     from oracle import oracle
     with open(weights_io.packaged_blob_path(version), "rb") as f:
         blob = f.read()
     om = oracle.OracleModel(blob, "f64")
-    rng = np.random.default_rng(1000 + version)
+    rng = np.random.default_rng(1000 + version + 17 * seed)
     POOL = 300
-    audio = make_streams(POOL, 64, seed=31 + version)            # every logical stream has 64 frames to play
-    tol = 2e-5 if version == 5 else 1e-4                            # V4: tests/test_gpu_v4.py on its conditioning
+    audio = make_streams(POOL, 64, seed=31 + version + 5 * seed)            # every logical stream has 64 frames to play
+    # Every call is checked LOCALLY: the oracle starts from the device's own state before the call (vad_stream_get_state
+    # after the previous one), so a deviation is attributed to the call that made it and is not carried on by the LSTM.
+    # V4 is ill-conditioned on rare frames (log(1 + |X| 2^20): tests/test_gpu_v4.py, DESIGN "Numerics"): a V4 frame may
+    # differ by the bar + 10 x the f64 oracle's own response to a relative input perturbation of 1e-7 (< 1 float32 ulp,
+    # worst of 3 draws) from the same state.
+    tol = 2e-5 if version == 5 else 3e-5
+    COND_K, TRIALS = 10.0, 3
+    prng = np.random.default_rng(99 + seed)
     with Engine(blob, model_version=version, max_streams=POOL) as eng:
         slot_of, pos, state, saved = {}, {}, {}, {}
-        worst, checked = 0.0, 0
+        worst, worst_state, checked = 0.0, 0.0, 0
         for it in range(260):
             op = rng.choice(["open", "step", "step", "step", "multi", "close", "reset", "save", "restore"])
             live = sorted(slot_of)
@@ -34,6 +48,7 @@ def test_random_api_sequence_matches_per_stream_oracle(version):
                 for i in rng.choice(free, size=min(len(free), int(rng.integers(1, 40))), replace=False):
                     slot_of[int(i)] = int(eng.open_stream())
                     pos[int(i)], state[int(i)] = 0, np.zeros((1, 256), np.float32)
+                    assert not eng.get_state(slot_of[int(i)]).any()
             elif op in ("step", "multi"):
                 k = int(rng.integers(1, len(live) + 1))
                 ids = [int(i) for i in rng.choice(live, size=k, replace=False)]
@@ -55,11 +70,24 @@ def test_random_api_sequence_matches_per_stream_oracle(version):
                 else:
                     got, _ = eng.step_multi(slots, send)
                 for r, i in enumerate(ids):
+                    st = state[i].copy()
+                    stp = [state[i].copy() for _ in range(TRIALS)] if version == 4 else []
                     for t in range(T):
-                        ref = om.step_batch(oracle.denoise(fr_ref[r, t]).reshape(1, 512), state[i], nthreads=1)[0]
-                        worst = max(worst, abs(float(got[r, t]) - float(ref)))
+                        ref = om.step_batch(oracle.denoise(fr_ref[r, t]).reshape(1, 512), st, nthreads=1)[0]
+                        cond = 0.0
+                        for sp in stp:
+                            noisy = (fr_ref[r, t].astype(np.float64) * (1.0 + 1e-7 * prng.standard_normal(512))).astype(np.float32)
+                            refp = om.step_batch(oracle.denoise(noisy).reshape(1, 512), sp, nthreads=1)[0]
+                            cond = max(cond, abs(float(refp) - float(ref)))
+                        worst = max(worst, abs(float(got[r, t]) - float(ref)) - COND_K * cond)
                         checked += 1
                     pos[i] += T
+                    dev = eng.get_state(slot_of[i]).reshape(1, 256)
+                    dstate = float(np.abs(dev - st).max())
+                    if stp:
+                        dstate -= COND_K * max(float(np.abs(sp - st).max()) for sp in stp)
+                    worst_state = max(worst_state, dstate)
+                    state[i] = dev.copy()                 # the next call's oracle starts where the device is
             elif op == "close" and len(live) > 8:
                 for i in rng.choice(live, size=int(rng.integers(1, 6)), replace=False):
                     eng.close_stream(slot_of.pop(int(i)))
@@ -69,6 +97,7 @@ def test_random_api_sequence_matches_per_stream_oracle(version):
                 eng.reset([slot_of[i] for i in ids])
                 for i in ids:
                     state[i] = np.zeros((1, 256), np.float32)
+                    assert not eng.get_state(slot_of[i]).any()
             elif op == "save":
                 i = int(rng.choice(live))
                 saved[i] = (eng.save_stream(slot_of[i]), pos[i], state[i].copy())
@@ -77,7 +106,8 @@ def test_random_api_sequence_matches_per_stream_oracle(version):
                 blob_i, p_i, st_i = saved[i]
                 eng.restore_stream(slot_of[i], blob_i)
                 pos[i], state[i] = p_i, st_i.copy()
-        assert checked > 1500 and worst <= tol, (checked, worst)
+                assert np.array_equal(eng.get_state(slot_of[i]).reshape(1, 256), st_i)      # the blob carries (h, c) bit for bit
+        assert checked > 1500 and worst <= tol and worst_state <= 2e-4, (checked, worst, worst_state)
         # bookkeeping survived: a slot cannot be stepped twice in one call, closed slots are refused
         s = slot_of[sorted(slot_of)[0]]
         with pytest.raises(Exception):
