@@ -96,6 +96,7 @@ struct vad_engine {
         return code;
     }
     int hip_fail(hipError_t e, const char *what) const {
+        (void)hipGetLastError();      // reported here; do not leave it in HIP's process-wide last-error slot
         return fail(VAD_ERR_HIP, "Model prediction failed: %s: %s", what, hipGetErrorString(e));
     }
 };
@@ -287,6 +288,7 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
     e->max_streams = desc->max_streams;
     auto bail = [&](hipError_t hr, const char *what) {
         g_create_error = std::string("Failed to load model: ") + what + ": " + hipGetErrorString(hr);
+        (void)hipGetLastError();      // consumed here: HIP keeps the failure in a process-wide slot otherwise
         vad_engine_destroy(e);
         return VAD_ERR_HIP;
     };

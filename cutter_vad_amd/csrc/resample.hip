@@ -268,6 +268,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) vadk_resample_512(const vadk::Res
 }
 
 extern "C" hipError_t vadk_launch_resample(const vadk::ResampleParams *p, hipStream_t stream) {
+    (void)hipGetLastError();   // HIP's last-error slot is sticky and process-wide: a stale failure from anywhere else must not become ours
     const int tiles = p->tile_start[p->nseg];
     if (tiles <= 0) return hipSuccess;
     // up to 256 chunk tiles: two workgroups per tile (finer grain also evens out mixed-rate launches, whose 48 kHz tiles run

@@ -784,6 +784,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P
 
 // host-callable launcher: the T frames of a call run as T launches on one stream (state lives in HBM between them)
 extern "C" hipError_t vadk_launch_silero_v4(const vadk::StepParams *p, hipStream_t stream) {
+    (void)hipGetLastError();   // HIP's last-error slot is sticky and process-wide: a stale failure from anywhere else must not become ours
     const int tiles = (p->n + vadk::MT - 1) / vadk::MT;
     if (tiles <= 0) return hipSuccess;
     for (int t = 0; t < p->T; ++t) {

@@ -610,6 +610,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
 
 // host-callable launcher (engine.cpp is plain C++ and never sees <<<>>>)
 extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream_t stream) {
+    (void)hipGetLastError();   // HIP's last-error slot is sticky and process-wide: a stale failure from anywhere else must not become ours
     const int tiles = (p->n + vadk::MT - 1) / vadk::MT;
     if (tiles <= 0) return hipSuccess;
     if (p->fmt == 0)

@@ -20,6 +20,7 @@ extern "C" __global__ void vadk_sm_replay(SmSlot *sm, int slot, const float *pro
 
 extern "C" hipError_t vadk_launch_sm_replay(SmSlot *sm, int slot, const float *probs, int n, uint8_t *events, int32_t *seg,
                                             hipStream_t stream) {
+    (void)hipGetLastError();   // HIP's last-error slot is sticky and process-wide: a stale failure from anywhere else must not become ours
     hipLaunchKernelGGL(vadk_sm_replay, dim3(1), dim3(64), 0, stream, sm, slot, probs, n, events, seg);
     return hipGetLastError();
 }

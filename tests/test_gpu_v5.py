@@ -260,3 +260,20 @@ def test_c_caller_gets_the_same_probabilities(tmp_path):
     with open(path, "rb") as f, Engine(f.read(), model_version=5, max_streams=8) as eng:
         ref = eng.step(eng.open_streams(3), frames)
     assert got.shape == (3,) and np.abs(got - ref).max() <= 1e-6      # printed with 6 decimals
+
+
+def test_create_with_an_impossible_pool_fails_cleanly_and_the_next_create_works():
+    """max_streams beyond HBM: vad_engine_create reports the HIP failure (no partial engine, no crash) and the device is
+    still usable afterwards."""
+    from cutter_vad_amd import VADError
+    from cutter_vad_amd.engine import Engine
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        blob = f.read()
+    with pytest.raises(Exception) as ei:
+        Engine(blob, model_version=5, max_streams=2_000_000_000)          # 2 TB of recurrent state
+    assert "hipMalloc" in str(ei.value) or "memory" in str(ei.value).lower(), str(ei.value)
+    with Engine(blob, model_version=5, max_streams=64) as eng:
+        s = eng.open_streams(3)
+        p = eng.step(s, np.zeros((3, 512), np.float32))
+        assert np.isfinite(p).all()
+    assert VADError is not None
