@@ -277,3 +277,61 @@ def test_create_with_an_impossible_pool_fails_cleanly_and_the_next_create_works(
         p = eng.step(s, np.zeros((3, 512), np.float32))
         assert np.isfinite(p).all()
     assert VADError is not None
+
+
+def test_raw_c_abi_refuses_bad_arguments_and_keeps_working(engine):
+    """The entry points called directly (ctypes, no Python-side validation) with null pointers, empty / negative counts,
+    unknown formats, wrong chunk lengths, too many segments, stale slots: a negative status every time, never a crash,
+    and the engine serves a correct step afterwards."""
+    import ctypes as C
+    from cutter_vad_amd import _ffi
+    lib, h = engine._lib, engine.handle
+    f32p, i64p = C.POINTER(C.c_float), C.POINTER(C.c_int64)
+    s = engine.open_streams(2)
+    sl = s.ctypes.data_as(i64p)
+    x = np.zeros((2, 512), np.float32)
+    xp = x.ctypes.data_as(C.c_void_p)
+    p = np.zeros(2, np.float32)
+    pp = p.ctypes.data_as(f32p)
+    try:
+        bad = [
+            lib.vad_step(h, None, 2, xp, _ffi.VAD_FMT_F32, 0.01, pp),
+            lib.vad_step(h, sl, 2, None, _ffi.VAD_FMT_F32, 0.01, pp),
+            lib.vad_step(h, sl, 2, xp, _ffi.VAD_FMT_F32, 0.01, None),
+            lib.vad_step(h, sl, -1, xp, _ffi.VAD_FMT_F32, 0.01, pp),
+            lib.vad_step(h, sl, 2, xp, 77, 0.01, pp),
+            lib.vad_step(None, sl, 2, xp, _ffi.VAD_FMT_F32, 0.01, pp),
+            lib.vad_step_multi(h, sl, 2, 0, xp, _ffi.VAD_FMT_F32, 0.01, pp, None),
+            lib.vad_step_multi(h, sl, 2, -3, xp, _ffi.VAD_FMT_F32, 0.01, pp, None),
+            lib.vad_stream_close(h, 4000),
+            lib.vad_stream_close(h, -1),
+            lib.vad_stream_get_state(h, 4000, pp),
+            lib.vad_stream_get_state(h, int(s[0]), None),
+            lib.vad_stream_set_state(h, int(s[0]), None),
+            lib.vad_stream_reset(h, None, 2),
+            lib.vad_resample(h, x.ctypes.data_as(f32p), 2, 512, 48000, pp),          # 48 kHz chunks are 1 536 samples
+            lib.vad_resample(h, x.ctypes.data_as(f32p), 2, 256, 44100, pp),          # unsupported rate
+            lib.vad_resample(h, None, 2, 256, 8000, pp),
+            lib.vad_resample(h, x.ctypes.data_as(f32p), -5, 256, 8000, pp),
+        ]
+        assert all(rc < 0 for rc in bad), bad
+        assert lib.vad_last_error(h)                                  # a message is there
+        # zero streams is a no-op, not an error
+        assert lib.vad_step(h, sl, 0, xp, _ffi.VAD_FMT_F32, 0.01, pp) == 0
+        # five segments in one resample launch
+        k = 5
+        d_in, d_out = (C.c_void_p * k)(), (C.c_void_p * k)()
+        n = (C.c_int64 * k)(*[1] * k)
+        n_in = (C.c_int32 * k)(*[256] * k)
+        sr = (C.c_int32 * k)(*[8000] * k)
+        assert lib.vad_resample_multi_device(h, k, d_in, n, n_in, sr, d_out, None) < 0
+        # double close
+        t = engine.open_stream()
+        engine.close_stream(t)
+        assert lib.vad_stream_close(h, int(t)) < 0
+        # and the engine is fine
+        ref = engine.step(s, x)
+        assert np.isfinite(ref).all() and ref.shape == (2,)
+    finally:
+        for q in s:
+            engine.close_stream(int(q))
