@@ -56,6 +56,15 @@ __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) {
     return f32x4{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
 }
 
+// a double moved across lanes inside each group of 4 (DPP quad_perm on its two halves)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ float log1p20(float mag) {   // log(1 + mag * 2^20): Mul, Add, Log of the graph
     return __builtin_amdgcn_logf(1.0f + mag * 1048576.0f) * 0.69314718055994531f;
 }
@@ -80,8 +89,10 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P
     f32x4 *const XP = lds;
     f32x4 *const UV = lds + K1_XS_F4;
     constexpr int XPQ = K1_XP_QUADS;               // u/v of the two columns in flight: rows 64c' + q | 64c' + 32 + q
-    float *const nyqv = reinterpret_cast<float *>(UV + K1_UV_ROWS * QS);   // [2][32]
-    float *const fcor = nyqv + 64;                  // [2 columns][y128, a64, b64][32 streams]
+    f32x4 *const WT = UV + K1_UV_ROWS * QS;         // w[n], 64 quads (the stored basis' k = 0 row)
+    float *const nyqv = reinterpret_cast<float *>(WT + K1_WT_F4);   // [2][32] |X128| of the two columns in flight
+    float *const dcv = nyqv + 64;                   // [2][32] X0 (signed)
+    float *const fcor = dcv + 64;                   // [2 columns][y128, a64, b64][32 streams]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -145,6 +156,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P
             }
         }
     }
+    if (tid < K1_WT_F4) WT[tid] = ldw(wrs, tid * 16, (int)P.sect[0][S_NYQ]);
     __syncthreads();
     // mirrored edges: xp[i] = x[96 - i] (i < 96) and xp[608 + i] = x[510 - i]; in xp coordinates x[k] = xp[96 + k].
     //   left  quad Q  < 24 : {x[96-4Q], x[95-4Q], x[94-4Q], x[93-4Q]} = {lo.x, hi.w, hi.z, hi.y}, lo = xp quad 48-Q, hi = 47-Q
@@ -255,25 +267,43 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P
                 st2(&UV[(64 * cp + 48 + fq) * QS + ms], qo);
             }
         }
+        // ---- the two REAL bins, k = 0 and k = 128, in float64 straight from the samples: X0 = E + O, X128 = E - O with
+        //      E / O = sum over even / odd n of w[n] xp[n] (the products of two floats are exact in double, the sums carry
+        //      ~1e-16).  These are the inputs on which log(1 + |X| 2^20) is ill-conditioned: a real sum of 256 terms of size
+        //      ~0.1 lands within 1e-5 of zero about once in 10^4 columns, and there an fp32 accumulation error of 4e-7 moves
+        //      the log by 0.1 and the probability by 6e-4 (tools/v4_real_bins.py; a complex bin needs re and im to cancel
+        //      together).  64 (column, stream) pairs, 4 lanes each; lane `part` sums samples 64 part .. 64 part + 63,
+        //      quad order XOR-swizzled by (stream & 3, part) so that 16 neighbouring lanes read 16 different banks.
+        {
+            const int pair = tid >> 2, part = tid & 3;
+            const int cp = pair >> 5, ms = pair & 31;
+            const unsigned sw = (unsigned)(4 * (ms & 3) + part);
+            const unsigned bx = ((unsigned)(ms * XPQ + 16 * (2 * grp + cp) + 16 * part) ^ sw) << 4;   // byte offsets; both bases are multiples of 16 quads
+            const unsigned bw = ((unsigned)(K1_XS_F4 + K1_UV_ROWS * QS + 16 * part) ^ sw) << 4;
+            const char *const lb = reinterpret_cast<const char *>(lds);
+            double e0 = 0., e1 = 0., o0 = 0., o1 = 0.;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(lb + (bx ^ (unsigned)(i << 4)));
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(lb + (bw ^ (unsigned)(i << 4)));
+                e0 = __builtin_fma((double)wv.x, (double)xv.x, e0);
+                o0 = __builtin_fma((double)wv.y, (double)xv.y, o0);
+                e1 = __builtin_fma((double)wv.z, (double)xv.z, e1);
+                o1 = __builtin_fma((double)wv.w, (double)xv.w, o1);
+            }
+            double e = e0 + e1, o = o0 + o1;
+            e += dpp_f64<0xB1>(e); o += dpp_f64<0xB1>(o);      // quad_perm [1,0,3,2]
+            e += dpp_f64<0x4E>(e); o += dpp_f64<0x4E>(o);      // quad_perm [2,3,0,1]
+            if (part == 0) {
+                dcv[cp * 32 + ms] = (float)(e + o);
+                nyqv[cp * 32 + ms] = fabsf((float)(e - o));
+            }
+        }
         f32x4 Are = ldw(wrs, lane16, ws), Aim = ldw(wrs, lane16, ws + 1);
         SB();
         if (grp == 0) STAMP(2);
         __syncthreads();
         if (grp == 0) STAMP(3);
-        // ---- bin 128 on the VALU: re = sum_n pe[n] (-1)^n + y128 + a64, im == 0; 64 (column, stream) pairs, 4 lanes each
-        {
-            const int pair = tid >> 2, part = tid & 3;
-            const int cp = pair >> 5, ms = pair & 31;
-            float a = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 pp = UV[(64 * cp + part * 4 + i) * QS + ms];
-                a += (pp.x - pp.y) + (pp.z - pp.w);
-            }
-            a += __shfl_xor(a, 1);
-            a += __shfl_xor(a, 2);
-            if (part == 0) nyqv[cp * 32 + ms] = fabsf(a + fcor[(cp * 3 + 0) * 32 + ms] + fcor[(cp * 3 + 1) * 32 + ms]);
-        }
         // ---- MFMA: wave w = bins bin_of_channel(32 w + r): cos on pe | po, -sin on qe | qo (even | odd bins), two columns, K = 64
         // the accumulators start from the rank-1 terms of n = 0, 64, 128 (register 4g+i holds tile row r = 8g+4h+i: (-1)^r = (-1)^i)
         //   even bins: re += y128 + a64 (-1)^r ; odd bins: re -= y128, im -= b64 (-1)^r
@@ -310,6 +340,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P
 #undef K1_MMA
         }
         if (grp == 0) STAMP(4);
+        {   // bin 0 (wave 0, tile row 0 = register 0 of the lower half-wave) takes the float64 sum; its im is identically 0
+            const bool own0 = (w == 0) & (h == 0);
+            const float d0 = dcv[m], d1 = dcv[32 + m];
+            are[0].s0 = own0 ? d0 : are[0].s0;
+            are[1].s0 = own0 ? d1 : are[1].s0;
+        }
         // ---- magnitudes: kept in registers until the STFT operands in LDS are dead
 #pragma unroll
         for (int cp = 0; cp < 2; ++cp) {
@@ -320,10 +356,10 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P
             }
         }
         if (grp == 0) STAMP(5);
-        __syncthreads();       // nyqv complete; every wave done with UV / fcor before the next fold overwrites them
+        nyq[grp] = nyqv[(tid < 64 ? h : 0) * 32 + m];
+        __syncthreads();       // every wave done with UV / fcor / dcv before the next fold overwrites them
         if (grp == 0) STAMP(6);
         if (grp == 3) STAMP(7);
-        nyq[grp] = nyqv[(tid < 64 ? h : 0) * 32 + m];
     }
 
 

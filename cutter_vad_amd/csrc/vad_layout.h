@@ -91,11 +91,16 @@ enum Section {
 constexpr int MAG_Q = 33;                      // quads per STFT column: 128 bins + Nyquist (+3 pad channels)
 constexpr int MAG_ROWS = 8 * MAG_Q;            // 264 rows per tile, row = 33 t + q
 // STFT part, LDS: reflect-padded frame [32][704] f32 + the 4-way fold of two columns (2 x 64 quad rows: pe, po, qe, qo as in
-// V5) + Nyquist magnitudes [2][32] + fold corrections [2][3][32]
+// V5) + window table w[256] + |X0|, |X128| of the two columns [2][2][32] + fold corrections [2][3][32].
+// The two REAL bins (k = 0, k = 128) are summed in float64 from the samples: they are the graph's ill-conditioned
+// inputs (log(1 + |X| 2^20) of a real sum that may cancel to ~1e-6 of its terms; a complex bin needs re AND im to
+// cancel, which is ~100 x rarer) - DESIGN.md §3 "Numerics".
 constexpr int K1_XP_QUADS = 176;               // reflect-padded frame: 704 samples per stream
 constexpr int K1_XS_F4 = 32 * K1_XP_QUADS;
 constexpr int K1_UV_ROWS = 128;
-constexpr int K1_LDS_F4 = K1_XS_F4 + K1_UV_ROWS * QS + 16 + 48;
+constexpr int K1_WT_F4 = 64;                   // w[n] as 64 quads, 256-byte aligned (the readers XOR-swizzle the quad index)
+constexpr int K1_LDS_F4 = K1_XS_F4 + K1_UV_ROWS * QS + K1_WT_F4 + 32 + 48;
+static_assert((K1_XS_F4 + K1_UV_ROWS * QS) % 16 == 0, "window table must start on a 16-quad boundary");
 // tail, LDS rows
 constexpr int R_A16 = MAG_ROWS;                // first-layer output: 264 + 4 t' + quad
 constexpr int K2_ROWS = MAG_ROWS + 16;

@@ -1,0 +1,98 @@
+"""BASELINE.json configs that no other GPU test runs at their own size.
+
+configs[1]: batch = 1 024 concurrent streams, Silero V5, 16 kHz, one MI355X.
+configs[4]: the per-GPU share of the 65 536-stream job - 4 096 Silero V4 + 4 096 Silero V5 streams co-resident on one GPU,
+            two engines stepping concurrently on two HIP streams (the 8-GPU part is 8 independent copies of this: no
+            collective).
+Checks: a sample of streams against the f64 oracle, and bit-identity with the same engine running alone (concurrency and
+batch size must not change a single bit: streams are independent).
+"""
+
+import numpy as np
+import pytest
+
+from cutter_vad_amd import weights_io
+from tests.signals import make_streams
+
+pytestmark = pytest.mark.gpu
+TOL = {5: 2e-5, 4: 3e-5}      # bar: 1e-4
+
+
+def _blob(v):
+    with open(weights_io.packaged_blob_path(v), "rb") as f:
+        return f.read()
+
+
+def _oracle_sample(v, frames, pick):
+    from oracle import oracle
+    om = oracle.OracleModel(_blob(v), "f64")
+    st = np.zeros((pick.size, 256), np.float32)
+    out = np.empty((pick.size, frames.shape[1]), np.float32)
+    for t in range(frames.shape[1]):
+        out[:, t] = om.step_batch(oracle.denoise(frames[pick, t]).reshape(pick.size, 512), st, nthreads=8)
+    return out, st
+
+
+def test_config1_batch_1024_v5():
+    from cutter_vad_amd.engine import Engine
+    B, T = 1024, 12
+    frames = make_streams(B, T, seed=1234)                # BASELINE.md §4 generator, the bench's seed
+    with Engine(_blob(5), model_version=5, max_streams=B) as eng:
+        slots = eng.open_streams(B)
+        got = np.stack([eng.step(slots, frames[:, t]) for t in range(T)], axis=1)
+        assert got.shape == (B, T) and np.isfinite(got).all() and (got >= 0).all() and (got <= 1).all()
+        ref, ref_s = _oracle_sample(5, frames, np.arange(B))          # all 1 024 streams
+        assert np.abs(got - ref).max() <= TOL[5]
+        st = np.stack([eng.get_state(int(s)) for s in slots[::16]])
+        assert np.abs(st - ref_s[::16]).max() <= 2e-4
+        # the same 1 024 streams as 12 frames in ONE launch, and in a pool 8 x larger with scattered slots: same bits
+        eng.reset(slots)
+        multi, _ = eng.step_multi(slots, frames)
+        assert np.array_equal(multi, got)
+    with Engine(_blob(5), model_version=5, max_streams=8192) as big:
+        all_slots = big.open_streams(8192)
+        scattered = np.random.default_rng(5).permutation(all_slots)[:B]
+        again = np.stack([big.step(scattered, frames[:, t]) for t in range(T)], axis=1)
+        assert np.array_equal(again, got)
+
+
+def test_config4_share_v4_and_v5_engines_concurrent_on_two_hip_streams():
+    import torch
+    from cutter_vad_amd import _ffi
+    from cutter_vad_amd.engine import Engine
+    B, T = 4096, 6
+    frames = make_streams(2 * B, T, seed=1234)
+    dev = torch.device("cuda:0")
+    d_frames = torch.from_numpy(frames).to(dev)                       # [2B, T, 512]
+    with Engine(_blob(5), model_version=5, max_streams=B) as e5, Engine(_blob(4), model_version=4, max_streams=B) as e4:
+        e5.open_streams(B)
+        e4.open_streams(B)
+        s5, s4 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        p5 = torch.zeros(T, B, device=dev)
+        p4 = torch.zeros(T, B, device=dev)
+        ev5 = torch.zeros(T, B, dtype=torch.uint8, device=dev)
+        ev4 = torch.zeros(T, B, dtype=torch.uint8, device=dev)
+        x5 = [d_frames[:B, t].contiguous() for t in range(T)]
+        x4 = [d_frames[B:, t].contiguous() for t in range(T)]
+        torch.cuda.synchronize()
+        for t in range(T):          # both engines enqueue frame t back to back: the two kernels share the GPU
+            e5.step_device(B, x5[t].data_ptr(), p5[t].data_ptr(), d_events=ev5[t].data_ptr(), stream=s5.cuda_stream)
+            e4.step_device(B, x4[t].data_ptr(), p4[t].data_ptr(), d_events=ev4[t].data_ptr(), stream=s4.cuda_stream)
+        s5.synchronize()
+        s4.synchronize()
+        got5, got4 = p5.cpu().numpy().T, p4.cpu().numpy().T           # [B, T]
+        st5 = e5.get_state(77)
+        st4 = e4.get_state(77)
+    pick = np.random.default_rng(11).choice(B, 128, replace=False)
+    ref5, _ = _oracle_sample(5, frames[:B], pick)
+    ref4, _ = _oracle_sample(4, frames[B:], pick)
+    assert np.abs(got5[pick] - ref5).max() <= TOL[5]
+    assert np.abs(got4[pick] - ref4).max() <= TOL[4]
+    # alone, through the host-pointer API: bit-identical probabilities and recurrent state
+    for v, got, st, x in ((5, got5, st5, frames[:B]), (4, got4, st4, frames[B:])):
+        with Engine(_blob(v), model_version=v, max_streams=B) as solo:
+            slots = solo.open_streams(B)
+            alone = np.stack([solo.step(slots, x[:, t]) for t in range(T)], axis=1)
+            assert np.array_equal(alone, got), v
+            assert np.array_equal(solo.get_state(int(slots[77])), st), v
+    assert _ffi.VAD_OK == 0

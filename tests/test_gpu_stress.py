@@ -31,12 +31,8 @@ def test_random_api_sequence_matches_per_stream_oracle(version, seed):
     audio = make_streams(POOL, 64, seed=31 + version + 5 * seed)            # every logical stream has 64 frames to play
     # Every call is checked LOCALLY: the oracle starts from the device's own state before the call (vad_stream_get_state
     # after the previous one), so a deviation is attributed to the call that made it and is not carried on by the LSTM.
-    # V4 is ill-conditioned on rare frames (log(1 + |X| 2^20): tests/test_gpu_v4.py, DESIGN "Numerics"): a V4 frame may
-    # differ by the bar + 10 x the f64 oracle's own response to a relative input perturbation of 1e-7 (< 1 float32 ulp,
-    # worst of 3 draws) from the same state.
+    # Fixed bars for both models (V4's two real STFT bins are summed in float64: tests/test_gpu_v4.py, DESIGN "Numerics").
     tol = 2e-5 if version == 5 else 3e-5
-    COND_K, TRIALS = 10.0, 3
-    prng = np.random.default_rng(99 + seed)
     with Engine(blob, model_version=version, max_streams=POOL) as eng:
         slot_of, pos, state, saved = {}, {}, {}, {}
         worst, worst_state, checked = 0.0, 0.0, 0
@@ -71,21 +67,13 @@ def test_random_api_sequence_matches_per_stream_oracle(version, seed):
                     got, _ = eng.step_multi(slots, send)
                 for r, i in enumerate(ids):
                     st = state[i].copy()
-                    stp = [state[i].copy() for _ in range(TRIALS)] if version == 4 else []
                     for t in range(T):
                         ref = om.step_batch(oracle.denoise(fr_ref[r, t]).reshape(1, 512), st, nthreads=1)[0]
-                        cond = 0.0
-                        for sp in stp:
-                            noisy = (fr_ref[r, t].astype(np.float64) * (1.0 + 1e-7 * prng.standard_normal(512))).astype(np.float32)
-                            refp = om.step_batch(oracle.denoise(noisy).reshape(1, 512), sp, nthreads=1)[0]
-                            cond = max(cond, abs(float(refp) - float(ref)))
-                        worst = max(worst, abs(float(got[r, t]) - float(ref)) - COND_K * cond)
+                        worst = max(worst, abs(float(got[r, t]) - float(ref)))
                         checked += 1
                     pos[i] += T
                     dev = eng.get_state(slot_of[i]).reshape(1, 256)
                     dstate = float(np.abs(dev - st).max())
-                    if stp:
-                        dstate -= COND_K * max(float(np.abs(sp - st).max()) for sp in stp)
                     worst_state = max(worst_state, dstate)
                     state[i] = dev.copy()                 # the next call's oracle starts where the device is
             elif op == "close" and len(live) > 8:

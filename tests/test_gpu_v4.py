@@ -9,11 +9,10 @@ from tests.signals import make_streams
 pytestmark = pytest.mark.gpu
 TOL_P = 3e-5      # bar: 1e-4
 TOL_S = 5e-4
-# V4 takes log(1 + |X| 2^20) of the spectrum: on some frames the GRAPH ITSELF is ill-conditioned - perturbing the input
-# by 1e-7 relative (less than one float32 ulp) moves the f64 oracle's probability by more than the 1e-4 bar (measured:
-# 1.5e-4 on one frame in 120 000, and the LSTM carries it for ~20 frames).  No fp32 engine can hold a fixed bar there, so
-# the V4 asserts allow, per frame, COND_K x the oracle's own response to sub-ulp input noise on top of TOL_P.
-COND_K = 10.0
+# V4 takes log(1 + |X| 2^20) of the spectrum, which is ill-conditioned where a bin cancels to ~1e-6 of its terms.  That
+# happens to the two REAL bins (k = 0, 128) about once in 10^4 columns and practically never to a complex bin
+# (tools/v4_real_bins.py), so silero_v4.hip sums exactly those two in float64 and the fixed bar below holds; the sweep
+# in profiles/r02_parity_sweep.json (1 M frames) has the kernel closer to the f64 oracle than the oracle's own float32 build.
 
 
 @pytest.fixture(scope="module")
@@ -49,17 +48,6 @@ def _oracle_run(om, frames, gate):
     return out, st
 
 
-def conditioning(om, frames, gate, ref_p, trials=2, eps=1e-7):
-    """Per-frame response of the f64 oracle to a relative input perturbation of `eps` (< 1 float32 ulp)."""
-    rng = np.random.default_rng(12345)
-    worst = np.zeros_like(ref_p, dtype=np.float64)
-    for _ in range(trials):
-        noisy = (frames.astype(np.float64) * (1.0 + eps * rng.standard_normal(frames.shape))).astype(np.float32)
-        p, _ = _oracle_run(om, noisy, gate)
-        worst = np.maximum(worst, np.abs(p.astype(np.float64) - ref_p))
-    return worst
-
-
 @pytest.mark.parametrize("n", [1, 7, 32, 33, 200])
 def test_step_matches_oracle(engine, om, n):
     T = 10
@@ -67,9 +55,8 @@ def test_step_matches_oracle(engine, om, n):
     slots = engine.open_streams(n)
     try:
         ref_p, ref_s = _oracle_run(om, frames, 0.01)
-        cond = conditioning(om, frames, 0.01, ref_p)
         got = np.stack([engine.step(slots, frames[:, t]) for t in range(T)], axis=1)
-        assert (np.abs(got - ref_p) <= TOL_P + COND_K * cond).all(), float(np.abs(got - ref_p).max())
+        assert np.abs(got - ref_p).max() <= TOL_P
         assert np.median(np.abs(got - ref_p)) <= 1e-6
         st = np.stack([engine.get_state(s) for s in slots])          # ONNX order: h[2][64] then c[2][64]
         assert np.abs(st - ref_s).max() <= TOL_S
@@ -164,9 +151,8 @@ def test_8k_submodel_matches_oracle(setup8k, n):
     slots = eng.open_streams(n)
     try:
         ref_p, ref_s = _oracle_run(om8, frames, 0.01)
-        cond = conditioning(om8, frames, 0.01, ref_p)
         got = np.stack([eng.step(slots, frames[:, t]) for t in range(T)], axis=1)
-        assert (np.abs(got - ref_p) <= TOL_P + COND_K * cond).all(), float(np.abs(got - ref_p).max())
+        assert np.abs(got - ref_p).max() <= TOL_P
         assert np.median(np.abs(got - ref_p)) <= 1e-6
         st = np.stack([eng.get_state(s) for s in slots])
         assert np.abs(st - ref_s).max() <= TOL_S
