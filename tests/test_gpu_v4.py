@@ -7,7 +7,7 @@ from cutter_vad_amd import weights_io
 from tests.signals import make_streams
 
 pytestmark = pytest.mark.gpu
-TOL_P = 3e-5      # bar: 1e-4
+TOL_P = 2e-5      # bar: 1e-4 (1 M-frame sweep: max 5.1e-6, profiles/r02_parity_sweep.json)
 TOL_S = 5e-4
 # V4 takes log(1 + |X| 2^20) of the spectrum, which is ill-conditioned where a bin cancels to ~1e-6 of its terms.  That
 # happens to the two REAL bins (k = 0, 128) about once in 10^4 columns and practically never to a complex bin
