@@ -146,18 +146,20 @@ class SileroVADModel:
 
     def select_rate(self, sample_rate: int) -> None:
         """What ``Equal(sr, 16000)`` does inside the graph: choose the sub-model for this call.  The recurrent state
-        is the graph's ``h`` / ``c`` inputs, shared by both branches, so it moves with the switch."""
+        is the graph's ``h`` / ``c`` inputs, shared by both branches, so it moves with the switch - and so does the rest
+        of the stream (thresholds, counters and histories of the device state machine, which belong to the processor,
+        not to a sub-model): the whole slot travels as one ``vad_stream_save`` / ``vad_stream_restore`` blob."""
         self._check_rate(sample_rate, self.config.model_version)
         k8 = weights_io.is_8k_variant(_VERSION_INT[self.config.model_version], sample_rate)
         if k8 == self._k8:
             return
-        hc = self.engine.get_state(self._slot)
+        stream = self.engine.save_stream(self._slot)
         if k8 in self._variants:
             self.session, self._slot = self._variants[k8]
             self._k8 = k8
         else:
             self._load_model(sample_rate)
-        self.engine.set_state(self._slot, hc)
+        self.engine.restore_stream(self._slot, stream)
 
     @property
     def engine(self):
@@ -395,9 +397,10 @@ class VADProcessor:
         c = self.config
         cur = (c.vad_start_probability, c.vad_end_probability, c.voice_start_ratio, c.voice_end_ratio,
                c.voice_start_frame_count, c.voice_end_frame_count)
-        if cur != self._synced:
+        key = (id(self.model.engine), self.model.slot, cur)      # per (engine, slot): a rate switch changes both
+        if key != self._synced:
             self.model.engine.set_thresholds(self.model.slot, *cur)
-            self._synced = cur
+            self._synced = key
 
     # -- silero_model.py:723-762
     def process_frame(self, audio_frame: np.ndarray) -> ProcessingResult:
@@ -405,8 +408,8 @@ class VADProcessor:
             if self.model is None:
                 raise ModelInitializationError(self.config.model_version.value, "Model not loaded")
             kept = self._preprocess_audio_frame(audio_frame)
+            self.model.select_rate(int(self.config.sample_rate))     # first: the thresholds go to the slot that will run
             self._sync_thresholds()
-            self.model.select_rate(int(self.config.sample_rate))
             frame = SileroVADModel._prepare_audio_input(np.asarray(audio_frame))
             thr = 0.01 if self.config.enable_denoising else None
             try:
@@ -452,8 +455,8 @@ class VADProcessor:
         F = len(kept)
         if F:
             try:
-                self._sync_thresholds()
                 self.model.select_rate(int(self.config.sample_rate))
+                self._sync_thresholds()
                 x = np.stack([SileroVADModel._prepare_audio_input(np.asarray(f))[0] for f in frames[:F]])[None]
                 thr = 0.01 if self.config.enable_denoising else None
                 eng, slot = self.model.engine, self.model.slot

@@ -57,7 +57,9 @@ class FakeEngine:
             self.state[int(s)] = np.zeros(256, np.float32)
 
     def set_thresholds(self, s, *t):
-        # values only: rebuild the machine with the same dynamic state is not needed by these tests
+        # values only, like vad_stream_set_thresholds: unchanged values leave the machine (counters, history) alone
+        if self.thr.get(int(s)) == tuple(t) and int(s) in self.sm:
+            return
         self.thr[int(s)] = tuple(t)
         self.sm[int(s)] = oracle.StateMachine(*t)
 

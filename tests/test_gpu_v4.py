@@ -255,3 +255,38 @@ def test_shared_pool_on_the_8k_submodel_with_int16_wire_frames():
             assert np.abs(got - ref).max() <= TOL_P, t
     finally:
         pool.close()
+
+
+def test_8k_wrapper_custom_thresholds_and_rate_switch_inside_a_segment():
+    """(1) thresholds must land on the slot of the sub-model that runs; (2) a rate switch while a segment is open
+    moves the device state machine with the stream (vad_stream_save / restore), so host and device keep agreeing."""
+    import os
+    from cutter_vad_amd import SampleRate, SileroModelVersion, VADConfig, VADWrapper
+    from cutter_vad_amd.core.silero_model import VADProcessor
+    pcm = np.load(os.path.join(os.path.dirname(__file__), "golden", "speech16k_i16.npz"))["pcm"]
+    sp = (pcm.astype(np.float32) / np.float32(32767.0))[: 300 * 512].reshape(300, 512)
+    cfg = dict(model_version=SileroModelVersion.V4, vad_start_probability=0.4, vad_end_probability=0.3,
+               voice_start_frame_count=3, voice_end_frame_count=6)
+    ev = []
+    with VADWrapper(VADConfig(sample_rate=SampleRate(8000), **cfg)) as w:
+        w.set_callbacks(voice_start_callback=lambda: ev.append("S"), voice_end_callback=lambda b: ev.append("E"),
+                        voice_continue_callback=lambda b: None)
+        for f in sp:
+            w.process_audio_data(f)                      # raised "state machine divergence" before the fix
+    assert ev[:2] == ["S", "E"] and ev.count("E") >= 2
+    proc = VADProcessor(VADConfig(sample_rate=SampleRate(16000), **cfg))
+    try:
+        t = 0
+        while not proc.is_voice_active:
+            proc.process_frame(sp[t])
+            t += 1
+        slot16 = proc.model.slot
+        proc.config = proc.config.model_copy(update={"sample_rate": SampleRate(8000)})
+        proc._seg.config = proc.config
+        ended = False
+        for f in sp[t:]:
+            r = proc.process_frame(f)
+            ended |= r.voice_ended
+        assert ended and (proc.model.engine is not None) and proc.model._k8 and slot16 is not None
+    finally:
+        proc.close()

@@ -393,3 +393,31 @@ def test_chunk_batching_keeps_the_abort_contract(wrapper):
         for r in p.process_frames(frames):
             got.append(r)
     assert len(got) == 2 and eng.sm[slot].counts()["seg_samples"] == 8
+
+
+# ------------------------------------------------------------------ V4 sub-model selection keeps the whole stream
+def test_v4_8k_wrapper_uses_the_configured_thresholds_on_the_slot_that_runs():
+    """V4 at 8 kHz with non-default thresholds through START and END: the thresholds must reach the slot of the 8 kHz
+    sub-model (the one that runs), not the 16 kHz slot the processor was born with."""
+    probs = [0.9] * 3 + [0.1] * 4 + [0.9] * 2
+    proc, eng = _processor(probs, model_version=SileroModelVersion.V4, sample_rate=SampleRate(8000),
+                           vad_start_probability=0.5, vad_end_probability=0.3, voice_start_frame_count=3,
+                           voice_end_frame_count=4)
+    out = [proc.process_frame(np.full(512, 0.1, np.float32)) for _ in probs]
+    assert [r.voice_started for r in out].index(True) == 2
+    assert [r.voice_ended for r in out].index(True) == 6 and out[6].wav_data
+    assert proc.model.slot == 1 and eng.thr[1] == (0.5, 0.3, 0.8, 0.95, 3, 4)
+
+
+def test_v4_rate_switch_inside_a_segment_moves_the_state_machine_with_the_stream():
+    probs = [0.9] * 4 + [0.1] * 3
+    proc, eng = _processor(probs, model_version=SileroModelVersion.V4, vad_start_probability=0.5,
+                           vad_end_probability=0.3, voice_start_frame_count=2, voice_end_frame_count=3)
+    x = np.full(512, 0.1, np.float32)
+    a = [proc.process_frame(x) for _ in range(3)]
+    assert a[1].voice_started and proc.is_voice_active and proc.model.slot == 0
+    proc.config = proc.config.model_copy(update={"sample_rate": SampleRate(8000)})   # the graph's `sr` input changes mid-segment
+    proc._seg.config = proc.config
+    b = [proc.process_frame(x) for _ in range(4)]
+    assert proc.model.slot == 1 and getattr(eng, "restores", 0) == 1
+    assert all(r.voice_continuing for r in b) and b[3].voice_ended and not proc.is_voice_active
