@@ -11,12 +11,20 @@ machine), inputs already resident in HBM (ring [32][B][512] f32).  Streams are i
 the barrier around the timed region and the max-over-ranks of the elapsed time ("weak" scaling:
 per-GPU work is fixed).
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself (torchrun, before this process
+touches a GPU) and refuses to run if fewer than N devices are visible: it never reports n_gpus smaller than asked.
+`--mix v4v5` is BASELINE.json's configs[4] per-GPU share: 4096 Silero V4 + 4096 Silero V5 streams, two engines stepping
+concurrently on two HIP streams (default: configs[2], all V5).
+
 The JSON line carries, besides the driver's contract:
   roofline     - dominant kernel (silero_v5_step) against the fp32 MFMA peak, from HIP events
                  recorded on the launch stream around the timed region;
   cpu_baseline - the oracle's C port (oracle/silero_oracle.c, float accumulators) timed on this
                  host's cores on a bounded sample of the same workload (rank 0, N=1 only), which
-                 also yields the in-run parity figure.
+                 also yields the in-run parity figure; `single_thread` inside it is the reference's own
+                 configuration (one stream, one thread: silero_model.py:316-317).
+Before the W warm-up steps an untimed clock-ramp preamble runs the same step for ~0.4 s (`preamble_steps` in the line):
+with W = 5 and K = 20 the whole measurement is 1.4 ms long and would otherwise be taken while the GPU clocks are still rising.
 """
 
 from __future__ import annotations
@@ -24,6 +32,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,9 +45,9 @@ if ROOT not in sys.path:
 
 B_PER_GPU = 8192
 RING = 32
-FLOP_PER_FRAME = 988160          # SURVEY §8 d: 494 080 valid-tap MAC, V5 16 kHz
-BYTES_PER_FRAME = 4100           # SURVEY §8 d: 2048 in + 1024 state R + 1024 state W + 4 prob
-# What the kernel EXECUTES per frame: 1 221 v_mfma_f32_32x32x2_f32 per wave (recurrent half 256, 4-way folded
+FLOP_PER_FRAME = {5: 988160, 4: 1380000}   # SURVEY §8 d: V5 494 080 valid-tap MAC; V4 ~0.69 M MAC
+BYTES_PER_FRAME = 4100                     # SURVEY §8 d: 2048 in + 1024 state R + 1024 state W + 4 prob
+# What the V5 kernel EXECUTES per frame: 1 221 v_mfma_f32_32x32x2_f32 per wave (recurrent half 256, 4-way folded
 # DFT 192, Toom-3 enc0 325, enc1 128, enc2 32, enc3 32, LSTM input half 256) x 4 waves x 2048 MAC / 32 streams.  Fewer than
 # the algorithmic count because the folds and the Toom-3 product are exact algebraic reductions of the graph's sums.
 EXECUTED_FLOP_PER_FRAME = 1221 * 4 * 2048 * 2 // 32
@@ -45,6 +55,7 @@ PEAK_FP32_MFMA = 157.3e12        # /opt/skills/guides/MI355X_MICROARCH.md "Peak 
 PEAK_HBM = 8.0e12                # same guide, HBM3E spec
 PARITY_STEPS = 4
 CPU_STREAMS = 2048
+PREAMBLE_S = 0.4
 
 
 def synth_ring(first_stream: int, n: int) -> np.ndarray:
@@ -97,6 +108,15 @@ def cpu_leg(ring: np.ndarray, gpu_probs: np.ndarray, budget_s: float = 12.0) -> 
         step += 1
         if (elapsed >= budget_s and step >= gpu_probs.shape[0]) or step >= 400:
             break
+    # the reference's own configuration: ONE stream per session, intra_op = inter_op = 1 (silero_model.py:316-317)
+    st1 = np.zeros(256, np.float32)
+    x1 = [oracle.denoise(ring[k % RING, 1]).reshape(512) for k in range(RING)]
+    t0, k = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 3.0:
+        for _ in range(256):
+            om.step(x1[k % RING], st1)
+            k += 1
+    single = k / (time.perf_counter() - t0)
     base = {
         "value": frames_done / elapsed,
         "unit": "frames/s",
@@ -104,94 +124,172 @@ def cpu_leg(ring: np.ndarray, gpu_probs: np.ndarray, budget_s: float = 12.0) -> 
         "kind": "port",
         "sample": f"{n} streams x {step} steps of the same workload (oracle/silero_oracle.c, float accumulators, "
                   f"{threads} pthreads; onnxruntime is not installed on this box)",
+        "single_thread": {"value": single, "unit": "frames/s", "cores": 1,
+                          "sample": f"1 stream x {k} sequential frames, 1 thread: the reference's session options "
+                                    "(batch 1, intra_op = inter_op = 1, silero_model.py:316-317), same C port"},
     }
     parity = {"max_abs_dp": worst, "mean_abs_dp": total_dp / max(cnt, 1), "frames": cnt,
               "against": "oracle C port (f32) on identical inputs", "bar": 1e-4}
     return base, parity
 
 
-def main() -> None:
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv) -> int:
+    """`--gpus N` without a launcher: start the N ranks ourselves.  Runs BEFORE any GPU call in this process (counting
+    devices does not initialise the GPU); the parent only relays the children's output and exit code."""
+    fake = os.environ.get("VAD_BENCH_FAKE") == "1"
+    if not fake and os.environ.get("VAD_BENCH_SINGLE_DEVICE") != "1":
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to run a smaller job "
+                             "under the requested name\n")
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+class FakeStepper:
+    """CPU rehearsal of the launcher / timing / aggregation plumbing (tests/test_sharding.py, VAD_BENCH_FAKE=1): a "step"
+    sleeps 1 ms.  Never used on a GPU box; its JSON line says so."""
+    kernel = "fake (CPU rehearsal of the launch path)"
+
+    def __init__(self, B):
+        self.B = B
+
+    def step(self, i):
+        time.sleep(0.001)
+
+
+def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--streams", type=int, default=B_PER_GPU, help="streams per GPU (headline: 8192)")
+    ap.add_argument("--mix", choices=["v5", "v4v5"], default="v5", help="v4v5 = configs[4] per-GPU share (4096 V4 + 4096 V5)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])
 
     import torch
     from cutter_vad_amd import sharding
     info = sharding.RankInfo.from_env()
     rank, local_rank, world = info.rank, info.local_rank, info.world
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
+    fake = os.environ.get("VAD_BENCH_FAKE") == "1"
+    if not fake and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     # rehearsal knobs for a 1-GPU box (never set by the driver): all ranks on device 0, gloo for the two
     # control-plane collectives.  The real multi-GPU run is one rank per GPU over RCCL.
     if os.environ.get("VAD_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
-    backend = os.environ.get("VAD_BENCH_BACKEND", "nccl")              # "nccl" == RCCL on ROCm
-    torch.cuda.set_device(local_rank)
+    backend = "gloo" if fake else os.environ.get("VAD_BENCH_BACKEND", "nccl")              # "nccl" == RCCL on ROCm
+    if not fake:
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
+        torch.cuda.set_device(local_rank)
     dist = sharding.init_process_group(info, backend, torch.device("cuda", local_rank) if backend == "nccl" else None)
 
-    from cutter_vad_amd import weights_io
-    from cutter_vad_amd.engine import Engine
-
     B = args.streams
-    with open(weights_io.packaged_blob_path(5), "rb") as f:
-        blob = f.read()
-    eng = Engine(blob, model_version=5, device_id=local_rank, max_streams=B)
-    eng.open_streams(B)                       # slots 0..B-1, zero state, default thresholds
     first_stream, _ = sharding.stream_shard(world * B, world, rank)   # weak scaling: B streams per rank
-    ring_h = synth_ring(first_stream, B)
-    ring = torch.from_numpy(ring_h).cuda()
-    probs = torch.empty(B, device="cuda")
-    events = torch.empty(B, dtype=torch.uint8, device="cuda")
-    ts = torch.cuda.Stream()
-    torch.cuda.synchronize()
-
-    ring_ptrs = [ring[i].data_ptr() for i in range(RING)]
-    probs_ptr, events_ptr, stream_handle = probs.data_ptr(), events.data_ptr(), ts.cuda_stream
     host_enqueue = [0.0]
-
-    def step(i: int) -> None:
-        eng.step_device(B, ring_ptrs[i % RING], probs_ptr, d_events=events_ptr, denoise=0.01, stream=stream_handle)
-
-    with torch.cuda.stream(ts):
-        gpu_probs = torch.empty(PARITY_STEPS, B, device="cuda")
-        for i in range(PARITY_STEPS):       # from zero state: these frames are what the CPU leg replays
-            step(i)
-            gpu_probs[i].copy_(probs)
+    if fake:
+        stepper, sync, kernel_s = FakeStepper(B), (lambda: None), [None]
         for i in range(args.warmup):
-            step(PARITY_STEPS + i)
-        ts.synchronize()
+            stepper.step(i)
+
+        def run():
+            for i in range(args.steps):
+                stepper.step(i)
+        elapsed = sharding.timed_region(dist, run, sync, device="cpu")
+        preamble, ring_h, gpu_probs, versions = 0, None, None, [5]
+    else:
+        from cutter_vad_amd import weights_io
+        from cutter_vad_amd.engine import Engine
+        versions = [5] if args.mix == "v5" else [5, 4]
+        nb = B // len(versions)                       # streams per engine
+        engines, streams, probs, events = [], [], [], []
+        for v in versions:
+            with open(weights_io.packaged_blob_path(v), "rb") as f:
+                e = Engine(f.read(), model_version=v, device_id=local_rank, max_streams=nb)
+            e.open_streams(nb)                        # slots 0..nb-1, zero state, default thresholds
+            engines.append(e)
+            streams.append(torch.cuda.Stream())
+            probs.append(torch.empty(nb, device="cuda"))
+            events.append(torch.empty(nb, dtype=torch.uint8, device="cuda"))
+        ring_h = synth_ring(first_stream, B)
+        ring = torch.from_numpy(ring_h).cuda()
+        torch.cuda.synchronize()
+        ptrs = [[ring[i, k * nb:(k + 1) * nb].data_ptr() for i in range(RING)] for k in range(len(versions))]
+        ts = streams[0]
+
+        def step(i: int) -> None:
+            for k, e in enumerate(engines):
+                e.step_device(nb, ptrs[k][i % RING], probs[k].data_ptr(), d_events=events[k].data_ptr(), denoise=0.01,
+                              stream=streams[k].cuda_stream)
+
+        def join() -> None:                           # the other engines' streams meet on the first one (mix only)
+            for s in streams[1:]:
+                ts.wait_stream(s)
+
+        gpu_probs = torch.empty(PARITY_STEPS, B, device="cuda")
+        for i in range(PARITY_STEPS):                 # from zero state: these frames are what the CPU leg replays
+            step(i)
+            for k in range(len(versions)):
+                with torch.cuda.stream(streams[k]):
+                    gpu_probs[i, k * nb:(k + 1) * nb].copy_(probs[k])
+        torch.cuda.synchronize()
+        # clock ramp (untimed, not part of W): the same step until PREAMBLE_S of wall time have passed
+        t0, preamble = time.perf_counter(), 0
+        while time.perf_counter() - t0 < PREAMBLE_S:
+            for _ in range(64):
+                step(PARITY_STEPS + preamble)
+                preamble += 1
+            torch.cuda.synchronize()
+        base = PARITY_STEPS + preamble
+        for i in range(args.warmup):
+            step(base + i)
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
         def run() -> None:
+            for s in streams[1:]:
+                s.wait_stream(ts)
             e0.record(ts)
             h0 = time.perf_counter()
             for i in range(args.steps):
-                step(PARITY_STEPS + args.warmup + i)
+                step(base + args.warmup + i)
             host_enqueue[0] = time.perf_counter() - h0
+            join()
             e1.record(ts)
 
         elapsed = sharding.timed_region(dist, run, torch.cuda.synchronize, device="cuda" if backend == "nccl" else "cpu")
-    kernel_s = e0.elapsed_time(e1) * 1e-3 / args.steps      # avg launch duration on the launch stream
-    assert bool(torch.isfinite(probs).all()) and float(probs.min()) >= 0.0 and float(probs.max()) <= 1.0
+        kernel_s = [e0.elapsed_time(e1) * 1e-3 / args.steps]     # avg launch duration on the launch stream(s)
+        for p in probs:
+            assert bool(torch.isfinite(p).all()) and float(p.min()) >= 0.0 and float(p.max()) <= 1.0
 
     if rank == 0:
         value = sharding.aggregate_rate(B, args.steps, world, elapsed)
-        achieved = FLOP_PER_FRAME * B / kernel_s
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        mixed = len(versions) > 1
+        workload = ("configs[2]: batch=8192 concurrent streams per GPU, Silero V5, 16 kHz, one 512-sample frame per stream "
+                    "per step, denoise gate 0.01, state machine on") if not mixed else (
+                    "configs[4] per-GPU share: 4096 Silero V4 + 4096 Silero V5 streams per GPU (two engines, two HIP streams), "
+                    "16 kHz, one 512-sample frame per stream per step, denoise gate 0.01, state machines on")
         out = {
-            "metric": "512-sample frames/sec, Silero V5 16kHz, batch=8192 streams per GPU",
+            "metric": "512-sample frames/sec, Silero V5 16kHz, batch=8192 streams per GPU" if not mixed else
+                      "512-sample frames/sec, Silero V4 + V5 mixed, 8192 streams per GPU",
             "value": value,
             "unit": "frames/s",
             "n_gpus": world,
@@ -204,42 +302,63 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "configs[2]: batch=8192 concurrent streams per GPU, Silero V5, 16 kHz, "
-                            "one 512-sample frame per stream per step, denoise gate 0.01, state machine on",
+                "workload": workload,
                 "streams_per_gpu": B,
                 "frames_per_step_per_gpu": B,
                 "ring_frames": RING,
                 "sharding": f"{world} independent per-GPU stream pools, no collective",
             },
-            "roofline": {
+            "preamble_steps": preamble,
+        }
+        if fake:
+            out["data"] = "none (VAD_BENCH_FAKE=1: CPU rehearsal of the launch path, not a measurement)"
+            out["roofline"] = None
+        else:
+            ks = kernel_s[0]
+            flop = sum(FLOP_PER_FRAME[v] for v in versions) * (B // len(versions))
+            achieved = flop / ks
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if not mixed and os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured in this run)"
+                except Exception:
+                    traffic = None
+            out["roofline"] = {
                 "bound": "mfma",
-                "kernel": "silero_v5_step",
+                "kernel": "silero_v5_step" if not mixed else "silero_v5_step + silero_v4_step (concurrent)",
                 "achieved": achieved / 1e12,
                 "peak": PEAK_FP32_MFMA / 1e12,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_MFMA,
                 "traffic": traffic,
-                "kernel_us": kernel_s * 1e6,
-                "host_enqueue_us_per_launch": host_enqueue[0] / args.steps * 1e6,
-                "algorithmic_flop_per_launch": FLOP_PER_FRAME * B,
-                "executed_mfma_flop_per_launch": EXECUTED_FLOP_PER_FRAME * B,
-                "executed_frac_of_peak": EXECUTED_FLOP_PER_FRAME * B / kernel_s / PEAK_FP32_MFMA,
+                "traffic_source": traffic_src,
+                "kernel_us": ks * 1e6,
+                "host_enqueue_us_per_launch": host_enqueue[0] / args.steps / len(versions) * 1e6,
+                "algorithmic_flop_per_launch": flop,
                 "note": "frac = ALGORITHMIC FLOPs (the graph's dense sums, SURVEY 8d) / launch time / peak, as the bench "
-                        "contract prescribes; the kernel executes 63 % of them (folded DFT, Toom-3 enc0), so frac can "
-                        "exceed 1 while the MFMA pipe is busy executed_frac_of_peak of the time",
-                "hbm_algorithmic_GBps": BYTES_PER_FRAME * B / kernel_s / 1e9,
-                "hbm_frac": BYTES_PER_FRAME * B / kernel_s / PEAK_HBM,
-            },
-        }
-        if world == 1 and not args.no_cpu:
-            base, parity = cpu_leg(ring_h, gpu_probs.cpu().numpy())
-            out["cpu_baseline"] = base
-            out["parity"] = parity
+                        "contract prescribes; the V5 kernel executes 63 % of them (folded DFT, Toom-3 enc0), so frac can "
+                        "exceed 1 while the MFMA pipe is busy executed_frac_of_peak of the time: read executed_frac_of_peak "
+                        "as the utilisation",
+                "hbm_algorithmic_GBps": BYTES_PER_FRAME * B / ks / 1e9,
+                "hbm_frac": BYTES_PER_FRAME * B / ks / PEAK_HBM,
+            }
+            if not mixed:
+                out["roofline"]["executed_mfma_flop_per_launch"] = EXECUTED_FLOP_PER_FRAME * B
+                out["roofline"]["executed_frac_of_peak"] = EXECUTED_FLOP_PER_FRAME * B / ks / PEAK_FP32_MFMA
+            if world == 1 and not args.no_cpu and not mixed:
+                base_, parity = cpu_leg(ring_h, gpu_probs.cpu().numpy())
+                out["cpu_baseline"] = base_
+                out["parity"] = parity
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
-    eng.close()
+    if not fake:
+        for e in engines:
+            e.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -72,3 +72,34 @@ def test_single_process_needs_no_process_group():
     assert sharding.init_process_group(sharding.RankInfo(0, 0, 1), "gloo") is None
     t = sharding.timed_region(None, lambda: None, lambda: None)
     assert 0 <= t < 0.1
+
+
+# ------------------------------------------------------------------ bench.py's own launcher (`--gpus N` without torchrun)
+def _bench(*argv, **env):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True, env=e,
+                          timeout=300)
+
+
+def test_bench_gpus_n_launches_n_ranks_itself_and_reports_n():
+    """VAD_BENCH_FAKE=1: the launch / barrier / MAX-of-ranks / aggregation path of bench.py with a sleeping step (gloo)."""
+    import json
+    r = _bench("--gpus", "2", "--steps", "20", "--warmup", "2", VAD_BENCH_FAKE="1")
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 prints, once
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["value"] == pytest.approx(2 * 8192 * 20 / (out["ms_per_step"] * 1e-3 * 20))
+    assert out["ms_per_step"] >= 1.0 and "FAKE" in out["data"] and out["roofline"] is None
+
+
+def test_bench_refuses_to_run_fewer_gpus_than_asked():
+    r = _bench("--gpus", "8")                                 # no GPU in the CPU suite's container; 1 on a gpurun box
+    assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()
+    r = _bench("--gpus", "2", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
