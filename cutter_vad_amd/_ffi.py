@@ -22,6 +22,7 @@ VAD_ERR_HIP = -4
 VAD_ERR_NO_SLOT = -5
 VAD_ERR_BAD_SLOT = -6
 VAD_ERR_UNSUPPORTED = -7
+VAD_ERR_BUSY = -8
 
 VAD_FMT_F32, VAD_FMT_I16_32767, VAD_FMT_I16_32768 = 0, 1, 2
 VAD_EV_START, VAD_EV_END, VAD_EV_CONTINUE = 1, 2, 4
@@ -59,6 +60,8 @@ class EngineInfo(C.Structure):
         ("frames", C.c_int64),
         ("device_name", C.c_char * 64),
         ("arch", C.c_char * 32),
+        ("frame_samples", C.c_int32),
+        ("sample_rate", C.c_int32),
     ]
 
 
@@ -88,12 +91,16 @@ SIGNATURES = {
     "vad_stream_get_state": (C.c_int, [_vp, C.c_int64, _f32p]),
     "vad_stream_set_state": (C.c_int, [_vp, C.c_int64, _f32p]),
     "vad_stream_set_thresholds": (C.c_int, [_vp, C.c_int64, C.POINTER(Thresholds)]),
+    "vad_stream_set_thresholds_many": (C.c_int, [_vp, _i64p, C.c_int64, C.POINTER(Thresholds), C.c_int64]),
     "vad_stream_save": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64]),
     "vad_stream_restore": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64]),
     "vad_step": (C.c_int, [_vp, _i64p, C.c_int64, _vp, C.c_int, C.c_float, _f32p]),
     "vad_step_events": (C.c_int, [_vp, _i64p, C.c_int64, _vp, C.c_int, C.c_float, _f32p, _u8p, _i32p]),
     "vad_step_multi": (C.c_int, [_vp, _i64p, C.c_int64, C.c_int32, _vp, C.c_int, C.c_float, _f32p, _u8p]),
     "vad_step_device": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, C.c_float, _vp, _vp, _vp, _vp]),
+    "vad_step_multi_device": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, C.c_int, C.c_float, _vp, _vp, _vp, _vp]),
+    "vad_step_submit": (C.c_int, [_vp, _i64p, C.c_int64, C.c_int32, _vp, C.c_int, C.c_float, _i64p]),
+    "vad_step_collect": (C.c_int, [_vp, C.c_int64, _f32p, _u8p, _i32p]),
     "vad_resample": (C.c_int, [_vp, _f32p, C.c_int64, C.c_int32, C.c_int32, _f32p]),
     "vad_resample_multi_device": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_void_p), _i64p, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_void_p), _vp]),

@@ -26,12 +26,15 @@
 extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_silero_v4(const vadk::StepParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_resample(const vadk::ResampleParams *p, hipStream_t stream);
+extern "C" hipError_t vadk_launch_slot_control(vadk::SmSlot *sm, float *state, const int32_t *d_slots, int n, int op,
+                                               const vadk::SmSlot *def, const vad_thresholds *d_thr, int nthr, hipStream_t stream);
 extern "C" hipError_t vadk_launch_sm_replay(vadk::SmSlot *sm, int slot, const float *probs, int n, uint8_t *events,
                                             int32_t *seg, hipStream_t stream);
 
 namespace {
 
 thread_local std::string g_create_error;
+thread_local std::string g_error_copy;      // vad_last_error hands out a copy taken under the engine's mutex
 
 const vadk::SmSlot kDefaultSm = [] {
     vadk::SmSlot s;
@@ -66,6 +69,21 @@ struct vad_engine {
     std::vector<void *> host_blocks;                         // vad_host_alloc: freed with the engine
     uint8_t *d_small_in = nullptr, *d_small_out = nullptr;
     vadk::StepParams base{};
+    int sample_rate = 16000;
+    int frame_samples = VAD_FRAME_SAMPLES;   // samples per model step (512; Silero V5's 8 kHz sub-model: 256)
+    // batched slot control (open / reset / thresholds): one pinned block up, one kernel
+    uint8_t *h_ctl = nullptr, *d_ctl = nullptr; size_t ctl_cap = 0;
+    // pipelined host ingest (vad_step_submit / vad_step_collect): H2D of ticket t+1 on `copy_in` while the kernel of
+    // ticket t runs on `stream`; results come back on `copy_out` into a pinned block
+    static constexpr int PIPE_DEPTH = 2;
+    struct PipeBuf {
+        void *d_frames = nullptr; size_t d_frames_cap = 0;
+        uint8_t *d_io = nullptr, *h_io = nullptr; size_t io_cap = 0;   // [slots i32 n | probs f32 n T | seg i32 n | events u8 n T]
+        hipEvent_t copied = nullptr, done = nullptr, out = nullptr;
+        int64_t ticket = -1; int64_t n = 0; int32_t T = 0; bool busy = false;
+    } pipe[PIPE_DEPTH];
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    int64_t next_ticket = 0;
     struct ResampleOp {
         int n_in = 0;
         float *d_w = nullptr;
@@ -123,7 +141,19 @@ int ensure(vad_engine *e, T *&ptr, size_t &cap, size_t need) {
     return VAD_OK;
 }
 
-size_t frame_bytes(int fmt) { return fmt == VAD_FMT_F32 ? 4u * VAD_FRAME_SAMPLES : 2u * VAD_FRAME_SAMPLES; }
+size_t frame_bytes(const vad_engine *e, int fmt) { return (fmt == VAD_FMT_F32 ? 4u : 2u) * (size_t)e->frame_samples; }
+
+// The kernels address frames through a 32-bit buffer descriptor with signed 32-bit offset arithmetic: one call may not
+// span 2 GiB of frames (1 M float32 frames).  Rejected here instead of wrapping silently.
+int check_call_size(vad_engine *e, int64_t n, int32_t T, int fmt) {
+    if (n < 0 || T < 1 || n > e->max_streams)
+        return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: bad stream or frame count (n = %lld, T = %d, max_streams = %d)",
+                       (long long)n, T, e->max_streams);
+    if ((uint64_t)n * (uint64_t)T * frame_bytes(e, fmt) >= (1ull << 31))
+        return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: n * T * frame bytes = %llu exceeds the 2 GiB one call may address",
+                       (unsigned long long)((uint64_t)n * (uint64_t)T * frame_bytes(e, fmt)));
+    return VAD_OK;
+}
 
 int check_slots(vad_engine *e, const int64_t *slots, int64_t n) {
     if (++e->stamp_gen == 0) {
@@ -161,10 +191,10 @@ int step_host(vad_engine *e, const int64_t *slots, int64_t n, int32_t T, const v
     if (fmt < VAD_FMT_F32 || fmt > VAD_FMT_I16_32768)
         return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: unknown frame format %d", fmt);
     if (n == 0) return VAD_OK;
-    if (n > e->max_streams) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: n exceeds max_streams");
+    if (int rc = check_call_size(e, n, T, fmt)) return rc;
     if (int rc = check_slots(e, slots, n)) return rc;
     HIP_TRY(e, hipSetDevice(e->device));
-    const size_t fb = frame_bytes(fmt) * (size_t)n * T;
+    const size_t fb = frame_bytes(e, fmt) * (size_t)n * T;
     // ---- small calls: frames + slots travel as one pinned block, probs + seg + events come back as one; one
     //      synchronisation.  (The general path below issues 2 pageable H2D copies, waits, launches, 3 D2H copies, waits.)
     {
@@ -234,7 +264,12 @@ int step_host(vad_engine *e, const int64_t *slots, int64_t n, int32_t T, const v
 extern "C" {
 
 const char *vad_last_create_error(void) { return g_create_error.c_str(); }
-const char *vad_last_error(const vad_engine *e) { return e ? e->err.c_str() : "null engine"; }
+const char *vad_last_error(const vad_engine *e) {
+    if (!e) return "null engine";
+    std::lock_guard<std::mutex> lk(e->mu);      // other threads may be writing e->err: hand out a thread-local copy
+    g_error_copy = e->err;
+    return g_error_copy.c_str();
+}
 
 int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
     g_create_error.clear();
@@ -286,6 +321,7 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
     e->version = desc->model_version;
     e->device = desc->device_id;
     e->max_streams = desc->max_streams;
+    e->sample_rate = desc->sample_rate;
     auto bail = [&](hipError_t hr, const char *what) {
         g_create_error = std::string("Failed to load model: ") + what + ": " + hipGetErrorString(hr);
         (void)hipGetLastError();      // consumed here: HIP keeps the failure in a process-wide slot otherwise
@@ -300,6 +336,8 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
         return VAD_ERR_NO_DEVICE;
     }
     if ((r = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess) return bail(r, "hipStreamCreate");
+    if ((r = hipStreamCreateWithFlags(&e->copy_in, hipStreamNonBlocking)) != hipSuccess) return bail(r, "hipStreamCreate");
+    if ((r = hipStreamCreateWithFlags(&e->copy_out, hipStreamNonBlocking)) != hipSuccess) return bail(r, "hipStreamCreate");
     e->wbytes = pw.data.size() * sizeof(float);
     if ((r = hipMalloc((void **)&e->d_wstream, e->wbytes)) != hipSuccess) return bail(r, "hipMalloc(weights)");
     if ((r = hipMemcpy(e->d_wstream, pw.data.data(), e->wbytes, hipMemcpyHostToDevice)) != hipSuccess)
@@ -331,11 +369,22 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
 void vad_engine_destroy(vad_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (hipStream_t st : {e->copy_in, e->stream, e->copy_out})
+        if (st) (void)hipStreamSynchronize(st);
     void *bufs[] = {e->d_wstream, e->d_state, e->d_sm, e->d_frames, e->d_probs, e->d_events, e->d_seg, e->d_slots,
-                    e->d_rs_in, e->d_rs_out, e->d_small_in, e->d_small_out};
+                    e->d_rs_in, e->d_rs_out, e->d_small_in, e->d_small_out, e->d_ctl};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    for (auto &pb : e->pipe) {
+        if (pb.d_frames) (void)hipFree(pb.d_frames);
+        if (pb.d_io) (void)hipFree(pb.d_io);
+        if (pb.h_io) (void)hipHostFree(pb.h_io);
+        for (hipEvent_t ev : {pb.copied, pb.done, pb.out})
+            if (ev) (void)hipEventDestroy(ev);
+    }
+    if (e->copy_in) (void)hipStreamDestroy(e->copy_in);
+    if (e->copy_out) (void)hipStreamDestroy(e->copy_out);
+    if (e->h_ctl) (void)hipHostFree(e->h_ctl);
     if (e->h_small_in) (void)hipHostFree(e->h_small_in);
     if (e->h_small_out) (void)hipHostFree(e->h_small_out);
     for (void *b : e->host_blocks) (void)hipHostFree(b);
@@ -364,24 +413,41 @@ int vad_engine_info(const vad_engine *e, vad_info *info) {
     info->frames = e->frames;
     std::strncpy(info->device_name, e->prop.name, sizeof info->device_name - 1);
     std::strncpy(info->arch, e->prop.gcnArchName, sizeof info->arch - 1);
+    info->frame_samples = e->frame_samples;
+    info->sample_rate = e->sample_rate;
     return VAD_OK;
 }
 
-int vad_stream_open(vad_engine *e, int64_t *slot) {
-    if (!e || !slot) return VAD_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
-    if (e->free_list.empty()) return e->fail(VAD_ERR_NO_SLOT, "stream pool exhausted (%d slots)", e->max_streams);
-    const int64_t s = e->free_list.back();
+// One pinned block up (slots, optionally thresholds), ONE kernel for every listed slot, one synchronisation: open, reset and
+// threshold updates cost the same for 1 slot and for 8 192 (the per-slot form was 2 round trips per slot).
+static int slot_control(vad_engine *e, const int64_t *slots, int64_t n, int op, const vad_thresholds *thr, int64_t nthr) {
+    if (n == 0) return VAD_OK;
     HIP_TRY(e, hipSetDevice(e->device));
-    HIP_TRY(e, hipMemsetAsync(e->d_state + (size_t)s * VAD_STATE_FLOATS, 0, sizeof(float) * VAD_STATE_FLOATS, e->stream));
-    HIP_TRY(e, hipMemcpyAsync(e->d_sm + s, &kDefaultSm, sizeof kDefaultSm, hipMemcpyHostToDevice, e->stream));
+    const size_t o_thr = ((sizeof(int32_t) * (size_t)n) + 15) & ~(size_t)15;
+    const size_t need = o_thr + sizeof(vad_thresholds) * (size_t)nthr;
+    if (need > e->ctl_cap) {
+        const size_t cap = std::max(need, (size_t)(sizeof(int32_t) + sizeof(vad_thresholds)) * (size_t)e->max_streams + 16);
+        if (e->h_ctl) (void)hipHostFree(e->h_ctl);
+        if (e->d_ctl) (void)hipFree(e->d_ctl);
+        e->h_ctl = e->d_ctl = nullptr;
+        e->ctl_cap = 0;
+        HIP_TRY(e, hipHostMalloc((void **)&e->h_ctl, cap, hipHostMallocDefault));
+        HIP_TRY(e, hipMalloc((void **)&e->d_ctl, cap));
+        e->ctl_cap = cap;
+    }
+    int32_t *hs = reinterpret_cast<int32_t *>(e->h_ctl);
+    for (int64_t i = 0; i < n; ++i) hs[i] = (int32_t)slots[i];
+    if (nthr) std::memcpy(e->h_ctl + o_thr, thr, sizeof(vad_thresholds) * (size_t)nthr);
+    HIP_TRY(e, hipMemcpyAsync(e->d_ctl, e->h_ctl, need, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, vadk_launch_slot_control(e->d_sm, e->d_state, reinterpret_cast<const int32_t *>(e->d_ctl), (int)n, op, &kDefaultSm,
+                                        reinterpret_cast<const vad_thresholds *>(e->d_ctl + o_thr), (int)nthr, e->stream));
+    // callers may step on their own HIP stream next (vad_step_device): the slots must be ready when this returns
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    e->free_list.pop_back();
-    e->open[(size_t)s] = 1;
-    e->open_count += 1;
-    *slot = s;
     return VAD_OK;
 }
+enum { CTL_ZERO_STATE = 1, CTL_DEFAULT_SM = 2, CTL_RESET_DYNAMIC = 4, CTL_SET_THRESHOLDS = 8 };
+
+int vad_stream_open(vad_engine *e, int64_t *slot) { return vad_stream_open_many(e, 1, slot); }
 
 int vad_stream_open_many(vad_engine *e, int64_t n, int64_t *slots_out) {
     if (!e || n < 0 || (n > 0 && !slots_out)) return VAD_ERR_INVALID_ARG;
@@ -389,18 +455,11 @@ int vad_stream_open_many(vad_engine *e, int64_t n, int64_t *slots_out) {
     if ((int64_t)e->free_list.size() < n)
         return e->fail(VAD_ERR_NO_SLOT, "stream pool exhausted (%d slots, %d open, %lld requested)", e->max_streams,
                        e->open_count, (long long)n);
-    HIP_TRY(e, hipSetDevice(e->device));
+    for (int64_t i = 0; i < n; ++i) slots_out[i] = e->free_list[e->free_list.size() - 1 - (size_t)i];
+    if (int rc = slot_control(e, slots_out, n, CTL_ZERO_STATE | CTL_DEFAULT_SM, nullptr, 0)) return rc;
     for (int64_t i = 0; i < n; ++i) {
-        const int64_t s = e->free_list[e->free_list.size() - 1 - (size_t)i];
-        HIP_TRY(e, hipMemsetAsync(e->d_state + (size_t)s * VAD_STATE_FLOATS, 0, sizeof(float) * VAD_STATE_FLOATS, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(e->d_sm + s, &kDefaultSm, sizeof kDefaultSm, hipMemcpyHostToDevice, e->stream));
-    }
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    for (int64_t i = 0; i < n; ++i) {
-        const int64_t s = e->free_list.back();
+        e->open[(size_t)e->free_list.back()] = 1;
         e->free_list.pop_back();
-        e->open[(size_t)s] = 1;
-        slots_out[i] = s;
     }
     e->open_count += (int)n;
     return VAD_OK;
@@ -421,22 +480,8 @@ int vad_stream_reset(vad_engine *e, const int64_t *slots, int64_t n) {
     if (!e || (n > 0 && !slots) || n < 0) return VAD_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
     if (int rc = check_slots(e, slots, n)) return rc;
-    HIP_TRY(e, hipSetDevice(e->device));
-    for (int64_t i = 0; i < n; ++i) {
-        const int64_t s = slots[i];
-        // keep the slot's thresholds, reset the dynamic part (VADProcessor.reset, silero_model.py:951-968)
-        vadk::SmSlot cur;
-        HIP_TRY(e, hipMemcpyAsync(&cur, e->d_sm + s, sizeof cur, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        vadk::SmSlot fresh = kDefaultSm;
-        fresh.start_prob = cur.start_prob; fresh.end_prob = cur.end_prob;
-        fresh.start_ratio = cur.start_ratio; fresh.end_ratio = cur.end_ratio;
-        fresh.start_count = cur.start_count; fresh.end_count = cur.end_count;
-        HIP_TRY(e, hipMemcpyAsync(e->d_sm + s, &fresh, sizeof fresh, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(e, hipMemsetAsync(e->d_state + (size_t)s * VAD_STATE_FLOATS, 0, sizeof(float) * VAD_STATE_FLOATS, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-    }
-    return VAD_OK;
+    // keep the slots' thresholds, reset the dynamic part + (h, c) (VADProcessor.reset, silero_model.py:951-968)
+    return slot_control(e, slots, n, CTL_ZERO_STATE | CTL_RESET_DYNAMIC, nullptr, 0);
 }
 
 int vad_stream_get_state(vad_engine *e, int64_t slot, float *hc) {
@@ -500,24 +545,20 @@ int vad_stream_restore(vad_engine *e, int64_t slot, const void *buf, int64_t nby
 }
 
 int vad_stream_set_thresholds(vad_engine *e, int64_t slot, const vad_thresholds *t) {
-    if (!e || !t) return VAD_ERR_INVALID_ARG;
+    return vad_stream_set_thresholds_many(e, &slot, 1, t, 1);
+}
+
+int vad_stream_set_thresholds_many(vad_engine *e, const int64_t *slots, int64_t n, const vad_thresholds *t, int64_t nt) {
+    if (!e || n < 0 || (n > 0 && (!slots || !t))) return VAD_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
-    if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
-        return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
-    if (t->start_frame_count < 1 || t->end_frame_count < 1)
-        return e->fail(VAD_ERR_INVALID_ARG, "frame counts must be >= 1");
-    HIP_TRY(e, hipSetDevice(e->device));
+    if (n == 0) return VAD_OK;
+    if (nt != 1 && nt != n) return e->fail(VAD_ERR_INVALID_ARG, "thresholds: pass 1 (shared) or n (one per slot) entries, got %lld for %lld slots", (long long)nt, (long long)n);
+    if (int rc = check_slots(e, slots, n)) return rc;
+    for (int64_t i = 0; i < nt; ++i)
+        if (t[i].start_frame_count < 1 || t[i].end_frame_count < 1) return e->fail(VAD_ERR_INVALID_ARG, "frame counts must be >= 1");
     // values only: the dynamic part (counters, history) is untouched.  VADWrapper.set_thresholds resets the
     // processor afterwards (vad_wrapper.py:412-413) through vad_stream_reset.
-    vadk::SmSlot s;
-    HIP_TRY(e, hipMemcpyAsync(&s, e->d_sm + slot, sizeof s, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    s.start_prob = t->start_probability; s.end_prob = t->end_probability;
-    s.start_ratio = t->start_ratio; s.end_ratio = t->end_ratio;
-    s.start_count = t->start_frame_count; s.end_count = t->end_frame_count;
-    HIP_TRY(e, hipMemcpyAsync(e->d_sm + slot, &s, sizeof s, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    return VAD_OK;
+    return slot_control(e, slots, n, CTL_SET_THRESHOLDS, t, nt);
 }
 
 int vad_step(vad_engine *e, const int64_t *slots, int64_t n, const void *frames, int frame_fmt, float denoise_thresh,
@@ -541,13 +582,19 @@ int vad_step_multi(vad_engine *e, const int64_t *slots, int64_t n, int32_t T, co
 
 int vad_step_device(vad_engine *e, const int32_t *d_slots, int64_t n, const void *d_frames, int frame_fmt,
                     float denoise_thresh, float *d_probs, uint8_t *d_events, int32_t *d_seg_frames, void *stream) {
+    return vad_step_multi_device(e, d_slots, n, 1, d_frames, frame_fmt, denoise_thresh, d_probs, d_events, d_seg_frames, stream);
+}
+
+int vad_step_multi_device(vad_engine *e, const int32_t *d_slots, int64_t n, int32_t T, const void *d_frames, int frame_fmt,
+                          float denoise_thresh, float *d_probs, uint8_t *d_events, int32_t *d_seg_frames, void *stream) {
     if (!e) return VAD_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
-    if (n < 0 || n > e->max_streams || (n > 0 && (!d_frames || !d_probs)))
-        return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: null buffer or bad count");
     if (frame_fmt < VAD_FMT_F32 || frame_fmt > VAD_FMT_I16_32768)
         return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: unknown frame format %d", frame_fmt);
+    if (int rc = check_call_size(e, n, T, frame_fmt)) return rc;
+    if (n > 0 && (!d_frames || !d_probs)) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: null buffer");
     if (n == 0) return VAD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
     vadk::StepParams p = e->base;
     p.slots = d_slots;
     p.frames = d_frames;
@@ -555,10 +602,103 @@ int vad_step_device(vad_engine *e, const int32_t *d_slots, int64_t n, const void
     p.events = d_events;
     p.seg_frames = d_seg_frames;
     p.n = (int32_t)n;
-    p.T = 1;
+    p.T = T;
     p.fmt = frame_fmt;
     p.thresh = denoise_thresh;
     return launch(e, p, stream ? static_cast<hipStream_t>(stream) : e->stream);
+}
+
+// ---- pipelined host ingest ---------------------------------------------------------------------------------------
+int vad_step_submit(vad_engine *e, const int64_t *slots, int64_t n, int32_t T, const void *frames, int fmt, float thr,
+                    int64_t *ticket) {
+    if (!e || !ticket) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (fmt < VAD_FMT_F32 || fmt > VAD_FMT_I16_32768)
+        return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: unknown frame format %d", fmt);
+    if (int rc = check_call_size(e, n, T, fmt)) return rc;
+    if (n < 1 || !slots || !frames) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: null buffer or bad count");
+    vad_engine::PipeBuf &pb = e->pipe[e->next_ticket % vad_engine::PIPE_DEPTH];
+    if (pb.busy)
+        return e->fail(VAD_ERR_BUSY, "Model prediction failed: %d tickets are outstanding - collect ticket %lld first",
+                       vad_engine::PIPE_DEPTH, (long long)pb.ticket);
+    if (int rc = check_slots(e, slots, n)) return rc;
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (!pb.copied) {
+        HIP_TRY(e, hipEventCreateWithFlags(&pb.copied, hipEventDisableTiming));
+        HIP_TRY(e, hipEventCreateWithFlags(&pb.done, hipEventDisableTiming));
+        HIP_TRY(e, hipEventCreateWithFlags(&pb.out, hipEventDisableTiming));
+    }
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t fb = frame_bytes(e, fmt) * (size_t)n * T;
+    const size_t o_probs = up16(sizeof(int32_t) * (size_t)n), o_seg = o_probs + up16(sizeof(float) * (size_t)n * T);
+    const size_t o_ev = o_seg + up16(sizeof(int32_t) * (size_t)n), io_bytes = o_ev + up16((size_t)n * T);
+    if (int rc = ensure(e, pb.d_frames, pb.d_frames_cap, fb)) return rc;
+    if (io_bytes > pb.io_cap) {
+        if (pb.d_io) (void)hipFree(pb.d_io);
+        if (pb.h_io) (void)hipHostFree(pb.h_io);
+        pb.d_io = pb.h_io = nullptr;
+        pb.io_cap = 0;
+        HIP_TRY(e, hipMalloc((void **)&pb.d_io, io_bytes));
+        HIP_TRY(e, hipHostMalloc((void **)&pb.h_io, io_bytes, hipHostMallocDefault));
+        pb.io_cap = io_bytes;
+    }
+    int32_t *hs = reinterpret_cast<int32_t *>(pb.h_io);
+    for (int64_t i = 0; i < n; ++i) hs[i] = (int32_t)slots[i];
+    // in: slots + frames on the copy-in stream (true DMA when `frames` is page-locked: vad_host_alloc)
+    HIP_TRY(e, hipMemcpyAsync(pb.d_io, pb.h_io, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, e->copy_in));
+    HIP_TRY(e, hipMemcpyAsync(pb.d_frames, frames, fb, hipMemcpyHostToDevice, e->copy_in));
+    HIP_TRY(e, hipEventRecord(pb.copied, e->copy_in));
+    // compute: after the copy; kernels of successive tickets run in submission order on the engine's stream
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, pb.copied, 0));
+    vadk::StepParams p = e->base;
+    p.slots = reinterpret_cast<const int32_t *>(pb.d_io);
+    p.frames = pb.d_frames;
+    p.probs = reinterpret_cast<float *>(pb.d_io + o_probs);
+    p.seg_frames = reinterpret_cast<int32_t *>(pb.d_io + o_seg);
+    p.events = pb.d_io + o_ev;
+    p.n = (int32_t)n;
+    p.T = T;
+    p.fmt = fmt;
+    p.thresh = thr;
+    if (int rc = launch(e, p, e->stream)) return rc;
+    HIP_TRY(e, hipEventRecord(pb.done, e->stream));
+    // out: probs | seg | events as one block on the copy-out stream
+    HIP_TRY(e, hipStreamWaitEvent(e->copy_out, pb.done, 0));
+    HIP_TRY(e, hipMemcpyAsync(pb.h_io + o_probs, pb.d_io + o_probs, io_bytes - o_probs, hipMemcpyDeviceToHost, e->copy_out));
+    HIP_TRY(e, hipEventRecord(pb.out, e->copy_out));
+    pb.busy = true;
+    pb.ticket = e->next_ticket;
+    pb.n = n;
+    pb.T = T;
+    *ticket = e->next_ticket++;
+    return VAD_OK;
+}
+
+int vad_step_collect(vad_engine *e, int64_t ticket, float *probs_out, uint8_t *events_out, int32_t *seg_frames_out) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    hipEvent_t out_ev = nullptr;
+    vad_engine::PipeBuf *pb = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (ticket < 0) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: bad ticket");
+        pb = &e->pipe[ticket % vad_engine::PIPE_DEPTH];
+        if (!pb->busy || pb->ticket != ticket)
+            return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: ticket %lld is not outstanding", (long long)ticket);
+        if (!probs_out) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: probs_out is null");
+        out_ev = pb->out;
+    }
+    // wait WITHOUT the engine's mutex: another thread may submit the next ticket meanwhile (that is the overlap)
+    hipError_t r = hipEventSynchronize(out_ev);
+    std::lock_guard<std::mutex> lk(e->mu);
+    pb->busy = false;
+    if (r != hipSuccess) return e->hip_fail(r, "hipEventSynchronize(ticket)");
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t n = (size_t)pb->n, T = (size_t)pb->T;
+    const size_t o_probs = up16(sizeof(int32_t) * n), o_seg = o_probs + up16(sizeof(float) * n * T), o_ev = o_seg + up16(sizeof(int32_t) * n);
+    std::memcpy(probs_out, pb->h_io + o_probs, sizeof(float) * n * T);
+    if (seg_frames_out) std::memcpy(seg_frames_out, pb->h_io + o_seg, sizeof(int32_t) * n);
+    if (events_out) std::memcpy(events_out, pb->h_io + o_ev, n * T);
+    return VAD_OK;
 }
 
 namespace {

@@ -34,7 +34,9 @@ struct Blob {
     const float *get(const char *name, uint64_t expect) const {
         for (uint32_t i = 0; i < n; ++i) {
             if (std::strncmp(tab[i].name, name, sizeof tab[i].name) == 0) {
-                if (tab[i].nelem != expect || tab[i].offset + 4 * tab[i].nelem > len) break;
+                // overflow-safe range check: offset and nelem come from the file (an offset near 2^64 must not wrap past `len`)
+                if (tab[i].nelem != expect || tab[i].offset > len || tab[i].nelem > (len - tab[i].offset) / 4) break;
+                if (tab[i].offset % 4 != 0) break;      // tensors are read as float*
                 return reinterpret_cast<const float *>(p + tab[i].offset);
             }
         }

@@ -140,6 +140,14 @@ class Engine:
                             end_frame_count)
         self._check(self._lib.vad_stream_set_thresholds(self._h, int(slot), C.byref(t)), VADError)
 
+    def set_thresholds_many(self, slots, thresholds) -> None:
+        """``thresholds``: one 6-tuple (shared by all slots) or one per slot, in the order of ``set_thresholds``' arguments
+        (``vad_stream_set_thresholds_many``: one launch for the lot)."""
+        s = np.ascontiguousarray(slots, dtype=np.int64).reshape(-1)
+        rows = [thresholds] if np.isscalar(thresholds[0]) else list(thresholds)
+        arr = (_ffi.Thresholds * len(rows))(*[_ffi.Thresholds(*r) for r in rows])
+        self._check(self._lib.vad_stream_set_thresholds_many(self._h, _ptr(s, C.c_int64), s.size, arr, len(rows)), VADError)
+
     def debug_sm_replay(self, slot: int, probs) -> Tuple[np.ndarray, np.ndarray]:
         """Diagnostic: run scripted probabilities through one slot's device state machine."""
         p = np.ascontiguousarray(probs, np.float32)
@@ -208,6 +216,44 @@ class Engine:
         thr = -1.0 if denoise is None else float(denoise)
         self._check(self._lib.vad_step_device(self._h, d_slots or None, n, d_frames, fmt, thr, d_probs,
                                               d_events or None, d_seg or None, stream or None))
+
+    def step_multi_device(self, n: int, T: int, d_frames: int, d_probs: int, d_slots: int = 0, d_events: int = 0,
+                          d_seg: int = 0, fmt: int = _ffi.VAD_FMT_F32, denoise: Optional[float] = 0.01, stream: int = 0) -> None:
+        """``step_device`` with T frames per stream: d_frames [n, T, frame], d_probs [n, T] (``vad_step_multi_device``)."""
+        thr = -1.0 if denoise is None else float(denoise)
+        self._check(self._lib.vad_step_multi_device(self._h, d_slots or None, n, T, d_frames, fmt, thr, d_probs,
+                                                    d_events or None, d_seg or None, stream or None))
+
+    # ------------------------------------------------------------------ pipelined host ingest
+    def submit(self, slots, frames, denoise: Optional[float] = 0.01, i16_scale: int = 32767) -> int:
+        """Enqueue copy-in -> step -> copy-out for ``frames`` [n, frame] or [n, T, frame] and return a ticket
+        (``vad_step_submit``).  ``slots`` / ``frames`` must stay alive and unchanged until ``collect(ticket)``; frames in a
+        ``pinned_array`` are DMA'd asynchronously, so the copy of this ticket overlaps the kernel of the previous one."""
+        f0 = np.asarray(frames)
+        T = int(f0.shape[1]) if f0.ndim == 3 else 1
+        s, f, fmt = self._prep(slots, f0, T if f0.ndim == 3 else None)
+        if fmt != _ffi.VAD_FMT_F32 and i16_scale == 32768:
+            fmt = _ffi.VAD_FMT_I16_32768
+        thr = -1.0 if denoise is None else float(denoise)
+        t = C.c_int64()
+        self._check(self._lib.vad_step_submit(self._h, _ptr(s, C.c_int64), s.size, T, f.ctypes.data_as(C.c_void_p), fmt, thr,
+                                              C.byref(t)))
+        self._tickets = getattr(self, "_tickets", {})
+        self._tickets[int(t.value)] = (s, f, T, f0.ndim == 3)      # keeps the buffers alive until collected
+        return int(t.value)
+
+    def collect(self, ticket: int):
+        """-> (probs, events, seg_frames) of a submitted ticket; blocks until its results are on the host."""
+        s, _f, T, multi = self._tickets[int(ticket)]
+        probs = np.empty((s.size, T), np.float32)
+        ev = np.zeros((s.size, T), np.uint8)
+        seg = np.zeros(s.size, np.int32)
+        try:
+            self._check(self._lib.vad_step_collect(self._h, int(ticket), _ptr(probs, C.c_float), _ptr(ev, C.c_uint8),
+                                                   _ptr(seg, C.c_int32)))
+        finally:
+            self._tickets.pop(int(ticket), None)
+        return (probs, ev, seg) if multi else (probs[:, 0], ev[:, 0], seg)
 
     def resample_multi_device(self, segments, stream: int = 0) -> None:
         """One launch for up to 4 segments ``(d_in, n, n_in, sr_in, d_out)`` of device pointers (integers)."""

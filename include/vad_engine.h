@@ -42,7 +42,7 @@ extern "C" {
 #define VAD_API
 #endif
 
-#define VAD_ABI_VERSION 1
+#define VAD_ABI_VERSION 2
 #define VAD_FRAME_SAMPLES 512   /* core/silero_model.py:464-468: frames are padded/truncated to 512 */
 #define VAD_STATE_FLOATS 256    /* V5: state[2][1][128]; V4: h[2][1][64] then c[2][1][64]  (silero_model.py:391-401) */
 
@@ -54,7 +54,8 @@ typedef enum vad_status {
     VAD_ERR_HIP = -4,           /* a HIP runtime call failed -> AudioProcessingError("Model prediction failed: ...") :444-447 */
     VAD_ERR_NO_SLOT = -5,       /* stream pool exhausted */
     VAD_ERR_BAD_SLOT = -6,      /* slot not open / out of range / duplicated within one step */
-    VAD_ERR_UNSUPPORTED = -7    /* e.g. Silero V5 with sample_rate != 16000 (its 8 kHz graph branch cannot take 512-sample frames) */
+    VAD_ERR_UNSUPPORTED = -7,   /* e.g. an input rate the resampler has no operator for */
+    VAD_ERR_BUSY = -8           /* vad_step_submit: every pipeline buffer holds an uncollected ticket */
 } vad_status;
 
 typedef enum vad_frame_format {
@@ -96,6 +97,8 @@ typedef struct vad_info {
     int64_t frames;                /* frames processed so far */
     char device_name[64];
     char arch[32];                 /* "gfx950..." */
+    int32_t frame_samples;         /* samples per model step: 512 (core/silero_model.py:464-468); 256 for Silero V5's 8 kHz sub-model */
+    int32_t sample_rate;           /* the `sr` the engine was created for */
 } vad_info;
 
 /* thresholds of one stream's state machine: VADConfig fields core/config.py:54-94 */
@@ -135,6 +138,10 @@ VAD_API int vad_stream_set_state(vad_engine *e, int64_t slot, const float *hc);
 /* VADWrapper.set_thresholds  core/vad_wrapper.py:367-419: values only (validation lives in the host mirror);
  * the counters/history of the slot are NOT reset here - the wrapper calls vad_stream_reset next, as :412-413 does */
 VAD_API int vad_stream_set_thresholds(vad_engine *e, int64_t slot, const vad_thresholds *t);
+/* the same for n slots in ONE launch: t holds nt = 1 (shared by all) or nt = n (one per slot) entries.  vad_stream_reset,
+ * vad_stream_open_many and this call cost one small copy + one kernel + one synchronisation whatever n is (a shared-pool
+ * server resets / reconfigures thousands of sessions per tick: websocket_service/server/vad_websocket_server.py:277, 420-470) */
+VAD_API int vad_stream_set_thresholds_many(vad_engine *e, const int64_t *slots, int64_t n, const vad_thresholds *t, int64_t nt);
 /* Everything a stream is between two frames, as one opaque blob: (h, c) + the state machine's thresholds,
  * counters and history (VAD_STREAM_SAVE_BYTES).  No reference counterpart: the reference processes a chunk's frames
  * one by one and a callback that raises leaves the later frames unprocessed (core/vad_wrapper.py:638-647); the host
@@ -182,6 +189,38 @@ VAD_API int vad_step_multi(vad_engine *e, const int64_t *slots, int64_t n, int32
  */
 VAD_API int vad_step_device(vad_engine *e, const int32_t *d_slots, int64_t n, const void *d_frames, int frame_fmt,
                     float denoise_thresh, float *d_probs, uint8_t *d_events, int32_t *d_seg_frames, void *stream);
+/*
+ * The same with T consecutive frames per stream (vad_step_multi on device pointers): d_frames [n][T][frame], d_probs [n][T],
+ * d_events [n][T] or NULL, d_seg_frames [n] or NULL (length of the LAST segment that ended inside the call, else 0).
+ * Rules for both device entry points:
+ *   - d_slots is trusted (it lives on the GPU, the host cannot validate it): every entry must be an OPEN slot of this engine
+ *     and must appear AT MOST ONCE per call - a duplicate makes two workgroups read-modify-write the same (h, c) and state
+ *     machine, and the result is undefined (the host-pointer entry points check this and return VAD_ERR_BAD_SLOT);
+ *   - calls that touch the same slot must be ordered by the caller (same HIP stream, or events between streams);
+ *   - one call may address at most 2 GiB of frames (n * T * frame bytes), else VAD_ERR_INVALID_ARG.
+ */
+VAD_API int vad_step_multi_device(vad_engine *e, const int32_t *d_slots, int64_t n, int32_t T, const void *d_frames,
+                                  int frame_fmt, float denoise_thresh, float *d_probs, uint8_t *d_events,
+                                  int32_t *d_seg_frames, void *stream);
+
+/*
+ * Pipelined host ingest.  vad_step* on host pointers are copy -> kernel -> copy -> wait; at 8 192 streams the PCIe copy is
+ * 5-8 x the kernel, so a serving loop should overlap the copy of tick t+1 with the kernel of tick t:
+ *
+ *     vad_step_submit(e, slots, n, T, frames_t1, fmt, thr, &ticket1);     // enqueues H2D -> kernel -> D2H, returns at once
+ *     vad_step_collect(e, ticket0, probs, events, seg);                   // blocks until tick t's results are on the host
+ *
+ * Up to 2 tickets may be outstanding (a third submit returns VAD_ERR_BUSY); each ticket is collected exactly once, in any
+ * order.  `frames` must stay valid and unchanged until its ticket is collected; allocate it
+ * with vad_host_alloc for a true asynchronous DMA (a pageable buffer works, but the runtime then stages it synchronously).
+ * Kernels of successive tickets run in submission order on the engine's stream, so a slot may appear in consecutive
+ * tickets.  Results are identical, bit for bit, to vad_step_multi on the same inputs.
+ * The reference has no counterpart: it calls session.run synchronously per frame (core/silero_model.py:433, 471-499).
+ */
+VAD_API int vad_step_submit(vad_engine *e, const int64_t *slots, int64_t n, int32_t T, const void *frames, int frame_fmt,
+                            float denoise_thresh, int64_t *ticket);
+VAD_API int vad_step_collect(vad_engine *e, int64_t ticket, float *probs_out /*[n][T]*/, uint8_t *events_out /*[n][T] or NULL*/,
+                             int32_t *seg_frames_out /*[n] or NULL*/);
 
 /*
  * AudioUtils.resample_audio (utils/audio.py:19-55 -> scipy.signal.resample, Fourier method)

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header():
     assert C.sizeof(_ffi.EngineDesc) == 40
     assert C.sizeof(_ffi.Thresholds) == 40
-    assert C.sizeof(_ffi.EngineInfo) == 32 + 32 + 64 + 32
+    assert C.sizeof(_ffi.EngineInfo) == 32 + 32 + 64 + 32 + 8
 
 
 def test_create_fails_loudly_without_gpu():

@@ -1,0 +1,151 @@
+"""ABI v2 additions through the C ABI on the GPU: batched slot control, T > 1 on device pointers, the per-call size bound,
+and the pipelined host ingest (vad_step_submit / vad_step_collect)."""
+
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+from cutter_vad_amd import _ffi, weights_io
+from tests.signals import make_streams
+
+pytestmark = pytest.mark.gpu
+
+
+def _blob(v=5):
+    with open(weights_io.packaged_blob_path(v), "rb") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from cutter_vad_amd.engine import Engine
+    e = Engine(_blob(5), model_version=5, max_streams=8192)
+    yield e
+    e.close()
+
+
+def test_batched_reset_and_thresholds_are_one_launch(eng):
+    slots = eng.open_streams(8192)
+    try:
+        x = make_streams(8192, 2, seed=3)
+        eng.step(slots, x[:, 0])
+        assert eng.get_state(int(slots[4000])).any()
+        eng.reset(slots[:1])                                  # warm (pinned control block allocated)
+        t0 = time.perf_counter()
+        eng.reset(slots)
+        dt = time.perf_counter() - t0
+        assert dt < 1e-3, dt                                  # r01: 8 192 x 2 round trips = tens of ms; target < 100 us
+        for s in (0, 4000, 8191):
+            assert not eng.get_state(int(slots[s])).any()
+        # per-slot thresholds in one call; the state machine of slot k then fires START after k % 3 + 1 frames above 0.5
+        thr = [(0.5, 0.3, 0.8, 0.95, int(k % 3 + 1), 2) for k in range(8192)]
+        eng.set_thresholds_many(slots, thr)
+        for k in (0, 1, 2, 8191):
+            ev, _ = eng.debug_sm_replay(int(slots[k]), [0.9] * 4)
+            assert list(ev).index(_ffi.VAD_EV_START) == k % 3, k
+        eng.set_thresholds_many(slots, (0.7, 0.7, 0.8, 0.95, 10, 50))          # shared entry
+        eng.reset(slots)
+        ev, _ = eng.debug_sm_replay(int(slots[17]), [0.9] * 12)
+        assert list(ev).index(_ffi.VAD_EV_START) == 9
+        with pytest.raises(Exception, match="1 .shared. or n"):
+            eng.set_thresholds_many(slots[:5], thr[:3])
+        print(f"\n8192-slot vad_stream_reset: {dt * 1e6:.0f} us")
+    finally:
+        eng.reset(slots)
+        for s in slots:
+            eng.close_stream(int(s))
+
+
+def test_step_multi_device_T_frames_equals_host_multi(eng):
+    import torch
+    n, T = 700, 5
+    x = make_streams(n, T, seed=21)
+    slots = eng.open_streams(n)
+    try:
+        want_p, want_ev = eng.step_multi(slots, x)
+        want_state = eng.get_state(int(slots[123]))
+        eng.reset(slots)
+        d_x = torch.from_numpy(x).cuda()
+        d_slots = torch.from_numpy(slots.astype(np.int32)).cuda()
+        d_p = torch.zeros(n, T, device="cuda")
+        d_ev = torch.zeros(n, T, dtype=torch.uint8, device="cuda")
+        d_seg = torch.zeros(n, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        eng.step_multi_device(n, T, d_x.data_ptr(), d_p.data_ptr(), d_slots=d_slots.data_ptr(), d_events=d_ev.data_ptr(),
+                              d_seg=d_seg.data_ptr())
+        eng.synchronize()
+        assert np.array_equal(d_p.cpu().numpy(), want_p) and np.array_equal(d_ev.cpu().numpy(), want_ev)
+        assert np.array_equal(eng.get_state(int(slots[123])), want_state)
+    finally:
+        for s in slots:
+            eng.close_stream(int(s))
+
+
+def test_one_call_may_not_address_2_gib(eng):
+    lib = _ffi.lib()
+    # n * T * 2048 B >= 2^31: refused before anything is launched (the kernels' 32-bit frame addressing would wrap)
+    rc = lib.vad_step_multi_device(eng.handle, None, 8192, 128, 1, _ffi.VAD_FMT_F32, C.c_float(0.01), 1, None, None, None)
+    assert rc == _ffi.VAD_ERR_INVALID_ARG and b"2 GiB" in lib.vad_last_error(eng.handle)
+    rc = lib.vad_step_multi_device(eng.handle, None, 8192, 127, None, _ffi.VAD_FMT_F32, C.c_float(0.01), None, None, None, None)
+    assert rc == _ffi.VAD_ERR_INVALID_ARG and b"null buffer" in lib.vad_last_error(eng.handle)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int16])
+def test_submit_collect_is_bit_identical_and_overlaps_the_copy(eng, dtype):
+    n, ticks = 8192, 12
+    x = make_streams(n, ticks, seed=5)
+    if dtype == np.int16:
+        x = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)
+    slots = eng.open_streams(n)
+    try:
+        want = [eng.step_events(slots, np.ascontiguousarray(x[:, t])) for t in range(ticks)]
+        want_state = eng.get_state(int(slots[999]))
+        eng.reset(slots)
+        # two page-locked frame buffers, filled alternately: the copy of tick t+1 runs while the kernel of tick t does
+        bufs = [eng.pinned_array((n, 512), dtype) for _ in range(2)]
+        got = [None] * ticks
+        bufs[0][:] = x[:, 0]
+        prev = eng.submit(slots, bufs[0])
+        for t in range(1, ticks):
+            bufs[t & 1][:] = x[:, t]
+            cur = eng.submit(slots, bufs[t & 1])
+            got[t - 1] = eng.collect(prev)
+            prev = cur
+        got[ticks - 1] = eng.collect(prev)
+        for t in range(ticks):
+            for a, b in zip(got[t], want[t]):
+                assert np.array_equal(a, b), t
+        assert np.array_equal(eng.get_state(int(slots[999])), want_state)
+        # a third outstanding ticket is refused, an unknown ticket too
+        t0 = eng.submit(slots, bufs[0])
+        t1 = eng.submit(slots, bufs[1])
+        with pytest.raises(Exception, match="outstanding"):
+            eng.submit(slots, bufs[0])
+        eng.collect(t1)
+        eng.collect(t0)
+        with pytest.raises(Exception):
+            eng.collect(t0)
+        # throughput of the two forms, host pointers in, results on the host out
+        def sync_loop(k):
+            for t in range(k):
+                eng.step_events(slots, bufs[t & 1])
+        def pipe_loop(k):
+            p = eng.submit(slots, bufs[0])
+            for t in range(1, k):
+                c = eng.submit(slots, bufs[t & 1])
+                eng.collect(p)
+                p = c
+            eng.collect(p)
+        for fn in (sync_loop, pipe_loop):
+            fn(5)
+        K = 60
+        t0 = time.perf_counter(); sync_loop(K); t_sync = (time.perf_counter() - t0) / K
+        t0 = time.perf_counter(); pipe_loop(K); t_pipe = (time.perf_counter() - t0) / K
+        print(f"\nPCIe-inclusive, {np.dtype(dtype).name}, B = 8192: synchronous {t_sync * 1e6:.0f} us/tick = {n / t_sync / 1e6:.1f} M frames/s; "
+              f"pipelined {t_pipe * 1e6:.0f} us/tick = {n / t_pipe / 1e6:.1f} M frames/s")
+        assert t_pipe < t_sync
+    finally:
+        for s in slots:
+            eng.close_stream(int(s))

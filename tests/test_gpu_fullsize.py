@@ -116,8 +116,7 @@ def test_device_state_machines_follow_the_oracle_at_full_size(setup):
     x[:, 14:24] *= 0.01                               # a quiet block: segments end and start again
     x = np.tile(x, (8, 1, 1))
     eng.reset(slots)
-    for s in slots:
-        eng.set_thresholds(int(s), 0.5, 0.35, 0.8, 0.95, 3, 4)
+    eng.set_thresholds_many(slots, (0.5, 0.35, 0.8, 0.95, 3, 4))          # one launch for the 8 192 slots
     sms = [oracle.StateMachine(0.5, 0.35, 0.8, 0.95, 3, 4) for _ in range(B // 8)]
     starts = ends = 0
     try:
@@ -132,8 +131,7 @@ def test_device_state_machines_follow_the_oracle_at_full_size(setup):
             ends += int(((ev & 2) != 0).sum())
         assert starts > 1000 and ends > 1000, (starts, ends)
     finally:
-        for s in slots:
-            eng.set_thresholds(int(s))
+        eng.set_thresholds_many(slots, (0.7, 0.7, 0.8, 0.95, 10, 50))
 
 
 def test_reset_repeats_the_run(setup, frames):

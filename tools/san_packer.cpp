@@ -1,5 +1,6 @@
 // ASan/UBSan harness for the host-side packers: see tools/sanitize_packer.sh
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iterator>
 #include <string>
@@ -18,6 +19,15 @@ int main(int argc, char **argv) {
             vadk::PackedWeights q; std::string e2;
             bool k2 = std::string(argv[i]).find("v5") != std::string::npos ? vadk::pack_silero_v5(b.data(), cut, q, e2) : vadk::pack_silero_v4(b.data(), cut, q, e2);
             if (k2) printf("  cut %zu unexpectedly ok\n", cut);
+        }
+        // a tensor-table entry whose offset is near 2^64 (offset + 4 * nelem wraps to a small number) must be refused, not read
+        if (b.size() > 16 + 88) {
+            std::vector<char> evil(b);
+            const unsigned long long off = ~0ull - 1023;       // entry 0 starts at byte 16; its offset field follows name[48], ndim, dims[4], reserved = byte 72
+            std::memcpy(evil.data() + 16 + 72, &off, 8);
+            vadk::PackedWeights q; std::string e2;
+            bool k2 = std::string(argv[i]).find("v5") != std::string::npos ? vadk::pack_silero_v5(evil.data(), evil.size(), q, e2) : vadk::pack_silero_v4(evil.data(), evil.size(), q, e2);
+            printf("  wrapped offset: %s (%s)\n", k2 ? "UNEXPECTEDLY OK" : "refused", e2.c_str());
         }
     }
     for (int n : {256, 768, 1536}) {
