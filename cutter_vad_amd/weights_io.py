@@ -68,8 +68,13 @@ def _iofc_to_ifgo(a: np.ndarray, hidden: int) -> np.ndarray:
     return np.concatenate([i, f, c, o], axis=0)
 
 
-def _extract_v5(model: onnx_lite.Model) -> Dict[str, np.ndarray]:
-    _, g = _find_branch(model, "then_branch")
+def _extract_v5(model: onnx_lite.Model, sample_rate: int = 16000) -> Dict[str, np.ndarray]:
+    """16 kHz sub-model (``If_0`` then-branch) or the 8 kHz one (else-branch: window 128, hop 64, 65 bins,
+    ``encoder.0`` 65 -> 128, its own weights throughout; it runs on 256-sample frames - SURVEY a9 / f3).  Same tensor
+    names; the 8 kHz blob carries ``meta.variant = 8000``."""
+    k8 = sample_rate != 16000
+    nfft, nbin = (128, 65) if k8 else (256, 129)
+    _, g = _find_branch(model, "else_branch" if k8 else "then_branch")
     c = {}
     for node in g.nodes:
         if node.op_type == "Constant" and node.outputs:
@@ -77,7 +82,7 @@ def _extract_v5(model: onnx_lite.Model) -> Dict[str, np.ndarray]:
             c[node.outputs[0].split("__Inline_0__")[-1]] = node.attrs["value"]
     try:
         t = {
-            "stft.basis": c["stft.forward_basis_buffer"].reshape(258, 256),
+            "stft.basis": c["stft.forward_basis_buffer"].reshape(2 * nbin, nfft),
             "lstm.w_ih": c["decoder.rnn.weight_ih"],
             "lstm.w_hh": c["decoder.rnn.weight_hh"],
             "lstm.b_ih": c["decoder.rnn.bias_ih"],
@@ -88,6 +93,10 @@ def _extract_v5(model: onnx_lite.Model) -> Dict[str, np.ndarray]:
         for i in range(4):
             t[f"enc{i}.w"] = c[f"encoder.{i}.reparam_conv.weight"]
             t[f"enc{i}.b"] = c[f"encoder.{i}.reparam_conv.bias"]
+        if t["enc0.w"].shape != (128, nbin, 3):
+            raise WeightFormatError(f"not a Silero V5 graph: encoder.0 has shape {t['enc0.w'].shape}")
+        if k8:
+            t["meta.variant"] = np.array([8000.0], np.float32)
     except KeyError as e:  # pragma: no cover - wrong file
         raise WeightFormatError(f"not a Silero V5 graph: missing tensor {e}") from e
     return t
@@ -162,7 +171,7 @@ def extract_from_onnx(path: str, version: int, sample_rate: int = 16000) -> Dict
         raise WeightFormatError(f"Expected {exp_in} inputs, got {n_in}")
     if n_out != exp_out:
         raise WeightFormatError(f"Expected {exp_out} outputs, got {n_out}")
-    t = _extract_v5(model) if version == 5 else _extract_v4(model, sample_rate)
+    t = _extract_v5(model, sample_rate) if version == 5 else _extract_v4(model, sample_rate)
     return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in t.items()}
 
 
@@ -211,9 +220,16 @@ def unpack_svw(blob: bytes) -> Tuple[int, Dict[str, np.ndarray]]:
 
 
 def is_8k_variant(version: int, sample_rate: int) -> bool:
-    """V4's graph runs its 8 kHz sub-model for every rate but 16 000 (``Equal(sr, 16000)``); V5's 8 kHz branch
-    cannot take the reference's 512-sample frames and is not built."""
-    return version == 4 and int(sample_rate) != 16000
+    """Both graphs run their 8 kHz sub-model for every rate but 16 000 (``Equal(sr, 16000)``).  V4's takes the
+    reference's 512-sample frames at any of those rates; V5's only makes sense on native 8 kHz audio in 256-sample
+    frames (:func:`frame_samples`) - with 512-sample frames a 3-D tensor reaches its LSTM and onnxruntime refuses
+    (SURVEY a9), which the host mirror reproduces for every other combination."""
+    return int(sample_rate) != 16000
+
+
+def frame_samples(version: int, sample_rate: int) -> int:
+    """Samples one model step consumes: 512 (core/silero_model.py:464-468), except Silero V5's 8 kHz sub-model: 256."""
+    return 256 if version == 5 and is_8k_variant(version, sample_rate) else 512
 
 
 def packaged_blob_path(version: int, sample_rate: int = 16000) -> str:
@@ -235,4 +251,4 @@ def load_weight_blob(model_path: str, version: int, sample_rate: int = 16000) ->
             raise WeightFormatError(f"weight blob is the {'8' if 'meta.variant' in t else '16'} kHz sub-model, "
                                     f"requested sample rate {sample_rate}")
         return blob
-    return pack_svw(version, extract_from_onnx(model_path, version, sample_rate if version == 4 else 16000))
+    return pack_svw(version, extract_from_onnx(model_path, version, sample_rate))

@@ -40,6 +40,7 @@ def _lib(acc: str = "f64") -> C.CDLL:
     lib.svo_load.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
     lib.svo_free.argtypes = [C.c_void_p]
     lib.svo_version.argtypes = [C.c_void_p]
+    lib.svo_frame_samples.argtypes = [C.c_void_p]
     lib.svo_step.argtypes = [C.c_void_p, f32p, f32p, f32p]
     lib.svo_step_batch.argtypes = [C.c_void_p, f32p, C.c_int, f32p, f32p, C.c_int]
     lib.svo_denoise.argtypes = [f32p, C.c_int, C.c_float]
@@ -78,6 +79,7 @@ class OracleModel:
         if not self._h:
             raise ValueError(err.value.decode())
         self.version = self._lib.svo_version(self._h)
+        self.frame_samples = self._lib.svo_frame_samples(self._h)      # 512; 256 for V5's 8 kHz sub-model
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -86,7 +88,7 @@ class OracleModel:
 
     def step(self, frame: np.ndarray, state: np.ndarray) -> float:
         """frame [512] f32, state [256] f32 (updated in place) -> probability."""
-        assert frame.dtype == np.float32 and frame.shape == (512,) and frame.flags.c_contiguous
+        assert frame.dtype == np.float32 and frame.shape == (self.frame_samples,) and frame.flags.c_contiguous
         assert state.dtype == np.float32 and state.shape == (256,) and state.flags.c_contiguous
         p = C.c_float()
         self._lib.svo_step(self._h, _fp(frame), _fp(state), C.byref(p))
@@ -95,7 +97,7 @@ class OracleModel:
     def step_batch(self, frames: np.ndarray, states: np.ndarray, nthreads: int = 1) -> np.ndarray:
         """frames [n,512], states [n,256] (in place) -> probs [n]."""
         n = frames.shape[0]
-        assert frames.dtype == np.float32 and frames.shape == (n, 512) and frames.flags.c_contiguous
+        assert frames.dtype == np.float32 and frames.shape == (n, self.frame_samples) and frames.flags.c_contiguous
         assert states.dtype == np.float32 and states.shape == (n, 256) and states.flags.c_contiguous
         probs = np.empty(n, np.float32)
         self._lib.svo_step_batch(self._h, _fp(frames), n, _fp(states), _fp(probs), nthreads)

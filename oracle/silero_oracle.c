@@ -76,6 +76,7 @@ typedef struct svo_model {
     const float *filt;
     const float *dw_w[4], *dw_b[4], *pw_w[4], *pw_b[4], *pj_w[4], *pj_b[4], *s_w[4], *s_b[4];
     const float *l_wih[2], *l_whh[2], *l_bih[2], *l_bhh[2];
+    int v5_8k;   /* V5's else-branch (sr != 16000): window 128, hop 64, 65 bins, encoder.0 65 -> 128, 256-sample frames */
     int v4_8k;   /* the graph's else-branch (sr != 16000): third stride conv has stride 1 -> 2 time steps reach the LSTMs */
 } svo_model;
 
@@ -118,9 +119,15 @@ SVO_API svo_model *svo_load(const void *blob, size_t len, char *err, size_t errl
         snprintf(err, errlen, "weight blob: truncated table");
         goto fail;
     }
-    NEED(m->stft, "stft.basis", 258 * 256);
+    {
+        const float *var = svw_find(m, "meta.variant", 1);
+        m->v5_8k = m->version == 5 && var && var[0] == 8000.0f;
+    }
+    if (m->v5_8k) NEED(m->stft, "stft.basis", 130 * 128);
+    else NEED(m->stft, "stft.basis", 258 * 256);
     if (m->version == 5) {
-        static const int co[4] = {128, 64, 64, 128}, ci[4] = {129, 128, 64, 64};
+        static const int co[4] = {128, 64, 64, 128};
+        const int ci[4] = {m->v5_8k ? 65 : 129, 128, 64, 64};
         for (int i = 0; i < 4; ++i) {
             snprintf(nm, sizeof nm, "enc%d.w", i);
             NEED(m->enc_w[i], nm, (uint64_t)co[i] * ci[i] * 3);
@@ -179,6 +186,8 @@ SVO_API void svo_free(svo_model *m) {
 }
 
 SVO_API int svo_version(const svo_model *m) { return m->version; }
+/* samples one model step consumes: 512, or 256 for V5's 8 kHz sub-model */
+SVO_API int svo_frame_samples(const svo_model *m) { return m->v5_8k ? 256 : 512; }
 
 /* ------------------------------------------------------------------ small helpers */
 
@@ -191,16 +200,20 @@ static inline acc_t dot_f(const float *a, const float *b, int n) {
     return s;
 }
 
-/* windowed-DFT conv: out[f][t] = sum_n basis[f][n] * xin[t*hop + n]; magnitude of (re,im)=(f,f+129) */
-static void stft_mag(const float *basis, const float *xin, int hop, int T, float *mag /*[129][T]*/) {
+/* windowed-DFT conv: out[f][t] = sum_n basis[f][n] * xin[t*hop + n]; magnitude of (re,im)=(f,f+nbin); nfft = 2 (nbin - 1) */
+static void stft_mag_n(const float *basis, const float *xin, int nfft, int hop, int T, float *mag /*[nbin][T]*/) {
+    const int nbin = nfft / 2 + 1;
     for (int t = 0; t < T; ++t) {
         const float *seg = xin + t * hop;
-        for (int c = 0; c < 129; ++c) {
-            acc_t re = dot_f(basis + (size_t)c * 256, seg, 256);
-            acc_t im = dot_f(basis + (size_t)(129 + c) * 256, seg, 256);
+        for (int c = 0; c < nbin; ++c) {
+            acc_t re = dot_f(basis + (size_t)c * nfft, seg, nfft);
+            acc_t im = dot_f(basis + (size_t)(nbin + c) * nfft, seg, nfft);
             mag[c * T + t] = (float)SVO_SQRT(re * re + im * im);
         }
     }
+}
+static void stft_mag(const float *basis, const float *xin, int hop, int T, float *mag /*[129][T]*/) {
+    stft_mag_n(basis, xin, 256, hop, T, mag);
 }
 
 /* ONNX Conv (cross-correlation), 1-D, group 1, zero padding `pad` both sides, + bias, optional relu.
@@ -246,9 +259,15 @@ static void lstm_cell(const float *x, int In, int H, const float *w_ih, const fl
 
 static void step_v5(const svo_model *m, const float *x /*[512]*/, float *state /*[h128|c128]*/, float *prob) {
     float mag[129 * 3], e0[128 * 3], e1[64 * 2], e2[64], e3[128];
-    /* a7 step 1-3: the right reflect pad (64) is never read when L=512: columns start at 0,128,256 */
-    stft_mag(m->stft, x, 128, 3, mag);
-    conv1d(mag, 129, 3, m->enc_w[0], m->enc_b[0], 128, 3, 1, 1, 1, e0, 3); /* step 4 */
+    if (m->v5_8k) {
+        /* else-branch on a 256-sample frame: right reflect pad 32 (never read), window 128, hop 64 -> columns at 0, 64, 128 */
+        stft_mag_n(m->stft, x, 128, 64, 3, mag);
+        conv1d(mag, 65, 3, m->enc_w[0], m->enc_b[0], 128, 3, 1, 1, 1, e0, 3);
+    } else {
+        /* a7 step 1-3: the right reflect pad (64) is never read when L=512: columns start at 0,128,256 */
+        stft_mag(m->stft, x, 128, 3, mag);
+        conv1d(mag, 129, 3, m->enc_w[0], m->enc_b[0], 128, 3, 1, 1, 1, e0, 3); /* step 4 */
+    }
     conv1d(e0, 128, 3, m->enc_w[1], m->enc_b[1], 64, 3, 2, 1, 1, e1, 2);   /* step 5 */
     conv1d(e1, 64, 2, m->enc_w[2], m->enc_b[2], 64, 3, 2, 1, 1, e2, 1);    /* step 6 */
     conv1d(e2, 64, 1, m->enc_w[3], m->enc_b[3], 128, 3, 1, 1, 1, e3, 1);   /* step 7 */
@@ -378,7 +397,7 @@ typedef struct {
 static void *svo_worker(void *p) {
     svo_job *j = (svo_job *)p;
     for (int i = j->begin; i < j->end; ++i)
-        svo_step(j->m, j->frames + (size_t)i * 512, j->states + (size_t)i * 256, j->probs + i);
+        svo_step(j->m, j->frames + (size_t)i * svo_frame_samples(j->m), j->states + (size_t)i * 256, j->probs + i);
     return NULL;
 }
 

@@ -44,3 +44,23 @@ def model_cases(speech_i16: np.ndarray):
     long_ = (0.2 * rng.standard_normal((8, 600))).astype(np.float32)
     cases["long600_truncated"] = dict(frames=long_[:, :512].copy(), regen="default_rng(4242) (continued): 0.2*standard_normal((8,600))[:, :512]")
     return cases
+
+
+def model_cases_8k(speech_i16):
+    """Inputs for Silero V5's 8 kHz sub-model: native 8 kHz audio in 256-sample frames.  The speech is the committed 16 kHz
+    fixture, every second sample (tests/golden/speech16k_i16.npz -> 8 kHz); the rest are seeded."""
+    sp = (speech_i16[::2].astype(np.float32) / np.float32(32767.0)).astype(np.float32)
+    n = sp.size // 256
+    sp = sp[: n * 256].reshape(n, 256)
+    c = {"speech_gate": gate(sp), "speech_nogate_first120": sp[:120]}
+    for sigma in (0.02, 0.3):
+        c[f"noise_{sigma}"] = gate((sigma * np.random.default_rng(int(sigma * 1e4) + 8).standard_normal((40, 256))).astype(np.float32))
+    t = np.arange(40 * 256) / 8000.0
+    h = 0.3 * (0.4 * np.sin(2 * np.pi * 150 * t) + 0.3 * np.sin(2 * np.pi * 300 * t) + 0.2 * np.sin(2 * np.pi * 600 * t)) \
+        + 0.03 * np.random.default_rng(88).standard_normal(t.size)
+    c["harmonic"] = gate(np.clip(h, -1, 1).astype(np.float32).reshape(40, 256))
+    c["zeros"] = np.zeros((8, 256), np.float32)
+    c["square_fullscale"] = np.where(np.arange(256 * 8) % 64 < 32, 1.0, -1.0).astype(np.float32).reshape(8, 256)
+    short = (0.2 * np.random.default_rng(4243).standard_normal((8, 200))).astype(np.float32)
+    c["short200_padded"] = np.pad(short, ((0, 0), (0, 56)))
+    return c

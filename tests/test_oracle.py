@@ -85,6 +85,28 @@ def test_v4_8k_submodel_matches_interpreter_goldens(acc, tol, speech):
     assert np.abs(p16 - g["speech_gate.probs"]).max() > 0.05
 
 
+@pytest.mark.parametrize("acc,tol", [("f64", 2e-6), ("f32", 2e-5)])
+def test_v5_8k_submodel_matches_interpreter_goldens(acc, tol, speech):
+    """V5's else-branch on native 8 kHz audio in 256-sample frames (window 128, hop 64, 65 bins).
+    Goldens: oracle/onnx_interp.py on the reference's silero_vad_v5.onnx with sr = 8000; confirmed by PyTorch's operators
+    (tools/torch_crosscheck.py)."""
+    from tests.signals import model_cases_8k
+    g = np.load(os.path.join(GOLD, "model_v5_8k.npz"))
+    with open(weights_io.packaged_blob_path(5, 8000), "rb") as f:
+        om = oracle.OracleModel(f.read(), acc)
+    assert om.frame_samples == 256
+    for name, fr in model_cases_8k(speech).items():
+        p, st = om.run_stream(fr)
+        assert np.abs(p - g[f"{name}.probs"]).max() <= tol, name
+        assert np.abs(st - g[f"{name}.state"]).max() <= 200 * tol, name
+    fb = gate(make_streams(7, 5, seed=78).reshape(7, 10, 256))
+    st = np.zeros((7, 256), np.float32)
+    for t in range(10):
+        p = om.step_batch(np.ascontiguousarray(fb[:, t]), st, nthreads=3)
+        assert np.abs(p - g["batch7.probs"][:, t]).max() <= tol
+    assert g["speech_gate.probs"].max() > 0.9 and g["speech_gate.probs"].min() < 0.05     # a real speech / silence contrast
+
+
 def test_state_machine_matches_reference_traces():
     with open(os.path.join(GOLD, "state_machine.json")) as f:
         scen = json.load(f)["scenarios"]

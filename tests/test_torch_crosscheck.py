@@ -18,7 +18,7 @@ def test_torch_operators_reproduce_the_goldens():
                        timeout=600)
     rows = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
     assert r.returncode == 0, r.stdout + r.stderr
-    assert [x["model"] for x in rows] == ["v5_16k", "v4_16k", "v4_8k"]
+    assert [x["model"] for x in rows] == ["v5_16k", "v5_8k", "v4_16k", "v4_8k"]
     for x in rows:
         assert x["identical"] == x["tensors_compared_with_onnx_lite"] > 200
         assert x["torch_f64_vs_golden_max_dp"] <= 2e-6 and x["torch_f64_vs_golden_max_dstate"] <= 2e-6

@@ -4,7 +4,7 @@
 Usage: python tools/extract_weights.py [MODEL_DIR] [OUT_DIR]
 Defaults: /root/reference/src/real_time_vad/models -> cutter_vad_amd/weights
 
-The blobs carry only the float32 tensors of one graph branch (V5 16 kHz; V4 16 kHz and V4 8 kHz) under canonical names
+The blobs carry only the float32 tensors of one graph branch (V5 16 kHz / 8 kHz; V4 16 kHz / 8 kHz) under canonical names
 (see cutter_vad_amd/weights_io.py); they are data, the graph itself is not copied.
 """
 import hashlib
@@ -20,7 +20,8 @@ def main() -> None:
     dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(
         os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cutter_vad_amd", "weights")
     os.makedirs(dst, exist_ok=True)
-    for version, fname, sr in ((5, "silero_vad_v5.onnx", 16000), (4, "silero_vad.onnx", 16000), (4, "silero_vad.onnx", 8000)):
+    for version, fname, sr in ((5, "silero_vad_v5.onnx", 16000), (5, "silero_vad_v5.onnx", 8000),
+                               (4, "silero_vad.onnx", 16000), (4, "silero_vad.onnx", 8000)):
         path = os.path.join(src, fname)
         tensors = weights_io.extract_from_onnx(path, version, sr)
         blob = weights_io.pack_svw(version, tensors)

@@ -34,7 +34,7 @@ MODELS = os.path.join(REF, "src/real_time_vad/models")
 OUT = os.path.join(ROOT, "tests", "golden")
 
 from oracle.onnx_interp import SileroOnnxSession  # noqa: E402
-from tests.signals import gate, make_streams, model_cases  # noqa: E402
+from tests.signals import gate, make_streams, model_cases, model_cases_8k  # noqa: E402
 
 
 # --------------------------------------------------------------------------------------
@@ -151,6 +151,42 @@ def make_v4_8k_goldens(speech_i16):
     out["_meta"] = np.frombuffer(json.dumps({"source": "onnx_interp float64, sr = 8000 (24000 / 48000 verified identical)",
                                              "cases": meta}).encode(), np.uint8)
     np.savez_compressed(os.path.join(OUT, "model_v4_8k.npz"), **out)
+
+
+def make_v5_8k_goldens(speech_i16):
+    """V5's else-branch (sr = 8000) on 256-sample frames - the frame length its graph is built for (with the
+    reference's 512-sample frames a 3-D tensor reaches the LSTM and onnxruntime refuses; verified on the interpreter)."""
+    path = os.path.join(MODELS, "silero_vad_v5.onnx")
+    sr = np.array([8000], np.int64)
+    out, meta = {}, {}
+
+    def run(frames):            # [B, T, 256]
+        sess = SileroOnnxSession(path, np.float64)
+        st = np.zeros((2, frames.shape[0], 128), np.float32)
+        p = np.empty(frames.shape[:2], np.float32)
+        for t in range(frames.shape[1]):
+            o, st = sess.run(None, {"input": frames[:, t], "state": st, "sr": sr})
+            p[:, t] = o[:, 0]
+        return p, np.concatenate([st[0], st[1]], axis=1)
+
+    for name, fr in model_cases_8k(speech_i16).items():
+        p, s = run(fr[None])
+        out[f"{name}.probs"], out[f"{name}.state"] = p[0], s[0]
+        meta[name] = "tests/signals.py: model_cases_8k"
+    fb = gate(make_streams(7, 5, seed=78).reshape(7, 10, 256))
+    p, s = run(fb)
+    out["batch7.probs"], out["batch7.state"] = p, s
+    meta["batch7"] = "gate(tests.signals.make_streams(7,5,seed=78).reshape(7,10,256)), one batched run per frame"
+    try:
+        SileroOnnxSession(path, np.float64).run(None, {"input": np.zeros((1, 512), np.float32),
+                                                       "state": np.zeros((2, 1, 128), np.float32), "sr": sr})
+        raise SystemExit("V5 at sr = 8000 accepted a 512-sample frame: SURVEY a9 says it cannot")
+    except ValueError:
+        pass
+    out["_meta"] = np.frombuffer(json.dumps({"source": "onnx_interp float64, silero_vad_v5.onnx, sr = 8000, 256-sample frames",
+                                             "cases": meta}).encode(), np.uint8)
+    np.savez_compressed(os.path.join(OUT, "model_v5_8k.npz"), **out)
+    print(f"  model_v5_8k: {sorted(k for k in out if k.endswith('.probs'))}")
 
 
 # --------------------------------------------------------------------------------------
@@ -286,6 +322,9 @@ def main():
     if "--only-v4-8k" in sys.argv:
         make_v4_8k_goldens(speech)
         return
+    if "--only-v5-8k" in sys.argv:
+        make_v5_8k_goldens(speech)
+        return
     np.savez_compressed(os.path.join(OUT, "speech16k_i16.npz"), pcm=speech,
                         _meta=np.frombuffer(b"examples/audios/SampleVoiceMono.wav [::3] (48 kHz -> 16 kHz), int16", np.uint8))
     print(f"speech: {speech.size} samples @16k")
@@ -293,6 +332,7 @@ def main():
     print("model goldens (onnx_interp):")
     make_model_goldens(speech)
     make_v4_8k_goldens(speech)
+    make_v5_8k_goldens(speech)
     print("state machine goldens (reference VADProcessor):")
     make_state_machine_goldens(rtv)
     print("end-to-end golden (reference VADWrapper over onnx_interp):")

@@ -198,10 +198,11 @@ def _suffix(tensors, suffix, within=None):
 
 
 class TorchV5:
-    """silero_vad_v5.onnx, If_0 then-branch (sr == 16000): SURVEY §8 a7"""
+    """silero_vad_v5.onnx, If_0 then-branch (sr == 16000): SURVEY §8 a7; k8: its else-branch on 256-sample frames (a9)"""
 
-    def __init__(self, tensors, dt):
-        br = "then_branch"
+    def __init__(self, tensors, dt, k8=False):
+        br = "else_branch" if k8 else "then_branch"
+        self.k8 = k8
         g = lambda s: _t(_suffix(tensors, s, br), dt)
         self.basis = g("stft.forward_basis_buffer")
         self.enc = [(g(f"encoder.{i}.reparam_conv.weight"), g(f"encoder.{i}.reparam_conv.bias")) for i in range(4)]
@@ -213,9 +214,10 @@ class TorchV5:
     def features(self, x):
         import torch
         import torch.nn.functional as F
-        x = F.pad(x[:, None, :], (0, 64), mode="reflect")
-        s = F.conv1d(x, self.basis, stride=128)
-        y = torch.sqrt(s[:, :129] ** 2 + s[:, 129:] ** 2)
+        nb = 65 if self.k8 else 129
+        x = F.pad(x[:, None, :], (0, 32 if self.k8 else 64), mode="reflect")
+        s = F.conv1d(x, self.basis, stride=64 if self.k8 else 128)
+        y = torch.sqrt(s[:, :nb] ** 2 + s[:, nb:] ** 2)
         for (w, b), stride in zip(self.enc, (1, 2, 2, 1)):
             y = F.relu(F.conv1d(y, w, b, stride=stride, padding=1))
         return y[:, :, 0]
@@ -229,7 +231,7 @@ class TorchV5:
         if single:
             fr = fr[None]
         B, T, _ = fr.shape
-        feats = self.features(fr.reshape(B * T, 512)).reshape(B, T, 128)     # everything before the LSTM is per frame
+        feats = self.features(fr.reshape(B * T, fr.shape[-1])).reshape(B, T, 128)     # everything before the LSTM is per frame
         h = torch.zeros(B, 128, dtype=self.dt)
         c = torch.zeros(B, 128, dtype=self.dt)
         probs = []
@@ -352,13 +354,15 @@ def compare_readers(path, tensors):
 
 def main():
     import torch
-    from tests.signals import gate, make_streams, model_cases
+    from tests.signals import gate, make_streams, model_cases, model_cases_8k
     torch.set_num_threads(4)
     pcm = np.load(os.path.join(ROOT, "tests/golden/speech16k_i16.npz"))["pcm"]
     cases = model_cases(pcm)
+    cases8 = model_cases_8k(pcm)
     ok = True
     for label, fname, gold, build in (
             ("v5_16k", "silero_vad_v5.onnx", "model_v5.npz", lambda t, n, dt: TorchV5(t, dt)),
+            ("v5_8k", "silero_vad_v5.onnx", "model_v5_8k.npz", lambda t, n, dt: TorchV5(t, dt, k8=True)),
             ("v4_16k", "silero_vad.onnx", "model_v4.npz", lambda t, n, dt: TorchV4(t, n, dt)),
             ("v4_8k", "silero_vad.onnx", "model_v4_8k.npz", lambda t, n, dt: TorchV4(t, n, dt, k8=True))):
         path = os.path.join(MODELS, fname)
@@ -369,7 +373,11 @@ def main():
         worst_p = worst_s = worst32 = 0.0
         frames_checked = 0
         for name in sorted({k.split(".probs")[0] for k in g.files if k.endswith(".probs")}):
-            if name == "batch7":
+            if name == "batch7" and label == "v5_8k":
+                x = gate(make_streams(7, 5, seed=78).reshape(7, 10, 256))
+            elif label == "v5_8k":
+                x = cases8[name]
+            elif name == "batch7":
                 x = gate(make_streams(7, 10, seed=77))                # tools/make_goldens.py: the batched-call golden
             else:
                 x = cases[name]["frames"]
