@@ -283,11 +283,13 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
         return VAD_ERR_INVALID_ARG;
     }
     // `sample_rate` is the graph's `sr` input (core/silero_model.py:491): 16000 selects the 16 kHz sub-model, every other
-    // value the graph's else-branch.  V5's else-branch cannot run on 512-sample frames; V4's is the 8 kHz
-    // sub-model and needs the blob that holds ITS weights (meta.variant = 8000).
+    // value the graph's else-branch = the 8 kHz sub-model, which needs the blob that holds ITS weights (meta.variant = 8000).
+    // V4's takes the same 512-sample frames at 8 / 24 / 48 kHz.  V5's is built for native 8 kHz audio in
+    // 256-sample frames (with 512-sample frames a 3-D tensor reaches its LSTM and onnxruntime refuses): sample_rate 8000
+    // creates that engine (vad_info.frame_samples = 256); 24 / 48 kHz audio has to be resampled first.
     const bool want_8k = desc->sample_rate != 16000;
-    if (want_8k && desc->model_version == 5) {
-        g_create_error = "Failed to load model: Silero V5 runs 512-sample frames only through its 16 kHz branch (resample first)";
+    if (want_8k && desc->model_version == 5 && desc->sample_rate != 8000) {
+        g_create_error = "Failed to load model: Silero V5 takes 16 kHz audio (512-sample frames) or native 8 kHz audio (256-sample frames); resample other rates first";
         return VAD_ERR_UNSUPPORTED;
     }
     if (desc->max_streams < 1) {
@@ -303,8 +305,8 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
         return VAD_ERR_BAD_WEIGHTS;
     }
     if (want_8k != (pw.variant == 1)) {
-        g_create_error = want_8k ? "Failed to load model: sample_rate selects Silero V4's 8 kHz sub-model but the weight blob holds the 16 kHz one"
-                                 : "Failed to load model: sample_rate 16000 but the weight blob holds Silero V4's 8 kHz sub-model";
+        g_create_error = want_8k ? "Failed to load model: sample_rate selects the graph's 8 kHz sub-model but the weight blob holds the 16 kHz one"
+                                 : "Failed to load model: sample_rate 16000 but the weight blob holds the graph's 8 kHz sub-model";
         return VAD_ERR_BAD_WEIGHTS;
     }
     int ndev = 0;
@@ -322,6 +324,7 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
     e->device = desc->device_id;
     e->max_streams = desc->max_streams;
     e->sample_rate = desc->sample_rate;
+    e->frame_samples = (desc->model_version == 5 && want_8k) ? vadk::v5::FRAME_8K : VAD_FRAME_SAMPLES;
     auto bail = [&](hipError_t hr, const char *what) {
         g_create_error = std::string("Failed to load model: ") + what + ": " + hipGetErrorString(hr);
         (void)hipGetLastError();      // consumed here: HIP keeps the failure in a process-wide slot otherwise

@@ -109,13 +109,15 @@ class StreamBuilder {
 };
 
 // the folded STFT relies on exact symmetries of the stored basis; refuse weights that lack them
-bool check_stft_symmetry(const float *stft, std::string &err) {
-    for (int k = 0; k <= 128; ++k) {
-        const float *c = stft + (size_t)k * 256, *sn = stft + (size_t)(129 + k) * 256;
-        bool ok = c[0] == 0.f && sn[0] == 0.f && sn[128] == 0.f;
-        for (int n = 1; n < 128 && ok; ++n) ok = c[n] == c[256 - n] && sn[n] == -sn[256 - n];
-        if (k == 0 || k == 128)
-            for (int n = 0; n < 256 && ok; ++n) ok = sn[n] == 0.f;
+// N = window length (256; 128 for Silero V5's 8 kHz sub-model): rows 0..N/2 cosine, N/2+1..N+1 minus sine
+bool check_stft_symmetry(const float *stft, std::string &err, int N = 256) {
+    const int H = N / 2;
+    for (int k = 0; k <= H; ++k) {
+        const float *c = stft + (size_t)k * N, *sn = stft + (size_t)(H + 1 + k) * N;
+        bool ok = c[0] == 0.f && sn[0] == 0.f && sn[H] == 0.f;
+        for (int n = 1; n < H && ok; ++n) ok = c[n] == c[N - n] && sn[n] == -sn[N - n];
+        if (k == 0 || k == H)
+            for (int n = 0; n < N && ok; ++n) ok = sn[n] == 0.f;
         if (!ok) {
             err = "Failed to load model: STFT basis is not the symmetric windowed DFT the kernel assumes";
             return false;
@@ -126,14 +128,15 @@ bool check_stft_symmetry(const float *stft, std::string &err) {
 
 // The 4-way folded DFT (vad_layout.h, v5; V4 uses the same) uses analytic cos/sin and the window taken from the k = 0 row: the stored
 // basis must BE that windowed DFT (it is for Silero: max |stored - w cos| = 5.7e-8)
-bool check_windowed_dft(const float *stft, std::string &err) {
+bool check_windowed_dft(const float *stft, std::string &err, int N = 256) {
     const double two_pi = 6.283185307179586476925286766559;
+    const int H = N / 2;
     double worst = 0;
-    for (int k = 0; k <= 128; ++k)
-        for (int n = 0; n < 256; ++n) {
-            const double ph = two_pi * (double)((k * n) & 255) / 256.0, w = stft[n];
-            worst = std::max(worst, std::fabs((double)stft[(size_t)k * 256 + n] - w * std::cos(ph)));
-            worst = std::max(worst, std::fabs((double)stft[(size_t)(129 + k) * 256 + n] + w * std::sin(ph)));
+    for (int k = 0; k <= H; ++k)
+        for (int n = 0; n < N; ++n) {
+            const double ph = two_pi * (double)((k * n) & (N - 1)) / (double)N, w = stft[n];
+            worst = std::max(worst, std::fabs((double)stft[(size_t)k * N + n] - w * std::cos(ph)));
+            worst = std::max(worst, std::fabs((double)stft[(size_t)(H + 1 + k) * N + n] + w * std::sin(ph)));
         }
     if (worst > 2e-7) {
         err = "Failed to load model: STFT basis is not a windowed DFT (the kernels evaluate it as a folded DFT)";
@@ -144,6 +147,15 @@ bool check_windowed_dft(const float *stft, std::string &err) {
 
 // cos / -sin blocks of the 4-way folded DFT: wave w owns the 32 bins bin_of_channel(32 w + r); k-iteration j
 // contracts n = 8j .. 8j+7 (n = 0 is an unused slot: weight 0)
+// the same for a window of 128 (Silero V5's 8 kHz sub-model): 4 k-iterations, parity `par` owns the bins 2 r + par, r = 0..31
+void pack_dft4_wave_128(StreamBuilder &sb, int par) {
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int j = 0; j < 4; ++j) {
+        sb.weight_block([&](int np, int n) { const int k = 2 * np + par; return n == 0 ? 0.f : (float)std::cos(two_pi * (double)((k * n) & 127) / 128.0); }, j);
+        sb.weight_block([&](int np, int n) { const int k = 2 * np + par; return n == 0 ? 0.f : (float)-std::sin(two_pi * (double)((k * n) & 127) / 128.0); }, j);
+    }
+}
+
 void pack_dft4_wave(StreamBuilder &sb, int w) {
     const double two_pi = 6.283185307179586476925286766559;
     for (int j = 0; j < 8; ++j) {
@@ -162,9 +174,19 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
         err = "Failed to load model: weight blob is not Silero V5";
         return false;
     }
-    const float *stft = B.get("stft.basis", 258 * 256);
+    // the graph's 8 kHz sub-model (else-branch): window 128, 65 bins, encoder.0 65 -> 128, 256-sample frames
+    bool k8 = false;
+    for (uint32_t i = 0; i < B.n; ++i)
+        if (std::strncmp(B.tab[i].name, "meta.variant", sizeof B.tab[i].name) == 0) {
+            const float *v = B.get("meta.variant", 1);
+            k8 = v && v[0] == 8000.0f;
+        }
+    out.variant = k8 ? 1 : 0;
+    const int N = k8 ? 128 : 256, NB = N / 2 + 1;         // window, bins
+    const float *stft = B.get("stft.basis", (uint64_t)2 * NB * N);
     const float *ew[4], *eb[4];
-    static const int co[4] = {128, 64, 64, 128}, ci[4] = {129, 128, 64, 64};
+    static const int co[4] = {128, 64, 64, 128};
+    const int ci[4] = {NB, 128, 64, 64};
     for (int i = 0; i < 4; ++i) {
         char nm[32];
         std::snprintf(nm, sizeof nm, "enc%d.w", i);
@@ -176,8 +198,8 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
     const float *b_ih = B.get("lstm.b_ih", 512), *b_hh = B.get("lstm.b_hh", 512);
     const float *head_w = B.get("head.w", 128), *head_b = B.get("head.b", 1);
     if (!err.empty()) return false;
-    if (!check_stft_symmetry(stft, err)) return false;
-    if (!check_windowed_dft(stft, err)) return false;
+    if (!check_stft_symmetry(stft, err, N)) return false;
+    if (!check_windowed_dft(stft, err, N)) return false;
 
     StreamBuilder sb;
     auto convw = [&](int layer, int o, int c, int tap) -> float {
@@ -187,15 +209,16 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
         // STFT on the folded input (vad_layout.h): bins 32w..32w+31, {re, im} per k-iteration;
         // k-iteration j contracts n = 8j+1 .. 8j+8 (quad 2j on the lower half-wave, 2j+1 on the upper)
         out.sect[w][S_STFT] = sb.blocks();
-        pack_dft4_wave(sb, w);
+        if (!k8) pack_dft4_wave(sb, w);
+        else if (w < 2) pack_dft4_wave_128(sb, w);        // 64 bins = two 32-row tiles: waves 0 (even bins) and 1 (odd bins)
         // enc0 as a Toom-3 product (vad_layout.h): out channels 32w.., per k-iteration the five point-wise weight blocks
         // V(0) = w2, V(1)/2, V(-1)/2, V(2), V(inf) = w0 of V(z) = w2 + w1 z + w0 z^2 (evaluated in double); then the
         // Nyquist input channel: block A = points 0, 1, -1, 2 in the four components (lower half-wave), block B = inf
         out.sect[w][S_ENC0] = sb.blocks();
         sb.vector_blocks([&](int c) { return eb[0][32 * w + c]; });
         auto toom = [&](int o, int c129, int p) -> float {
-            const double v0 = ew[0][((size_t)o * 129 + c129) * 3 + 2], v1 = ew[0][((size_t)o * 129 + c129) * 3 + 1],
-                         v2 = ew[0][((size_t)o * 129 + c129) * 3 + 0];
+            const double v0 = ew[0][((size_t)o * NB + c129) * 3 + 2], v1 = ew[0][((size_t)o * NB + c129) * 3 + 1],
+                         v2 = ew[0][((size_t)o * NB + c129) * 3 + 0];
             switch (p) {
                 case 0: return (float)v0;
                 case 1: return (float)(0.5 * (v0 + v1 + v2));
@@ -204,15 +227,15 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
                 default: return (float)v2;
             }
         };
-        for (int j = 0; j < 16; ++j)
+        for (int j = 0; j < (k8 ? 8 : 16); ++j)
             for (int p = 0; p < 5; ++p)
-                sb.weight_block([&](int np, int c) { return toom(32 * w + np, bin_of_channel(c), p); }, j);
+                sb.weight_block([&](int np, int c) { return toom(32 * w + np, k8 ? bin_of_channel_8k(c) : bin_of_channel(c), p); }, j);
         {
             float *a = sb.new_block();
             for (int l = 0; l < 32; ++l)
-                for (int p = 0; p < 4; ++p) a[l * 4 + p] = toom(32 * w + l, 128, p);
+                for (int p = 0; p < 4; ++p) a[l * 4 + p] = toom(32 * w + l, NB - 1, p);
             float *b = sb.new_block();
-            for (int l = 0; l < 32; ++l) b[l * 4] = toom(32 * w + l, 128, 4);
+            for (int l = 0; l < 32; ++l) b[l * 4] = toom(32 * w + l, NB - 1, 4);
         }
         // enc1: n-tile w&1, output column w>>1; taps (1,2) for column 0, (0,1) for column 1
         out.sect[w][S_ENC1] = sb.blocks();
@@ -257,7 +280,7 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
     // bin 128 of the folded STFT (VALU): floats 0..127 = C[128][1..128]; its sine row is exactly zero
     // the window of the stored basis: its k = 0 cosine row
     const uint32_t nb = sb.blocks();
-    std::memcpy(sb.new_block(), stft, 256 * sizeof(float));
+    std::memcpy(sb.new_block(), stft, (size_t)N * sizeof(float));
     for (int w = 0; w < NWAVES; ++w) {
         out.sect[w][S_HEADB] = hb;
         out.sect[w][S_NYQ] = nb;

@@ -36,9 +36,18 @@ using namespace vadk::dev;
 
 // F32IN: frames are float32 (else int16).  A template parameter, not a branch: the frame fold must stay in one basic
 // block with the recurrent-half MFMAs for the instruction interleave below to be possible.
-template <bool F32IN>
+// K8: the graph's 8 kHz sub-model (If_0 else-branch) on 256-sample frames: the same dataflow at half the
+// front-end size (vad_layout.h): window 128, hop 64, K = 32 per folded contraction, 64 complex bins on waves 0 / 1 (waves 2 / 3
+// sit out the STFT MFMAs), bin 64 on the VALU, encoder.0 with 65 input channels; everything from enc1 on is identical.
+template <bool F32IN, bool K8>
 __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P) {
     using namespace vadk::v5;
+    constexpr int QL = K8 ? 8 : 16;               // lanes per stream in the loader = quads per quarter column
+    constexpr int CS = 4 * QL;                    // folded-operand rows per column (pe | po | qe | qo)
+    constexpr int PS = K8 ? 16 : 32;              // quad rows per Toom-3 plane (|STFT| channels / 4)
+    constexpr int ROWN = K8 ? ROW_NYQ_8K : ROW_NYQ;
+    constexpr int NJ = K8 ? 4 : 8;                // k-iterations of the folded DFT
+    constexpr int NJ0 = K8 ? 8 : 16;              // k-iterations of enc0
     __shared__ f32x4 lds[LDS_F4];
     f32x4 *const RX = lds;                       // the activation region (row map: vad_layout.h)
     f32x4 *const RE = lds + ROW_E * QS;          // its upper half
@@ -74,13 +83,13 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
 
     // ---- frame ingest set-up (loop-invariant) ----
     const float thr = P.thresh;
-    const int q = tid & 15;
+    const int q = tid & (QL - 1);
     const bool q0 = q == 0;
     constexpr bool f32in = F32IN;
     constexpr int qsh = f32in ? 4 : 3;             // log2(bytes per 4-sample quad)
     const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
+        const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * ((f32in ? 2048u : 1024u) >> (K8 ? 1 : 0))), 0x00020000);
     u32x4 xa_[8], xb_[8];                          // raw quads of a column (both 16-stream halves), as bits
     // Column c of frame tt -> XR: lane q of a 16-lane row (one stream per row) loads quads q, 16+q, 32+q, 48+q of the
     // column: every sample once, 4 branch-free 16-byte loads per lane and stream half.
@@ -91,6 +100,14 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
            of the 16 loaded are ignored); a format branch here breaks the compiler's vmcnt bookkeeping */        \
         _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                           \
             XR[rr * 4 + k] = __builtin_amdgcn_raw_buffer_load_b128(frs, (fq + 16 * k) << qsh, 0, 0);            \
+    }
+    // 8 kHz: a frame is 64 quads, column c = quads 16c .. 16c + 31; 8 lanes per stream, lane q loads quads q, 8+q, 16+q, 24+q
+    // of the column into XR[XO .. XO + 3]; one call covers the tile's 32 streams
+#define X_ISSUE8(c, XR, XO, tt)                                                                                 \
+    {                                                                                                           \
+        const int fq = ((tile0 + (tid >> 3)) * T + (tt)) * 64 + 16 * (c) + q;                                   \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                           \
+            XR[(XO) + k] = __builtin_amdgcn_raw_buffer_load_b128(frs, (fq + 8 * k) << qsh, 0, 0);               \
     }
 
     // ---- prologue: h_{t-1} -> LDS quads, c_{t-1} -> registers (this lane's 16 units) -------
@@ -104,8 +121,8 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             hv[qq] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    const f32x4 W1 = ldw(wrs, q * 16, o_nyq), W3 = ldw(wrs, (32 + q) * 16, o_nyq);   // window w[n], w[128+n] = w[128-n]
-    const float w64 = ldw(wrs, 16 * 16, o_nyq).x;                                       // w[64] = w[192]
+    const f32x4 W1 = ldw(wrs, q * 16, o_nyq), W3 = ldw(wrs, (2 * QL + q) * 16, o_nyq);   // window w[n], w[128+n] = w[128-n]  (8 kHz: w[64+n])
+    const float w64 = ldw(wrs, QL * 16, o_nyq).x;                                           // w[64] = w[192]                     (8 kHz: w[32] = w[96])
     f32x16 cst;   // c state of units 32w + 8g + 4h + i  (reg 4g+i)
     {
         f32x4 c4[4];
@@ -175,20 +192,25 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             };
             // reversed reads come from the other lanes of the row: row_mirror hands lane q the value of lane 15 - q
             // (quad 31 - q of B, 63 - q of D); one more row_shr:1 gives quad 32 - q / 64 - q (lane 0 keeps `edge`)
+            // (8 kHz: 8 lanes per stream - row_half_mirror, and lane 8 of a row, which row_shr:1 would feed from the
+            // neighbouring stream's lane 7, takes `edge` by a select)
             auto mirror = [](float v) -> float {      // every lane of a row has a source: no `old` value to materialise
-                return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+                return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K8 ? 0x141 : 0x140, 0xf, 0xf, true));
             };
-            auto shr1 = [](float edge, float v) -> float {
-                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+            auto shr1 = [&](float edge, float v) -> float {
+                const float r = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+                return (K8 && q0) ? edge : r;
             };
             // Fold of (column c, stream half rr): n = 4q + j.  y1 = w[n] x[n] (A), y3 = w[128+n] x[128+n] (C),
             // y2 = w[128-n] x[128-n] (B reversed), y4 = w[256-n] x[256-n] (D reversed); w is symmetric about 128.
-#define X_FOLD1(c, rr, XR)                                                                                      \
+#define X_FOLD1(c, rr, XR) X_FOLDG(c, (rr) * 16 + (tid >> 4), XR, (rr) * 4)
+#define X_FOLD8(c, XR, XO) X_FOLDG(c, tid >> 3, XR, XO)
+#define X_FOLDG(c, MS, XR, XO)                                                                                  \
     {                                                                                                           \
         _Pragma("clang fp contract(off)")   /* same roundings in the f32 and int16 instantiations */            \
-        const int ms = (rr) * 16 + (tid >> 4);                                                                  \
-        const f32x4 xA = decode(XR[(rr) * 4 + 0]), xB = decode(XR[(rr) * 4 + 1]);                               \
-        const f32x4 xC = decode(XR[(rr) * 4 + 2]), xD = decode(XR[(rr) * 4 + 3]);                               \
+        const int ms = (MS);                                                                                    \
+        const f32x4 xA = decode(XR[(XO) + 0]), xB = decode(XR[(XO) + 1]);                                       \
+        const f32x4 xC = decode(XR[(XO) + 2]), xD = decode(XR[(XO) + 3]);                                       \
         const float mBx = mirror(xB.x), mDx = mirror(xD.x);                                                     \
         const f32x4 y1 = f32x4{xA.x * W1.x, xA.y * W1.y, xA.z * W1.z, xA.w * W1.w};                             \
         const f32x4 y3 = f32x4{xC.x * W3.x, xC.y * W3.y, xC.z * W3.z, xC.w * W3.w};                             \
@@ -213,10 +235,10 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
         }                                                                                                       \
         /* stored as two 8-byte halves each: the sums come out of the packed adds as register PAIRS, a 16-byte store      \
            would first copy them into four consecutive registers */                                            \
-        st2(&RX[(64 * (c) + q) * QS + ms], pe);                                                                 \
-        st2(&RX[(64 * (c) + 16 + q) * QS + ms], po);                                                            \
-        st2(&RX[(64 * (c) + 32 + q) * QS + ms], qe);                                                            \
-        st2(&RX[(64 * (c) + 48 + q) * QS + ms], qo);                                                            \
+        st2(&RX[(CS * (c) + q) * QS + ms], pe);                                                                 \
+        st2(&RX[(CS * (c) + QL + q) * QS + ms], po);                                                            \
+        st2(&RX[(CS * (c) + 2 * QL + q) * QS + ms], qe);                                                        \
+        st2(&RX[(CS * (c) + 3 * QL + q) * QS + ms], qo);                                                        \
     }
 #define H_LDW(WS, g) _Pragma("unroll") for (int k = 0; k < 8; ++k) WS[k] = WL(wh + 8 * (g) + k);
 #define H_MMA(WS, g)                                                                                            \
@@ -240,7 +262,8 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             for (int k = 0; k < 16; ++k) nb[k] = WL(ws_l + k);
             H_LDW(wA, 0)
             SB();
-            H_LDW(wB, 1) X_ISSUE(0, xa_, t) SB();
+            if constexpr (K8) { H_LDW(wB, 1) X_ISSUE8(0, xa_, 0, t) X_ISSUE8(1, xa_, 4, t) SB(); }
+            else { H_LDW(wB, 1) X_ISSUE(0, xa_, t) SB(); }
             // (0) h_{t-1} visible.  The barrier sits INSIDE the loop, behind the first requests: the loop-invariant
             // address arithmetic the compiler hoists into the preheader and the weight / frame requests above then run
             // while the state loads of the prologue are still in flight.  For t > 0 it follows barrier (8) and costs nothing.
@@ -249,6 +272,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             gfo = acc_of(nb[4], nb[5], nb[6], nb[7]);
             gg = acc_of(nb[8], nb[9], nb[10], nb[11]);
             go = acc_of(nb[12], nb[13], nb[14], nb[15]);
+            if constexpr (!K8) {
             H_MMA(wA, 0) SB(); STAMP(20);
             H_LDW(wA, 2) X_ISSUE(1, xb_, t) SB(); H_MMA(wB, 1) SB(); STAMP(21);
             H_LDW(wB, 3) SB(); H_MMA(wA, 2) X_FOLD1(0, 0, xa_) H_MIX(6) SB(); STAMP(22);
@@ -257,10 +281,22 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             H_LDW(wA, 6) SB(); H_MMA(wB, 5) X_FOLD1(1, 1, xb_) H_MIX(6) SB(); STAMP(25);
             H_LDW(wB, 7) SB(); H_MMA(wA, 6) X_FOLD1(2, 0, xa_) H_MIX(6) SB(); STAMP(26);
             H_MMA(wB, 7) X_FOLD1(2, 1, xa_) H_MIX(6) SB(); STAMP(27);
+            } else {           // 8 kHz: three columns of 32 quads, one fold call each (8 lanes per stream)
+            H_MMA(wA, 0) SB();
+            H_LDW(wA, 2) X_ISSUE8(2, xb_, 0, t) SB(); H_MMA(wB, 1) SB();
+            H_LDW(wB, 3) SB(); H_MMA(wA, 2) X_FOLD8(0, xa_, 0) H_MIX(6) SB();
+            H_LDW(wA, 4) SB(); H_MMA(wB, 3) X_FOLD8(1, xa_, 4) H_MIX(6) SB();
+            H_LDW(wB, 5) SB(); H_MMA(wA, 4) X_FOLD8(2, xb_, 0) H_MIX(6) SB();
+            H_LDW(wA, 6) SB(); H_MMA(wB, 5) SB();
+            H_LDW(wB, 7) SB(); H_MMA(wA, 6) SB();
+            H_MMA(wB, 7) SB();
+            }
 #undef H_MIX
 #undef H_MMA
 #undef H_LDW
 #undef X_FOLD1
+#undef X_FOLD8
+#undef X_FOLDG
         }
         // weights of the first STFT iteration are requested before the barrier (they never depend on LDS)
         f32x4 Are = WL(ws_stft), Aim = WL(ws_stft + 1);
@@ -277,8 +313,8 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             float a = 0.f;
             if (pr < 24) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const f32x4 pp = RX[(64 * c + half * 8 + i) * QS + ms];
+                for (int i = 0; i < QL / 2; ++i) {
+                    const f32x4 pp = RX[(CS * c + half * (QL / 2) + i) * QS + ms];
                     a += (pp.x - pp.y) + (pp.z - pp.w);
                 }
             }
@@ -293,37 +329,41 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             // The accumulators START from the rank-1 terms of n = 0, 64, 128 (the samples the fold cannot pair), so the
             // epilogue only takes magnitudes.  Register 4g+i holds tile row r = 8g+4h+i: (-1)^r = (-1)^i.
             //   even bins: re += y128 + a64 (-1)^r ; odd bins: re -= y128, im -= b64 (-1)^r
+            const bool even = K8 ? w == 0 : w < 2;          // this wave's bins: even | odd
+            const bool stft_wave = !K8 || w < 2;             // 8 kHz: 64 complex bins = two tiles, waves 2 / 3 have none
             f32x16 are[3], aim[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float y128 = fcor[(c * 3 + 0) * 32 + m], a64 = fcor[(c * 3 + 1) * 32 + m], b64 = fcor[(c * 3 + 2) * 32 + m];
-                const float rp = w < 2 ? y128 + a64 : -y128, rm = w < 2 ? y128 - a64 : -y128;
-                const float ip = w < 2 ? 0.f : -b64, im_ = w < 2 ? 0.f : b64;
+                const float rp = even ? y128 + a64 : -y128, rm = even ? y128 - a64 : -y128;
+                const float ip = even ? 0.f : -b64, im_ = even ? 0.f : b64;
                 const f32x4 qr = f32x4{rp, rm, rp, rm}, qi = f32x4{ip, im_, ip, im_};
                 are[c] = acc_of(qr, qr, qr, qr);
                 aim[c] = acc_of(qi, qi, qi, qi);
             }
-            const int rR = w < 2 ? 0 : 16, rI = w < 2 ? 32 : 48;     // even bins read pe / qe, odd bins po / qo
+            const int rR = even ? 0 : QL, rI = even ? 2 * QL : 3 * QL;     // even bins read pe / qe, odd bins po / qo
             const f32x4 *const XR = RX + rR * QS + hq, *const XI = RX + rI * QS + hq;
-            f32x4 Au0 = XR[0], Au1 = XR[64 * QS], Au2 = XR[128 * QS];
-            f32x4 Av0 = XI[0], Av1 = XI[64 * QS], Av2 = XI[128 * QS];
+            if (stft_wave) {
+            f32x4 Au0 = XR[0], Au1 = XR[CS * QS], Au2 = XR[2 * CS * QS];
+            f32x4 Av0 = XI[0], Av1 = XI[CS * QS], Av2 = XI[2 * CS * QS];
             f32x4 Bre, Bim, Bu0, Bu1, Bu2, Bv0, Bv1, Bv2;
 #define STFT_LD(S, jj)                                                                     \
     S##re = WL(ws_stft + 2 * (jj)); S##im = WL(ws_stft + 2 * (jj) + 1);                    \
-    S##u0 = XR[(2 * (jj)) * QS]; S##u1 = XR[(64 + 2 * (jj)) * QS]; S##u2 = XR[(128 + 2 * (jj)) * QS]; \
-    S##v0 = XI[(2 * (jj)) * QS]; S##v1 = XI[(64 + 2 * (jj)) * QS]; S##v2 = XI[(128 + 2 * (jj)) * QS];
+    S##u0 = XR[(2 * (jj)) * QS]; S##u1 = XR[(CS + 2 * (jj)) * QS]; S##u2 = XR[(2 * CS + 2 * (jj)) * QS]; \
+    S##v0 = XI[(2 * (jj)) * QS]; S##v1 = XI[(CS + 2 * (jj)) * QS]; S##v2 = XI[(2 * CS + 2 * (jj)) * QS];
 #define STFT_MMA(S)                                                                        \
     are[0] = mfma4(S##re, S##u0, are[0]); are[1] = mfma4(S##re, S##u1, are[1]); are[2] = mfma4(S##re, S##u2, are[2]); \
     aim[0] = mfma4(S##im, S##v0, aim[0]); aim[1] = mfma4(S##im, S##v1, aim[1]); aim[2] = mfma4(S##im, S##v2, aim[2]);
-            for (int j = 0; j < 8; j += 2) {
+            for (int j = 0; j < NJ; j += 2) {
                 STFT_LD(B, j + 1) SB();
                 STFT_MMA(A) SB();
-                const int jn = j + 2 < 8 ? j + 2 : 6;
+                const int jn = j + 2 < NJ ? j + 2 : NJ - 2;
                 STFT_LD(A, jn) SB();
                 STFT_MMA(B) SB();
             }
 #undef STFT_LD
 #undef STFT_MMA
+            }
             // request enc0's bias + first weights now: they land while the magnitudes are written
             e0b0 = WL(ws_e0); e0b1 = WL(ws_e0 + 1); e0b2 = WL(ws_e0 + 2); e0b3 = WL(ws_e0 + 3);
 #pragma unroll
@@ -333,7 +373,8 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             __syncthreads();   // (1b) every wave is done reading u/v: the magnitudes may overwrite them
             // magnitudes.  The three columns
             // m0, m1, m2 of a bin go to enc0 as the Toom-3 evaluations of m0 + m1 z + m2 z^2 (vad_layout.h):
-            // rows 32p + 8w + 2g + h, p = 0..4 for z = 0, 1, -1, 2, inf
+            // rows 32p + 8w + 2g + h, p = 0..4 for z = 0, 1, -1, 2, inf  (8 kHz: 16p + 8w + 2g + h on waves 0 / 1)
+            if (stft_wave) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 mg[3];
@@ -345,18 +386,19 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
                 const f32x4 s02 = f32x4{mg[0].x + mg[2].x, mg[0].y + mg[2].y, mg[0].z + mg[2].z, mg[0].w + mg[2].w};
                 f32x4 *o = RX + (8 * w + 2 * g) * QS + hq;
                 st2(o, mg[0]);
-                st2(o + 32 * QS, f32x4{s02.x + mg[1].x, s02.y + mg[1].y, s02.z + mg[1].z, s02.w + mg[1].w});
-                st2(o + 64 * QS, f32x4{s02.x - mg[1].x, s02.y - mg[1].y, s02.z - mg[1].z, s02.w - mg[1].w});
-                st2(o + 96 * QS, f32x4{fmaf(4.f, mg[2].x, fmaf(2.f, mg[1].x, mg[0].x)), fmaf(4.f, mg[2].y, fmaf(2.f, mg[1].y, mg[0].y)),
-                                       fmaf(4.f, mg[2].z, fmaf(2.f, mg[1].z, mg[0].z)), fmaf(4.f, mg[2].w, fmaf(2.f, mg[1].w, mg[0].w))});
-                st2(o + 128 * QS, mg[2]);
+                st2(o + PS * QS, f32x4{s02.x + mg[1].x, s02.y + mg[1].y, s02.z + mg[1].z, s02.w + mg[1].w});
+                st2(o + 2 * PS * QS, f32x4{s02.x - mg[1].x, s02.y - mg[1].y, s02.z - mg[1].z, s02.w - mg[1].w});
+                st2(o + 3 * PS * QS, f32x4{fmaf(4.f, mg[2].x, fmaf(2.f, mg[1].x, mg[0].x)), fmaf(4.f, mg[2].y, fmaf(2.f, mg[1].y, mg[0].y)),
+                                           fmaf(4.f, mg[2].z, fmaf(2.f, mg[1].z, mg[0].z)), fmaf(4.f, mg[2].w, fmaf(2.f, mg[1].w, mg[0].w))});
+                st2(o + 4 * PS * QS, mg[2]);
+            }
             }
             // |X128|: rows 160 / 161 = (points 0, 1, -1, 2) / zeros, rows 162 / 163 = (inf, 0, 0, 0) / zeros
             if (tid < 64) {
                 const float n0 = nyqv[m], n1 = nyqv[32 + m], n2 = nyqv[64 + m];
                 const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                RX[ROW_NYQ * QS + hq] = h == 0 ? f32x4{n0, (n0 + n2) + n1, (n0 + n2) - n1, fmaf(4.f, n2, fmaf(2.f, n1, n0))} : z4;
-                RX[(ROW_NYQ + 2) * QS + hq] = h == 0 ? f32x4{n2, 0.f, 0.f, 0.f} : z4;
+                RX[ROWN * QS + hq] = h == 0 ? f32x4{n0, (n0 + n2) + n1, (n0 + n2) - n1, fmaf(4.f, n2, fmaf(2.f, n1, n0))} : z4;
+                RX[(ROWN + 2) * QS + hq] = h == 0 ? f32x4{n2, 0.f, 0.f, 0.f} : z4;
             }
         }
         STAMP(3);
@@ -373,17 +415,17 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
             for (int p = 0; p < 5; ++p) acc[p] = (f32x16)(0.f);
             f32x4 Aw[5], Bw[5], Aa[5], Ba[5];
 #pragma unroll
-            for (int p = 0; p < 5; ++p) { Aw[p] = E0w[p]; Aa[p] = RX[(32 * p) * QS + hq]; }
+            for (int p = 0; p < 5; ++p) { Aw[p] = E0w[p]; Aa[p] = RX[(PS * p) * QS + hq]; }
 #define E0_LD(S, jj)                                                                       \
     _Pragma("unroll") for (int p = 0; p < 5; ++p) {                                        \
         S##w[p] = WL(ws + 5 * (jj) + p);                                                   \
-        S##a[p] = RX[(32 * p + 2 * (jj)) * QS + hq];                                       \
+        S##a[p] = RX[(PS * p + 2 * (jj)) * QS + hq];                                       \
     }
 #define E0_MMA(S) _Pragma("unroll") for (int p = 0; p < 5; ++p) acc[p] = mfma4(S##w[p], S##a[p], acc[p]);
-            for (int j = 0; j < 16; j += 2) {
+            for (int j = 0; j < NJ0; j += 2) {
                 E0_LD(B, j + 1) SB();
                 E0_MMA(A) SB();
-                const int jn = j + 2 < 16 ? j + 2 : 14;
+                const int jn = j + 2 < NJ0 ? j + 2 : NJ0 - 2;
                 E0_LD(A, jn) SB();
                 E0_MMA(B) SB();
             }
@@ -391,8 +433,8 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
 #undef E0_MMA
             STAMP(17);
             {   // input channel 128 (Nyquist bin): one MFMA per point (K = 2 with the upper half-wave at zero)
-                const f32x4 an = RX[ROW_NYQ * QS + hq], bn = RX[(ROW_NYQ + 2) * QS + hq];
-                const f32x4 wna = WL(ws + 80), wnb = WL(ws + 81);
+                const f32x4 an = RX[ROWN * QS + hq], bn = RX[(ROWN + 2) * QS + hq];
+                const f32x4 wna = WL(ws + 5 * NJ0), wnb = WL(ws + 5 * NJ0 + 1);
                 // enc1's bias and first group of weights
                 e1b0 = WL(ws_e1); e1b1 = WL(ws_e1 + 1); e1b2 = WL(ws_e1 + 2); e1b3 = WL(ws_e1 + 3);
                 E1w0 = WL(ws_e1 + 4); E1w1 = WL(ws_e1 + 5); E1w2 = WL(ws_e1 + 6); E1w3 = WL(ws_e1 + 7);
@@ -604,6 +646,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
     }
 
 #undef X_ISSUE
+#undef X_ISSUE8
     // ---- epilogue ----
     if (sm_thread && P.seg_frames) P.seg_frames[tile0 + tid] = seg_last;
 }
@@ -613,9 +656,14 @@ extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream
     (void)hipGetLastError();   // HIP's last-error slot is sticky and process-wide: a stale failure from anywhere else must not become ours
     const int tiles = (p->n + vadk::MT - 1) / vadk::MT;
     if (tiles <= 0) return hipSuccess;
-    if (p->fmt == 0)
-        hipLaunchKernelGGL(silero_v5_step<true>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+    if (p->variant == 1) {       // the 8 kHz sub-model, 256-sample frames
+        if (p->fmt == 0)
+            hipLaunchKernelGGL((silero_v5_step<true, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+        else
+            hipLaunchKernelGGL((silero_v5_step<false, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+    } else if (p->fmt == 0)
+        hipLaunchKernelGGL((silero_v5_step<true, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
     else
-        hipLaunchKernelGGL(silero_v5_step<false>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+        hipLaunchKernelGGL((silero_v5_step<false, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
     return hipGetLastError();
 }

@@ -55,6 +55,15 @@ enum Section { S_STFT = 0, S_NYQ, S_ENC0, S_ENC1, S_ENC2, S_ENC3, S_LSTM, S_HEAD
 __host__ __device__ constexpr int bin_of_channel(int ch) {
     return (ch >> 5) < 2 ? 64 * (ch >> 5) + 2 * (ch & 31) : 64 * ((ch >> 5) - 2) + 2 * (ch & 31) + 1;
 }
+// The graph's 8 kHz sub-model (If_0 else-branch) is the same dataflow at half the front-end size: 256-sample
+// frames, window N = 128, hop 64 -> three columns at 0, 64, 128; 65 bins; 4-way fold with n = 1..31 (K = 32), unpaired samples
+// n = 0, 32, 64; the 64 complex bins are two 32-row tiles - wave 0: even bins 2 r, wave 1: odd bins 2 r + 1 - and bin 64
+// (even) is the alternating sum on the VALU; encoder.0 has 65 input channels.
+//   loader : column c: pe -> rows 32c + q, po -> 32c + 8 + q, qe -> 32c + 16 + q, qo -> 32c + 24 + q   (q = 0..7, n = 4q..4q+3)
+//   |STFT| : Toom-3 planes rows 16p + ch/4 (p = 0..4), rows 80/81 and 82/83 for |X64| as ROW_NYQ below
+__host__ __device__ constexpr int bin_of_channel_8k(int ch) { return 2 * (ch & 31) + (ch >> 5); }
+constexpr int ROW_NYQ_8K = 80;
+constexpr int FRAME_8K = 256;
 
 // LDS, in quad rows.  One activation region X, reused by every layer:
 //   loader : column c: pe -> rows 64c + q, po -> 64c + 16 + q, qe -> 64c + 32 + q, qo -> 64c + 48 + q   (q = 0..15, n = 4q..4q+3)
@@ -146,7 +155,7 @@ struct StepParams {
     int32_t T;                     // frames per stream in this call
     int32_t fmt;                   // vad_frame_format
     float thresh;                  // denoise gate, < 0 = off
-    int32_t variant;               // V4 only: 1 = 8 kHz sub-model (pack_weights.h)
+    int32_t variant;               // 1 = the graph's 8 kHz sub-model (pack_weights.h): V4 two LSTM steps per frame, V5 256-sample frames
 #ifdef VADK_STAMPS
     unsigned long long *stamps;    // diagnostic builds only (tools/kbench.cpp): [block][wave][16] s_memtime stamps
 #endif

@@ -47,6 +47,8 @@ class Engine:
         self.model_version = model_version
         self.max_streams = max_streams
         self.device_id = device_id
+        self.sample_rate = sample_rate
+        self.frame_samples = 256 if (model_version == 5 and sample_rate != 16000) else 512   # vad_info.frame_samples
 
     # ------------------------------------------------------------------ lifetime
     def close(self) -> None:
@@ -158,14 +160,13 @@ class Engine:
         return ev, seg
 
     # ------------------------------------------------------------------ hot path
-    @staticmethod
-    def _prep(slots, frames, T: Optional[int]) -> Tuple[np.ndarray, np.ndarray, int]:
+    def _prep(self, slots, frames, T: Optional[int]) -> Tuple[np.ndarray, np.ndarray, int]:
         s = np.ascontiguousarray(slots, dtype=np.int64).reshape(-1)
         f = np.asarray(frames)
         if f.dtype not in _FMT:
             f = f.astype(np.float32)
         f = np.ascontiguousarray(f)
-        want = (s.size, 512) if T is None else (s.size, T, 512)
+        want = (s.size, self.frame_samples) if T is None else (s.size, T, self.frame_samples)
         if f.shape != want:
             raise AudioProcessingError(f"Model prediction failed: frames have shape {f.shape}, expected {want}")
         return s, f, _FMT[f.dtype]

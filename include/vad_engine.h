@@ -43,7 +43,7 @@ extern "C" {
 #endif
 
 #define VAD_ABI_VERSION 2
-#define VAD_FRAME_SAMPLES 512   /* core/silero_model.py:464-468: frames are padded/truncated to 512 */
+#define VAD_FRAME_SAMPLES 512   /* core/silero_model.py:464-468: frames are padded/truncated to 512 (Silero V5 8 kHz engines: 256, see vad_info) */
 #define VAD_STATE_FLOATS 256    /* V5: state[2][1][128]; V4: h[2][1][64] then c[2][1][64]  (silero_model.py:391-401) */
 
 typedef enum vad_status {
@@ -77,8 +77,9 @@ typedef struct vad_engine_desc {
     size_t weights_len;
     int32_t device_id;          /* HIP device ordinal; one engine drives one GPU */
     int32_t max_streams;        /* capacity of the per-GPU stream pool (slots) */
-    int32_t sample_rate;        /* the graph's `sr` input (core/silero_model.py:491): 16000, or - Silero V4 only, with the blob of its 8 kHz
-                                   sub-model - 8000 / 24000 / 48000 */
+    int32_t sample_rate;        /* the graph's `sr` input (core/silero_model.py:491): 16000, or - with the blob of the graph's 8 kHz
+                                   sub-model - V4: 8000 / 24000 / 48000 (same 512-sample frames), V5: 8000 (native 8 kHz audio in
+                                   256-sample frames: every [512] below reads [vad_info.frame_samples]) */
     uint32_t flags;             /* reserved, 0 */
 } vad_engine_desc;
 

@@ -20,6 +20,7 @@ MT = 32
 
 
 def packed_streams(version: int, blob: bytes):
+    """-> (W [blocks, 64, 4], section offsets [4 waves, 16]) exactly as vad_engine_create uploads them"""
     lib = _ffi.lib()
     n = C.c_size_t()
     sect = (C.c_uint32 * 64)()
@@ -61,9 +62,15 @@ def _store_tile(region, row0, acc, relu=True):
             region[row0 + 2 * g + h] = v[8 * g + 4 * h:8 * g + 4 * h + 4].T  # [32 m, 4]
 
 
-def v5_step(W, sect, x, hc, gate=0.01):
+def v5_step(W, sect, x, hc, gate=0.01, k8=False):
     """x [32,512] f32, hc [32,256] -> (prob [32], new hc [32,256]).  float64 contractions.
-    Mirrors silero_v5.hip: folded loader, one activation region RX (row map in vad_layout.h)."""
+    Mirrors silero_v5.hip: folded loader, one activation region RX (row map in vad_layout.h).
+    k8: the 8 kHz sub-model instantiation (x [32,256]; window 128, hop 64, waves 0 / 1 own the 64 complex bins)."""
+    N = 128 if k8 else 256                      # window
+    H, Q4 = N // 2, N // 4
+    QL = Q4 // 4                                # quad rows per folded operand (16 | 8)
+    CS, PS, ROWN = 4 * QL, (16 if k8 else 32), (80 if k8 else 160)
+    NJ, NJ0 = (4, 8) if k8 else (8, 16)
     x = x.astype(np.float64)
     if gate is not None and gate >= 0:
         x = np.where(np.abs(x) > gate, x, 0.0)
@@ -71,58 +78,60 @@ def v5_step(W, sect, x, hc, gate=0.01):
     RH = np.zeros((32, 32, 4))
     RE = RX[164:]
     # loader: window + 4-way fold of every column (vad_layout.h, v5): rows 64c + {0,16,32,48} + q hold pe, po, qe, qo
-    wtab = W[sect[0][S_NYQ]].reshape(-1)[:256].astype(np.float64)         # w[n], the k = 0 row of the stored basis
+    wtab = W[sect[0][S_NYQ]].reshape(-1)[:N].astype(np.float64)           # w[n], the k = 0 row of the stored basis
     fcor = np.zeros((3, 3, 32))
     for c in range(3):
-        y = x[:, 128 * c:128 * c + 256] * wtab[None, :] if c < 2 else x[:, 256:512] * wtab[None, :]
-        n = np.arange(64)
-        y1, y2, y3, y4 = y[:, n], y[:, 128 - n], y[:, 128 + n], y[:, (256 - n) % 256]
+        y = x[:, H * c:H * c + N] * wtab[None, :]
+        n = np.arange(Q4)
+        y1, y2, y3, y4 = y[:, n], y[:, H - n], y[:, H + n], y[:, (N - n) % N]
         pe, po = y1 + y4 + y2 + y3, y1 + y4 - y2 - y3
         qe, qo = y1 - y4 - y2 + y3, y1 - y4 + y2 - y3
         for k, arr in enumerate((pe, po, qe, qo)):
             arr = arr.copy()
             arr[:, 0] = 0.0                                                   # n = 0 is not part of the folded sums
-            RX[64 * c + 16 * k:64 * c + 16 * k + 16] = arr.reshape(32, 16, 4).transpose(1, 0, 2)
-        fcor[c, 0], fcor[c, 1], fcor[c, 2] = y[:, 128], y[:, 64] + y[:, 192], y[:, 64] - y[:, 192]
+            RX[CS * c + QL * k:CS * c + QL * k + QL] = arr.reshape(32, QL, 4).transpose(1, 0, 2)
+        fcor[c, 0], fcor[c, 1], fcor[c, 2] = y[:, H], y[:, Q4] + y[:, H + Q4], y[:, Q4] - y[:, H + Q4]
     RH[:] = hc[:, :128].astype(np.float64).reshape(32, 32, 4).transpose(1, 0, 2)
     c_prev = hc[:, 128:].astype(np.float64)
     # bin 128: alternating sum of pe + rank-1 terms
     nyq = np.zeros((3, 32))
     for c in range(3):
-        pe = RX[64 * c:64 * c + 16]                                           # [16, 32, 4]
+        pe = RX[CS * c:CS * c + QL]                                           # [16, 32, 4]
         alt = (pe[:, :, 0] - pe[:, :, 1] + pe[:, :, 2] - pe[:, :, 3]).sum(0)
         nyq[c] = np.abs(alt + fcor[c, 0] + fcor[c, 1])
     # STFT: wave w owns bins bin_of_channel(32w + r); even bins contract pe / qe, odd bins po / qo
     mags = {}
     sgn = np.where(np.arange(32) % 2 == 0, 1.0, -1.0)[:, None]                # (-1)^r per tile row
-    for w in range(4):
+    stft_waves = (0, 1) if k8 else (0, 1, 2, 3)
+    for w in stft_waves:
         ws = sect[w][S_STFT]
-        rR, rI = (0, 32) if w < 2 else (16, 48)
+        even = (w == 0) if k8 else (w < 2)
+        rR, rI = (0, 2 * QL) if even else (QL, 3 * QL)
         are = [np.zeros((32, 32)) for _ in range(3)]
         aim = [np.zeros((32, 32)) for _ in range(3)]
-        for j in range(8):
+        for j in range(NJ):
             wre, wim = W[ws + 2 * j], W[ws + 2 * j + 1]
             for c in range(3):
-                are[c] += _mfma4(wre, _rows(RX, 64 * c + rR + 2 * j, 64 * c + rR + 2 * j + 1))
-                aim[c] += _mfma4(wim, _rows(RX, 64 * c + rI + 2 * j, 64 * c + rI + 2 * j + 1))
+                are[c] += _mfma4(wre, _rows(RX, CS * c + rR + 2 * j, CS * c + rR + 2 * j + 1))
+                aim[c] += _mfma4(wim, _rows(RX, CS * c + rI + 2 * j, CS * c + rI + 2 * j + 1))
         mags[w] = []
         for c in range(3):
             y128, a64, b64 = fcor[c, 0][None, :], fcor[c, 1][None, :], fcor[c, 2][None, :]
-            if w < 2:
+            if even:
                 re, im = are[c] + y128 + sgn * a64, aim[c]
             else:
                 re, im = are[c] - y128, aim[c] - sgn * b64
             mags[w].append(np.sqrt(re ** 2 + im ** 2))
     # enc0 input: Toom-3 evaluations of m0 + m1 z + m2 z^2 at z = 0, 1, -1, 2, inf -> rows 32 p + ch/4
-    for w in range(4):
+    for w in stft_waves:
         m0, m1, m2 = mags[w]
         for p, v in enumerate((m0, (m0 + m2) + m1, (m0 + m2) - m1, m0 + 2 * m1 + 4 * m2, m2)):
-            _store_tile(RX, 32 * p + 8 * w, v, relu=False)
+            _store_tile(RX, PS * p + 8 * w, v, relu=False)
     n0, n1, n2 = nyq
-    RX[160] = np.stack([n0, (n0 + n2) + n1, (n0 + n2) - n1, n0 + 2 * n1 + 4 * n2], axis=1)
-    RX[162] = np.stack([n2, np.zeros(32), np.zeros(32), np.zeros(32)], axis=1)
-    RX[161] = 0
-    RX[163] = 0
+    RX[ROWN] = np.stack([n0, (n0 + n2) + n1, (n0 + n2) - n1, n0 + 2 * n1 + 4 * n2], axis=1)
+    RX[ROWN + 2] = np.stack([n2, np.zeros(32), np.zeros(32), np.zeros(32)], axis=1)
+    RX[ROWN + 1] = 0
+    RX[ROWN + 3] = 0
     # enc0: five point-wise contractions, then the interpolation (vad_layout.h)
     E0 = {}
     for w in range(4):
@@ -130,11 +139,11 @@ def v5_step(W, sect, x, hc, gate=0.01):
         bias = np.repeat(_vec(W[ws:ws + 4])[:, None], 32, 1)
         P = [np.zeros((32, 32)) for _ in range(5)]
         ws += 4
-        for j in range(16):
+        for j in range(NJ0):
             for p in range(5):
-                P[p] += _mfma4(W[ws + 5 * j + p], _rows(RX, 32 * p + 2 * j, 32 * p + 2 * j + 1))
-        an, bn = _rows(RX, 160, 161), _rows(RX, 162, 163)
-        wa, wb = W[ws + 80].astype(np.float64).reshape(2, 32, 4), W[ws + 81].astype(np.float64).reshape(2, 32, 4)
+                P[p] += _mfma4(W[ws + 5 * j + p], _rows(RX, PS * p + 2 * j, PS * p + 2 * j + 1))
+        an, bn = _rows(RX, ROWN, ROWN + 1), _rows(RX, ROWN + 2, ROWN + 3)
+        wa, wb = W[ws + 5 * NJ0].astype(np.float64).reshape(2, 32, 4), W[ws + 5 * NJ0 + 1].astype(np.float64).reshape(2, 32, 4)
         for p in range(4):     # one K = 2 MFMA per point: component p of block A against component p of the activation quad
             P[p] += np.einsum("hn,hm->nm", wa[:, :, p], an.reshape(2, 32, 4)[:, :, p])
         P[4] += np.einsum("hn,hm->nm", wb[:, :, 0], bn.reshape(2, 32, 4)[:, :, 0])

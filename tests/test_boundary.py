@@ -92,6 +92,26 @@ def test_packed_layout_reproduces_the_oracle():
             assert np.abs(hc - hc_o).max() <= 1e-4
 
 
+def test_packed_layout_of_the_v5_8k_submodel_reproduces_the_oracle():
+    """The same model of the kernel's dataflow, 8 kHz instantiation (256-sample frames, window 128, 64 + 1 bins)."""
+    from oracle import oracle
+    from tests import kernel_model as KM
+    from tests.signals import make_streams
+    with open(weights_io.packaged_blob_path(5, 8000), "rb") as f:
+        blob = f.read()
+    W, sect = KM.packed_streams(5, blob)
+    om = oracle.OracleModel(blob, "f64")
+    x = make_streams(32, 2, seed=6).reshape(32, 4, 256)
+    hc = np.zeros((32, 256), np.float32)
+    hc_o = hc.copy()
+    with np.errstate(over="ignore"):
+        for t in range(4):
+            p, hc = KM.v5_step(W, sect, x[:, t], hc, gate=0.01, k8=True)
+            po = om.step_batch(oracle.denoise(x[:, t]).reshape(32, 256), hc_o)
+            assert np.abs(p - po).max() <= 5e-6
+            assert np.abs(hc - hc_o).max() <= 1e-4
+
+
 def test_weights_blob_roundtrip_and_reference_arity_rule(tmp_path):
     with open(weights_io.packaged_blob_path(5), "rb") as f:
         blob = f.read()
@@ -116,7 +136,7 @@ def test_v4_blobs_name_their_graph_branch(tmp_path):
     b16 = open(weights_io.packaged_blob_path(4), "rb").read()
     b8 = open(weights_io.packaged_blob_path(4, 48000), "rb").read()
     assert weights_io.packaged_blob_path(4, 8000) == weights_io.packaged_blob_path(4, 24000) != weights_io.packaged_blob_path(4)
-    assert weights_io.packaged_blob_path(5, 8000) == weights_io.packaged_blob_path(5)      # V5 has no second blob
+    assert weights_io.packaged_blob_path(5, 8000).endswith("silero_v5_8k.svw")             # V5's 8 kHz sub-model (256-sample frames)
     t16, t8 = weights_io.unpack_svw(b16)[1], weights_io.unpack_svw(b8)[1]
     assert "meta.variant" not in t16 and float(t8["meta.variant"][0]) == 8000.0
     assert set(t8) - {"meta.variant"} == set(t16) and not np.array_equal(t8["l0.pw.w"], t16["l0.pw.w"])
