@@ -144,12 +144,16 @@ class SileroVADModel:
             raise ModelInitializationError(self.config.model_version.value,
                                            f"Failed to load model from {self.config.model_path}: {e}")
 
-    def select_rate(self, sample_rate: int) -> None:
+    def frame_samples(self, sample_rate: int) -> int:
+        """Samples one model step takes at this `sr`: 512, or 256 on Silero V5's 8 kHz sub-model."""
+        return weights_io.frame_samples(_VERSION_INT[self.config.model_version], sample_rate)
+
+    def select_rate(self, sample_rate: int, frame_len: int = 512) -> None:
         """What ``Equal(sr, 16000)`` does inside the graph: choose the sub-model for this call.  The recurrent state
         is the graph's ``h`` / ``c`` inputs, shared by both branches, so it moves with the switch - and so does the rest
         of the stream (thresholds, counters and histories of the device state machine, which belong to the processor,
         not to a sub-model): the whole slot travels as one ``vad_stream_save`` / ``vad_stream_restore`` blob."""
-        self._check_rate(sample_rate, self.config.model_version)
+        self._check_rate(sample_rate, self.config.model_version, frame_len)
         k8 = weights_io.is_8k_variant(_VERSION_INT[self.config.model_version], sample_rate)
         if k8 == self._k8:
             return
@@ -188,8 +192,8 @@ class SileroVADModel:
         try:
             if self.session is None:
                 raise ModelInitializationError(self.config.model_version.value, "Model not loaded")
-            frame = self._prepare_audio_input(audio_chunk)
-            self.select_rate(sample_rate)
+            self.select_rate(sample_rate, len(audio_chunk))
+            frame = self._prepare_audio_input(audio_chunk, self.frame_samples(sample_rate))
             p = float(self.engine.step([self._slot], frame, denoise=None)[0])
             p = self._extract_probability(p)
             self.prediction_count += 1
@@ -200,23 +204,26 @@ class SileroVADModel:
             raise AudioProcessingError(f"Model prediction failed: {e}")
 
     @staticmethod
-    def _check_rate(sample_rate: int, model_version: SileroModelVersion = SileroModelVersion.V5) -> None:
+    def _check_rate(sample_rate: int, model_version: SileroModelVersion = SileroModelVersion.V5, frame_len: int = 512) -> None:
         # The graphs select the 16 kHz weights only for sr == 16000.  V4's other branch (its 8 kHz sub-model, taken for
-        # 8 / 24 / 48 kHz alike) is built; V5's cannot take the reference's 512-sample frames - a 3-D tensor reaches its
-        # LSTM-cell subgraph and onnxruntime refuses (reproduced by oracle/onnx_interp.py) - so it raises
-        # here as it does there.
+        # 8 / 24 / 48 kHz alike) takes the same 512-sample frames.  V5's is built for native 8 kHz audio in 256-sample frames
+        # (VADConfig(sample_rate=8000, buffer_size=256)): that is served; with the reference's 512-sample frames - or at
+        # 24 / 48 kHz - a 3-D tensor reaches its LSTM-cell subgraph and onnxruntime refuses (reproduced by
+        # oracle/onnx_interp.py), so those raise here as they do there.
         if int(sample_rate) != 16000 and model_version == SileroModelVersion.V5:
+            if int(sample_rate) == 8000 and frame_len <= 256:
+                return
             raise AudioProcessingError(
-                f"Model prediction failed: sample rate {sample_rate} selects the 8 kHz graph branch, "
-                "which is not available for 512-sample frames; resample to 16 kHz first")
+                f"Model prediction failed: sample rate {sample_rate} selects the 8 kHz graph branch, which takes native "
+                f"8 kHz audio in 256-sample frames (got sr = {sample_rate}, {frame_len} samples); resample to 16 kHz first")
 
     # -- silero_model.py:449-474
     @staticmethod
-    def _prepare_audio_input(audio_chunk: np.ndarray) -> np.ndarray:
+    def _prepare_audio_input(audio_chunk: np.ndarray, frame_samples: int = 512) -> np.ndarray:
         try:
-            n = len(audio_chunk)
-            if n != 512:
-                audio_chunk = np.pad(audio_chunk, (0, 512 - n)) if n < 512 else audio_chunk[:512]
+            n, L = len(audio_chunk), frame_samples
+            if n != L:
+                audio_chunk = np.pad(audio_chunk, (0, L - n)) if n < L else audio_chunk[:L]
             return np.ascontiguousarray(audio_chunk, dtype=np.float32).reshape(1, -1)
         except Exception as e:
             raise AudioProcessingError(f"Audio input preparation failed: {e}")
@@ -408,9 +415,10 @@ class VADProcessor:
             if self.model is None:
                 raise ModelInitializationError(self.config.model_version.value, "Model not loaded")
             kept = self._preprocess_audio_frame(audio_frame)
-            self.model.select_rate(int(self.config.sample_rate))     # first: the thresholds go to the slot that will run
+            sr = int(self.config.sample_rate)
+            self.model.select_rate(sr, len(audio_frame))             # first: the thresholds go to the slot that will run
             self._sync_thresholds()
-            frame = SileroVADModel._prepare_audio_input(np.asarray(audio_frame))
+            frame = SileroVADModel._prepare_audio_input(np.asarray(audio_frame), self.model.frame_samples(sr))
             thr = 0.01 if self.config.enable_denoising else None
             try:
                 p, ev, _seg = self.model.engine.step_events([self.model.slot], frame, denoise=thr)
@@ -455,9 +463,11 @@ class VADProcessor:
         F = len(kept)
         if F:
             try:
-                self.model.select_rate(int(self.config.sample_rate))
+                sr = int(self.config.sample_rate)
+                self.model.select_rate(sr, frames.shape[1])
                 self._sync_thresholds()
-                x = np.stack([SileroVADModel._prepare_audio_input(np.asarray(f))[0] for f in frames[:F]])[None]
+                L = self.model.frame_samples(sr)
+                x = np.stack([SileroVADModel._prepare_audio_input(np.asarray(f), L)[0] for f in frames[:F]])[None]
                 thr = 0.01 if self.config.enable_denoising else None
                 eng, slot = self.model.engine, self.model.slot
                 saved = eng.save_stream(slot)

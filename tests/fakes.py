@@ -74,7 +74,7 @@ class FakeEngine:
         if frames.dtype == np.int16:                       # the engine's int16 ingest: true division by the scale
             frames = frames.astype(np.float32) / np.float32(i16_scale)
         frames = np.asarray(frames, np.float32).reshape(len(slots), -1)
-        assert frames.shape[1] == 512, "callers must pad to 512"
+        assert frames.shape[1] in (512, 256), "callers must pad to the model's frame length (512; 256 on V5's 8 kHz sub-model)"
         self.frames_seen.append(frames.copy())
         self.denoise_seen.append(denoise)
         return np.array([self._p(f) for f in frames], np.float64)  # exact scripted values

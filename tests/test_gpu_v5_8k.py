@@ -76,7 +76,8 @@ def test_interpreter_goldens_gate_int16_and_edges(engine, om):
             engine.reset([s])
             got = np.array([engine.step([s], f[None], denoise=None)[0] for f in cases[name]], np.float32)   # cases are pre-gated
             assert np.abs(got - g[f"{name}.probs"]).max() <= TOL_P, name
-            assert np.abs(engine.get_state(s) - g[f"{name}.state"]).max() <= 2e-4, name
+            ref_s = g[f"{name}.state"]                            # c reaches tens over 529 speech frames: relative bar
+            assert (np.abs(engine.get_state(s) - ref_s) <= 2e-4 * np.maximum(1.0, np.abs(ref_s))).all(), name
         # the gate in the kernel == the gate of the fixture generator; no gate on the ungated speech
         engine.reset([s])
         sp = (pcm[::2].astype(np.float32) / np.float32(32767.0))[: 120 * 256].reshape(120, 256)
@@ -144,3 +145,27 @@ def test_full_size_tile_independence_and_state_machine(engine):
     finally:
         for s in slots:
             engine.close_stream(int(s))
+
+
+def test_wrapper_selects_the_8k_submodel_for_256_sample_buffers(om):
+    """VADConfig(sample_rate=8000, buffer_size=256): the drop-in wrapper runs native 8 kHz audio through the sub-model; the
+    reference's own combination (512-sample frames at 8 kHz) raises as onnxruntime does there."""
+    from cutter_vad_amd import AudioProcessingError, SampleRate, VADConfig, VADWrapper
+    from oracle import oracle
+    pcm = np.load(os.path.join(GOLD, "speech16k_i16.npz"))["pcm"]
+    sp = (pcm[::2].astype(np.float32) / np.float32(32767.0))[: 200 * 256].reshape(200, 256)
+    ev = []
+    with VADWrapper(VADConfig(sample_rate=SampleRate(8000), buffer_size=256, vad_start_probability=0.5, vad_end_probability=0.3,
+                              voice_start_frame_count=3, voice_end_frame_count=8)) as w:
+        w.set_callbacks(voice_start_callback=lambda: ev.append("S"), voice_end_callback=lambda b: ev.append(("E", len(b))),
+                        voice_continue_callback=lambda b: None)
+        st = np.zeros(256, np.float32)
+        for f in sp:
+            w.process_audio_data(f)
+            ref = om.step(oracle.denoise(f).reshape(256), st)
+            assert abs(w.processor.voice_probabilities[-1] - ref) <= TOL_P
+        assert w.processor.get_model_info()["state_shape"]["state"] == (2, 1, 128)
+    assert ev and ev[0] == "S" and any(isinstance(e, tuple) for e in ev)
+    with VADWrapper(VADConfig(sample_rate=SampleRate(8000), buffer_size=512)) as w:
+        with pytest.raises(AudioProcessingError, match="Model prediction failed"):
+            w.process_audio_data(np.zeros(512, np.float32))

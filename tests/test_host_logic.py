@@ -421,3 +421,20 @@ def test_v4_rate_switch_inside_a_segment_moves_the_state_machine_with_the_stream
     b = [proc.process_frame(x) for _ in range(4)]
     assert proc.model.slot == 1 and getattr(eng, "restores", 0) == 1
     assert all(r.voice_continuing for r in b) and b[3].voice_ended and not proc.is_voice_active
+
+
+def test_v5_at_8k_runs_native_256_sample_frames_and_refuses_what_the_reference_cannot_run():
+    """V5's 8 kHz graph branch takes 256-sample frames.  VADConfig(sample_rate=8000, buffer_size=256) is
+    served natively (frames reach the engine 256 long, short ones right-zero-padded to 256); the reference's own
+    combination - 512-sample frames at 8 kHz - fails in onnxruntime, and here with the same exception class and prefix."""
+    proc, eng = _processor([0.2, 0.9, 0.9], sample_rate=SampleRate(8000), buffer_size=256)
+    for n in (256, 200, 256):
+        proc.process_frame(np.full(n, 0.1, np.float32))
+    assert [f.shape for f in eng.frames_seen] == [(1, 256)] * 3 and not eng.frames_seen[1][0, 200:].any()
+    assert proc.model.slot == 1                                   # a slot of the 8 kHz engine, opened on first use
+    proc512, _ = _processor([0.5], sample_rate=SampleRate(8000), buffer_size=512)
+    with pytest.raises(AudioProcessingError, match="Model prediction failed: sample rate 8000"):
+        proc512.process_frame(np.zeros(512, np.float32))
+    proc48, _ = _processor([0.5], sample_rate=SampleRate(48000), buffer_size=256)
+    with pytest.raises(AudioProcessingError, match="Model prediction failed"):
+        proc48.process_frame(np.zeros(256, np.float32))
