@@ -101,6 +101,10 @@ SIGNATURES = {
     "vad_step_multi_device": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, C.c_int, C.c_float, _vp, _vp, _vp, _vp]),
     "vad_step_submit": (C.c_int, [_vp, _i64p, C.c_int64, C.c_int32, _vp, C.c_int, C.c_float, _i64p]),
     "vad_step_collect": (C.c_int, [_vp, C.c_int64, _f32p, _u8p, _i32p]),
+    "vad_step_rates_device": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_void_p), _i64p, C.POINTER(C.c_int32), _vp, C.c_float,
+                                        _vp, _vp, _vp, _vp]),
+    "vad_step_rates": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_void_p), _i64p, C.POINTER(C.c_int32), _i64p, C.c_float,
+                                 _f32p, _u8p, _i32p]),
     "vad_resample": (C.c_int, [_vp, _f32p, C.c_int64, C.c_int32, C.c_int32, _f32p]),
     "vad_resample_multi_device": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_void_p), _i64p, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_void_p), _vp]),

@@ -825,6 +825,116 @@ int vad_resample_multi_device(vad_engine *e, int32_t nseg, const float *const *d
     return VAD_OK;
 }
 
+// ---- one tick for streams at other input rates: resample on the GPU -> model step, chained on the device -----------------
+namespace {
+int step_rates_enqueue(vad_engine *e, int32_t nseg, const float *const *d_in, const int64_t *n, const int32_t *sr_in,
+                       const int32_t *d_slots, float thr, float *d_probs, uint8_t *d_events, int32_t *d_seg, hipStream_t s) {
+    if (e->frame_samples != VAD_FRAME_SAMPLES)
+        return e->fail(VAD_ERR_UNSUPPORTED, "Model prediction failed: this engine runs an 8 kHz sub-model on %d-sample frames; "
+                       "resampled streams need the 16 kHz one", e->frame_samples);
+    int64_t total = 0;
+    for (int k = 0; k < nseg; ++k) {
+        if (n[k] < 0 || (n[k] > 0 && !d_in[k])) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: null buffer or bad count in segment %d", k);
+        total += n[k];
+    }
+    if (int rc = check_call_size(e, total, 1, VAD_FMT_F32)) return rc;
+    if (total == 0) return VAD_OK;
+    if (!d_probs) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: null buffer");
+    // the 16 kHz frames of the tick: [total][512] f32, engine-owned, written by the resampler and read by the model launch
+    // right behind it on the same HIP stream - they never leave the GPU
+    if (int rc = ensure(e, e->d_rs_out, e->d_rs_out_cap, sizeof(float) * VAD_FRAME_SAMPLES * (size_t)total)) return rc;
+    vadk::ResampleParams rp{};
+    int32_t tiles = 0, nrs = 0;
+    int64_t row = 0;
+    for (int k = 0; k < nseg; ++k) {
+        float *dst = e->d_rs_out + (size_t)row * VAD_FRAME_SAMPLES;
+        row += n[k];
+        if (n[k] == 0) continue;
+        if (sr_in[k] == 16000) {      // already 16 kHz (AudioUtils.resample_audio returns its input: utils/audio.py:39-40)
+            HIP_TRY(e, hipMemcpyAsync(dst, d_in[k], sizeof(float) * VAD_FRAME_SAMPLES * (size_t)n[k], hipMemcpyDeviceToDevice, s));
+            continue;
+        }
+        if (nrs == vadk::RESAMPLE_MAX_SEGS) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: at most %d resampled segments per call", vadk::RESAMPLE_MAX_SEGS);
+        if (int rc = resample_segment(e, d_in[k], n[k], resample_chunk_len(sr_in[k]), sr_in[k], dst, rp.seg[nrs])) return rc;
+        rp.tile_start[nrs++] = tiles;
+        tiles += (int32_t)((n[k] + vadk::MT - 1) / vadk::MT);
+    }
+    if (nrs) {
+        rp.nseg = nrs;
+        rp.tile_start[nrs] = tiles;
+        hipError_t r = vadk_launch_resample(&rp, s);
+        if (r != hipSuccess) return e->hip_fail(r, "resample kernel launch");
+    }
+    vadk::StepParams p = e->base;
+    p.slots = d_slots;
+    p.frames = e->d_rs_out;
+    p.probs = d_probs;
+    p.events = d_events;
+    p.seg_frames = d_seg;
+    p.n = (int32_t)total;
+    p.T = 1;
+    p.fmt = VAD_FMT_F32;
+    p.thresh = thr;
+    return launch(e, p, s);
+}
+}  // namespace
+
+int vad_step_rates_device(vad_engine *e, int32_t nseg, const float *const *d_in, const int64_t *n, const int32_t *sr_in,
+                          const int32_t *d_slots, float denoise_thresh, float *d_probs, uint8_t *d_events, int32_t *d_seg_frames,
+                          void *stream) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (nseg < 1 || nseg > 8 || !d_in || !n || !sr_in) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: 1..8 segments, non-null tables");
+    HIP_TRY(e, hipSetDevice(e->device));
+    return step_rates_enqueue(e, nseg, d_in, n, sr_in, d_slots, denoise_thresh, d_probs, d_events, d_seg_frames,
+                              stream ? static_cast<hipStream_t>(stream) : e->stream);
+}
+
+int vad_step_rates(vad_engine *e, int32_t nseg, const float *const *in, const int64_t *n, const int32_t *sr_in, const int64_t *slots,
+                   float denoise_thresh, float *probs_out, uint8_t *events_out, int32_t *seg_frames_out) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (nseg < 1 || nseg > 8 || !in || !n || !sr_in || !slots || !probs_out)
+        return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: 1..8 segments, non-null tables");
+    int64_t total = 0;
+    size_t in_floats = 0;
+    for (int k = 0; k < nseg; ++k) {
+        const int len = sr_in[k] == 16000 ? VAD_FRAME_SAMPLES : resample_chunk_len(sr_in[k]);
+        if (len == 0)
+            return e->fail(VAD_ERR_UNSUPPORTED, "Failed to resample audio from %dHz to 16000Hz: supported input rates are 8000, 16000, 24000, 48000", sr_in[k]);
+        if (n[k] < 0 || (n[k] > 0 && !in[k])) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: null buffer or bad count in segment %d", k);
+        total += n[k];
+        in_floats += (size_t)n[k] * len;
+    }
+    if (int rc = check_call_size(e, total, 1, VAD_FMT_F32)) return rc;
+    if (total == 0) return VAD_OK;
+    if (int rc = check_slots(e, slots, total)) return rc;
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (int rc = ensure(e, e->d_rs_in, e->d_rs_in_cap, sizeof(float) * in_floats)) return rc;
+    if (int rc = ensure(e, e->d_probs, e->d_probs_cap, sizeof(float) * total)) return rc;
+    if (int rc = ensure(e, e->d_events, e->d_events_cap, (size_t)total)) return rc;
+    if (int rc = ensure(e, e->d_seg, e->d_seg_cap, sizeof(int32_t) * total)) return rc;
+    if (int rc = ensure(e, e->d_slots, e->d_slots_cap, sizeof(int32_t) * total)) return rc;
+    std::vector<int32_t> s32((size_t)total);
+    for (int64_t i = 0; i < total; ++i) s32[(size_t)i] = (int32_t)slots[i];
+    HIP_TRY(e, hipMemcpyAsync(e->d_slots, s32.data(), sizeof(int32_t) * total, hipMemcpyHostToDevice, e->stream));
+    const float *d_in[8];
+    size_t off = 0;
+    for (int k = 0; k < nseg; ++k) {
+        const size_t len = sr_in[k] == 16000 ? VAD_FRAME_SAMPLES : (size_t)resample_chunk_len(sr_in[k]);
+        d_in[k] = e->d_rs_in + off;
+        if (n[k]) HIP_TRY(e, hipMemcpyAsync(e->d_rs_in + off, in[k], sizeof(float) * len * (size_t)n[k], hipMemcpyHostToDevice, e->stream));
+        off += len * (size_t)n[k];
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));       // pageable sources must not change under the copies
+    if (int rc = step_rates_enqueue(e, nseg, d_in, n, sr_in, e->d_slots, denoise_thresh, e->d_probs, e->d_events, e->d_seg, e->stream)) return rc;
+    HIP_TRY(e, hipMemcpyAsync(probs_out, e->d_probs, sizeof(float) * total, hipMemcpyDeviceToHost, e->stream));
+    if (events_out) HIP_TRY(e, hipMemcpyAsync(events_out, e->d_events, (size_t)total, hipMemcpyDeviceToHost, e->stream));
+    if (seg_frames_out) HIP_TRY(e, hipMemcpyAsync(seg_frames_out, e->d_seg, sizeof(int32_t) * total, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return VAD_OK;
+}
+
 int vad_debug_resample_operator(int32_t n_in, float *R, size_t r_floats) {
     g_create_error.clear();
     if (n_in < 8 || n_in % 8 || !R || r_floats < (size_t)n_in * VAD_FRAME_SAMPLES) {

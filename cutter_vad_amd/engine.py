@@ -256,6 +256,45 @@ class Engine:
             self._tickets.pop(int(ticket), None)
         return (probs, ev, seg) if multi else (probs[:, 0], ev[:, 0], seg)
 
+    def step_rates(self, segments, slots, denoise: Optional[float] = 0.01):
+        """One tick for streams at other input rates (``vad_step_rates``): ``segments`` = [(chunks [n_k, n_in_k] float32,
+        sr_in_k), ...] with n_in = 256 / 512 / 768 / 1536 at 8 / 16 / 24 / 48 kHz; ``slots`` lists the streams of all
+        segments in order.  Resample + model step chained on the GPU -> (probs, events, seg_frames)."""
+        k = len(segments)
+        arrs = [np.ascontiguousarray(a, np.float32) for a, _ in segments]
+        for a in arrs:
+            if a.ndim != 2:
+                raise AudioProcessingError(f"Failed to resample audio: expected [n, n_in], got {a.shape}")
+        ptrs = (C.c_void_p * k)(*[a.ctypes.data for a in arrs])
+        n = (C.c_int64 * k)(*[a.shape[0] for a in arrs])
+        sr = (C.c_int32 * k)(*[int(r) for _, r in segments])
+        for a, (_, r) in zip(arrs, segments):
+            want = {8000: 256, 16000: 512, 24000: 768, 48000: 1536}.get(int(r))
+            if want is not None and a.shape[1] != want:
+                raise AudioProcessingError(f"Failed to resample audio from {r}Hz to 16000Hz: a chunk must hold {want} samples, got {a.shape[1]}")
+        s = np.ascontiguousarray(slots, dtype=np.int64).reshape(-1)
+        total = sum(a.shape[0] for a in arrs)
+        if s.size != total:
+            raise AudioProcessingError(f"Model prediction failed: {s.size} slots for {total} chunks")
+        probs = np.empty(total, np.float32)
+        ev = np.zeros(total, np.uint8)
+        seg = np.zeros(total, np.int32)
+        thr = -1.0 if denoise is None else float(denoise)
+        self._check(self._lib.vad_step_rates(self._h, k, ptrs, n, sr, _ptr(s, C.c_int64), thr, _ptr(probs, C.c_float),
+                                             _ptr(ev, C.c_uint8), _ptr(seg, C.c_int32)))
+        return probs, ev, seg
+
+    def step_rates_device(self, segments, d_probs: int, d_slots: int = 0, d_events: int = 0, d_seg: int = 0,
+                          denoise: Optional[float] = 0.01, stream: int = 0) -> None:
+        """Device-pointer form: ``segments`` = [(d_in, n, sr_in), ...] (``vad_step_rates_device``), asynchronous."""
+        k = len(segments)
+        ptrs = (C.c_void_p * k)(*[int(a[0]) for a in segments])
+        n = (C.c_int64 * k)(*[int(a[1]) for a in segments])
+        sr = (C.c_int32 * k)(*[int(a[2]) for a in segments])
+        thr = -1.0 if denoise is None else float(denoise)
+        self._check(self._lib.vad_step_rates_device(self._h, k, ptrs, n, sr, d_slots or None, thr, d_probs, d_events or None,
+                                                    d_seg or None, stream or None))
+
     def resample_multi_device(self, segments, stream: int = 0) -> None:
         """One launch for up to 4 segments ``(d_in, n, n_in, sr_in, d_out)`` of device pointers (integers)."""
         k = len(segments)

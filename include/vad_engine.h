@@ -238,6 +238,23 @@ VAD_API int vad_resample_multi_device(vad_engine *e, int32_t nseg, const float *
                                       const int32_t *n_in, const int32_t *sr_in, float *const *d_out, void *stream);
 
 /*
+ * One tick for streams whose audio arrives at another rate: VADConfig.auto_convert_sample_rate.  The reference's hook for it
+ * is core/vad_wrapper.py:621-624 - a `pass` - and the function it was meant to call is AudioUtils.resample_audio
+ * (utils/audio.py:19-55); this entry point is that path, on the GPU: segment k holds n[k] chunks of one tick at sr_in[k]
+ * (256 samples @ 8 kHz, 768 @ 24 kHz, 1536 @ 48 kHz - one 512-sample 16 kHz frame each; 512 @ 16 kHz passes through, as
+ * resample_audio does at :39-40); all segments are resampled in ONE launch into engine-owned HBM and every stream advances one
+ * frame in ONE model launch right behind it on the same HIP stream - the 16 kHz frames never travel.  slots / probs / events /
+ * seg_frames are the concatenation of the segments, in order.  16 kHz engines only (Silero V5, or V4's 16 kHz sub-model).
+ * The device form is asynchronous like vad_step_device and follows its slot rules; calls on one engine must use one stream.
+ */
+VAD_API int vad_step_rates_device(vad_engine *e, int32_t nseg, const float *const *d_in, const int64_t *n, const int32_t *sr_in,
+                                  const int32_t *d_slots, float denoise_thresh, float *d_probs, uint8_t *d_events,
+                                  int32_t *d_seg_frames, void *stream);
+VAD_API int vad_step_rates(vad_engine *e, int32_t nseg, const float *const *in, const int64_t *n, const int32_t *sr_in,
+                           const int64_t *slots, float denoise_thresh, float *probs_out, uint8_t *events_out,
+                           int32_t *seg_frames_out);
+
+/*
  * Diagnostic (no GPU needed): run the host-side weight packer and return the per-wave MFMA
  * weight streams exactly as vad_engine_create uploads them.  out may be NULL to query the size.
  * sect_out receives [4 waves][16 sections] block offsets (1 block = 256 floats).  Used by the

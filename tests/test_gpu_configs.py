@@ -96,3 +96,61 @@ def test_config4_share_v4_and_v5_engines_concurrent_on_two_hip_streams():
             assert np.array_equal(alone, got), v
             assert np.array_equal(solo.get_state(int(slots[77])), st), v
     assert _ffi.VAD_OK == 0
+
+
+def test_config3_mixed_input_rates_one_product_call():
+    """configs[3]: batch = 4 096 streams with 8 / 24 / 48 kHz input (+ a 16 kHz pass-through segment) -> on-GPU resample -> V5,
+    as ONE call of the C ABI (vad_step_rates: the auto_convert_sample_rate path the reference leaves as `pass`,
+    vad_wrapper.py:621-624).  Checked against the oracle chain scipy-style Fourier resample -> gate -> model on a sample of
+    streams, against the two-call form (vad_resample + vad_step) bit for bit, and through device pointers."""
+    import torch
+    from cutter_vad_amd.engine import Engine
+    from oracle import oracle
+    rates = ((8000, 256), (24000, 768), (48000, 1536), (16000, 512))
+    per, T = 1024, 5
+    B = per * len(rates)
+    rng = np.random.default_rng(33)
+    base = make_streams(B, T * 3, seed=1234).reshape(B, -1)           # enough samples for the 48 kHz chunks
+    om = oracle.OracleModel(_blob(5), "f64")
+    with Engine(_blob(5), model_version=5, max_streams=B) as eng, Engine(_blob(5), model_version=5, max_streams=B) as two:
+        slots = eng.open_streams(B)
+        slots2 = two.open_streams(B)
+        pick = np.concatenate([k * per + rng.choice(per, 24, replace=False) for k in range(len(rates))])
+        st = np.zeros((pick.size, 256), np.float32)
+        d_x = []
+        for t in range(T):
+            segs = [(np.ascontiguousarray(base[k * per:(k + 1) * per, t * n_in:(t + 1) * n_in]), sr) for k, (sr, n_in) in enumerate(rates)]
+            p, ev, seg = eng.step_rates(segs, slots)
+            # oracle chain on the sample
+            x16 = np.stack([oracle.resample(segs[i // per][0][i % per], 512) if rates[i // per][0] != 16000 else segs[i // per][0][i % per]
+                            for i in pick]).astype(np.float32)
+            ref = om.step_batch(oracle.denoise(x16).reshape(pick.size, 512), st, nthreads=8)
+            assert np.abs(p[pick] - ref).max() <= 5e-5, t            # bar 1e-4; the resampler adds <= 1e-5 on the samples
+            # the same tick as two calls per segment on another engine: identical bits
+            f16 = np.concatenate([two.resample(a, sr) if sr != 16000 else a for a, sr in segs])
+            p2, ev2, _ = two.step_events(slots2, f16)
+            assert np.array_equal(p, p2) and np.array_equal(ev, ev2)
+            d_x.append(segs)
+        # device pointers, asynchronous: replay the 5 ticks from zero state
+        eng.reset(slots)
+        dev = torch.device("cuda:0")
+        d_p = torch.zeros(T, B, device=dev)
+        ts = torch.cuda.Stream(dev)
+        keep = []
+        for t in range(T):
+            d_segs = []
+            for a, sr in d_x[t]:
+                ta = torch.from_numpy(a).to(dev)
+                keep.append(ta)
+                d_segs.append((ta.data_ptr(), a.shape[0], sr))
+            torch.cuda.synchronize()
+            eng.step_rates_device(d_segs, d_p[t].data_ptr(), stream=ts.cuda_stream)
+        ts.synchronize()
+        two.reset(slots2)
+        for t in range(T):
+            f16 = np.concatenate([two.resample(a, sr) if sr != 16000 else a for a, sr in d_x[t]])
+            assert np.array_equal(d_p[t].cpu().numpy(), two.step(slots2, f16)), t
+        with pytest.raises(Exception, match="must hold 768"):
+            eng.step_rates([(np.zeros((2, 700), np.float32), 24000)], slots[:2])
+        with pytest.raises(Exception, match="supported input rates"):
+            eng.step_rates([(np.zeros((2, 441), np.float32), 44100)], slots[:2])

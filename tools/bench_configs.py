@@ -58,19 +58,18 @@ def config3():
     eng.open_streams(B)
     rates = ((8000, 256), (24000, 768), (48000, 1536))
     rings = [(0.1 * torch.randn(8, per, n_in, device="cuda")).contiguous() for _, n_in in rates]
-    f16 = torch.empty(3 * per, 512, device="cuda")
     probs = torch.empty(3 * per, device="cuda")
     ts = torch.cuda.Stream()
 
     def step(i):
-        # the three input rates of the tick in ONE resample launch, then the model step, all on one HIP stream
-        eng.resample_multi_device([(rings[k][i % 8].data_ptr(), per, n_in, sr, f16[k * per:(k + 1) * per].data_ptr())
-                                   for k, (sr, n_in) in enumerate(rates)], stream=ts.cuda_stream)
-        eng.step_device(3 * per, f16.data_ptr(), probs.data_ptr(), stream=ts.cuda_stream)
+        # ONE product call (vad_step_rates_device): the three input rates of the tick in one resample launch into engine-owned
+        # HBM, the model step right behind it on the same HIP stream
+        eng.step_rates_device([(rings[k][i % 8].data_ptr(), per, sr) for k, (sr, _n) in enumerate(rates)], probs.data_ptr(),
+                              stream=ts.cuda_stream)
 
     dt = timed(step, [ts])
     eng.close()
-    return {"config": "configs[3]: batch=4095 (3 x 1365) mixed 8/24/48 kHz -> resample (one launch) -> V5", "us_per_step": dt * 1e6,
+    return {"config": "configs[3]: batch=4095 (3 x 1365) mixed 8/24/48 kHz -> vad_step_rates_device (resample launch + V5 launch)", "us_per_step": dt * 1e6,
             "frames_per_s": 3 * per / dt}
 
 
