@@ -76,6 +76,20 @@ class Thresholds(C.Structure):
     ]
 
 
+class TickResult(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("n", C.c_int64),
+        ("slots", C.POINTER(C.c_int64)),
+        ("probs", C.POINTER(C.c_float)),
+        ("events", C.POINTER(C.c_uint8)),
+        ("seg_frames", C.POINTER(C.c_int32)),
+        ("group_start", C.c_int64 * 7),
+        ("group_frames", C.c_void_p * 6),
+        ("nsamples", C.POINTER(C.c_int32)),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/vad_engine.h one-to-one
 _vp, _i64p, _f32p, _u8p, _i32p = C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
 SIGNATURES = {
@@ -101,6 +115,9 @@ SIGNATURES = {
     "vad_step_multi_device": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, C.c_int, C.c_float, _vp, _vp, _vp, _vp]),
     "vad_step_submit": (C.c_int, [_vp, _i64p, C.c_int64, C.c_int32, _vp, C.c_int, C.c_float, _i64p]),
     "vad_step_collect": (C.c_int, [_vp, C.c_int64, _f32p, _u8p, _i32p]),
+    "vad_tick_push": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, C.c_int, C.c_int]),
+    "vad_tick_cancel": (C.c_int, [_vp, C.c_int64]),
+    "vad_tick_run": (C.c_int, [_vp, C.c_float, C.POINTER(TickResult)]),
     "vad_step_rates_device": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_void_p), _i64p, C.POINTER(C.c_int32), _vp, C.c_float,
                                         _vp, _vp, _vp, _vp]),
     "vad_step_rates": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_void_p), _i64p, C.POINTER(C.c_int32), _i64p, C.c_float,

@@ -16,8 +16,10 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "pack_weights.h"
@@ -84,6 +86,27 @@ struct vad_engine {
     } pipe[PIPE_DEPTH];
     hipStream_t copy_in = nullptr, copy_out = nullptr;
     int64_t next_ticket = 0;
+    // tick assembler (vad_tick_push / vad_tick_run): producers write a slot's next frame straight into the page-locked
+    // staging row of the coming tick, grouped by (frame format, gate on/off) = the launches of that tick; double-buffered so
+    // that frames keep arriving while a tick runs.  A slot's further frames wait in `tick_overflow` (one frame per slot and tick).
+    static constexpr int TICK_GROUPS = 6;            // group = frame_fmt * 2 + gate_on
+    struct TickBuf {
+        uint8_t *h = nullptr;                        // pinned: [cap] rows of frame bytes, then [cap] int32 slots, then [cap] int32 lengths
+        int64_t cap = 0, count = 0;
+        size_t row_bytes = 0;
+        uint8_t *row(int64_t r) const { return h + (size_t)r * row_bytes; }
+        int32_t *slots() const { return reinterpret_cast<int32_t *>(h + (size_t)cap * row_bytes); }
+        int32_t *lens() const { return slots() + cap; }   // samples the caller pushed (before padding / truncation)
+    };
+    struct TickPending { std::vector<uint8_t> data; int32_t nsamples /* as pushed */, kept /* samples in data */; int group; };
+    std::mutex tick_mu;
+    int tick_cur = 0;
+    TickBuf tick_buf[2][TICK_GROUPS];
+    std::vector<uint32_t> tick_gen;                  // per slot: == tick_generation <=> the slot has a frame in the coming tick
+    uint32_t tick_generation = 1;
+    std::unordered_map<int64_t, std::deque<TickPending>> tick_overflow;
+    uint8_t *h_tick_out = nullptr, *d_tick_out = nullptr; size_t tick_out_cap = 0;   // [slots i64 | probs f32 | seg i32 | events u8] x max n
+    void *d_tick_frames = nullptr; size_t d_tick_frames_cap = 0;
     struct ResampleOp {
         int n_in = 0;
         float *d_w = nullptr;
@@ -363,6 +386,7 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
     e->base.sm = e->d_sm;
     e->open.assign((size_t)e->max_streams, 0);
     e->stamp.assign((size_t)e->max_streams, 0);
+    e->tick_gen.assign((size_t)e->max_streams, 0);
     e->free_list.reserve((size_t)e->max_streams);
     for (int64_t s = e->max_streams - 1; s >= 0; --s) e->free_list.push_back(s);
     *out = e;
@@ -388,6 +412,12 @@ void vad_engine_destroy(vad_engine *e) {
     if (e->copy_in) (void)hipStreamDestroy(e->copy_in);
     if (e->copy_out) (void)hipStreamDestroy(e->copy_out);
     if (e->h_ctl) (void)hipHostFree(e->h_ctl);
+    for (auto &bb : e->tick_buf)
+        for (auto &tb : bb)
+            if (tb.h) (void)hipHostFree(tb.h);
+    if (e->h_tick_out) (void)hipHostFree(e->h_tick_out);
+    if (e->d_tick_out) (void)hipFree(e->d_tick_out);
+    if (e->d_tick_frames) (void)hipFree(e->d_tick_frames);
     if (e->h_small_in) (void)hipHostFree(e->h_small_in);
     if (e->h_small_out) (void)hipHostFree(e->h_small_out);
     for (void *b : e->host_blocks) (void)hipHostFree(b);
@@ -932,6 +962,178 @@ int vad_step_rates(vad_engine *e, int32_t nseg, const float *const *in, const in
     if (events_out) HIP_TRY(e, hipMemcpyAsync(events_out, e->d_events, (size_t)total, hipMemcpyDeviceToHost, e->stream));
     if (seg_frames_out) HIP_TRY(e, hipMemcpyAsync(seg_frames_out, e->d_seg, sizeof(int32_t) * total, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return VAD_OK;
+}
+
+// ---- tick assembler: the multi-stream caller's side of vad_step_events, in C ---------------------------------------------
+namespace {
+// one frame of `slot` into the staging of the coming tick (tick_mu held)
+int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int group) {
+    vad_engine::TickBuf &tb = e->tick_buf[e->tick_cur][group];
+    const size_t ss = group >= 2 ? 2 : 4;                       // bytes per sample: groups 0,1 = float32
+    const size_t rb = ss * (size_t)e->frame_samples;
+    if (tb.count == tb.cap) {
+        const int64_t cap = std::min<int64_t>(e->max_streams, std::max<int64_t>(256, 2 * tb.cap));
+        if (cap <= tb.cap) return e->fail(VAD_ERR_INVALID_ARG, "tick: more pending frames than slots");
+        uint8_t *nh = nullptr;
+        hipError_t r = hipSetDevice(e->device);
+        if (r == hipSuccess) r = hipHostMalloc((void **)&nh, (size_t)cap * (rb + 2 * sizeof(int32_t)), hipHostMallocDefault);
+        if (r != hipSuccess) return e->hip_fail(r, "hipHostMalloc(tick staging)");
+        if (tb.count) {
+            std::memcpy(nh, tb.h, (size_t)tb.count * rb);
+            std::memcpy(nh + (size_t)cap * rb, tb.slots(), sizeof(int32_t) * (size_t)tb.count);
+            std::memcpy(nh + (size_t)cap * (rb + sizeof(int32_t)), tb.lens(), sizeof(int32_t) * (size_t)tb.count);
+        }
+        if (tb.h) (void)hipHostFree(tb.h);
+        tb.h = nh;
+        tb.cap = cap;
+        tb.row_bytes = rb;
+    }
+    // SileroVADModel._prepare_audio_input (core/silero_model.py:464-468): right-zero-pad short frames, truncate long ones
+    const size_t take = std::min<size_t>((size_t)nsamples, (size_t)e->frame_samples) * ss;
+    uint8_t *dst = tb.row(tb.count);
+    std::memcpy(dst, samples, take);
+    if (take < rb) std::memset(dst + take, 0, rb - take);
+    tb.slots()[tb.count] = (int32_t)slot;
+    tb.lens()[tb.count] = nsamples;
+    tb.count += 1;
+    e->tick_gen[(size_t)slot] = e->tick_generation;
+    return VAD_OK;
+}
+}  // namespace
+
+int vad_tick_push(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int gate_on) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->tick_mu);
+    if (!samples || nsamples < 1 || frame_fmt < VAD_FMT_F32 || frame_fmt > VAD_FMT_I16_32768)
+        return e->fail(VAD_ERR_INVALID_ARG, "tick: null frame, empty frame or unknown format");
+    if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
+        return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
+    const int group = frame_fmt * 2 + (gate_on ? 1 : 0);
+    if (e->tick_gen[(size_t)slot] != e->tick_generation) return tick_place(e, slot, samples, nsamples, group);
+    // the slot already has its frame of the coming tick: later frames wait their turn (one per tick, submission order)
+    auto &q = e->tick_overflow[slot];
+    if (q.size() >= 256) return e->fail(VAD_ERR_BUSY, "tick: slot %lld has 256 frames waiting - is vad_tick_run being called?", (long long)slot);
+    const size_t ss = frame_fmt == VAD_FMT_F32 ? 4 : 2;
+    const int32_t keep = std::min<int32_t>(nsamples, e->frame_samples);
+    const uint8_t *src = static_cast<const uint8_t *>(samples);
+    q.push_back(vad_engine::TickPending{std::vector<uint8_t>(src, src + ss * (size_t)keep), nsamples, keep, group});
+    return VAD_OK;
+}
+
+int vad_tick_cancel(vad_engine *e, int64_t slot) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->tick_mu);
+    if (slot < 0 || slot >= e->max_streams) return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is out of range", (long long)slot);
+    e->tick_overflow.erase(slot);
+    if (e->tick_gen[(size_t)slot] == e->tick_generation) {
+        for (auto &tb : e->tick_buf[e->tick_cur])
+            for (int64_t r = 0; r < tb.count; ++r)
+                if (tb.slots()[r] == (int32_t)slot) {          // the last row fills the hole
+                    const int64_t last = tb.count - 1;
+                    if (r != last) {
+                        std::memcpy(tb.row(r), tb.row(last), tb.row_bytes);
+                        tb.slots()[r] = tb.slots()[last];
+                        tb.lens()[r] = tb.lens()[last];
+                    }
+                    tb.count = last;
+                    break;
+                }
+        e->tick_gen[(size_t)slot] = 0;
+    }
+    return VAD_OK;
+}
+
+int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
+    if (!e || !out || out->struct_size < sizeof(vad_tick_result)) return VAD_ERR_INVALID_ARG;
+    int b;
+    {   // swap the staging buffers; every slot that has more frames waiting gets its next one into the new buffer
+        std::lock_guard<std::mutex> lk(e->tick_mu);
+        b = e->tick_cur;
+        e->tick_cur ^= 1;
+        for (auto &tb : e->tick_buf[e->tick_cur]) tb.count = 0;
+        if (++e->tick_generation == 0) {
+            std::fill(e->tick_gen.begin(), e->tick_gen.end(), 0u);
+            e->tick_generation = 1;
+        }
+        for (auto it = e->tick_overflow.begin(); it != e->tick_overflow.end();) {
+            vad_engine::TickPending &p = it->second.front();
+            if (int rc = tick_place(e, it->first, p.data.data(), p.kept, p.group)) return rc;
+            e->tick_buf[e->tick_cur][p.group].lens()[e->tick_buf[e->tick_cur][p.group].count - 1] = p.nsamples;
+            it->second.pop_front();
+            it = it->second.empty() ? e->tick_overflow.erase(it) : std::next(it);
+        }
+    }
+    std::lock_guard<std::mutex> lk(e->mu);
+    vad_engine::TickBuf *tbs = e->tick_buf[b];
+    int64_t total = 0;
+    size_t frame_total = 0;
+    for (int g = 0; g < vad_engine::TICK_GROUPS; ++g) {
+        out->group_start[g] = total;
+        out->group_frames[g] = tbs[g].count ? tbs[g].h : nullptr;
+        total += tbs[g].count;
+        frame_total += ((size_t)tbs[g].count * tbs[g].row_bytes + 255) & ~(size_t)255;
+    }
+    out->group_start[vad_engine::TICK_GROUPS] = total;
+    out->n = total;
+    out->slots = nullptr; out->probs = nullptr; out->events = nullptr; out->seg_frames = nullptr; out->nsamples = nullptr;
+    if (total == 0) return VAD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_probs = up16(sizeof(int64_t) * (size_t)total), o_seg = o_probs + up16(sizeof(float) * (size_t)total);
+    const size_t o_ev = o_seg + up16(sizeof(int32_t) * (size_t)total), o_s32 = o_ev + up16((size_t)total);
+    const size_t o_len = o_s32 + up16(sizeof(int32_t) * (size_t)total);
+    const size_t out_bytes = o_len + up16(sizeof(int32_t) * (size_t)total);
+    if (out_bytes > e->tick_out_cap) {
+        const size_t cap = std::max(out_bytes, (size_t)e->max_streams * 28 + 128);
+        if (e->h_tick_out) (void)hipHostFree(e->h_tick_out);
+        if (e->d_tick_out) (void)hipFree(e->d_tick_out);
+        e->h_tick_out = e->d_tick_out = nullptr;
+        e->tick_out_cap = 0;
+        HIP_TRY(e, hipHostMalloc((void **)&e->h_tick_out, cap, hipHostMallocDefault));
+        HIP_TRY(e, hipMalloc((void **)&e->d_tick_out, cap));
+        e->tick_out_cap = cap;
+    }
+    if (int rc = ensure(e, e->d_tick_frames, e->d_tick_frames_cap, frame_total)) return rc;
+    int64_t *h_slots = reinterpret_cast<int64_t *>(e->h_tick_out);
+    int32_t *h_s32 = reinterpret_cast<int32_t *>(e->h_tick_out + o_s32);
+    for (int g = 0; g < vad_engine::TICK_GROUPS; ++g)
+        for (int64_t r = 0; r < tbs[g].count; ++r) {
+            const int32_t sl = tbs[g].slots()[r];
+            if (sl < 0 || sl >= e->max_streams || !e->open[(size_t)sl])
+                return e->fail(VAD_ERR_BAD_SLOT, "tick: slot %d was closed with a frame pending (vad_tick_cancel it first)", sl);
+            h_slots[out->group_start[g] + r] = sl;
+            h_s32[out->group_start[g] + r] = sl;
+            reinterpret_cast<int32_t *>(e->h_tick_out + o_len)[out->group_start[g] + r] = tbs[g].lens()[r];
+        }
+    HIP_TRY(e, hipMemcpyAsync(e->d_tick_out + o_s32, h_s32, sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, e->stream));
+    size_t foff = 0;
+    for (int g = 0; g < vad_engine::TICK_GROUPS; ++g) {        // one launch per (format, gate) group: one in practice
+        const int64_t cnt = tbs[g].count;
+        if (!cnt) continue;
+        const size_t fbytes = (size_t)cnt * tbs[g].row_bytes;
+        uint8_t *d_fr = static_cast<uint8_t *>(e->d_tick_frames) + foff;
+        HIP_TRY(e, hipMemcpyAsync(d_fr, tbs[g].h, fbytes, hipMemcpyHostToDevice, e->stream));
+        vadk::StepParams p = e->base;
+        p.slots = reinterpret_cast<const int32_t *>(e->d_tick_out + o_s32) + out->group_start[g];
+        p.frames = d_fr;
+        p.probs = reinterpret_cast<float *>(e->d_tick_out + o_probs) + out->group_start[g];
+        p.seg_frames = reinterpret_cast<int32_t *>(e->d_tick_out + o_seg) + out->group_start[g];
+        p.events = e->d_tick_out + o_ev + out->group_start[g];
+        p.n = (int32_t)cnt;
+        p.T = 1;
+        p.fmt = g / 2;
+        p.thresh = (g & 1) ? denoise_thresh : -1.0f;
+        if (int rc = launch(e, p, e->stream)) return rc;
+        foff += (fbytes + 255) & ~(size_t)255;
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->h_tick_out + o_probs, e->d_tick_out + o_probs, o_s32 - o_probs, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    out->slots = h_slots;
+    out->probs = reinterpret_cast<const float *>(e->h_tick_out + o_probs);
+    out->seg_frames = reinterpret_cast<const int32_t *>(e->h_tick_out + o_seg);
+    out->events = e->h_tick_out + o_ev;
+    out->nsamples = reinterpret_cast<const int32_t *>(e->h_tick_out + o_len);
     return VAD_OK;
 }
 

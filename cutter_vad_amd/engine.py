@@ -225,6 +225,54 @@ class Engine:
         self._check(self._lib.vad_step_multi_device(self._h, d_slots or None, n, T, d_frames, fmt, thr, d_probs,
                                                     d_events or None, d_seg or None, stream or None))
 
+    # ------------------------------------------------------------------ tick assembler (shared-pool serving)
+    def tick_push(self, slot: int, frame, gate_on: bool = True, i16_scale: int = 32767) -> None:
+        """Queue one frame for ``slot`` (``vad_tick_push``): ``bytes`` = little-endian int16 PCM as it came off the wire,
+        or a float32 array.  Written straight into the coming tick's page-locked staging; padded / truncated to the
+        model's frame length."""
+        if isinstance(frame, (bytes, bytearray, memoryview)):
+            fmt = _ffi.VAD_FMT_I16_32768 if i16_scale == 32768 else _ffi.VAD_FMT_I16_32767
+            self._check(self._lib.vad_tick_push(self._h, int(slot), bytes(frame), len(frame) // 2, fmt, int(gate_on)))
+            return
+        f = np.ascontiguousarray(frame)
+        if f.dtype == np.int16:
+            fmt = _ffi.VAD_FMT_I16_32768 if i16_scale == 32768 else _ffi.VAD_FMT_I16_32767
+        else:
+            f = np.ascontiguousarray(f, np.float32)
+            fmt = _ffi.VAD_FMT_F32
+        self._check(self._lib.vad_tick_push(self._h, int(slot), f.ctypes.data_as(C.c_void_p), f.size, fmt, int(gate_on)))
+
+    def tick_cancel(self, slot: int) -> None:
+        self._check(self._lib.vad_tick_cancel(self._h, int(slot)), VADError)
+
+    def tick_run(self, denoise: float = 0.01):
+        """Advance every slot with a pending frame by one frame (``vad_tick_run``) ->
+        ``(slots, probs, events, seg_frames, group_start, frames, nsamples)``: arrays over the stepped streams (views of
+        engine-owned page-locked memory, valid until the next ``tick_run``), ``group_start`` [7], ``frames[g]`` = the staged
+        audio of group g = fmt * 2 + gate_on as an array [count, frame] (float32 for g < 2, int16 above) or None, and
+        ``nsamples`` = the length each frame had when it was pushed."""
+        r = _ffi.TickResult()
+        r.struct_size = C.sizeof(_ffi.TickResult)
+        self._check(self._lib.vad_tick_run(self._h, float(denoise), C.byref(r)))
+        n = int(r.n)
+        gs = np.array(list(r.group_start), np.int64)
+        if n == 0:
+            e = np.empty(0)
+            return (e.astype(np.int64), e.astype(np.float32), e.astype(np.uint8), e.astype(np.int32), gs, [None] * 6,
+                    e.astype(np.int32))
+        as_arr = np.ctypeslib.as_array
+        slots, probs = as_arr(r.slots, (n,)), as_arr(r.probs, (n,))
+        events, seg = as_arr(r.events, (n,)), as_arr(r.seg_frames, (n,))
+        frames = []
+        for g in range(6):
+            cnt = int(gs[g + 1] - gs[g])
+            if cnt == 0 or not r.group_frames[g]:
+                frames.append(None)
+                continue
+            ct = C.c_float if g < 2 else C.c_int16
+            frames.append(as_arr(C.cast(r.group_frames[g], C.POINTER(ct)), (cnt, self.frame_samples)))
+        return slots, probs, events, seg, gs, frames, as_arr(r.nsamples, (n,))
+
     # ------------------------------------------------------------------ pipelined host ingest
     def submit(self, slots, frames, denoise: Optional[float] = 0.01, i16_scale: int = 32767) -> int:
         """Enqueue copy-in -> step -> copy-out for ``frames`` [n, frame] or [n, T, frame] and return a ticket

@@ -18,6 +18,7 @@ the reference's own message (:645-655).
 from __future__ import annotations
 
 import asyncio
+import logging
 import contextlib
 import json
 import time
@@ -255,7 +256,12 @@ def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0
         while True:
             t0 = time.perf_counter()
             if p.session_count:
-                await loop.run_in_executor(None, p.tick)        # the launch + fan-out never block the event loop
+                try:
+                    await loop.run_in_executor(None, p.tick)    # the launch + fan-out never block the event loop
+                except asyncio.CancelledError:
+                    raise
+                except Exception:                               # one bad tick must not stop every client's VAD events
+                    logging.getLogger(__name__).exception("tick failed")
             await asyncio.sleep(max(0.0, tick_interval - (time.perf_counter() - t0)))
 
     def ensure_ticker() -> None:

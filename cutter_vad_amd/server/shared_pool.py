@@ -16,8 +16,11 @@ the host only keeps the audio: pre-roll = the above-threshold frames before STAR
 carries the frame's float32 bytes (:891-895), END carries the WAV of the segment (:925-949).
 A session's frames are processed in submission order, at most one per tick.
 
-The host work per tick is vectorised over sessions; Python touches a session individually only when it has
-an event, is inside a segment or is collecting pre-roll.
+The tick itself - queueing, padding, grouping by (wire format, gate), staging in page-locked memory, the launches and the
+compaction of the results - runs in C behind ``vad_tick_push`` / ``vad_tick_run`` (include/vad_engine.h): ``submit*`` writes
+a frame straight into the coming tick's staging row, ``tick`` gets back arrays over the stepped streams.  Python works on
+those arrays at once and touches a session individually only when it has an event, is inside a segment or is collecting
+pre-roll.
 """
 
 from __future__ import annotations
@@ -37,20 +40,20 @@ from ..pool import EnginePool, default_pool, resolve_model_path
 from ..utils.audio import AudioUtils
 from ..utils.wav_writer import WAVWriter
 
-FRAME = 512
+FRAME = 512      # the model's frame at 16 kHz; a pool's own frame length is ``SharedStreamPool.frame`` (256 on V5's 8 kHz sub-model)
 
 
 class PooledSession:
     """One client stream: a slot of the shared engine + the host half of its voice segments."""
 
-    __slots__ = ("pool", "slot", "config", "pending", "on_start", "on_end", "on_continue", "on_error", "preroll",
+    __slots__ = ("pool", "slot", "config", "long_frames", "on_start", "on_end", "on_continue", "on_error", "preroll",
                  "segment", "closed", "wav_writer", "user")
 
     def __init__(self, pool: "SharedStreamPool", slot: int, config: VADConfig) -> None:
         self.pool = pool
         self.slot = slot
         self.config = config
-        self.pending: Deque = deque()              # float32 arrays or raw little-endian int16 bytes
+        self.long_frames: Deque = deque()          # frames longer than the model's frame, whole: segments keep all of a frame
         self.on_start: Optional[Callable[[], None]] = None
         self.on_end: Optional[Callable[[bytes], None]] = None
         self.on_continue: Optional[Callable[[bytes], None]] = None
@@ -97,9 +100,11 @@ class SharedStreamPool:
     def __init__(self, model_version: SileroModelVersion = SileroModelVersion.V5, device_id: Optional[int] = None,
                  max_streams: Optional[int] = None, pool: Optional[EnginePool] = None,
                  tick_interval: float = 0.010, sample_rate: int = 16000) -> None:
-        SileroVADModel._check_rate(sample_rate, model_version)
-        self._base = VADConfig(model_version=model_version, sample_rate=sample_rate)
-        self._k8 = weights_io.is_8k_variant(4 if model_version == SileroModelVersion.V4 else 5, sample_rate)
+        vi = 4 if model_version == SileroModelVersion.V4 else 5
+        self.frame = weights_io.frame_samples(vi, sample_rate)     # 512; 256 on Silero V5's 8 kHz sub-model
+        SileroVADModel._check_rate(sample_rate, model_version, self.frame)
+        self._base = VADConfig(model_version=model_version, sample_rate=sample_rate, buffer_size=self.frame)
+        self._k8 = weights_io.is_8k_variant(vi, sample_rate)
         self._pool = pool or default_pool()
         self.engine = self._pool.engine_for(resolve_model_path(self._base), model_version, device_id, max_streams,
                                             sample_rate)
@@ -107,7 +112,7 @@ class SharedStreamPool:
         self._lock = threading.Lock()              # sessions / pending queues
         self._tick_lock = threading.Lock()         # one tick at a time
         self._sessions: Dict[int, PooledSession] = {}
-        self._ready: Dict[int, PooledSession] = {}  # sessions with at least one pending frame (insertion-ordered)
+        self._by_slot: List[Optional[PooledSession]] = []
         self._thread: Optional[threading.Thread] = None
         self._stop = threading.Event()
         self._grow(1024)
@@ -133,6 +138,7 @@ class SharedStreamPool:
         ext("_gate", bool)             # enable_denoising
         ext("_lastp", np.float32)
         ext("_done", np.int64)
+        self._by_slot.extend([None] * (n - len(self._by_slot)))
 
     def _init_slot(self, slot: int, cfg: VADConfig) -> None:
         self._grow(slot + 1)
@@ -150,6 +156,7 @@ class SharedStreamPool:
         self._check_session_rate(cfg)
         slot = int(self.engine.open_stream())
         try:
+            self.engine.tick_cancel(slot)          # a recycled slot starts with no frames waiting
             self.engine.set_thresholds(slot, cfg.vad_start_probability, cfg.vad_end_probability, cfg.voice_start_ratio,
                                        cfg.voice_end_ratio, cfg.voice_start_frame_count, cfg.voice_end_frame_count)
         except Exception:
@@ -159,12 +166,13 @@ class SharedStreamPool:
         with self._lock:
             self._init_slot(slot, cfg)
             self._sessions[slot] = s
+            self._by_slot[slot] = s
         return s
 
     def _check_session_rate(self, cfg: VADConfig) -> None:
         # V5 + a rate other than 16 kHz: the reference's graph fails on every frame; V4: the pool's engine is
         # one of the graph's two sub-models, a session must ask for the same one
-        SileroVADModel._check_rate(cfg.sample_rate, cfg.model_version)
+        SileroVADModel._check_rate(cfg.sample_rate, cfg.model_version, self.frame)
         if weights_io.is_8k_variant(4 if cfg.model_version == SileroModelVersion.V4 else 5, cfg.sample_rate) != self._k8:
             raise AudioProcessingError(f"Model prediction failed: this pool runs the {'8' if self._k8 else '16'} kHz "
                                        f"sub-model, the session asks for sample rate {int(cfg.sample_rate)}")
@@ -175,9 +183,10 @@ class SharedStreamPool:
                 if s.closed:
                     return
                 s.closed = True
-                s.pending.clear()
+                s.long_frames.clear()
                 self._sessions.pop(s.slot, None)
-                self._ready.pop(s.slot, None)
+                self._by_slot[s.slot] = None
+            self.engine.tick_cancel(s.slot)
             self.engine.close_stream(s.slot)
 
     def reconfigure(self, s: PooledSession, config: VADConfig) -> None:
@@ -186,8 +195,8 @@ class SharedStreamPool:
         self._check_session_rate(config)
         with self._tick_lock:
             with self._lock:
-                s.pending.clear()
-                self._ready.pop(s.slot, None)
+                s.long_frames.clear()
+            self.engine.tick_cancel(s.slot)
             self.engine.reset([s.slot])
             self.engine.set_thresholds(s.slot, config.vad_start_probability, config.vad_end_probability,
                                        config.voice_start_ratio, config.voice_end_ratio, config.voice_start_frame_count,
@@ -205,7 +214,7 @@ class SharedStreamPool:
 
     # ------------------------------------------------------------------ ingest
     def submit(self, s: PooledSession, frame) -> None:
-        """Queue one frame (float32 in [-1, 1], any length; the model sees it padded / truncated to 512)."""
+        """Queue one frame (float32 in [-1, 1], any length; the model sees it padded / truncated to its frame length)."""
         x = np.asarray(frame)
         if x.dtype != np.float32:
             x = x.astype(np.float32)
@@ -218,8 +227,9 @@ class SharedStreamPool:
         with self._lock:
             if s.closed:
                 raise AudioProcessingError("session is closed")
-            s.pending.append(x)
-            self._ready[s.slot] = s
+            self.engine.tick_push(s.slot, x, bool(self._gate[s.slot]))
+            if x.size > self.frame:
+                s.long_frames.append(x)
 
     def submit_pcm16(self, s: PooledSession, data: bytes) -> None:
         """Queue one frame as it arrives on the wire: little-endian int16 PCM.  The bytes go to the GPU as they are
@@ -231,106 +241,77 @@ class SharedStreamPool:
         with self._lock:
             if s.closed:
                 raise AudioProcessingError("session is closed")
-            s.pending.append(bytes(data))
-            self._ready[s.slot] = s
+            self.engine.tick_push(s.slot, data, bool(self._gate[s.slot]))
+            if len(data) > 2 * self.frame:
+                s.long_frames.append(np.frombuffer(data, dtype="<i2").astype(np.float32) / np.float32(32767.0))
 
     # ------------------------------------------------------------------ the tick
-    @staticmethod
-    def _as_float(item) -> np.ndarray:
-        if isinstance(item, bytes):
-            return np.frombuffer(item, dtype="<i2").astype(np.float32) / 32767.0
-        return item
-
-    def _launch(self, slots: np.ndarray, items: list, gate_on: bool):
-        """One launch for sessions whose pending frames share a format -> (probs, events)."""
-        n = len(items)
-        if isinstance(items[0], bytes):
-            x = np.zeros((n, FRAME), np.int16)
-            L = len(items[0])
-            if all(len(b) == L for b in items):                  # the usual case: every client sends 30 ms frames
-                m = min(L // 2, FRAME)
-                x[:, :m] = np.frombuffer(b"".join(items), dtype="<i2").reshape(n, L // 2)[:, :m]
-            else:
-                for i, b in enumerate(items):
-                    v = np.frombuffer(b, dtype="<i2")
-                    m = min(v.size, FRAME)
-                    x[i, :m] = v[:m]
-        else:
-            x = np.zeros((n, FRAME), np.float32)
-            for i, f in enumerate(items):
-                m = min(f.size, FRAME)
-                x[i, :m] = f[:m]
-        p, ev, _ = self.engine.step_events(slots, x, denoise=0.01 if gate_on else None)
-        self.launches += 1
-        return p, ev, x
-
     def tick(self) -> int:
         """Advance every session that has a frame pending by ONE frame — one launch per (wire format, gate) group,
-        i.e. one launch when all clients speak the same format.  Returns the number of frames processed.  Callbacks
-        run on the calling thread, outside the pool's locks, in slot order."""
+        i.e. one launch when all clients speak the same format (``vad_tick_run``).  Returns the number of frames
+        processed.  Callbacks run on the calling thread, in the order the frames were submitted; ticks (and their
+        callbacks) never overlap, frames may be submitted while one runs."""
         with self._tick_lock:
-            with self._lock:
-                batch = list(self._ready.values())
-                items = [s.pending.popleft() for s in batch]
-                self._ready = {s.slot: s for s in batch if s.pending}
-            n = len(batch)
+            try:
+                slots, p, ev, _seg, gs, frames, nsamp = self.engine.tick_run(0.01)
+            except Exception as e:                  # engine failure: every session hears about it
+                for s in list(self._sessions.values()):
+                    self._report(s, AudioProcessingError(f"Model prediction failed: {e}"))
+                return 0
+            n = int(slots.size)
             if n == 0:
                 return 0
-            slots = np.fromiter((s.slot for s in batch), np.int64, n)
-            is_pcm = np.fromiter((isinstance(it, bytes) for it in items), bool, n)
-            key = is_pcm.astype(np.int8) * 2 + self._gate[slots]
-            p = np.empty(n, np.float32)
-            ev = np.zeros(n, np.uint8)
-            err: Optional[Exception] = None
-            staged = []
-            for k in np.unique(key):
-                ii = np.nonzero(key == k)[0]
-                try:
-                    sub = items if ii.size == n else [items[i] for i in ii]
-                    p[ii], ev[ii], x = self._launch(slots[ii], sub, bool(k & 1))
-                    staged.append((ii, x, bool(k & 1)))
-                except Exception as e:              # engine failure: every session of the launch hears about it
-                    err = e
-                    p[ii], ev[ii] = np.nan, 0
+            self.launches += sum(1 for g in range(6) if gs[g + 1] > gs[g])
             self.ticks += 1
             self.frames += n
             self._lastp[slots] = p
             self._done[slots] += 1
             p64 = p.astype(np.float64)
-            busy = np.nonzero((ev != 0) | self._active[slots] | self._pre[slots] | (p64 >= self._thr[slots])
-                              | ~np.isfinite(p64))[0]
-        # the audio that segments keep (float32, gated like utils/audio.py:104-121), for all busy sessions of a launch
-        # at once; frames longer than the model's 512 samples take the per-session path
-        kept: Dict[int, np.ndarray] = {}
-        is_busy = np.zeros(n, bool)
-        is_busy[busy] = True
-        for ii, x, gate_on in staged:
-            rows = np.nonzero(is_busy[ii])[0]
-            if rows.size == 0:
-                continue
-            xf = x[rows].astype(np.float32) / np.float32(32767.0) if x.dtype == np.int16 else x[rows]
-            if gate_on:
-                xf = AudioUtils.denoise_audio(xf)
-            for r, row in zip(rows, xf):
-                it = items[ii[r]]
-                L = len(it) // 2 if isinstance(it, bytes) else it.size
-                if L <= FRAME:
-                    kept[int(ii[r])] = row[:L]
-        for i in busy:                             # idle sessions cost no Python at all
-            s = batch[i]
-            try:
-                if not np.isfinite(p[i]):
-                    raise AudioProcessingError(f"Model prediction failed: {err}")
-                k = kept.get(int(i))
-                if k is None:
-                    k = self._as_float(items[i])
-                    if s.config.enable_denoising:
-                        k = AudioUtils.denoise_audio(k)
-                self._advance(s, k, float(p[i]), int(ev[i]))
-            except Exception as e:
-                if s.on_error is not None:
-                    s.on_error(e)
+            busy = np.nonzero((ev != 0) | self._active[slots] | self._pre[slots] | (p64 >= self._thr[slots]))[0]
+            is_busy = np.zeros(n, bool)
+            is_busy[busy] = True
+            for i in np.nonzero((nsamp > self.frame) & ~is_busy)[0]:     # an over-long frame of an idle session: nothing is kept
+                s = self._by_slot[int(slots[i])]
+                if s is not None and s.long_frames:
+                    s.long_frames.popleft()
+            if busy.size == 0:                      # idle sessions cost no Python at all
+                return n
+            # the audio that segments keep (float32, gated like utils/audio.py:104-121), for all busy sessions of a group at once
+            for g in range(6):
+                lo, hi = int(gs[g]), int(gs[g + 1])
+                rows = busy[(busy >= lo) & (busy < hi)]
+                if rows.size == 0:
+                    continue
+                x = frames[g][rows - lo]
+                xf = x.astype(np.float32) / np.float32(32767.0 if g < 4 else 32768.0) if g >= 2 else x.copy()
+                if g & 1:
+                    xf = AudioUtils.denoise_audio(xf)
+                for i, row in zip(rows, xf):
+                    s = self._by_slot[int(slots[i])]
+                    if s is None or s.closed:
+                        continue
+                    try:
+                        L = int(nsamp[i])
+                        if L > self.frame:          # the model saw the first `frame` samples, the segment keeps them all
+                            k = s.long_frames.popleft()
+                            if s.config.enable_denoising:
+                                k = AudioUtils.denoise_audio(k)
+                        else:
+                            k = row[:L]
+                        self._advance(s, k, float(p[i]), int(ev[i]))
+                    except Exception as e:
+                        self._report(s, e)
         return n
+
+    @staticmethod
+    def _report(s: PooledSession, e: Exception) -> None:
+        """A session's error hook must not take the ticker down with it (a closing event loop raises in call_soon_threadsafe)."""
+        if s.on_error is None:
+            return
+        try:
+            s.on_error(e)
+        except Exception:
+            pass
 
     def _advance(self, s: PooledSession, kept: np.ndarray, p: float, ev: int) -> None:
         slot = s.slot
@@ -390,7 +371,10 @@ class SharedStreamPool:
         def loop():
             while not self._stop.is_set():
                 t0 = time.perf_counter()
-                self.tick()
+                try:
+                    self.tick()
+                except Exception:                   # the ticker outlives any single bad tick
+                    pass
                 self._stop.wait(max(0.0, self.tick_interval - (time.perf_counter() - t0)))
 
         self._thread = threading.Thread(target=loop, name="vad-pool-ticker", daemon=True)

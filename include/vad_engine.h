@@ -238,6 +238,38 @@ VAD_API int vad_resample_multi_device(vad_engine *e, int32_t nseg, const float *
                                       const int32_t *n_in, const int32_t *sr_in, float *const *d_out, void *stream);
 
 /*
+ * Tick assembler: the serving loop's side of vad_step_events, in C.  The reference runs the model inside every websocket's
+ * receive loop, one client and one frame at a time (websocket_service/server/vad_websocket_server.py:326-382); a shared-pool
+ * server instead collects the frames that arrived since the last tick and advances all those streams together:
+ *
+ *   vad_tick_push(e, slot, samples, nsamples, fmt, gate_on)   from any thread, as frames arrive: the frame is written straight
+ *       into the page-locked staging row of the coming tick, right-zero-padded / truncated to the engine's frame length exactly
+ *       as _prepare_audio_input does (core/silero_model.py:464-468).  One frame per slot and tick: a slot's further frames
+ *       queue up and are fed in submission order, one per later tick (at most 256 waiting: VAD_ERR_BUSY).
+ *   vad_tick_run(e, thr, &res)   advances every slot that has a frame by ONE frame - one launch per (frame format, gate)
+ *       group, i.e. one launch when all clients speak one format - and returns compact arrays: res.slots[i], res.probs[i],
+ *       res.events[i] (VAD_EV_* bits), res.seg_frames[i]; entries group_start[g] .. group_start[g+1]-1 belong to group
+ *       g = frame_fmt * 2 + gate_on, in push order, and group_frames[g] is that group's staged audio [count][frame] in frame_fmt
+ *       (what segment assembly keeps).  All pointers are engine-owned and stay valid until the next vad_tick_run.
+ *       Pushes may continue while a tick runs (double-buffered staging).  `thr` is the gate threshold of the gate_on groups.
+ *   vad_tick_cancel(e, slot)   drops the slot's pending frames (call before vad_stream_close of a slot that may have some).
+ */
+typedef struct vad_tick_result {
+    uint32_t struct_size;          /* sizeof(vad_tick_result) */
+    int64_t n;
+    const int64_t *slots;
+    const float *probs;
+    const uint8_t *events;
+    const int32_t *seg_frames;
+    int64_t group_start[7];
+    const void *group_frames[6];
+    const int32_t *nsamples;       /* samples the caller pushed for entry i (before padding / truncation to the frame length) */
+} vad_tick_result;
+VAD_API int vad_tick_push(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int gate_on);
+VAD_API int vad_tick_cancel(vad_engine *e, int64_t slot);
+VAD_API int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out);
+
+/*
  * One tick for streams whose audio arrives at another rate: VADConfig.auto_convert_sample_rate.  The reference's hook for it
  * is core/vad_wrapper.py:621-624 - a `pass` - and the function it was meant to call is AudioUtils.resample_audio
  * (utils/audio.py:19-55); this entry point is that path, on the GPU: segment k holds n[k] chunks of one tick at sr_in[k]

@@ -98,6 +98,54 @@ class FakeEngine:
         self.multi_calls = getattr(self, "multi_calls", 0) + 1
         return p, ev
 
+    # ---- the C tick assembler (vad_tick_push / vad_tick_run), same semantics: one frame per slot and tick, submission
+    #      order, one step_events call per (format, gate) group
+    frame_samples = 512
+
+    def tick_push(self, slot, frame, gate_on=True, i16_scale=32767):
+        q = self.__dict__.setdefault("_tickq", {})
+        if isinstance(frame, (bytes, bytearray, memoryview)):
+            x = np.frombuffer(bytes(frame), dtype="<i2")
+            fmt = 2 if i16_scale == 32768 else 1
+        else:
+            x = np.ascontiguousarray(frame, np.float32)
+            fmt = 0
+        if len(q.setdefault(int(slot), [])) >= 257:
+            raise RuntimeError("tick: 256 frames waiting")
+        q[int(slot)].append((fmt * 2 + int(bool(gate_on)), x))
+
+    def tick_cancel(self, slot):
+        self.__dict__.setdefault("_tickq", {}).pop(int(slot), None)
+
+    def tick_run(self, denoise=0.01):
+        q = self.__dict__.setdefault("_tickq", {})
+        F = self.frame_samples
+        groups = {g: [] for g in range(6)}
+        for slot in list(q):
+            g, x = q[slot].pop(0)
+            if not q[slot]:
+                del q[slot]
+            groups[g].append((slot, x))
+        slots, probs, events, segs, ns, frames, gs = [], [], [], [], [], [None] * 6, [0]
+        for g in range(6):
+            rows = groups[g]
+            if rows:
+                arr = np.zeros((len(rows), F), np.int16 if g >= 2 else np.float32)
+                for i, (_, x) in enumerate(rows):
+                    m = min(x.size, F)
+                    arr[i, :m] = x[:m]
+                sl = [r[0] for r in rows]
+                p, ev, sg = self.step_events(sl, arr, denoise if g & 1 else None, 32768 if g >= 4 else 32767)
+                slots += sl
+                probs += list(p)
+                events += list(ev)
+                segs += list(sg)
+                ns += [r[1].size for r in rows]
+                frames[g] = arr
+            gs.append(len(slots))
+        return (np.array(slots, np.int64), np.array(probs, np.float32), np.array(events, np.uint8), np.array(segs, np.int32),
+                np.array(gs, np.int64), frames, np.array(ns, np.int32))
+
     def save_stream(self, s):
         import ctypes
         sm = self.sm[int(s)]
