@@ -117,6 +117,9 @@ SIGNATURES = {
     "vad_step_collect": (C.c_int, [_vp, C.c_int64, _f32p, _u8p, _i32p]),
     "vad_tick_push": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, C.c_int, C.c_int]),
     "vad_tick_cancel": (C.c_int, [_vp, C.c_int64]),
+    "vad_tick_push_many": (C.c_int, [_vp, _i64p, C.c_int64, _vp, C.c_int32, C.c_int, C.c_int]),
+    "vad_tick_enable_segments": (C.c_int, [_vp, C.c_int]),
+    "vad_tick_take_segment": (C.c_int, [_vp, C.c_int64, _f32p, C.c_int64, _i64p]),
     "vad_tick_run": (C.c_int, [_vp, C.c_float, C.POINTER(TickResult)]),
     "vad_step_rates_device": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_void_p), _i64p, C.POINTER(C.c_int32), _vp, C.c_float,
                                         _vp, _vp, _vp, _vp]),

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstring>
 #include <deque>
@@ -98,13 +99,20 @@ struct vad_engine {
         int32_t *slots() const { return reinterpret_cast<int32_t *>(h + (size_t)cap * row_bytes); }
         int32_t *lens() const { return slots() + cap; }   // samples the caller pushed (before padding / truncation)
     };
-    struct TickPending { std::vector<uint8_t> data; int32_t nsamples /* as pushed */, kept /* samples in data */; int group; };
+    struct TickPending { std::vector<uint8_t> data; int32_t nsamples; int group; };   // the whole frame as pushed
     std::mutex tick_mu;
     int tick_cur = 0;
     TickBuf tick_buf[2][TICK_GROUPS];
     std::vector<uint32_t> tick_gen;                  // per slot: == tick_generation <=> the slot has a frame in the coming tick
     uint32_t tick_generation = 1;
     std::unordered_map<int64_t, std::deque<TickPending>> tick_overflow;
+    std::unordered_map<int64_t, std::deque<std::vector<uint8_t>>> tick_tails;   // samples past the model's frame of over-long frames, push order
+    // segment assembly on the host side of the tick (vad_tick_enable_segments): what SegmentAssembler / VADProcessor keep per
+    // stream (core/silero_model.py:838-869, 891-895, 925-949) - pre-roll, the open segment, the finished one until taken
+    struct SegState { bool active = false; std::vector<float> pre, seg, done; };
+    bool tick_segments = false;
+    std::vector<SegState> seg_state;
+    std::vector<double> h_start_prob;                // host copy of each slot's vad_start_probability (pre-roll rule :832-839)
     uint8_t *h_tick_out = nullptr, *d_tick_out = nullptr; size_t tick_out_cap = 0;   // [slots i64 | probs f32 | seg i32 | events u8] x max n
     void *d_tick_frames = nullptr; size_t d_tick_frames_cap = 0;
     struct ResampleOp {
@@ -387,6 +395,7 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
     e->open.assign((size_t)e->max_streams, 0);
     e->stamp.assign((size_t)e->max_streams, 0);
     e->tick_gen.assign((size_t)e->max_streams, 0);
+    e->h_start_prob.assign((size_t)e->max_streams, kDefaultSm.start_prob);
     e->free_list.reserve((size_t)e->max_streams);
     for (int64_t s = e->max_streams - 1; s >= 0; --s) e->free_list.push_back(s);
     *out = e;
@@ -471,6 +480,15 @@ static int slot_control(vad_engine *e, const int64_t *slots, int64_t n, int op, 
     int32_t *hs = reinterpret_cast<int32_t *>(e->h_ctl);
     for (int64_t i = 0; i < n; ++i) hs[i] = (int32_t)slots[i];
     if (nthr) std::memcpy(e->h_ctl + o_thr, thr, sizeof(vad_thresholds) * (size_t)nthr);
+    {   // host mirrors used by the tick's segment assembly
+        std::lock_guard<std::mutex> tl(e->tick_mu);
+        for (int64_t i = 0; i < n; ++i) {
+            const size_t sl = (size_t)slots[i];
+            if (op & 2) e->h_start_prob[sl] = kDefaultSm.start_prob;
+            if (op & 8) e->h_start_prob[sl] = thr[nthr == 1 ? 0 : i].start_probability;
+            if ((op & (2 | 4)) && sl < e->seg_state.size()) e->seg_state[sl] = vad_engine::SegState();
+        }
+    }
     HIP_TRY(e, hipMemcpyAsync(e->d_ctl, e->h_ctl, need, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, vadk_launch_slot_control(e->d_sm, e->d_state, reinterpret_cast<const int32_t *>(e->d_ctl), (int)n, op, &kDefaultSm,
                                         reinterpret_cast<const vad_thresholds *>(e->d_ctl + o_thr), (int)nthr, e->stream));
@@ -994,6 +1012,10 @@ int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsample
     uint8_t *dst = tb.row(tb.count);
     std::memcpy(dst, samples, take);
     if (take < rb) std::memset(dst + take, 0, rb - take);
+    if (e->tick_segments && nsamples > e->frame_samples) {      // the model sees the head; a segment keeps the whole frame
+        const uint8_t *src = static_cast<const uint8_t *>(samples);
+        e->tick_tails[slot].emplace_back(src + take, src + ss * (size_t)nsamples);
+    }
     tb.slots()[tb.count] = (int32_t)slot;
     tb.lens()[tb.count] = nsamples;
     tb.count += 1;
@@ -1015,9 +1037,38 @@ int vad_tick_push(vad_engine *e, int64_t slot, const void *samples, int32_t nsam
     auto &q = e->tick_overflow[slot];
     if (q.size() >= 256) return e->fail(VAD_ERR_BUSY, "tick: slot %lld has 256 frames waiting - is vad_tick_run being called?", (long long)slot);
     const size_t ss = frame_fmt == VAD_FMT_F32 ? 4 : 2;
-    const int32_t keep = std::min<int32_t>(nsamples, e->frame_samples);
+    const int32_t keep = e->tick_segments ? nsamples : std::min<int32_t>(nsamples, e->frame_samples);
     const uint8_t *src = static_cast<const uint8_t *>(samples);
-    q.push_back(vad_engine::TickPending{std::vector<uint8_t>(src, src + ss * (size_t)keep), nsamples, keep, group});
+    q.push_back(vad_engine::TickPending{std::vector<uint8_t>(src, src + ss * (size_t)keep), nsamples, group});
+    return VAD_OK;
+}
+
+int vad_tick_enable_segments(vad_engine *e, int on) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->tick_mu);
+    e->tick_segments = on != 0;
+    if (e->tick_segments && e->seg_state.size() < (size_t)e->max_streams) e->seg_state.resize((size_t)e->max_streams);
+    return VAD_OK;
+}
+
+int vad_tick_take_segment(vad_engine *e, int64_t slot, float *out, int64_t cap, int64_t *nsamples) {
+    if (!e || !nsamples) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->tick_mu);
+    if (slot < 0 || (size_t)slot >= e->seg_state.size()) return e->fail(VAD_ERR_BAD_SLOT, "slot %lld has no segment state", (long long)slot);
+    std::vector<float> &d = e->seg_state[(size_t)slot].done;
+    *nsamples = (int64_t)d.size();
+    if (!out) return VAD_OK;                       // size query
+    if (cap < (int64_t)d.size()) return e->fail(VAD_ERR_INVALID_ARG, "segment buffer too small (%lld < %lld samples)", (long long)cap, (long long)d.size());
+    if (!d.empty()) std::memcpy(out, d.data(), d.size() * sizeof(float));
+    std::vector<float>().swap(d);
+    return VAD_OK;
+}
+
+int vad_tick_push_many(vad_engine *e, const int64_t *slots, int64_t n, const void *frames, int32_t nsamples, int frame_fmt, int gate_on) {
+    if (!e || n < 0 || (n > 0 && (!slots || !frames))) return VAD_ERR_INVALID_ARG;
+    const size_t stride = (frame_fmt == VAD_FMT_F32 ? 4 : 2) * (size_t)(nsamples > 0 ? nsamples : 0);
+    for (int64_t i = 0; i < n; ++i)
+        if (int rc = vad_tick_push(e, slots[i], static_cast<const uint8_t *>(frames) + (size_t)i * stride, nsamples, frame_fmt, gate_on)) return rc;
     return VAD_OK;
 }
 
@@ -1026,6 +1077,8 @@ int vad_tick_cancel(vad_engine *e, int64_t slot) {
     std::lock_guard<std::mutex> lk(e->tick_mu);
     if (slot < 0 || slot >= e->max_streams) return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is out of range", (long long)slot);
     e->tick_overflow.erase(slot);
+    e->tick_tails.erase(slot);
+    if ((size_t)slot < e->seg_state.size()) e->seg_state[(size_t)slot] = vad_engine::SegState();
     if (e->tick_gen[(size_t)slot] == e->tick_generation) {
         for (auto &tb : e->tick_buf[e->tick_cur])
             for (int64_t r = 0; r < tb.count; ++r)
@@ -1058,7 +1111,7 @@ int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
         }
         for (auto it = e->tick_overflow.begin(); it != e->tick_overflow.end();) {
             vad_engine::TickPending &p = it->second.front();
-            if (int rc = tick_place(e, it->first, p.data.data(), p.kept, p.group)) return rc;
+            if (int rc = tick_place(e, it->first, p.data.data(), (int32_t)(p.data.size() / (p.group >= 2 ? 2 : 4)), p.group)) return rc;
             e->tick_buf[e->tick_cur][p.group].lens()[e->tick_buf[e->tick_cur][p.group].count - 1] = p.nsamples;
             it->second.pop_front();
             it = it->second.empty() ? e->tick_overflow.erase(it) : std::next(it);
@@ -1134,6 +1187,66 @@ int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
     out->seg_frames = reinterpret_cast<const int32_t *>(e->h_tick_out + o_seg);
     out->events = e->h_tick_out + o_ev;
     out->nsamples = reinterpret_cast<const int32_t *>(e->h_tick_out + o_len);
+    if (e->tick_segments) {
+        // the host half of _process_voice_state, per stepped stream, on the staged audio: float32, gated like the model's input
+        // (utils/audio.py:117-118) when the group's gate is on
+        std::lock_guard<std::mutex> tl(e->tick_mu);
+        if (e->seg_state.size() < (size_t)e->max_streams) e->seg_state.resize((size_t)e->max_streams);
+        std::vector<float> kept;
+        for (int g = 0; g < vad_engine::TICK_GROUPS; ++g) {
+            const bool gate = g & 1;
+            const float sc = g < 4 ? 32767.0f : 32768.0f;
+            auto conv = [&](const uint8_t *src, size_t cnt) {
+                const size_t at = kept.size();
+                kept.resize(at + cnt);
+                if (g < 2) std::memcpy(kept.data() + at, src, cnt * 4);
+                else
+                    for (size_t k = 0; k < cnt; ++k) kept[at + k] = (float)reinterpret_cast<const int16_t *>(src)[k] / sc;
+                if (gate)
+                    for (size_t k = at; k < at + cnt; ++k)
+                        if (!(std::fabs(kept[k]) > denoise_thresh)) kept[k] = 0.f;
+            };
+            for (int64_t r = 0; r < tbs[g].count; ++r) {
+                const int64_t i = out->group_start[g] + r;
+                const size_t sl = (size_t)h_slots[i];
+                vad_engine::SegState &st = e->seg_state[sl];
+                const int ev = out->events[i];
+                const bool above = (double)out->probs[i] >= e->h_start_prob[sl];
+                const int32_t L = tbs[g].lens()[r];
+                const bool is_long = L > e->frame_samples;
+                if (!st.active && !above && !(ev & VAD_EV_START)) {          // idle stream: nothing is kept
+                    st.pre.clear();
+                    if (is_long) { auto &q = e->tick_tails[(int64_t)sl]; if (!q.empty()) q.pop_front(); }
+                    continue;
+                }
+                kept.clear();
+                conv(tbs[g].row(r), (size_t)std::min<int32_t>(L, e->frame_samples));
+                if (is_long) {
+                    auto &q = e->tick_tails[(int64_t)sl];
+                    if (!q.empty()) {
+                        conv(q.front().data(), q.front().size() / (g < 2 ? 4 : 2));
+                        q.pop_front();
+                    }
+                }
+                if (!st.active) {
+                    if (above) st.pre.insert(st.pre.end(), kept.begin(), kept.end());     // :838-839
+                    else st.pre.clear();                                               // :873-874
+                    if (ev & VAD_EV_START) {                                           // :860-869
+                        st.active = true;
+                        st.seg.swap(st.pre);
+                        st.pre.clear();
+                    }
+                } else {
+                    st.seg.insert(st.seg.end(), kept.begin(), kept.end());             // :891, :925-930
+                    if (ev & VAD_EV_END) {                                             // :932-949
+                        st.done.swap(st.seg);
+                        st.seg.clear();
+                        st.active = false;
+                    }
+                }
+            }
+        }
+    }
     return VAD_OK;
 }
 

@@ -242,6 +242,31 @@ class Engine:
             fmt = _ffi.VAD_FMT_F32
         self._check(self._lib.vad_tick_push(self._h, int(slot), f.ctypes.data_as(C.c_void_p), f.size, fmt, int(gate_on)))
 
+    def tick_push_many(self, slots, frames, gate_on: bool = True, i16_scale: int = 32767) -> None:
+        """frames [n, L] (float32 or int16), one per listed slot (``vad_tick_push_many``)."""
+        s = np.ascontiguousarray(slots, dtype=np.int64).reshape(-1)
+        f = np.ascontiguousarray(frames)
+        if f.dtype == np.int16:
+            fmt = _ffi.VAD_FMT_I16_32768 if i16_scale == 32768 else _ffi.VAD_FMT_I16_32767
+        else:
+            f = np.ascontiguousarray(f, np.float32)
+            fmt = _ffi.VAD_FMT_F32
+        if f.ndim != 2 or f.shape[0] != s.size:
+            raise AudioProcessingError(f"Model prediction failed: frames have shape {f.shape}, expected ({s.size}, L)")
+        self._check(self._lib.vad_tick_push_many(self._h, _ptr(s, C.c_int64), s.size, f.ctypes.data_as(C.c_void_p), f.shape[1],
+                                                 fmt, int(gate_on)))
+
+    def tick_enable_segments(self, on: bool = True) -> None:
+        self._check(self._lib.vad_tick_enable_segments(self._h, int(on)), VADError)
+
+    def tick_take_segment(self, slot: int) -> np.ndarray:
+        """The finished segment of ``slot`` as float32 samples (``vad_tick_take_segment``); empty if there is none."""
+        n = C.c_int64()
+        self._check(self._lib.vad_tick_take_segment(self._h, int(slot), None, 0, C.byref(n)), VADError)
+        out = np.empty(int(n.value), np.float32)
+        self._check(self._lib.vad_tick_take_segment(self._h, int(slot), _ptr(out, C.c_float), out.size, C.byref(n)), VADError)
+        return out
+
     def tick_cancel(self, slot: int) -> None:
         self._check(self._lib.vad_tick_cancel(self._h, int(slot)), VADError)
 

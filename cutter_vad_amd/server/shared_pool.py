@@ -19,8 +19,9 @@ A session's frames are processed in submission order, at most one per tick.
 The tick itself - queueing, padding, grouping by (wire format, gate), staging in page-locked memory, the launches and the
 compaction of the results - runs in C behind ``vad_tick_push`` / ``vad_tick_run`` (include/vad_engine.h): ``submit*`` writes
 a frame straight into the coming tick's staging row, ``tick`` gets back arrays over the stepped streams.  Python works on
-those arrays at once and touches a session individually only when it has an event, is inside a segment or is collecting
-pre-roll.
+those arrays at once; the segments' audio (pre-roll, open segment) is kept by the engine's tick as well
+(``vad_tick_enable_segments``), so a session is touched individually only on START, on END, or while it talks if it asked
+for ``voice_continue`` payloads.
 """
 
 from __future__ import annotations
@@ -46,8 +47,8 @@ FRAME = 512      # the model's frame at 16 kHz; a pool's own frame length is ``S
 class PooledSession:
     """One client stream: a slot of the shared engine + the host half of its voice segments."""
 
-    __slots__ = ("pool", "slot", "config", "long_frames", "on_start", "on_end", "on_continue", "on_error", "preroll",
-                 "segment", "closed", "wav_writer", "user")
+    __slots__ = ("pool", "slot", "config", "long_frames", "on_start", "on_end", "on_continue", "on_error", "closed",
+                 "wav_writer", "user")
 
     def __init__(self, pool: "SharedStreamPool", slot: int, config: VADConfig) -> None:
         self.pool = pool
@@ -58,8 +59,6 @@ class PooledSession:
         self.on_end: Optional[Callable[[bytes], None]] = None
         self.on_continue: Optional[Callable[[bytes], None]] = None
         self.on_error: Optional[Callable[[Exception], None]] = None
-        self.preroll: List[np.ndarray] = []
-        self.segment: List[np.ndarray] = []
         self.closed = False
         self.wav_writer = WAVWriter(sample_rate=config.output_wav_sample_rate, bit_depth=config.output_wav_bit_depth,
                                     channels=1)
@@ -82,6 +81,7 @@ class PooledSession:
                       error_callback=None) -> None:
         self.on_start, self.on_end, self.on_continue = voice_start_callback, voice_end_callback, voice_continue_callback
         self.on_error = error_callback
+        self.pool._cont[self.slot] = voice_continue_callback is not None
 
     def submit(self, frame) -> None:
         self.pool.submit(self, frame)
@@ -108,6 +108,7 @@ class SharedStreamPool:
         self._pool = pool or default_pool()
         self.engine = self._pool.engine_for(resolve_model_path(self._base), model_version, device_id, max_streams,
                                             sample_rate)
+        self.engine.tick_enable_segments(True)      # the segments' audio is kept by the engine's tick, not here
         self.tick_interval = tick_interval
         self._lock = threading.Lock()              # sessions / pending queues
         self._tick_lock = threading.Lock()         # one tick at a time
@@ -134,7 +135,7 @@ class SharedStreamPool:
             setattr(self, name, a)
         ext("_thr", np.float64)        # vad_start_probability
         ext("_active", bool)           # inside a segment
-        ext("_pre", bool)              # collecting pre-roll
+        ext("_cont", bool)             # registered a voice_continue callback
         ext("_gate", bool)             # enable_denoising
         ext("_lastp", np.float32)
         ext("_done", np.int64)
@@ -144,7 +145,7 @@ class SharedStreamPool:
         self._grow(slot + 1)
         self._thr[slot] = float(cfg.vad_start_probability)
         self._gate[slot] = bool(cfg.enable_denoising)
-        self._active[slot] = self._pre[slot] = False
+        self._active[slot] = self._cont[slot] = False
         self._lastp[slot] = 0.0
         self._done[slot] = 0
 
@@ -204,7 +205,6 @@ class SharedStreamPool:
             s.config = config
             with self._lock:
                 self._init_slot(s.slot, config)
-            s.preroll, s.segment = [], []
             s.wav_writer = WAVWriter(sample_rate=config.output_wav_sample_rate, bit_depth=config.output_wav_bit_depth,
                                      channels=1)
 
@@ -228,7 +228,7 @@ class SharedStreamPool:
             if s.closed:
                 raise AudioProcessingError("session is closed")
             self.engine.tick_push(s.slot, x, bool(self._gate[s.slot]))
-            if x.size > self.frame:
+            if x.size > self.frame:                 # only voice_continue payloads need the whole frame here (the engine keeps its own)
                 s.long_frames.append(x)
 
     def submit_pcm16(self, s: PooledSession, data: bytes) -> None:
@@ -250,7 +250,10 @@ class SharedStreamPool:
         """Advance every session that has a frame pending by ONE frame — one launch per (wire format, gate) group,
         i.e. one launch when all clients speak the same format (``vad_tick_run``).  Returns the number of frames
         processed.  Callbacks run on the calling thread, in the order the frames were submitted; ticks (and their
-        callbacks) never overlap, frames may be submitted while one runs."""
+        callbacks) never overlap, frames may be submitted while one runs.
+
+        The engine also keeps the segments' audio (``vad_tick_enable_segments``): Python touches a session only on START,
+        on END (to wrap the finished segment as WAV) and - if it asked for ``voice_continue`` payloads - while it talks."""
         with self._tick_lock:
             try:
                 slots, p, ev, _seg, gs, frames, nsamp = self.engine.tick_run(0.01)
@@ -266,41 +269,40 @@ class SharedStreamPool:
             self.frames += n
             self._lastp[slots] = p
             self._done[slots] += 1
-            p64 = p.astype(np.float64)
-            busy = np.nonzero((ev != 0) | self._active[slots] | self._pre[slots] | (p64 >= self._thr[slots]))[0]
-            is_busy = np.zeros(n, bool)
-            is_busy[busy] = True
-            for i in np.nonzero((nsamp > self.frame) & ~is_busy)[0]:     # an over-long frame of an idle session: nothing is kept
-                s = self._by_slot[int(slots[i])]
-                if s is not None and s.long_frames:
-                    s.long_frames.popleft()
-            if busy.size == 0:                      # idle sessions cost no Python at all
+            was_active = self._active[slots]
+            started = (ev & _ffi.VAD_EV_START) != 0
+            ended = (ev & _ffi.VAD_EV_END) != 0
+            self._active[slots] = (was_active | started) & ~ended
+            wants = self._cont[slots] & was_active          # voice_continue payloads: only for sessions that registered one
+            busy = np.nonzero(started | ended | wants | (nsamp > self.frame))[0]
+            if busy.size == 0:                      # idle and silently talking sessions cost no Python at all
                 return n
-            # the audio that segments keep (float32, gated like utils/audio.py:104-121), for all busy sessions of a group at once
-            for g in range(6):
-                lo, hi = int(gs[g]), int(gs[g + 1])
-                rows = busy[(busy >= lo) & (busy < hi)]
-                if rows.size == 0:
+            grp = np.searchsorted(gs[1:], busy, side="right")
+            for i, g in zip(busy, grp):
+                s = self._by_slot[int(slots[i])]
+                if s is None or s.closed:
                     continue
-                x = frames[g][rows - lo]
-                xf = x.astype(np.float32) / np.float32(32767.0 if g < 4 else 32768.0) if g >= 2 else x.copy()
-                if g & 1:
-                    xf = AudioUtils.denoise_audio(xf)
-                for i, row in zip(rows, xf):
-                    s = self._by_slot[int(slots[i])]
-                    if s is None or s.closed:
-                        continue
-                    try:
-                        L = int(nsamp[i])
-                        if L > self.frame:          # the model saw the first `frame` samples, the segment keeps them all
-                            k = s.long_frames.popleft()
-                            if s.config.enable_denoising:
-                                k = AudioUtils.denoise_audio(k)
-                        else:
-                            k = row[:L]
-                        self._advance(s, k, float(p[i]), int(ev[i]))
-                    except Exception as e:
-                        self._report(s, e)
+                try:
+                    L = int(nsamp[i])
+                    whole = s.long_frames.popleft() if (L > self.frame and s.long_frames) else None
+                    if started[i]:
+                        self._call(s.on_start, "voice_start")
+                    wav = None
+                    if ended[i]:
+                        wav = s.wav_writer.write_wav_data(self.engine.tick_take_segment(int(slots[i])))
+                    # order on the END frame as the reference's wrapper delivers it: voice_end, then voice_continue
+                    # (core/vad_wrapper.py:505-519)
+                    if wav is not None:
+                        self._call(s.on_end, "voice_end", wav)
+                    if wants[i] and s.on_continue is not None:
+                        if whole is None:
+                            x = frames[g][i - int(gs[g])][:L]
+                            whole = x.astype(np.float32) / np.float32(32767.0 if g < 4 else 32768.0) if g >= 2 else x.copy()
+                        if g & 1:
+                            whole = AudioUtils.denoise_audio(whole)
+                        self._call(s.on_continue, "voice_continue", whole.tobytes())
+                except Exception as e:
+                    self._report(s, e)
         return n
 
     @staticmethod
@@ -312,34 +314,6 @@ class SharedStreamPool:
             s.on_error(e)
         except Exception:
             pass
-
-    def _advance(self, s: PooledSession, kept: np.ndarray, p: float, ev: int) -> None:
-        slot = s.slot
-        if not self._active[slot]:
-            if p >= self._thr[slot]:
-                s.preroll.append(kept)
-            else:
-                s.preroll = []
-            self._pre[slot] = bool(s.preroll)
-            if ev & _ffi.VAD_EV_START:
-                self._active[slot] = True
-                self._pre[slot] = False
-                s.segment, s.preroll = s.preroll, []
-                self._call(s.on_start, "voice_start")
-            elif ev:
-                raise AudioProcessingError(f"state machine divergence: device events {ev} on an idle session")
-            return
-        s.segment.append(kept)
-        wav = None
-        if ev & _ffi.VAD_EV_END:
-            wav = s.wav_writer.write_wav_data(np.concatenate(s.segment))
-            self._active[slot] = False
-            s.segment = []
-        # order on the END frame as the reference's wrapper delivers it: voice_end, then voice_continue
-        # (core/vad_wrapper.py:505-519)
-        if wav is not None:
-            self._call(s.on_end, "voice_end", wav)
-        self._call(s.on_continue, "voice_continue", kept.tobytes())
 
     @staticmethod
     def _call(cb, name: str, *args) -> None:

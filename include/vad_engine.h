@@ -266,7 +266,21 @@ typedef struct vad_tick_result {
     const int32_t *nsamples;       /* samples the caller pushed for entry i (before padding / truncation to the frame length) */
 } vad_tick_result;
 VAD_API int vad_tick_push(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int gate_on);
+/* the same frame length / format / gate for n slots: frames [n][nsamples] (a front end that batches its sockets' frames) */
+VAD_API int vad_tick_push_many(vad_engine *e, const int64_t *slots, int64_t n, const void *frames, int32_t nsamples,
+                               int frame_fmt, int gate_on);
 VAD_API int vad_tick_cancel(vad_engine *e, int64_t slot);
+/*
+ * Segment assembly inside the tick (off by default).  When on, vad_tick_run also does the host half of
+ * VADProcessor._process_voice_state (core/silero_model.py:838-869, 891-895, 925-949) for every stepped stream, on the staged
+ * audio converted to float32 and gated like the model input (utils/audio.py:117-118): frames at or above the slot's
+ * vad_start_probability collect as pre-roll, START turns the pre-roll into the segment, frames of an open segment are appended
+ * (whole frames, also beyond the model's 512 samples), END closes it.  vad_tick_take_segment then hands over the finished
+ * segment's samples (out = NULL: size query; taking clears it) - the payload of voice_end_callback before WAV encoding.
+ * A serving loop then touches a stream in its own language only on START / END.
+ */
+VAD_API int vad_tick_enable_segments(vad_engine *e, int on);
+VAD_API int vad_tick_take_segment(vad_engine *e, int64_t slot, float *out, int64_t cap, int64_t *nsamples);
 VAD_API int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out);
 
 /*

@@ -116,6 +116,32 @@ class FakeEngine:
 
     def tick_cancel(self, slot):
         self.__dict__.setdefault("_tickq", {}).pop(int(slot), None)
+        self.__dict__.setdefault("_seg", {}).pop(int(slot), None)
+
+    def tick_enable_segments(self, on=True):
+        self._segments = bool(on)
+
+    def tick_take_segment(self, slot):
+        st = self.__dict__.setdefault("_seg", {}).get(int(slot))
+        if not st or st["done"] is None:
+            return np.empty(0, np.float32)
+        out, st["done"] = st["done"], None
+        return out
+
+    def _assemble(self, slot, g, x, p, ev, denoise):
+        """the host half of _process_voice_state on the frame as pushed (vad_tick_enable_segments)"""
+        st = self.__dict__.setdefault("_seg", {}).setdefault(int(slot), dict(active=False, pre=[], seg=[], done=None))
+        k = x.astype(np.float32) / np.float32(32768.0 if g >= 4 else 32767.0) if g >= 2 else x.astype(np.float32)
+        if g & 1:
+            k = np.where(np.abs(k) > np.float32(denoise), k, np.float32(0.0)).astype(np.float32)
+        if not st["active"]:
+            st["pre"] = st["pre"] + [k] if float(p) >= self.thr[int(slot)][0] else []
+            if ev & 1:
+                st["active"], st["seg"], st["pre"] = True, st["pre"], []
+        else:
+            st["seg"].append(k)
+            if ev & 2:
+                st["done"], st["seg"], st["active"] = np.concatenate(st["seg"]), [], False
 
     def tick_run(self, denoise=0.01):
         q = self.__dict__.setdefault("_tickq", {})
@@ -142,6 +168,9 @@ class FakeEngine:
                 segs += list(sg)
                 ns += [r[1].size for r in rows]
                 frames[g] = arr
+                if getattr(self, "_segments", False):
+                    for (slot, x), pi, ei in zip(rows, p, ev):
+                        self._assemble(slot, g, x, np.float32(pi), int(ei), denoise)
             gs.append(len(slots))
         return (np.array(slots, np.int64), np.array(probs, np.float32), np.array(events, np.uint8), np.array(segs, np.int32),
                 np.array(gs, np.int64), frames, np.array(ns, np.int32))

@@ -149,3 +149,73 @@ def test_submit_collect_is_bit_identical_and_overlaps_the_copy(eng, dtype):
     finally:
         for s in slots:
             eng.close_stream(int(s))
+
+
+def test_tick_assembler_matches_direct_steps_and_keeps_the_segments(eng):
+    """vad_tick_push / vad_tick_run / vad_tick_take_segment against vad_step_events on the same frames: one frame per slot
+    and tick in submission order, (format, gate) groups, short frames padded, long frames truncated for the model but kept
+    whole in the segment, cancel, and the segment audio == what SegmentAssembler keeps on the host."""
+    from cutter_vad_amd.core.config import VADConfig
+    from cutter_vad_amd.core.silero_model import SegmentAssembler
+    from cutter_vad_amd.utils.audio import AudioUtils
+    from cutter_vad_amd.utils.wav_writer import WAVWriter
+    n, T = 96, 14
+    x = make_streams(n, T + 2, seed=41)[:, :, :480]                      # 30 ms wire frames
+    x[:, 9:12] *= 0.01                                                   # a quiet stretch so that segments end
+    slots = eng.open_streams(n)
+    ref_slots = eng.open_streams(n)
+    thr = (0.3, 0.2, 0.8, 0.95, 2, 2)
+    cfg = VADConfig(vad_start_probability=0.3, vad_end_probability=0.2, voice_start_frame_count=2, voice_end_frame_count=2, buffer_size=480)
+    try:
+        eng.tick_enable_segments(True)
+        eng.set_thresholds_many(slots, thr)
+        eng.set_thresholds_many(ref_slots, thr)
+        q = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)
+        asm = [SegmentAssembler(cfg, WAVWriter(16000, 16, 1)) for _ in range(n)]
+        for t in range(T):
+            # streams 0..47 speak int16 on the wire, 48..95 float32; stream 5 sends a 700-sample frame, stream 50 a 100-sample one
+            fr = {}
+            for k in range(n):
+                f = q[k, t] if k < 48 else x[k, t]
+                if k == 5:
+                    f = np.concatenate([q[k, t], q[k, t + 1][:220]])
+                if k == 50:
+                    f = x[k, t][:100]
+                fr[k] = f
+                eng.tick_push(int(slots[k]), f.tobytes() if f.dtype == np.int16 else f, gate_on=(k % 2 == 0))
+            if t == 3:                                                   # a second frame for stream 7 waits for the next tick
+                eng.tick_push(int(slots[7]), q[7, t + 1].tobytes(), gate_on=False)
+            s, p, ev, seg, gs, frames, ns = eng.tick_run(0.01)
+            assert s.size == n and sorted(s.tolist()) == sorted(slots.tolist())
+            assert [int(gs[g + 1] - gs[g]) for g in range(6)] == [24, 24, 24, 24, 0, 0]
+            order = {int(sl): i for i, sl in enumerate(s)}
+            for k in range(n):
+                i = order[int(slots[k])]
+                f = fr[k]
+                if t == 4 and k == 7:
+                    f = q[7, 4]                                          # tick 4 consumed the frame queued at t = 3 ...
+                m = np.zeros(512, f.dtype)
+                m[:min(f.size, 512)] = f[:512]
+                rp, rev, _ = eng.step_events([int(ref_slots[k])], m[None], denoise=0.01 if k % 2 == 0 else None)
+                assert p[i] == rp[0] and ev[i] == rev[0], (t, k)
+                ff = f.astype(np.float32) / np.float32(32767.0) if f.dtype == np.int16 else f
+                kept = AudioUtils.denoise_audio(ff) if k % 2 == 0 else ff
+                res = asm[k].push(float(rp[0]), kept, int(rev[0]))
+                if res["voice_ended"]:
+                    got = eng.tick_take_segment(int(slots[k]))
+                    assert WAVWriter(16000, 16, 1).write_wav_data(got) == res["wav_data"], (t, k)
+            if t == 4:                                                   # ... so stream 7's own frame of tick 4 is still waiting
+                s2, *_ = eng.tick_run(0.01)
+                assert s2.tolist() == [int(slots[7])]
+                eng.step_events([int(ref_slots[7])], np.pad(q[7, 4], (0, 32))[None], denoise=None)
+                asm[7].push(0.0, np.zeros(480, np.float32), None)        # keep the host replica's counters out of the comparison
+                break
+        assert any(a.is_voice_active for a in asm)
+        eng.tick_push(int(slots[0]), q[0, 0].tobytes())
+        eng.tick_cancel(int(slots[0]))
+        assert eng.tick_run(0.01)[0].size == 0
+    finally:
+        eng.tick_enable_segments(False)
+        for s_ in list(slots) + list(ref_slots):
+            eng.tick_cancel(int(s_))
+            eng.close_stream(int(s_))
