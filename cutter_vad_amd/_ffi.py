@@ -87,6 +87,7 @@ class TickResult(C.Structure):
         ("group_start", C.c_int64 * 7),
         ("group_frames", C.c_void_p * 6),
         ("nsamples", C.POINTER(C.c_int32)),
+        ("host_us", C.c_float * 3),
     ]
 
 

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -109,7 +110,42 @@ struct vad_engine {
     std::unordered_map<int64_t, std::deque<std::vector<uint8_t>>> tick_tails;   // samples past the model's frame of over-long frames, push order
     // segment assembly on the host side of the tick (vad_tick_enable_segments): what SegmentAssembler / VADProcessor keep per
     // stream (core/silero_model.py:838-869, 891-895, 925-949) - pre-roll, the open segment, the finished one until taken
-    struct SegState { bool active = false; std::vector<float> pre, seg, done; };
+    // The audio stays in its wire format (int16 stays int16: half the bytes, a memcpy per frame) as runs of (group, samples,
+    // gate threshold); it becomes float32 - scaled with a true division and gated - when the finished segment is taken.
+    struct SegAudio {
+        struct Run { int group; float thr; int64_t samples; };
+        std::vector<uint8_t> raw;
+        std::vector<Run> runs;
+        int64_t samples = 0;
+        void clear() { raw.clear(); runs.clear(); samples = 0; }
+        void swap(SegAudio &o) { raw.swap(o.raw); runs.swap(o.runs); std::swap(samples, o.samples); }
+        void append(int group, float thr, const uint8_t *src, size_t cnt) {
+            const size_t bytes = cnt * (group >= 2 ? 2 : 4), at = raw.size();
+            if (raw.capacity() < at + bytes) raw.reserve(std::max<size_t>(2 * raw.capacity(), at + bytes + 32768));   // ~1 s of int16 audio ahead
+            raw.resize(at + bytes);
+            std::memcpy(raw.data() + at, src, bytes);
+            if (!runs.empty() && runs.back().group == group && runs.back().thr == thr) runs.back().samples += (int64_t)cnt;
+            else runs.push_back(Run{group, thr, (int64_t)cnt});
+            samples += (int64_t)cnt;
+        }
+        void to_float(float *o) const {
+            const uint8_t *src = raw.data();
+            for (const Run &r : runs) {
+                const size_t cnt = (size_t)r.samples;
+                if (r.group < 2) std::memcpy(o, src, cnt * 4);
+                else {
+                    const float sc = r.group < 4 ? 32767.0f : 32768.0f;     // np.int16 -> float32 / 32767.0 (true division)
+                    const int16_t *q = reinterpret_cast<const int16_t *>(src);
+                    for (size_t k = 0; k < cnt; ++k) o[k] = (float)q[k] / sc;
+                }
+                if (r.group & 1)                                             // utils/audio.py:117-118
+                    for (size_t k = 0; k < cnt; ++k) o[k] = std::fabs(o[k]) > r.thr ? o[k] : 0.f;
+                o += cnt;
+                src += cnt * (r.group >= 2 ? 2 : 4);
+            }
+        }
+    };
+    struct SegState { bool active = false; SegAudio pre, seg, done; };
     bool tick_segments = false;
     std::vector<SegState> seg_state;
     std::vector<double> h_start_prob;                // host copy of each slot's vad_start_probability (pre-roll rule :832-839)
@@ -1055,12 +1091,12 @@ int vad_tick_take_segment(vad_engine *e, int64_t slot, float *out, int64_t cap, 
     if (!e || !nsamples) return VAD_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->tick_mu);
     if (slot < 0 || (size_t)slot >= e->seg_state.size()) return e->fail(VAD_ERR_BAD_SLOT, "slot %lld has no segment state", (long long)slot);
-    std::vector<float> &d = e->seg_state[(size_t)slot].done;
-    *nsamples = (int64_t)d.size();
+    vad_engine::SegAudio &d = e->seg_state[(size_t)slot].done;
+    *nsamples = d.samples;
     if (!out) return VAD_OK;                       // size query
-    if (cap < (int64_t)d.size()) return e->fail(VAD_ERR_INVALID_ARG, "segment buffer too small (%lld < %lld samples)", (long long)cap, (long long)d.size());
-    if (!d.empty()) std::memcpy(out, d.data(), d.size() * sizeof(float));
-    std::vector<float>().swap(d);
+    if (cap < d.samples) return e->fail(VAD_ERR_INVALID_ARG, "segment buffer too small (%lld < %lld samples)", (long long)cap, (long long)d.samples);
+    d.to_float(out);
+    vad_engine::SegAudio().swap(d);
     return VAD_OK;
 }
 
@@ -1099,6 +1135,12 @@ int vad_tick_cancel(vad_engine *e, int64_t slot) {
 
 int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
     if (!e || !out || out->struct_size < sizeof(vad_tick_result)) return VAD_ERR_INVALID_ARG;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
+        return (float)std::chrono::duration<double, std::micro>(b2 - a).count();
+    };
+    const auto t0 = now();
+    out->host_us[0] = out->host_us[1] = out->host_us[2] = 0.f;
     int b;
     {   // swap the staging buffers; every slot that has more frames waiting gets its next one into the new buffer
         std::lock_guard<std::mutex> lk(e->tick_mu);
@@ -1118,6 +1160,8 @@ int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
         }
     }
     std::lock_guard<std::mutex> lk(e->mu);
+    const auto t1 = now();
+    out->host_us[0] = us(t0, t1);
     vad_engine::TickBuf *tbs = e->tick_buf[b];
     int64_t total = 0;
     size_t frame_total = 0;
@@ -1187,25 +1231,14 @@ int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
     out->seg_frames = reinterpret_cast<const int32_t *>(e->h_tick_out + o_seg);
     out->events = e->h_tick_out + o_ev;
     out->nsamples = reinterpret_cast<const int32_t *>(e->h_tick_out + o_len);
+    const auto t2 = now();
+    out->host_us[1] = us(t1, t2);
     if (e->tick_segments) {
         // the host half of _process_voice_state, per stepped stream, on the staged audio: float32, gated like the model's input
         // (utils/audio.py:117-118) when the group's gate is on
         std::lock_guard<std::mutex> tl(e->tick_mu);
         if (e->seg_state.size() < (size_t)e->max_streams) e->seg_state.resize((size_t)e->max_streams);
-        std::vector<float> kept;
         for (int g = 0; g < vad_engine::TICK_GROUPS; ++g) {
-            const bool gate = g & 1;
-            const float sc = g < 4 ? 32767.0f : 32768.0f;
-            auto conv = [&](const uint8_t *src, size_t cnt) {
-                const size_t at = kept.size();
-                kept.resize(at + cnt);
-                if (g < 2) std::memcpy(kept.data() + at, src, cnt * 4);
-                else
-                    for (size_t k = 0; k < cnt; ++k) kept[at + k] = (float)reinterpret_cast<const int16_t *>(src)[k] / sc;
-                if (gate)
-                    for (size_t k = at; k < at + cnt; ++k)
-                        if (!(std::fabs(kept[k]) > denoise_thresh)) kept[k] = 0.f;
-            };
             for (int64_t r = 0; r < tbs[g].count; ++r) {
                 const int64_t i = out->group_start[g] + r;
                 const size_t sl = (size_t)h_slots[i];
@@ -1214,38 +1247,32 @@ int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
                 const bool above = (double)out->probs[i] >= e->h_start_prob[sl];
                 const int32_t L = tbs[g].lens()[r];
                 const bool is_long = L > e->frame_samples;
-                if (!st.active && !above && !(ev & VAD_EV_START)) {          // idle stream: nothing is kept
+                std::deque<std::vector<uint8_t>> *tails = is_long ? &e->tick_tails[(int64_t)sl] : nullptr;
+                if (!st.active && !above) {                                            // idle stream: nothing is kept (:873-874)
                     st.pre.clear();
-                    if (is_long) { auto &q = e->tick_tails[(int64_t)sl]; if (!q.empty()) q.pop_front(); }
+                    if (tails && !tails->empty()) tails->pop_front();
                     continue;
                 }
-                kept.clear();
-                conv(tbs[g].row(r), (size_t)std::min<int32_t>(L, e->frame_samples));
-                if (is_long) {
-                    auto &q = e->tick_tails[(int64_t)sl];
-                    if (!q.empty()) {
-                        conv(q.front().data(), q.front().size() / (g < 2 ? 4 : 2));
-                        q.pop_front();
-                    }
+                vad_engine::SegAudio &dst = st.active ? st.seg : st.pre;               // :891 / :838-839
+                dst.append(g, denoise_thresh, tbs[g].row(r), (size_t)std::min<int32_t>(L, e->frame_samples));
+                if (tails && !tails->empty()) {
+                    dst.append(g, denoise_thresh, tails->front().data(), tails->front().size() / (g < 2 ? 4 : 2));
+                    tails->pop_front();
                 }
                 if (!st.active) {
-                    if (above) st.pre.insert(st.pre.end(), kept.begin(), kept.end());     // :838-839
-                    else st.pre.clear();                                               // :873-874
                     if (ev & VAD_EV_START) {                                           // :860-869
                         st.active = true;
                         st.seg.swap(st.pre);
                         st.pre.clear();
                     }
-                } else {
-                    st.seg.insert(st.seg.end(), kept.begin(), kept.end());             // :891, :925-930
-                    if (ev & VAD_EV_END) {                                             // :932-949
-                        st.done.swap(st.seg);
-                        st.seg.clear();
-                        st.active = false;
-                    }
+                } else if (ev & VAD_EV_END) {                                          // :932-949
+                    st.done.swap(st.seg);
+                    st.seg.clear();
+                    st.active = false;
                 }
             }
         }
+        out->host_us[2] = us(t2, now());
     }
     return VAD_OK;
 }

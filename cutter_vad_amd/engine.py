@@ -280,6 +280,7 @@ class Engine:
         r.struct_size = C.sizeof(_ffi.TickResult)
         self._check(self._lib.vad_tick_run(self._h, float(denoise), C.byref(r)))
         n = int(r.n)
+        self.last_tick_us = tuple(r.host_us)       # (swap, copies + launches + wait, segment assembly) of this tick
         gs = np.array(list(r.group_start), np.int64)
         if n == 0:
             e = np.empty(0)

@@ -264,6 +264,7 @@ typedef struct vad_tick_result {
     int64_t group_start[7];
     const void *group_frames[6];
     const int32_t *nsamples;       /* samples the caller pushed for entry i (before padding / truncation to the frame length) */
+    float host_us[3];              /* where this tick's wall time went: buffer swap + queued frames | copies + launches + wait | segment assembly */
 } vad_tick_result;
 VAD_API int vad_tick_push(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int gate_on);
 /* the same frame length / format / gate for n slots: frames [n][nsamples] (a front end that batches its sockets' frames) */

@@ -60,6 +60,7 @@ def run_batched(n, ticks=40):
     pcm = np.clip(x * 32767.0, -32768, 32767).astype("<i2")
     wire = [np.ascontiguousarray(pcm[np.arange(n) % pcm.shape[0], t]) for t in range(ticks + 5)]
     t_sub = t_tick = 0.0
+    c_us = [0.0, 0.0, 0.0]
     for t in range(ticks + 5):
         a = time.perf_counter()
         pool.engine.tick_push_many(slots, wire[t], gate_on=True)
@@ -69,8 +70,10 @@ def run_batched(n, ticks=40):
         if t >= 5:
             t_sub += b - a
             t_tick += c - b
+            for k in range(3):
+                c_us[k] += pool.engine.last_tick_us[k]
     pool.close()
-    return {"sessions": n, "ingest": "vad_tick_push_many", "submit_ms_per_tick": t_sub / ticks * 1e3, "tick_ms": t_tick / ticks * 1e3,
+    return {"sessions": n, "ingest": "vad_tick_push_many", "tick_in_C_us": {"swap": c_us[0] / ticks, "gpu": c_us[1] / ticks, "segments": c_us[2] / ticks}, "submit_ms_per_tick": t_sub / ticks * 1e3, "tick_ms": t_tick / ticks * 1e3,
             "frames_per_s_host_inclusive": n * ticks / (t_sub + t_tick),
             "real_time_factor": (n * ticks / (t_sub + t_tick)) / (n * 1000 / 30), "events": counts}
 
