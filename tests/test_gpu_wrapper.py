@@ -179,3 +179,58 @@ def test_chunk_in_one_launch_equals_frame_by_frame_and_keeps_the_abort_contract(
         assert eng.save_stream(batched.processor.model.slot) == eng.save_stream(serial.processor.model.slot)
         assert batched.get_statistics()["total_frames_processed"] == serial.get_statistics()["total_frames_processed"]
         assert batched.is_voice_active() and serial.is_voice_active()
+
+
+def test_async_wrapper_on_the_real_engine_equals_the_sync_wrapper():
+    """f4: AsyncVADWrapper (src/real_time_vad/core/async_vad_wrapper.py:214-229) over the HIP engine: the audio goes through the
+    executor thread, coroutine callbacks come back on the submitting loop; events, payloads and probabilities are those of the
+    synchronous wrapper on the same audio (1 024-sample chunks: three overlapping frames per call, one launch each)."""
+    import asyncio
+    import hashlib
+    import os
+    from cutter_vad_amd import AsyncVADWrapper, VADConfig, VADWrapper
+    pcm = np.load(os.path.join(os.path.dirname(__file__), "golden", "speech16k_i16.npz"))["pcm"]
+    sp = (pcm.astype(np.float32) / np.float32(32767.0))[: 120 * 1024].reshape(120, 1024)
+    cfg = dict(vad_start_probability=0.4, vad_end_probability=0.3, voice_start_frame_count=4, voice_end_frame_count=10)
+    want = []
+    with VADWrapper(VADConfig(**cfg)) as w:
+        w.set_callbacks(lambda: want.append("S"), lambda b: want.append(("E", hashlib.sha256(b).hexdigest())),
+                        lambda b: want.append(("C", len(b))))
+        for c in sp:
+            w.process_audio_data(c)
+        want_p = list(w.processor.voice_probabilities)
+
+    async def run():
+        got = []
+        aw = AsyncVADWrapper(VADConfig(**cfg))
+
+        async def on_start():
+            got.append("S")
+
+        async def on_end(b):
+            await asyncio.sleep(0)
+            got.append(("E", hashlib.sha256(b).hexdigest()))
+
+        async def on_cont(b):
+            got.append(("C", len(b)))
+        aw.set_async_callbacks(on_start, on_end, on_cont)
+        try:
+            for c in sp:
+                await aw.process_audio_data_async(c)
+                await asyncio.sleep(0)
+            for _ in range(20):                     # let the posted coroutines finish
+                await asyncio.sleep(0.005)
+            stats = await aw.get_statistics_async()
+            probs = list(aw.vad_wrapper.processor.voice_probabilities)
+            active = await aw.is_voice_active_async()
+        finally:
+            res = aw.cleanup()
+            if asyncio.iscoroutine(res):
+                await res
+        return got, stats, probs, active
+
+    got, stats, probs, _ = asyncio.run(run())
+    assert probs == want_p and stats["total_frames_processed"] == 360
+    assert [g for g in got if g == "S" or g[0] == "E"] == [x for x in want if x == "S" or x[0] == "E"]
+    assert sum(1 for g in got if g != "S" and g[0] == "C") == sum(1 for x in want if x != "S" and x[0] == "C")
+    assert any(g != "S" and g[0] == "E" for g in got)
