@@ -139,6 +139,7 @@ SIGNATURES = {
                                           C.POINTER(C.c_uint32)]),
     "vad_debug_sm_replay": (C.c_int, [_vp, C.c_int64, _f32p, C.c_int64, _u8p, _i32p]),
     "vad_engine_synchronize": (C.c_int, [_vp]),
+    "vad_debug_set_tile": (C.c_int, [_vp, C.c_int32]),
 }
 
 _lib = None

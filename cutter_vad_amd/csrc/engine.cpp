@@ -29,6 +29,7 @@
 
 extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_silero_v4(const vadk::StepParams *p, hipStream_t stream);
+extern "C" hipError_t vadk_launch_silero_v5_t16(const vadk::StepParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_resample(const vadk::ResampleParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_slot_control(vadk::SmSlot *sm, float *state, const int32_t *d_slots, int n, int op,
                                                const vadk::SmSlot *def, const vad_thresholds *d_thr, int nthr, hipStream_t stream);
@@ -73,6 +74,14 @@ struct vad_engine {
     std::vector<void *> host_blocks;                         // vad_host_alloc: freed with the engine
     uint8_t *d_small_in = nullptr, *d_small_out = nullptr;
     vadk::StepParams base{};
+    // Silero V5 16 kHz: the same weights packed for the 16-stream tile kernel (csrc/silero_v5_t16.hip), used when a call has at
+    // most T16_MAX_STREAMS streams: half-size tiles put a small batch on twice as many CUs (a 32-stream tile takes ~47 us
+    // however few tiles a launch has)
+    static constexpr int T16_MAX_STREAMS = 4096;
+    float *d_wstream16 = nullptr;
+    size_t wbytes16 = 0;
+    uint32_t sect16[vadk::NWAVES][16] = {};
+    int tile_policy = 0;                     // 0 = by batch size, 16 / 32 = forced (vad_debug_set_tile)
     int sample_rate = 16000;
     int frame_samples = VAD_FRAME_SAMPLES;   // samples per model step (512; Silero V5's 8 kHz sub-model: 256)
     // batched slot control (open / reset / thresholds): one pinned block up, one kernel
@@ -240,7 +249,14 @@ int check_slots(vad_engine *e, const int64_t *slots, int64_t n) {
 
 int launch(vad_engine *e, const vadk::StepParams &p, hipStream_t s) {
     hipError_t r = hipErrorInvalidValue;
-    if (e->version == 5) r = vadk_launch_silero_v5(&p, s);
+    const bool t16 = e->d_wstream16 && (e->tile_policy == 16 || (e->tile_policy == 0 && p.n <= vad_engine::T16_MAX_STREAMS));
+    if (e->version == 5 && t16) {
+        vadk::StepParams p16 = p;
+        p16.wstream = e->d_wstream16;
+        p16.wstream_bytes = (uint32_t)e->wbytes16;
+        std::memcpy(p16.sect, e->sect16, sizeof p16.sect);
+        r = vadk_launch_silero_v5_t16(&p16, s);
+    } else if (e->version == 5) r = vadk_launch_silero_v5(&p, s);
     else if (e->version == 4) r = vadk_launch_silero_v4(&p, s);
     if (r != hipSuccess) return e->hip_fail(r, "kernel launch");
     e->steps += 1;
@@ -412,6 +428,19 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
     if ((r = hipMalloc((void **)&e->d_wstream, e->wbytes)) != hipSuccess) return bail(r, "hipMalloc(weights)");
     if ((r = hipMemcpy(e->d_wstream, pw.data.data(), e->wbytes, hipMemcpyHostToDevice)) != hipSuccess)
         return bail(r, "hipMemcpy(weights)");
+    if (desc->model_version == 5 && !want_8k) {
+        vadk::PackedWeights pw16;
+        if (!vadk::pack_silero_v5_t16(desc->weights, desc->weights_len, pw16, perr)) {
+            g_create_error = perr;
+            vad_engine_destroy(e);
+            return VAD_ERR_BAD_WEIGHTS;
+        }
+        e->wbytes16 = pw16.data.size() * sizeof(float);
+        if ((r = hipMalloc((void **)&e->d_wstream16, e->wbytes16)) != hipSuccess) return bail(r, "hipMalloc(weights, 16-stream tiles)");
+        if ((r = hipMemcpy(e->d_wstream16, pw16.data.data(), e->wbytes16, hipMemcpyHostToDevice)) != hipSuccess)
+            return bail(r, "hipMemcpy(weights, 16-stream tiles)");
+        std::memcpy(e->sect16, pw16.sect, sizeof pw16.sect);
+    }
     const size_t sb = sizeof(float) * VAD_STATE_FLOATS * (size_t)e->max_streams;
     if ((r = hipMalloc((void **)&e->d_state, sb)) != hipSuccess) return bail(r, "hipMalloc(state)");
     if ((r = hipMemset(e->d_state, 0, sb)) != hipSuccess) return bail(r, "hipMemset(state)");
@@ -444,7 +473,7 @@ void vad_engine_destroy(vad_engine *e) {
     for (hipStream_t st : {e->copy_in, e->stream, e->copy_out})
         if (st) (void)hipStreamSynchronize(st);
     void *bufs[] = {e->d_wstream, e->d_state, e->d_sm, e->d_frames, e->d_probs, e->d_events, e->d_seg, e->d_slots,
-                    e->d_rs_in, e->d_rs_out, e->d_small_in, e->d_small_out, e->d_ctl};
+                    e->d_rs_in, e->d_rs_out, e->d_small_in, e->d_small_out, e->d_ctl, e->d_wstream16};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &pb : e->pipe) {
@@ -485,7 +514,7 @@ int vad_engine_info(const vad_engine *e, vad_info *info) {
     info->open_streams = e->open_count;
     info->compute_units = e->prop.multiProcessorCount;
     info->streams_per_workgroup = vadk::MT;
-    info->weight_bytes_device = (int64_t)e->wbytes;
+    info->weight_bytes_device = (int64_t)(e->wbytes + e->wbytes16);
     info->state_bytes_device = (int64_t)(sizeof(float) * VAD_STATE_FLOATS + sizeof(vadk::SmSlot)) * e->max_streams;
     info->steps = e->steps;
     info->frames = e->frames;
@@ -1319,9 +1348,11 @@ int vad_debug_pack_weights(int32_t model_version, const void *weights, size_t we
     g_create_error.clear();
     vadk::PackedWeights pw;
     std::string perr;
-    const bool ok = model_version == 5   ? vadk::pack_silero_v5(weights, weights_len, pw, perr)
-                    : model_version == 4 ? vadk::pack_silero_v4(weights, weights_len, pw, perr)
-                                         : false;
+    // model_version 516: Silero V5 packed for the 16-stream tile kernel (tests/kernel_model.py models both packings)
+    const bool ok = model_version == 5     ? vadk::pack_silero_v5(weights, weights_len, pw, perr)
+                    : model_version == 516 ? vadk::pack_silero_v5_t16(weights, weights_len, pw, perr)
+                    : model_version == 4   ? vadk::pack_silero_v4(weights, weights_len, pw, perr)
+                                           : false;
     if (!ok) {
         g_create_error = perr.empty() ? "Failed to load model: model_version must be 4 or 5" : perr;
         return VAD_ERR_BAD_WEIGHTS;
@@ -1335,6 +1366,17 @@ int vad_debug_pack_weights(int32_t model_version, const void *weights, size_t we
         }
         std::memcpy(out, pw.data.data(), pw.data.size() * sizeof(float));
     }
+    return VAD_OK;
+}
+
+int vad_debug_set_tile(vad_engine *e, int32_t streams_per_tile) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (streams_per_tile != 0 && streams_per_tile != 16 && streams_per_tile != 32)
+        return e->fail(VAD_ERR_INVALID_ARG, "tile: 0 (by batch size), 16 or 32");
+    if (streams_per_tile == 16 && !e->d_wstream16)
+        return e->fail(VAD_ERR_UNSUPPORTED, "the 16-stream tile kernel exists for Silero V5 at 16 kHz only");
+    e->tile_policy = streams_per_tile;
     return VAD_OK;
 }
 

@@ -289,6 +289,131 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
     return true;
 }
 
+// ---- Silero V5 16 kHz for the 16-stream tile kernel (csrc/silero_v5_t16.hip) -------------------------------------------------
+// Same sections and the same algebra (4-way folded DFT, Toom-3 enc0) as pack_silero_v5, but every contraction runs on
+// v_mfma_f32_16x16x4_f32: a wave's 32 output channels are TWO 16-row tiles rt = 0, 1, a k-iteration j contracts 16 channels, and a
+// 1 KiB block holds 16 rows x 16 channels: lane l = (row l & 15, channel group kq = l >> 4), component i = channel 16 j + 4 kq + i
+// (StreamBuilder::weight_block16).  A per-channel vector of a tile is ONE block in the tile's D layout (vector_block16).
+bool pack_silero_v5_t16(const void *blob, size_t len, PackedWeights &out, std::string &err) {
+    using namespace v5;
+    Blob B;
+    if (!open_blob(blob, len, B, err)) return false;
+    if (B.version != 5) {
+        err = "Failed to load model: weight blob is not Silero V5";
+        return false;
+    }
+    for (uint32_t i = 0; i < B.n; ++i)
+        if (std::strncmp(B.tab[i].name, "meta.variant", sizeof B.tab[i].name) == 0) {
+            err = "Failed to load model: the 16-stream tile kernel is built for Silero V5's 16 kHz sub-model";
+            return false;
+        }
+    const float *stft = B.get("stft.basis", 258 * 256);
+    const float *ew[4], *eb[4];
+    static const int co[4] = {128, 64, 64, 128}, ci[4] = {129, 128, 64, 64};
+    for (int i = 0; i < 4; ++i) {
+        char nm[32];
+        std::snprintf(nm, sizeof nm, "enc%d.w", i);
+        ew[i] = B.get(nm, (uint64_t)co[i] * ci[i] * 3);
+        std::snprintf(nm, sizeof nm, "enc%d.b", i);
+        eb[i] = B.get(nm, co[i]);
+    }
+    const float *w_ih = B.get("lstm.w_ih", 512 * 128), *w_hh = B.get("lstm.w_hh", 512 * 128);
+    const float *b_ih = B.get("lstm.b_ih", 512), *b_hh = B.get("lstm.b_hh", 512);
+    const float *head_w = B.get("head.w", 128), *head_b = B.get("head.b", 1);
+    if (!err.empty()) return false;
+    if (!check_stft_symmetry(stft, err)) return false;
+    if (!check_windowed_dft(stft, err)) return false;
+    const double two_pi = 6.283185307179586476925286766559;
+    out.variant = 0;
+    StreamBuilder sb;
+    auto convw = [&](int layer, int o, int c, int tap) -> float { return ew[layer][((size_t)o * ci[layer] + c) * 3 + tap]; };
+    auto toom = [&](int o, int c129, int p) -> float {
+        const double v0 = ew[0][((size_t)o * 129 + c129) * 3 + 2], v1 = ew[0][((size_t)o * 129 + c129) * 3 + 1],
+                     v2 = ew[0][((size_t)o * 129 + c129) * 3 + 0];
+        switch (p) {
+            case 0: return (float)v0;
+            case 1: return (float)(0.5 * (v0 + v1 + v2));
+            case 2: return (float)(0.5 * (v0 - v1 + v2));
+            case 3: return (float)(v0 + 2.0 * v1 + 4.0 * v2);
+            default: return (float)v2;
+        }
+    };
+    for (int w = 0; w < NWAVES; ++w) {
+        // STFT: per k-iteration (n = 16 j .. 16 j + 15): cos rt0, cos rt1, -sin rt0, -sin rt1
+        out.sect[w][S_STFT] = sb.blocks();
+        for (int j = 0; j < 4; ++j)
+            for (int part = 0; part < 2; ++part)
+                for (int rt = 0; rt < 2; ++rt)
+                    sb.weight_block16([&](int r, int n) {
+                        const int k = bin_of_channel(32 * w + 16 * rt + r);
+                        const double ph = two_pi * (double)((k * n) & 255) / 256.0;
+                        return n == 0 ? 0.f : (float)(part == 0 ? std::cos(ph) : -std::sin(ph));
+                    }, j);
+        // enc0 (Toom-3): bias rt0, rt1; per k-iteration the five points x two row tiles; Nyquist channel: points 0,1,-1,2 in the
+        // components of lanes kq = 0 (the other channel groups carry zeros), rt0, rt1; then the point at infinity, rt0, rt1
+        out.sect[w][S_ENC0] = sb.blocks();
+        for (int rt = 0; rt < 2; ++rt) sb.vector_block16([&](int c) { return eb[0][32 * w + 16 * rt + c]; });
+        for (int j = 0; j < 8; ++j)
+            for (int p = 0; p < 5; ++p)
+                for (int rt = 0; rt < 2; ++rt)
+                    sb.weight_block16([&](int r, int c) { return toom(32 * w + 16 * rt + r, bin_of_channel(c), p); }, j);
+        for (int part = 0; part < 2; ++part)
+            for (int rt = 0; rt < 2; ++rt) {
+                float *a = sb.new_block();
+                for (int r = 0; r < 16; ++r)
+                    for (int p = 0; p < (part == 0 ? 4 : 1); ++p) a[r * 4 + p] = toom(32 * w + 16 * rt + r, 128, part == 0 ? p : 4);
+            }
+        // enc1: n-tile w&1, output column w>>1; taps (1,2) for column 0, (0,1) for column 1; iteration it = 8 ti + j
+        out.sect[w][S_ENC1] = sb.blocks();
+        {
+            const int nt = w & 1, tp = w >> 1;
+            for (int rt = 0; rt < 2; ++rt) sb.vector_block16([&](int c) { return eb[1][32 * nt + 16 * rt + c]; });
+            for (int ti = 0; ti < 2; ++ti)
+                for (int j = 0; j < 8; ++j)
+                    for (int rt = 0; rt < 2; ++rt)
+                        sb.weight_block16([&](int r, int c) { return convw(1, 32 * nt + 16 * rt + r, c, (1 - tp) + ti); }, j);
+        }
+        // enc2: n-tile w&1 (packed for waves 0,1; waves 2,3 read the second K half of the same streams), taps 1,2 on columns 0,1
+        out.sect[w][S_ENC2] = sb.blocks();
+        if (w < 2) {
+            for (int rt = 0; rt < 2; ++rt) sb.vector_block16([&](int c) { return eb[2][32 * w + 16 * rt + c]; });
+            for (int ti = 0; ti < 2; ++ti)
+                for (int j = 0; j < 4; ++j)
+                    for (int rt = 0; rt < 2; ++rt)
+                        sb.weight_block16([&](int r, int c) { return convw(2, 32 * w + 16 * rt + r, c, 1 + ti); }, j);
+        }
+        // enc3: centre tap
+        out.sect[w][S_ENC3] = sb.blocks();
+        for (int rt = 0; rt < 2; ++rt) sb.vector_block16([&](int c) { return eb[3][32 * w + 16 * rt + c]; });
+        for (int j = 0; j < 4; ++j)
+            for (int rt = 0; rt < 2; ++rt)
+                sb.weight_block16([&](int r, int c) { return convw(3, 32 * w + 16 * rt + r, c, 1); }, j);
+        // LSTM: biases (gate q, rt), W_ih and W_hh per k-iteration (gate q, rt), head weights (rt)
+        out.sect[w][S_LSTM] = sb.blocks();
+        for (int q = 0; q < 4; ++q)
+            for (int rt = 0; rt < 2; ++rt)
+                sb.vector_block16([&](int c) { const int r = q * 128 + 32 * w + 16 * rt + c; return b_ih[r] + b_hh[r]; });
+        for (const float *W : {w_ih, w_hh})
+            for (int j = 0; j < 8; ++j)
+                for (int q = 0; q < 4; ++q)
+                    for (int rt = 0; rt < 2; ++rt)
+                        sb.weight_block16([&](int r, int c) { return W[(size_t)(q * 128 + 32 * w + 16 * rt + r) * 128 + c]; }, j);
+        for (int rt = 0; rt < 2; ++rt) sb.vector_block16([&](int c) { return head_w[32 * w + 16 * rt + c]; });
+    }
+    out.sect[2][S_ENC2] = out.sect[0][S_ENC2];
+    out.sect[3][S_ENC2] = out.sect[1][S_ENC2];
+    const uint32_t hb = sb.blocks();
+    sb.new_block()[0] = head_b[0];
+    const uint32_t nb = sb.blocks();
+    std::memcpy(sb.new_block(), stft, 256 * sizeof(float));
+    for (int w = 0; w < NWAVES; ++w) {
+        out.sect[w][S_HEADB] = hb;
+        out.sect[w][S_NYQ] = nb;
+    }
+    out.data = std::move(sb.data);
+    return true;
+}
+
 namespace {
 void build_resample_operator_d(int n_in, std::vector<double> &R);
 }

@@ -21,6 +21,8 @@ struct PackedWeights {
 // ModelInitializationError text, core/silero_model.py:330-334).
 bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::string &err);
 bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::string &err);
+// Silero V5 16 kHz repacked for the 16-stream tile kernel (16 x 16 x 4 MFMA tiles; csrc/silero_v5_t16.hip)
+bool pack_silero_v5_t16(const void *blob, size_t len, PackedWeights &out, std::string &err);
 
 // scipy.signal.resample(x, 512) for len(x) == n_in as a dense operator R[512][n_in] (row-major),
 // built in double precision from the closed form of the Fourier method (utils/audio.py:46-49).

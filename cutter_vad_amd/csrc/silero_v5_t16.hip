@@ -1,0 +1,512 @@
+// Silero-VAD V5 (16 kHz) step kernel on 16-STREAM tiles, for small and medium batches (gfx950).
+//
+// silero_v5.hip carries 32 streams per workgroup, so a launch of n streams occupies n / 32 of the 256 CUs: 1 024 streams
+// (BASELINE.json configs[1]) use 32 CUs, 4 096 (configs[3]) half the chip - and a tile takes the same ~47 us however few
+// there are.  This kernel is the same network, the same algebra (frame ingest under the recurrent gate half, 4-way folded DFT,
+// Toom-3 enc0, split-K enc2) and the same per-stream results, re-expressed on v_mfma_f32_16x16x4_f32: a workgroup (4 waves)
+// carries 16 streams, so the same batch spreads over twice as many CUs and every MFMA / VALU phase is half as long.
+// The engine picks it when a call has at most T16_MAX_STREAMS streams (engine.cpp).
+//
+// Fragment convention (v_mfma_f32_16x16x4_f32, D = A[16 x 4] B[4 x 16] + C): lane l = (n = l & 15, kq = l >> 4).
+//   A: lane (row n, kq) holds W[row][k = kq]       B: lane (stream n, kq) holds X[k = kq][n]
+//   D: lane (stream n, rq = kq) holds rows 4 rq .. 4 rq + 3 of the 16-row tile  ->  exactly one LDS quad.
+// One k-iteration j contracts 16 channels: lane (n, kq) reads activation quad row 4 j + kq of stream n (ONE ds_read_b128, the B
+// operands of 4 MFMAs: component i = channel 16 j + 4 kq + i) and a 1 KiB weight block gives it W[row n][16 j + 4 kq + i].
+// A wave owns 32 output channels = two row tiles rt = 0, 1: channel 32 w + 16 rt + 4 rq + i lives in quad row 8 w + 4 rt + rq.
+// LDS quad row: 16 streams x float4 (+1 of padding: stride QS16 = 17 float4).  Weight stream: pack_silero_v5_t16.
+#include <hip/hip_runtime.h>
+#include "vad_layout.h"
+#include "sm_device.h"
+#include "vadk_device.h"
+
+using namespace vadk;
+using namespace vadk::dev;
+
+namespace {
+
+constexpr int MT16 = 16;
+constexpr int QS16 = 17;
+// LDS rows (quads of 16 streams): the activation region X as in vad_layout.h (v5) except that the Nyquist channel takes 8 rows
+// (values on the kq = 0 row of a group of four, zeros on the other three): rows 160..163 = points 0, 1, -1, 2; 164..167 = infinity
+constexpr int T_ROW_NYQ = 160;
+constexpr int T_ROW_E = 168;              // enc0 output: 168 + 32 c + ch/4; enc2 partials: 168 + 16 half + ch/4
+constexpr int T_ROWS_X = 264;
+constexpr int T_ROWS_H = 32;
+constexpr int T_LDS_F4 = (T_ROWS_X + T_ROWS_H) * QS16 + 16 + 12 + 36 + 16 + 96;   // + head partials [4][16], |X128| [3][16], fold corrections [3][3][16], sink [64], state machines [16] x 96 B
+
+__device__ __forceinline__ f32x4 mfma16(f32x4 w, f32x4 a, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a.w, acc, 0, 0, 0);
+    return acc;
+}
+
+}  // namespace
+
+template <bool F32IN>
+__global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams P) {
+    using namespace vadk::v5;
+    __shared__ f32x4 lds[T_LDS_F4];
+    f32x4 *const RX = lds;
+    f32x4 *const RE = lds + T_ROW_E * QS16;
+    f32x4 *const RH = lds + T_ROWS_X * QS16;
+    float *const headp = reinterpret_cast<float *>(RH + T_ROWS_H * QS16);   // [4][16]
+    float *const nyqv = headp + 64;              // [3][16]
+    float *const fcor = nyqv + 48;               // [3 columns][y128, a64, b64][16 streams]
+    constexpr int FCOR_SINK = 144;               // [64] floats after fcor
+    SmSlot *const smL = reinterpret_cast<SmSlot *>(fcor + 144 + 64);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15;                      // stream of this lane's MFMA column
+    const int kq = lane >> 4;                     // channel group (B operand) = row quad of the D tile
+    const int nq = kq * QS16 + n;                 // lane's offset inside a group of 4 quad rows
+    const int tile0 = blockIdx.x * MT16;
+    const int gf = tile0 + n;
+    const bool live = gf < P.n;
+    const int slot = live ? (P.slots ? P.slots[gf] : gf) : 0;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wstream), 0, (int)P.wstream_bytes, 0x00020000);
+    const int lane16 = lane * 16;
+#define WL(blk) ldw(wrs, lane16, (blk))
+    const int o_stft = (int)P.sect[w][S_STFT], o_nyq = (int)P.sect[w][S_NYQ], o_e0 = (int)P.sect[w][S_ENC0];
+    const int o_e1 = (int)P.sect[w][S_ENC1], o_e2 = (int)P.sect[w][S_ENC2], o_e3 = (int)P.sect[w][S_ENC3];
+    const int o_l = (int)P.sect[w][S_LSTM];
+    const int T = P.T;
+
+    // ---- frame ingest set-up: 16 lanes per stream, 16 streams per fold call (ms = tid >> 4) ----
+    const float thr = P.thresh;
+    const int q = tid & 15;
+    const bool q0 = q == 0;
+    constexpr bool f32in = F32IN;
+    constexpr int qsh = f32in ? 4 : 3;
+    const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
+    u32x4 xa_[4], xb_[4], xc_[4];                  // raw quads of the three columns
+#define X_ISSUE(c, XR, tt)                                                                                      \
+    {                                                                                                           \
+        const int fq = ((tile0 + (tid >> 4)) * T + (tt)) * 128 + 32 * (c) + q;                                  \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                           \
+            XR[k] = __builtin_amdgcn_raw_buffer_load_b128(frs, (fq + 16 * k) << qsh, 0, 0);                     \
+    }
+
+    // ---- prologue: h_{t-1} -> LDS quads (32 rows x 16 streams), c_{t-1} -> registers, state machines -> LDS ----
+    f32x4 hv[2];
+    const int fm = tid & 15, part = tid >> 4;      // fm == n: ONE slot lookup serves h, c and the state machine
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(P.state + (size_t)slot * 256)[part * 2 + qq];
+        hv[qq] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x4 W1 = ldw(wrs, q * 16, o_nyq), W3 = ldw(wrs, (32 + q) * 16, o_nyq);
+    const float w64 = ldw(wrs, 16 * 16, o_nyq).x;
+    f32x4 cst[2];                                  // c of units 32 w + 16 rt + 4 kq + i
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(P.state + (size_t)slot * 256 + 128 + 32 * w + 16 * rt + 4 * kq);
+        cst[rt] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool sm_thread = (tid < MT16) && live;
+    const int sm_slot = slot;
+    f32x4 smq[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) smq[k] = reinterpret_cast<const f32x4 *>(P.sm + slot)[k];
+    SB();
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) RH[(part * 2 + qq) * QS16 + fm] = hv[qq];
+    int seg_last = 0;
+    if (tid < MT16) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) reinterpret_cast<f32x4 *>(smL + tid)[k] = smq[k];
+    }
+    const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];
+
+    for (int t = 0; t < T; ++t) {
+        int ws_stft = o_stft, ws_e0 = o_e0, ws_e1 = o_e1, ws_e2 = o_e2, ws_e3 = o_e3, ws_l = o_l;
+        asm volatile("" : "+s"(ws_stft), "+s"(ws_e0), "+s"(ws_e1), "+s"(ws_e2), "+s"(ws_e3), "+s"(ws_l));
+        // ---- recurrent gate half W_hh . h_{t-1} (8 k-iterations x {4 gates x 2 row tiles}) with the frame ingested under it ----
+        f32x4 G[8];                               // gate q, row tile rt -> G[2 q + rt]
+        {
+            const int wh = ws_l + 8 + 64;
+            auto decode = [&](u32x4 b) -> f32x4 {
+                f32x4 v = __builtin_bit_cast(f32x4, b);
+                if constexpr (!f32in) {
+                    const int s0 = (int)(short)(b.x & 0xffffu), s1 = (int)(short)(b.x >> 16);
+                    const int s2 = (int)(short)(b.y & 0xffffu), s3 = (int)(short)(b.y >> 16);
+                    v = f32x4{(float)s0 / sc, (float)s1 / sc, (float)s2 / sc, (float)s3 / sc};
+                }
+                return gate4(v, thr);
+            };
+            auto mirror = [](float v) -> float {
+                return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+            };
+            auto shr1 = [](float edge, float v) -> float {
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+            };
+            // the fold of silero_v5.hip, one call per column: stream ms = tid >> 4, n = 4 q + j
+#define X_FOLD(c, XR)                                                                                           \
+    {                                                                                                           \
+        _Pragma("clang fp contract(off)")                                                                       \
+        const int ms = tid >> 4;                                                                                \
+        const f32x4 xA = decode(XR[0]), xB = decode(XR[1]), xC = decode(XR[2]), xD = decode(XR[3]);             \
+        const float mBx = mirror(xB.x), mDx = mirror(xD.x);                                                     \
+        const f32x4 y1 = f32x4{xA.x * W1.x, xA.y * W1.y, xA.z * W1.z, xA.w * W1.w};                             \
+        const f32x4 y3 = f32x4{xC.x * W3.x, xC.y * W3.y, xC.z * W3.z, xC.w * W3.w};                             \
+        const f32x4 y2 = f32x4{shr1(xC.x, mBx) * W3.x, mirror(xB.w) * W3.y, mirror(xB.z) * W3.z, mirror(xB.y) * W3.w}; \
+        const f32x4 y4 = f32x4{shr1(0.f, mDx) * W1.x, mirror(xD.w) * W1.y, mirror(xD.z) * W1.z, mirror(xD.y) * W1.w};  \
+        const f32x4 s14 = f32x4{y1.x + y4.x, y1.y + y4.y, y1.z + y4.z, y1.w + y4.w};                            \
+        const f32x4 d14 = f32x4{y1.x - y4.x, y1.y - y4.y, y1.z - y4.z, y1.w - y4.w};                            \
+        const f32x4 s23 = f32x4{y2.x + y3.x, y2.y + y3.y, y2.z + y3.z, y2.w + y3.w};                            \
+        const f32x4 d23 = f32x4{y2.x - y3.x, y2.y - y3.y, y2.z - y3.z, y2.w - y3.w};                            \
+        f32x4 pe = f32x4{s14.x + s23.x, s14.y + s23.y, s14.z + s23.z, s14.w + s23.w};                           \
+        f32x4 po = f32x4{s14.x - s23.x, s14.y - s23.y, s14.z - s23.z, s14.w - s23.w};                           \
+        f32x4 qe = f32x4{d14.x - d23.x, d14.y - d23.y, d14.z - d23.z, d14.w - d23.w};                           \
+        f32x4 qo = f32x4{d14.x + d23.x, d14.y + d23.y, d14.z + d23.z, d14.w + d23.w};                           \
+        {                                                                                                       \
+            pe.x = q0 ? 0.f : pe.x; po.x = q0 ? 0.f : po.x; qe.x = q0 ? 0.f : qe.x; qo.x = q0 ? 0.f : qo.x;        \
+            const float y64 = xB.x * w64, y192 = xD.x * w64;                                                    \
+            const int fo = q0 ? (c) * 48 + ms : FCOR_SINK + lane;                                               \
+            fcor[fo] = y3.x;                                                                                    \
+            fcor[fo + (q0 ? 16 : 0)] = y64 + y192;                                                              \
+            fcor[fo + (q0 ? 32 : 0)] = y64 - y192;                                                              \
+        }                                                                                                       \
+        st2(&RX[(64 * (c) + q) * QS16 + ms], pe);                                                               \
+        st2(&RX[(64 * (c) + 16 + q) * QS16 + ms], po);                                                          \
+        st2(&RX[(64 * (c) + 32 + q) * QS16 + ms], qe);                                                          \
+        st2(&RX[(64 * (c) + 48 + q) * QS16 + ms], qo);                                                          \
+    }
+#define H_LDW(WS, g) _Pragma("unroll") for (int k = 0; k < 8; ++k) WS[k] = WL(wh + 8 * (g) + k);
+#define H_MMA(WS, g)                                                                                            \
+    {                                                                                                           \
+        const f32x4 av = RH[(4 * (g)) * QS16 + nq];                                                             \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) G[k] = mfma16(WS[k], av, G[k]);                           \
+    }
+#define H_MIX                                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x002, 40, 0);                                                     \
+    }
+            f32x4 wA[8], wB[8], nb[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) nb[k] = WL(ws_l + k);
+            H_LDW(wA, 0)
+            SB();
+            H_LDW(wB, 1) X_ISSUE(0, xa_, t) X_ISSUE(1, xb_, t) SB();
+            __syncthreads();   // (0) h_{t-1} visible (t > 0: follows barrier (8))
+#pragma unroll
+            for (int k = 0; k < 8; ++k) G[k] = nb[k];
+            H_MMA(wA, 0) SB();
+            H_LDW(wA, 2) X_ISSUE(2, xc_, t) SB(); H_MMA(wB, 1) SB();
+            H_LDW(wB, 3) SB(); H_MMA(wA, 2) X_FOLD(0, xa_) H_MIX SB();
+            H_LDW(wA, 4) SB(); H_MMA(wB, 3) SB();
+            H_LDW(wB, 5) SB(); H_MMA(wA, 4) X_FOLD(1, xb_) H_MIX SB();
+            H_LDW(wA, 6) SB(); H_MMA(wB, 5) SB();
+            H_LDW(wB, 7) SB(); H_MMA(wA, 6) X_FOLD(2, xc_) H_MIX SB();
+            H_MMA(wB, 7) SB();
+#undef H_MIX
+#undef H_MMA
+#undef H_LDW
+#undef X_FOLD
+        }
+        f32x4 Sw[4];                              // STFT blocks of k-iteration 0: cos rt0, cos rt1, -sin rt0, -sin rt1
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Sw[k] = WL(ws_stft + k);
+        SB();
+        __syncthreads();   // (1) folded x visible
+
+        // ---- bin 128 on the VALU: 48 (column, stream) pairs, 4 lanes each ----
+        {
+            const int pair = tid >> 2, pt = tid & 3;
+            const int c = pair >> 4, ms = pair & 15;
+            float a = 0.f;
+            if (pair < 48) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 pp = RX[(64 * c + pt * 4 + i) * QS16 + ms];
+                    a += (pp.x - pp.y) + (pp.z - pp.w);
+                }
+            }
+            a += __shfl_xor(a, 1);
+            a += __shfl_xor(a, 2);
+            if (pair < 48 && pt == 0) nyqv[c * 16 + ms] = fabsf(a + fcor[(c * 3 + 0) * 16 + ms] + fcor[(c * 3 + 1) * 16 + ms]);
+        }
+
+        // ---- STFT: wave w owns bins bin_of_channel(32 w + 16 rt + r): cos on pe | po, -sin on qe | qo, 3 columns, K = 64 ----
+        f32x4 e0b[2], E0w[10];
+        {
+            f32x4 are[3][2], aim[3][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float y128 = fcor[(c * 3 + 0) * 16 + n], a64 = fcor[(c * 3 + 1) * 16 + n], b64 = fcor[(c * 3 + 2) * 16 + n];
+                const float rp = w < 2 ? y128 + a64 : -y128, rm = w < 2 ? y128 - a64 : -y128;
+                const float ip = w < 2 ? 0.f : -b64, im_ = w < 2 ? 0.f : b64;
+                // register i of a D quad is tile row 4 rq + i (+ 16 rt): (-1)^row = (-1)^i
+                are[c][0] = are[c][1] = f32x4{rp, rm, rp, rm};
+                aim[c][0] = aim[c][1] = f32x4{ip, im_, ip, im_};
+            }
+            const int rR = w < 2 ? 0 : 16, rI = w < 2 ? 32 : 48;
+            const f32x4 *const XR = RX + rR * QS16 + nq, *const XI = RX + rI * QS16 + nq;
+            f32x4 Aw[4], Bw[4], Au[3], Av[3], Bu[3], Bv[3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Aw[k] = Sw[k];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { Au[c] = XR[(64 * c) * QS16]; Av[c] = XI[(64 * c) * QS16]; }
+#define S_LD(S, jj)                                                                        \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) S##w[k] = WL(ws_stft + 4 * (jj) + k);    \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) { S##u[c] = XR[(64 * c + 4 * (jj)) * QS16]; S##v[c] = XI[(64 * c + 4 * (jj)) * QS16]; }
+#define S_MMA(S)                                                                           \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                        \
+        are[c][0] = mfma16(S##w[0], S##u[c], are[c][0]); are[c][1] = mfma16(S##w[1], S##u[c], are[c][1]);   \
+        aim[c][0] = mfma16(S##w[2], S##v[c], aim[c][0]); aim[c][1] = mfma16(S##w[3], S##v[c], aim[c][1]);   \
+    }
+            for (int j = 0; j < 4; j += 2) {
+                S_LD(B, j + 1) SB();
+                S_MMA(A) SB();
+                const int jn = j + 2 < 4 ? j + 2 : 2;
+                S_LD(A, jn) SB();
+                S_MMA(B) SB();
+            }
+#undef S_LD
+#undef S_MMA
+            e0b[0] = WL(ws_e0); e0b[1] = WL(ws_e0 + 1);
+#pragma unroll
+            for (int k = 0; k < 10; ++k) E0w[k] = WL(ws_e0 + 2 + k);
+            SB();
+            __syncthreads();   // (1b) every wave is done reading the folded operands: the magnitudes may overwrite them
+            // |.| -> Toom-3 evaluation planes, rows 32 p + 8 w + 4 rt + kq
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                f32x4 mg[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x4 r = are[c][rt], i = aim[c][rt];
+                    mg[c] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
+                }
+                const f32x4 s02 = f32x4{mg[0].x + mg[2].x, mg[0].y + mg[2].y, mg[0].z + mg[2].z, mg[0].w + mg[2].w};
+                f32x4 *o = RX + (8 * w + 4 * rt) * QS16 + nq;
+                st2(o, mg[0]);
+                st2(o + 32 * QS16, f32x4{s02.x + mg[1].x, s02.y + mg[1].y, s02.z + mg[1].z, s02.w + mg[1].w});
+                st2(o + 64 * QS16, f32x4{s02.x - mg[1].x, s02.y - mg[1].y, s02.z - mg[1].z, s02.w - mg[1].w});
+                st2(o + 96 * QS16, f32x4{fmaf(4.f, mg[2].x, fmaf(2.f, mg[1].x, mg[0].x)), fmaf(4.f, mg[2].y, fmaf(2.f, mg[1].y, mg[0].y)),
+                                         fmaf(4.f, mg[2].z, fmaf(2.f, mg[1].z, mg[0].z)), fmaf(4.f, mg[2].w, fmaf(2.f, mg[1].w, mg[0].w))});
+                st2(o + 128 * QS16, mg[2]);
+            }
+            if (tid < 64) {      // |X128|: values on the kq = 0 rows (160, 164), zeros on the other three of each group
+                const float n0 = nyqv[n], n1 = nyqv[16 + n], n2 = nyqv[32 + n];
+                const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                RX[T_ROW_NYQ * QS16 + nq] = kq == 0 ? f32x4{n0, (n0 + n2) + n1, (n0 + n2) - n1, fmaf(4.f, n2, fmaf(2.f, n1, n0))} : z4;
+                RX[(T_ROW_NYQ + 4) * QS16 + nq] = kq == 0 ? f32x4{n2, 0.f, 0.f, 0.f} : z4;
+            }
+        }
+        __syncthreads();   // (2) magnitudes complete
+
+        // ---- enc0 (Toom-3): five point-wise contractions over 128 channels (8 k-iterations) + the Nyquist channel ----
+        f32x4 e1b[2], E1w[2];
+        {
+            const int ws = ws_e0 + 2;
+            f32x4 acc[5][2];
+#pragma unroll
+            for (int p = 0; p < 5; ++p) acc[p][0] = acc[p][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 Aw[10], Bw[10], Aa[5], Ba[5];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) Aw[k] = E0w[k];
+#pragma unroll
+            for (int p = 0; p < 5; ++p) Aa[p] = RX[(32 * p) * QS16 + nq];
+#define E0_LD(S, jj)                                                                       \
+    _Pragma("unroll") for (int k = 0; k < 10; ++k) S##w[k] = WL(ws + 10 * (jj) + k);       \
+    _Pragma("unroll") for (int p = 0; p < 5; ++p) S##a[p] = RX[(32 * p + 4 * (jj)) * QS16 + nq];
+#define E0_MMA(S)                                                                          \
+    _Pragma("unroll") for (int p = 0; p < 5; ++p) {                                        \
+        acc[p][0] = mfma16(S##w[2 * p], S##a[p], acc[p][0]); acc[p][1] = mfma16(S##w[2 * p + 1], S##a[p], acc[p][1]); \
+    }
+            for (int j = 0; j < 8; j += 2) {
+                E0_LD(B, j + 1) SB();
+                E0_MMA(A) SB();
+                const int jn = j + 2 < 8 ? j + 2 : 6;
+                E0_LD(A, jn) SB();
+                E0_MMA(B) SB();
+            }
+#undef E0_LD
+#undef E0_MMA
+            {   // input channel 128 (Nyquist bin): K = 4 MFMAs whose k = 1..3 slots are zero on both operands
+                const f32x4 an = RX[T_ROW_NYQ * QS16 + nq], bn = RX[(T_ROW_NYQ + 4) * QS16 + nq];
+                const f32x4 wa0 = WL(ws + 80), wa1 = WL(ws + 81), wb0 = WL(ws + 82), wb1 = WL(ws + 83);
+                e1b[0] = WL(ws_e1); e1b[1] = WL(ws_e1 + 1);
+                E1w[0] = WL(ws_e1 + 2); E1w[1] = WL(ws_e1 + 3);
+                SB();
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0.x, an.x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1.x, an.x, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0.y, an.y, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1.y, an.y, acc[1][1], 0, 0, 0);
+                acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0.z, an.z, acc[2][0], 0, 0, 0);
+                acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1.z, an.z, acc[2][1], 0, 0, 0);
+                acc[3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0.w, an.w, acc[3][0], 0, 0, 0);
+                acc[3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1.w, an.w, acc[3][1], 0, 0, 0);
+                acc[4][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb0.x, bn.x, acc[4][0], 0, 0, 0);
+                acc[4][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb1.x, bn.x, acc[4][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {      // interpolation (P(1), P(-1) arrive halved) + bias + ReLU -> rows 168 + 32 c + 8 w + 4 rt + kq
+                const f32x4 bias = e0b[rt];
+                const f32x4 y0 = acc[0][rt], y4 = acc[4][rt];
+                const f32x4 bb = acc[1][rt] - acc[2][rt];
+                const f32x4 y2 = (acc[1][rt] + acc[2][rt]) - y0 - y4;
+                const f32x4 t2 = (acc[3][rt] - y0) - 4.0f * y2 - 16.0f * y4;
+                const f32x4 y3 = t2 * (1.0f / 6.0f) - bb * (1.0f / 3.0f);
+                f32x4 *o = RE + (8 * w + 4 * rt) * QS16 + nq;
+                o[0] = relu4((bb - y3) + bias);
+                o[32 * QS16] = relu4(y2 + bias);
+                o[64 * QS16] = relu4(y3 + bias);
+            }
+        }
+        __syncthreads();   // (3) enc0 out
+
+        // ---- enc1: 128 -> 64 ch, k3 s2 p1, 3 -> 2 columns; wave w: n-tile w & 1, column w >> 1; 16 k-iterations ----
+        f32x4 e2b[2], E2w[2], e3b[2], E3w[2];
+        {
+            const int nt = w & 1, tp = w >> 1;
+            const int ws = ws_e1 + 2;
+            f32x4 acc[2] = {e1b[0], e1b[1]};
+#define E1_ROW(it) (RE + ((tp + ((it) >> 3)) * 32 + 4 * ((it) & 7)) * QS16 + nq)
+            f32x4 Aw[2] = {E1w[0], E1w[1]}, Bw[2], Aa = *E1_ROW(0), Ba;
+            for (int it = 0; it < 16; it += 2) {
+                Bw[0] = WL(ws + 2 * (it + 1)); Bw[1] = WL(ws + 2 * (it + 1) + 1); Ba = *E1_ROW(it + 1); SB();
+                acc[0] = mfma16(Aw[0], Aa, acc[0]); acc[1] = mfma16(Aw[1], Aa, acc[1]); SB();
+                const int itn = it + 2 < 16 ? it + 2 : 14;
+                Aw[0] = WL(ws + 2 * itn); Aw[1] = WL(ws + 2 * itn + 1); Aa = *E1_ROW(itn); SB();
+                if (it == 14) {     // next layers' first blocks (enc2: this wave's K half)
+                    const int ge = 2 + 8 * (w >> 1);
+                    e2b[0] = WL(ws_e2); e2b[1] = WL(ws_e2 + 1);
+                    E2w[0] = WL(ws_e2 + ge); E2w[1] = WL(ws_e2 + ge + 1);
+                    e3b[0] = WL(ws_e3); e3b[1] = WL(ws_e3 + 1);
+                    E3w[0] = WL(ws_e3 + 2); E3w[1] = WL(ws_e3 + 3);
+                    SB();
+                }
+                acc[0] = mfma16(Bw[0], Ba, acc[0]); acc[1] = mfma16(Bw[1], Ba, acc[1]); SB();
+            }
+#undef E1_ROW
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) RX[(16 * tp + 8 * nt + 4 * rt) * QS16 + nq] = relu4(acc[rt]);
+        }
+        __syncthreads();   // (4) enc1 out in rows 0..31
+
+        // ---- enc2: 64 -> 64 ch, k3 s2 p1, 2 -> 1 column; split-K: wave w = tile w & 1, K half (= input column) w >> 1 ----
+        {
+            const int kh = w >> 1;
+            const int ws = ws_e2 + 2 + 8 * kh;     // this half's 4 k-iterations x 2 row tiles
+            f32x4 acc[2];
+            acc[0] = kh == 0 ? e2b[0] : f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[1] = kh == 0 ? e2b[1] : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 wv[8], av[4];
+            wv[0] = E2w[0]; wv[1] = E2w[1];
+#pragma unroll
+            for (int k = 2; k < 8; ++k) wv[k] = WL(ws + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[j] = RX[(16 * kh + 4 * j) * QS16 + nq];
+            SB();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[0] = mfma16(wv[2 * j], av[j], acc[0]); acc[1] = mfma16(wv[2 * j + 1], av[j], acc[1]); }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) RE[(16 * kh + 8 * (w & 1) + 4 * rt) * QS16 + nq] = acc[rt];
+        }
+        __syncthreads();   // (5) enc2 partials
+
+        // ---- enc3: 64 -> 128 ch, centre tap; input = relu(partial of K half 0 + K half 1) ----
+        f32x4 Lw[8];
+        {
+            const int ws = ws_e3 + 2;
+            f32x4 acc[2] = {e3b[0], e3b[1]};
+            f32x4 wv[8], av[4];
+            wv[0] = E3w[0]; wv[1] = E3w[1];
+#pragma unroll
+            for (int k = 2; k < 8; ++k) wv[k] = WL(ws + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a = RE[(4 * j) * QS16 + nq], b2 = RE[(16 + 4 * j) * QS16 + nq];
+                av[j] = relu4(f32x4{a.x + b2.x, a.y + b2.y, a.z + b2.z, a.w + b2.w});
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) Lw[k] = WL(ws_l + 8 + k);      // first k-iteration of the LSTM's input half
+            SB();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[0] = mfma16(wv[2 * j], av[j], acc[0]); acc[1] = mfma16(wv[2 * j + 1], av[j], acc[1]); }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) RX[(8 * w + 4 * rt) * QS16 + nq] = relu4(acc[rt]);
+        }
+        __syncthreads();   // (6) LSTM input x in rows 0..31
+
+        // ---- LSTM: input half W_ih . x on top of the recurrent half, cell, head partial ----
+        {
+            const int ws = ws_l + 8;
+            f32x4 Aw[8], Bw[8], Aa = RX[nq], Ba, hw[2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) Aw[k] = Lw[k];
+#define L_LD(S, it) _Pragma("unroll") for (int k = 0; k < 8; ++k) S##w[k] = WL(ws + 8 * (it) + k); S##a = RX[(4 * (it)) * QS16 + nq];
+#define L_MMA(S) _Pragma("unroll") for (int k = 0; k < 8; ++k) G[k] = mfma16(S##w[k], S##a, G[k]);
+            for (int it = 0; it < 8; it += 2) {
+                L_LD(B, it + 1) SB();
+                L_MMA(A) SB();
+                const int itn = it + 2 < 8 ? it + 2 : 6;
+                L_LD(A, itn) SB();
+                if (it == 6) { hw[0] = WL(ws + 128); hw[1] = WL(ws + 129); SB(); }
+                L_MMA(B) SB();
+            }
+#undef L_LD
+#undef L_MMA
+            __syncthreads();   // (7) every wave is done reading h_{t-1}
+            float part_ = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const f32x4 i4 = G[0 + rt], f4 = G[2 + rt], g4 = G[4 + rt], o4 = G[6 + rt], c4 = cst[rt], hwv = hw[rt];
+                f32x4 cn, hn;
+#define CELL(k)                                                             \
+    cn.k = sigmoidf_(f4.k) * c4.k + sigmoidf_(i4.k) * tanhf_(g4.k);       \
+    hn.k = sigmoidf_(o4.k) * tanhf_(cn.k);                                \
+    part_ += hwv.k * fmaxf(hn.k, 0.f);
+                CELL(x) CELL(y) CELL(z) CELL(w)
+#undef CELL
+                RH[(8 * w + 4 * rt) * QS16 + nq] = hn;
+                if (t == T - 1 && live) {
+                    *reinterpret_cast<f32x4 *>(P.state + (size_t)slot * 256 + 32 * w + 16 * rt + 4 * kq) = hn;
+                    *reinterpret_cast<f32x4 *>(P.state + (size_t)slot * 256 + 128 + 32 * w + 16 * rt + 4 * kq) = cn;
+                }
+                cst[rt] = cn;
+            }
+            part_ += __shfl_xor(part_, 16);
+            part_ += __shfl_xor(part_, 32);
+            if (kq == 0) headp[w * 16 + n] = part_;
+        }
+        __syncthreads();   // (8) head partials + new h visible
+
+        if (tid < MT16) {
+            const float z = hb + ((headp[tid] + headp[16 + tid]) + (headp[32 + tid] + headp[48 + tid]));
+            const float p = fminf(sigmoidf_(z), 1.0f);
+            if (sm_thread) {
+                P.probs[(size_t)(tile0 + tid) * T + t] = p;
+                SmSlot sm = smL[tid];
+                int seg = 0;
+                const int ev = sm_step(sm, p, &seg);
+                if (t == T - 1) P.sm[sm_slot] = sm;
+                else smL[tid] = sm;
+                if (ev & 2) seg_last = seg;
+                if (P.events) P.events[(size_t)(tile0 + tid) * T + t] = (uint8_t)ev;
+            }
+        }
+    }
+#undef X_ISSUE
+#undef WL
+    if (sm_thread && P.seg_frames) P.seg_frames[tile0 + tid] = seg_last;
+}
+
+extern "C" hipError_t vadk_launch_silero_v5_t16(const vadk::StepParams *p, hipStream_t stream) {
+    (void)hipGetLastError();
+    const int tiles = (p->n + MT16 - 1) / MT16;
+    if (tiles <= 0) return hipSuccess;
+    if (p->fmt == 0)
+        hipLaunchKernelGGL(silero_v5_step16<true>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+    else
+        hipLaunchKernelGGL(silero_v5_step16<false>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+    return hipGetLastError();
+}

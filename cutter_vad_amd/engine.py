@@ -86,6 +86,10 @@ class Engine:
         out["arch"] = inf.arch.decode()
         return out
 
+    def set_tile(self, streams_per_tile: int = 0) -> None:
+        """Diagnostic (``vad_debug_set_tile``): 0 = pick the kernel shape by batch size, 16 / 32 = force it."""
+        self._check(self._lib.vad_debug_set_tile(self._h, int(streams_per_tile)), VADError)
+
     def synchronize(self) -> None:
         self._check(self._lib.vad_engine_synchronize(self._h))
 

@@ -334,6 +334,13 @@ VAD_API int vad_debug_pack_resample(int32_t n_in, float *out, size_t out_floats,
 VAD_API int vad_debug_sm_replay(vad_engine *e, int64_t slot, const float *probs, int64_t n, uint8_t *events_out,
                                 int32_t *seg_frames_out);
 
+/*
+ * Diagnostic: which kernel shape serves the step calls of a Silero V5 16 kHz engine.  0 (default) = by batch size: calls with
+ * at most 4 096 streams run on 16-stream tiles (twice as many workgroups, half as long each), larger ones on 32-stream tiles;
+ * 16 / 32 force one shape (the test-suite checks that both give the same bits; tools/bench_configs.py times them).
+ */
+VAD_API int vad_debug_set_tile(vad_engine *e, int32_t streams_per_tile);
+
 /* block until everything enqueued on the engine's own stream has finished */
 VAD_API int vad_engine_synchronize(vad_engine *e);
 

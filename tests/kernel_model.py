@@ -539,3 +539,161 @@ def resample_512(x):
     od = ops[2] @ row[Q:2 * Q].astype(np.float64) + row[2 * Q + 1] * mids[1]
     y[:, 128], y[:, 384] = e + od, e - od
     return y[:n]
+
+
+# ======================================================================================
+#  Silero V5 on 16-stream tiles: model of silero_v5_t16.hip over pack_silero_v5_t16's streams
+# ======================================================================================
+def _mfma16(wblk, a):
+    """wblk [64,4] (lane = kq*16 + row), a [64,4] (lane = kq*16 + m) -> D[row, m] contribution (K = 16 channels)."""
+    w = wblk.astype(np.float64).reshape(4, 16, 4)
+    x = a.astype(np.float64).reshape(4, 16, 4)
+    return np.einsum("kri,kmi->rm", w, x)
+
+
+def _rows16(region, base):
+    """activation fragment of one k-iteration: lane (m, kq) reads quad row base + kq of stream m"""
+    return np.concatenate([region[base + k] for k in range(4)], axis=0)      # [64, 4]
+
+
+def _vec16(block):
+    """one D-layout vector block -> per-channel vector [16] (channel = 4 rq + i)"""
+    return block.astype(np.float64).reshape(4, 16, 4)[:, 0, :].reshape(16)
+
+
+def _store16(region, row0, acc, relu=True):
+    v = np.maximum(acc, 0) if relu else acc
+    for rq in range(4):
+        region[row0 + rq] = v[4 * rq:4 * rq + 4].T                             # [16 m, 4]
+
+
+def v5_step_t16(W, sect, x, hc, gate=0.01):
+    """x [16,512] f32, hc [16,256] -> (prob [16], new hc [16,256]); float64 contractions; mirrors silero_v5_t16.hip."""
+    ROW_NYQ, ROW_E = 160, 168
+    x = x.astype(np.float64)
+    if gate is not None and gate >= 0:
+        x = np.where(np.abs(x) > gate, x, 0.0)
+    RX = np.zeros((264, 16, 4))
+    RE = RX[ROW_E:]
+    RH = hc[:, :128].astype(np.float64).reshape(16, 32, 4).transpose(1, 0, 2).copy()
+    c_prev = hc[:, 128:].astype(np.float64)
+    wtab = W[sect[0][S_NYQ]].reshape(-1)[:256].astype(np.float64)
+    fcor = np.zeros((3, 3, 16))
+    for c in range(3):
+        y = x[:, 128 * c:128 * c + 256] * wtab[None, :]
+        n = np.arange(64)
+        y1, y2, y3, y4 = y[:, n], y[:, 128 - n], y[:, 128 + n], y[:, (256 - n) % 256]
+        for k, arr in enumerate((y1 + y4 + y2 + y3, y1 + y4 - y2 - y3, y1 - y4 - y2 + y3, y1 - y4 + y2 - y3)):
+            arr = arr.copy()
+            arr[:, 0] = 0.0
+            RX[64 * c + 16 * k:64 * c + 16 * k + 16] = arr.reshape(16, 16, 4).transpose(1, 0, 2)
+        fcor[c] = y[:, 128], y[:, 64] + y[:, 192], y[:, 64] - y[:, 192]
+    nyq = np.zeros((3, 16))
+    for c in range(3):
+        pe = RX[64 * c:64 * c + 16]
+        nyq[c] = np.abs((pe[:, :, 0] - pe[:, :, 1] + pe[:, :, 2] - pe[:, :, 3]).sum(0) + fcor[c, 0] + fcor[c, 1])
+    sgn = np.where(np.arange(16) % 2 == 0, 1.0, -1.0)[:, None]
+    mags = {}
+    for w in range(4):
+        ws = sect[w][S_STFT]
+        rR, rI = (0, 32) if w < 2 else (16, 48)
+        are = [[np.zeros((16, 16)) for _ in range(2)] for _ in range(3)]
+        aim = [[np.zeros((16, 16)) for _ in range(2)] for _ in range(3)]
+        for j in range(4):
+            blk = W[ws + 4 * j:ws + 4 * j + 4]
+            for c in range(3):
+                u, v = _rows16(RX, 64 * c + rR + 4 * j), _rows16(RX, 64 * c + rI + 4 * j)
+                for rt in range(2):
+                    are[c][rt] += _mfma16(blk[rt], u)
+                    aim[c][rt] += _mfma16(blk[2 + rt], v)
+        for c in range(3):
+            y128, a64, b64 = fcor[c, 0][None, :], fcor[c, 1][None, :], fcor[c, 2][None, :]
+            for rt in range(2):
+                re, im = (are[c][rt] + y128 + sgn * a64, aim[c][rt]) if w < 2 else (are[c][rt] - y128, aim[c][rt] - sgn * b64)
+                mags[w, c, rt] = np.sqrt(re ** 2 + im ** 2)
+    for w in range(4):
+        for rt in range(2):
+            m0, m1, m2 = (mags[w, c, rt] for c in range(3))
+            for p, v in enumerate((m0, (m0 + m2) + m1, (m0 + m2) - m1, m0 + 2 * m1 + 4 * m2, m2)):
+                _store16(RX, 32 * p + 8 * w + 4 * rt, v, relu=False)
+    n0, n1, n2 = nyq
+    RX[ROW_NYQ:ROW_NYQ + 8] = 0
+    RX[ROW_NYQ] = np.stack([n0, (n0 + n2) + n1, (n0 + n2) - n1, n0 + 2 * n1 + 4 * n2], axis=1)
+    RX[ROW_NYQ + 4] = np.stack([n2, np.zeros(16), np.zeros(16), np.zeros(16)], axis=1)
+    E0 = {}
+    for w in range(4):
+        ws = sect[w][S_ENC0]
+        P = [[np.zeros((16, 16)) for _ in range(2)] for _ in range(5)]
+        for j in range(8):
+            for p in range(5):
+                a = _rows16(RX, 32 * p + 4 * j)
+                for rt in range(2):
+                    P[p][rt] += _mfma16(W[ws + 2 + 10 * j + 2 * p + rt], a)
+        an, bn = _rows16(RX, ROW_NYQ), _rows16(RX, ROW_NYQ + 4)
+        for rt in range(2):
+            wa = W[ws + 82 + rt].astype(np.float64).reshape(4, 16, 4)
+            wb = W[ws + 84 + rt].astype(np.float64).reshape(4, 16, 4)
+            for p in range(4):
+                P[p][rt] += np.einsum("kr,km->rm", wa[:, :, p], an.reshape(4, 16, 4)[:, :, p])
+            P[4][rt] += np.einsum("kr,km->rm", wb[:, :, 0], bn.reshape(4, 16, 4)[:, :, 0])
+            bias = np.repeat(_vec16(W[ws + rt])[:, None], 16, 1)
+            y0, y4 = P[0][rt], P[4][rt]
+            bb = P[1][rt] - P[2][rt]
+            y2 = (P[1][rt] + P[2][rt]) - y0 - y4
+            y3 = ((P[3][rt] - y0) - 4 * y2 - 16 * y4) / 6 - bb / 3
+            E0[w, rt] = [(bb - y3) + bias, y2 + bias, y3 + bias]
+    for (w, rt), cols in E0.items():
+        for c in range(3):
+            _store16(RE, 32 * c + 8 * w + 4 * rt, cols[c])
+    E1 = {}
+    for w in range(4):
+        nt, tp = w & 1, w >> 1
+        ws = sect[w][S_ENC1]
+        for rt in range(2):
+            acc = np.repeat(_vec16(W[ws + rt])[:, None], 16, 1)
+            for it in range(16):
+                acc += _mfma16(W[ws + 2 + 2 * it + rt], _rows16(RE, (tp + (it >> 3)) * 32 + 4 * (it & 7)))
+            E1[w, rt] = acc
+    for (w, rt), acc in E1.items():
+        _store16(RX, 16 * (w >> 1) + 8 * (w & 1) + 4 * rt, acc)
+    E2 = {}
+    for w in range(4):
+        kh = w >> 1
+        ws = sect[w][S_ENC2]
+        for rt in range(2):
+            acc = np.repeat(_vec16(W[ws + rt])[:, None], 16, 1) if kh == 0 else np.zeros((16, 16))
+            for j in range(4):
+                acc += _mfma16(W[ws + 2 + 8 * kh + 2 * j + rt], _rows16(RX, 16 * kh + 4 * j))
+            E2[w, rt] = acc
+    for (w, rt), acc in E2.items():
+        _store16(RE, 16 * (w >> 1) + 8 * (w & 1) + 4 * rt, acc, relu=False)
+    RE[0:16] = np.maximum(RE[0:16] + RE[16:32], 0.0)
+    E3 = {}
+    for w in range(4):
+        ws = sect[w][S_ENC3]
+        for rt in range(2):
+            acc = np.repeat(_vec16(W[ws + rt])[:, None], 16, 1)
+            for j in range(4):
+                acc += _mfma16(W[ws + 2 + 2 * j + rt], _rows16(RE, 4 * j))
+            E3[w, rt] = acc
+    for (w, rt), acc in E3.items():
+        _store16(RX, 8 * w + 4 * rt, acc)
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    h_new, c_new, z = np.zeros((16, 128)), np.zeros((16, 128)), np.zeros(16)
+    for w in range(4):
+        ws = sect[w][S_LSTM]
+        for rt in range(2):
+            g = [np.repeat(_vec16(W[ws + 2 * q + rt])[:, None], 16, 1) for q in range(4)]
+            for half, src in enumerate((RX, RH)):
+                for j in range(8):
+                    a = _rows16(src, 4 * j)
+                    for q in range(4):
+                        g[q] += _mfma16(W[ws + 8 + 64 * half + 8 * j + 2 * q + rt], a)
+            hw = _vec16(W[ws + 8 + 128 + rt])
+            u0 = 32 * w + 16 * rt
+            cn = sig(g[1]) * c_prev[:, u0:u0 + 16].T + sig(g[0]) * np.tanh(g[2])
+            hn = sig(g[3]) * np.tanh(cn)
+            h_new[:, u0:u0 + 16], c_new[:, u0:u0 + 16] = hn.T, cn.T
+            z += (hw[:, None] * np.maximum(hn, 0)).sum(0)
+    prob = sig(z + W[sect[0][S_HEADB]][0, 0])
+    return prob.astype(np.float32), np.concatenate([h_new, c_new], axis=1).astype(np.float32)

@@ -112,6 +112,26 @@ def test_packed_layout_of_the_v5_8k_submodel_reproduces_the_oracle():
             assert np.abs(hc - hc_o).max() <= 1e-4
 
 
+def test_packed_layout_for_the_16_stream_tile_kernel_reproduces_the_oracle():
+    """pack_silero_v5_t16 (16 x 16 x 4 MFMA tiles) through the model of silero_v5_t16.hip's dataflow == oracle."""
+    from oracle import oracle
+    from tests import kernel_model as KM
+    from tests.signals import make_streams
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        blob = f.read()
+    W, sect = KM.packed_streams(516, blob)
+    om = oracle.OracleModel(blob, "f64")
+    x = make_streams(16, 3, seed=8)
+    hc = np.zeros((16, 256), np.float32)
+    hc_o = hc.copy()
+    with np.errstate(over="ignore"):
+        for t in range(3):
+            p, hc = KM.v5_step_t16(W, sect, x[:, t], hc, gate=0.01)
+            po = om.step_batch(oracle.denoise(x[:, t]).reshape(16, 512), hc_o)
+            assert np.abs(p - po).max() <= 5e-6
+            assert np.abs(hc - hc_o).max() <= 1e-4
+
+
 def test_weights_blob_roundtrip_and_reference_arity_rule(tmp_path):
     with open(weights_io.packaged_blob_path(5), "rb") as f:
         blob = f.read()

@@ -51,6 +51,26 @@ def config1():
     return {"config": "configs[1]: batch=1024, V5, 16 kHz", "us_per_step": dt * 1e6, "frames_per_s": B / dt}
 
 
+def tile_shapes():
+    """V5, device-resident, both tile shapes at the batch sizes where the choice matters (vad_debug_set_tile)."""
+    out = []
+    for B in (256, 1024, 2048, 4096, 8192):
+        eng = Engine(blob(5), max_streams=B)
+        eng.open_streams(B)
+        ring = (0.1 * torch.randn(16, B, 512, device="cuda")).contiguous()
+        probs = torch.empty(B, device="cuda")
+        ts = torch.cuda.Stream()
+        row = {"config": f"batch={B}, V5, device-resident", "streams": B}
+        for tile in (32, 16):
+            eng.set_tile(tile)
+            dt = timed(lambda i: eng.step_device(B, ring[i % 16].data_ptr(), probs.data_ptr(), stream=ts.cuda_stream), [ts])
+            row[f"us_per_step_tile{tile}"] = dt * 1e6
+            row[f"frames_per_s_tile{tile}"] = B / dt
+        eng.close()
+        out.append(row)
+    return out
+
+
 def config3():
     B = 4096
     per = B // 3
