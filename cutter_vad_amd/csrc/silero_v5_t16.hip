@@ -13,7 +13,16 @@
 // One k-iteration j contracts 16 channels: lane (n, kq) reads activation quad row 4 j + kq of stream n (ONE ds_read_b128, the B
 // operands of 4 MFMAs: component i = channel 16 j + 4 kq + i) and a 1 KiB weight block gives it W[row n][16 j + 4 kq + i].
 // A wave owns 32 output channels = two row tiles rt = 0, 1: channel 32 w + 16 rt + 4 rq + i lives in quad row 8 w + 4 rt + rq.
-// LDS quad row: 16 streams x float4 (+1 of padding: stride QS16 = 17 float4).  Weight stream: pack_silero_v5_t16.
+// LDS quad row: 16 streams x float4.  The folded STFT operands are written TRANSPOSED by the loader (16 lanes of a stream write
+// 16 different rows), so that view of the memory has a padded row stride (QSL = 17 float4); every other tensor is written and
+// read in the D / B fragment layout (a group of 16 lanes = 256 contiguous bytes) and uses the dense stride QSD = 16.  With the
+// two views overlaid the workgroup needs 78.6 KB of LDS - under half a CU's 160 KB.
+// Two workgroups per CU were measured (__launch_bounds__(256, 2): 256 registers, 14 spilled; 8 192 streams = 512 tiles):
+// 51.8 us against 53.6 us for the two tiles of a CU one after the other and 49.5 us for the 32-stream tile kernel, and
+// +1.2 us on every batch of <= 4 096 streams - the second wave of a SIMD only hides waits; fp32 MFMAs and VALU work share the
+// vector datapath on this chip, also across waves.  So: one workgroup per CU, all 512 registers, and the engine uses this
+// kernel for calls of at most 4 096 streams (256 tiles = one per CU) and the 32-stream tiles above that.
+// Weight stream: pack_silero_v5_t16.
 #include <hip/hip_runtime.h>
 #include "vad_layout.h"
 #include "sm_device.h"
@@ -25,14 +34,18 @@ using namespace vadk::dev;
 namespace {
 
 constexpr int MT16 = 16;
-constexpr int QS16 = 17;
-// LDS rows (quads of 16 streams): the activation region X as in vad_layout.h (v5) except that the Nyquist channel takes 8 rows
-// (values on the kq = 0 row of a group of four, zeros on the other three): rows 160..163 = points 0, 1, -1, 2; 164..167 = infinity
+constexpr int QSL = 17;                   // loader view: rows 64 c + {0, 16, 32, 48} + q of the folded operands, 192 rows
+constexpr int QSD = 16;                   // dense view of the same memory, used by everything else:
+//   rows 0..159 Toom-3 planes (32 p + ch/4); the Nyquist channel takes 8 rows (values on the kq = 0 row of a group of four, zeros
+//   on the other three): 160..163 = points 0, 1, -1, 2; 164..167 = infinity; rows 0..31 later enc1 output, then the LSTM input;
+//   rows 168.. = enc0 output (168 + 32 c + ch/4), then the enc2 partials (168 + 16 half + ch/4); then h_{t-1} (32 rows)
 constexpr int T_ROW_NYQ = 160;
-constexpr int T_ROW_E = 168;              // enc0 output: 168 + 32 c + ch/4; enc2 partials: 168 + 16 half + ch/4
+constexpr int T_ROW_E = 168;
 constexpr int T_ROWS_X = 264;
 constexpr int T_ROWS_H = 32;
-constexpr int T_LDS_F4 = (T_ROWS_X + T_ROWS_H) * QS16 + 16 + 12 + 36 + 16 + 96;   // + head partials [4][16], |X128| [3][16], fold corrections [3][3][16], sink [64], state machines [16] x 96 B
+static_assert(T_ROWS_X * QSD >= 192 * QSL, "the loader view must end before h");
+constexpr int T_LDS_F4 = (T_ROWS_X + T_ROWS_H) * QSD + 16 + 12 + 36 + 16 + 96;   // + head partials [4][16], |X128| [3][16], fold corrections [3][3][16], sink [64], state machines [16] x 96 B
+static_assert(T_LDS_F4 * 16 <= 80 * 1024, "stays under half a CU's LDS");
 
 __device__ __forceinline__ f32x4 mfma16(f32x4 w, f32x4 a, f32x4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a.x, acc, 0, 0, 0);
@@ -49,9 +62,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     using namespace vadk::v5;
     __shared__ f32x4 lds[T_LDS_F4];
     f32x4 *const RX = lds;
-    f32x4 *const RE = lds + T_ROW_E * QS16;
-    f32x4 *const RH = lds + T_ROWS_X * QS16;
-    float *const headp = reinterpret_cast<float *>(RH + T_ROWS_H * QS16);   // [4][16]
+    f32x4 *const RE = lds + T_ROW_E * QSD;
+    f32x4 *const RH = lds + T_ROWS_X * QSD;
+    float *const headp = reinterpret_cast<float *>(RH + T_ROWS_H * QSD);   // [4][16]
     float *const nyqv = headp + 64;              // [3][16]
     float *const fcor = nyqv + 48;               // [3 columns][y128, a64, b64][16 streams]
     constexpr int FCOR_SINK = 144;               // [64] floats after fcor
@@ -62,7 +75,8 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15;                      // stream of this lane's MFMA column
     const int kq = lane >> 4;                     // channel group (B operand) = row quad of the D tile
-    const int nq = kq * QS16 + n;                 // lane's offset inside a group of 4 quad rows
+    const int nq = kq * QSD + n;                  // lane's offset inside a group of 4 quad rows (dense view)
+    const int nqL = kq * QSL + n;                 // the same in the loader view
     const int tile0 = blockIdx.x * MT16;
     const int gf = tile0 + n;
     const bool live = gf < P.n;
@@ -115,7 +129,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     for (int k = 0; k < 6; ++k) smq[k] = reinterpret_cast<const f32x4 *>(P.sm + slot)[k];
     SB();
 #pragma unroll
-    for (int qq = 0; qq < 2; ++qq) RH[(part * 2 + qq) * QS16 + fm] = hv[qq];
+    for (int qq = 0; qq < 2; ++qq) RH[(part * 2 + qq) * QSD + fm] = hv[qq];
     int seg_last = 0;
     if (tid < MT16) {
 #pragma unroll
@@ -172,15 +186,15 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
             fcor[fo + (q0 ? 16 : 0)] = y64 + y192;                                                              \
             fcor[fo + (q0 ? 32 : 0)] = y64 - y192;                                                              \
         }                                                                                                       \
-        st2(&RX[(64 * (c) + q) * QS16 + ms], pe);                                                               \
-        st2(&RX[(64 * (c) + 16 + q) * QS16 + ms], po);                                                          \
-        st2(&RX[(64 * (c) + 32 + q) * QS16 + ms], qe);                                                          \
-        st2(&RX[(64 * (c) + 48 + q) * QS16 + ms], qo);                                                          \
+        st2(&RX[(64 * (c) + q) * QSL + ms], pe);                                                               \
+        st2(&RX[(64 * (c) + 16 + q) * QSL + ms], po);                                                          \
+        st2(&RX[(64 * (c) + 32 + q) * QSL + ms], qe);                                                          \
+        st2(&RX[(64 * (c) + 48 + q) * QSL + ms], qo);                                                          \
     }
 #define H_LDW(WS, g) _Pragma("unroll") for (int k = 0; k < 8; ++k) WS[k] = WL(wh + 8 * (g) + k);
 #define H_MMA(WS, g)                                                                                            \
     {                                                                                                           \
-        const f32x4 av = RH[(4 * (g)) * QS16 + nq];                                                             \
+        const f32x4 av = RH[(4 * (g)) * QSD + nq];                                                             \
         _Pragma("unroll") for (int k = 0; k < 8; ++k) G[k] = mfma16(WS[k], av, G[k]);                           \
     }
 #define H_MIX                                                                                                   \
@@ -224,7 +238,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
             if (pair < 48) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 pp = RX[(64 * c + pt * 4 + i) * QS16 + ms];
+                    const f32x4 pp = RX[(64 * c + pt * 4 + i) * QSL + ms];
                     a += (pp.x - pp.y) + (pp.z - pp.w);
                 }
             }
@@ -247,15 +261,15 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
                 aim[c][0] = aim[c][1] = f32x4{ip, im_, ip, im_};
             }
             const int rR = w < 2 ? 0 : 16, rI = w < 2 ? 32 : 48;
-            const f32x4 *const XR = RX + rR * QS16 + nq, *const XI = RX + rI * QS16 + nq;
+            const f32x4 *const XR = RX + rR * QSL + nqL, *const XI = RX + rI * QSL + nqL;      // loader view
             f32x4 Aw[4], Bw[4], Au[3], Av[3], Bu[3], Bv[3];
 #pragma unroll
             for (int k = 0; k < 4; ++k) Aw[k] = Sw[k];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { Au[c] = XR[(64 * c) * QS16]; Av[c] = XI[(64 * c) * QS16]; }
+            for (int c = 0; c < 3; ++c) { Au[c] = XR[(64 * c) * QSL]; Av[c] = XI[(64 * c) * QSL]; }
 #define S_LD(S, jj)                                                                        \
     _Pragma("unroll") for (int k = 0; k < 4; ++k) S##w[k] = WL(ws_stft + 4 * (jj) + k);    \
-    _Pragma("unroll") for (int c = 0; c < 3; ++c) { S##u[c] = XR[(64 * c + 4 * (jj)) * QS16]; S##v[c] = XI[(64 * c + 4 * (jj)) * QS16]; }
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) { S##u[c] = XR[(64 * c + 4 * (jj)) * QSL]; S##v[c] = XI[(64 * c + 4 * (jj)) * QSL]; }
 #define S_MMA(S)                                                                           \
     _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                        \
         are[c][0] = mfma16(S##w[0], S##u[c], are[c][0]); are[c][1] = mfma16(S##w[1], S##u[c], are[c][1]);   \
@@ -285,19 +299,19 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
                     mg[c] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
                 }
                 const f32x4 s02 = f32x4{mg[0].x + mg[2].x, mg[0].y + mg[2].y, mg[0].z + mg[2].z, mg[0].w + mg[2].w};
-                f32x4 *o = RX + (8 * w + 4 * rt) * QS16 + nq;
+                f32x4 *o = RX + (8 * w + 4 * rt) * QSD + nq;
                 st2(o, mg[0]);
-                st2(o + 32 * QS16, f32x4{s02.x + mg[1].x, s02.y + mg[1].y, s02.z + mg[1].z, s02.w + mg[1].w});
-                st2(o + 64 * QS16, f32x4{s02.x - mg[1].x, s02.y - mg[1].y, s02.z - mg[1].z, s02.w - mg[1].w});
-                st2(o + 96 * QS16, f32x4{fmaf(4.f, mg[2].x, fmaf(2.f, mg[1].x, mg[0].x)), fmaf(4.f, mg[2].y, fmaf(2.f, mg[1].y, mg[0].y)),
+                st2(o + 32 * QSD, f32x4{s02.x + mg[1].x, s02.y + mg[1].y, s02.z + mg[1].z, s02.w + mg[1].w});
+                st2(o + 64 * QSD, f32x4{s02.x - mg[1].x, s02.y - mg[1].y, s02.z - mg[1].z, s02.w - mg[1].w});
+                st2(o + 96 * QSD, f32x4{fmaf(4.f, mg[2].x, fmaf(2.f, mg[1].x, mg[0].x)), fmaf(4.f, mg[2].y, fmaf(2.f, mg[1].y, mg[0].y)),
                                          fmaf(4.f, mg[2].z, fmaf(2.f, mg[1].z, mg[0].z)), fmaf(4.f, mg[2].w, fmaf(2.f, mg[1].w, mg[0].w))});
-                st2(o + 128 * QS16, mg[2]);
+                st2(o + 128 * QSD, mg[2]);
             }
             if (tid < 64) {      // |X128|: values on the kq = 0 rows (160, 164), zeros on the other three of each group
                 const float n0 = nyqv[n], n1 = nyqv[16 + n], n2 = nyqv[32 + n];
                 const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                RX[T_ROW_NYQ * QS16 + nq] = kq == 0 ? f32x4{n0, (n0 + n2) + n1, (n0 + n2) - n1, fmaf(4.f, n2, fmaf(2.f, n1, n0))} : z4;
-                RX[(T_ROW_NYQ + 4) * QS16 + nq] = kq == 0 ? f32x4{n2, 0.f, 0.f, 0.f} : z4;
+                RX[T_ROW_NYQ * QSD + nq] = kq == 0 ? f32x4{n0, (n0 + n2) + n1, (n0 + n2) - n1, fmaf(4.f, n2, fmaf(2.f, n1, n0))} : z4;
+                RX[(T_ROW_NYQ + 4) * QSD + nq] = kq == 0 ? f32x4{n2, 0.f, 0.f, 0.f} : z4;
             }
         }
         __syncthreads();   // (2) magnitudes complete
@@ -313,10 +327,10 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
 #pragma unroll
             for (int k = 0; k < 10; ++k) Aw[k] = E0w[k];
 #pragma unroll
-            for (int p = 0; p < 5; ++p) Aa[p] = RX[(32 * p) * QS16 + nq];
+            for (int p = 0; p < 5; ++p) Aa[p] = RX[(32 * p) * QSD + nq];
 #define E0_LD(S, jj)                                                                       \
     _Pragma("unroll") for (int k = 0; k < 10; ++k) S##w[k] = WL(ws + 10 * (jj) + k);       \
-    _Pragma("unroll") for (int p = 0; p < 5; ++p) S##a[p] = RX[(32 * p + 4 * (jj)) * QS16 + nq];
+    _Pragma("unroll") for (int p = 0; p < 5; ++p) S##a[p] = RX[(32 * p + 4 * (jj)) * QSD + nq];
 #define E0_MMA(S)                                                                          \
     _Pragma("unroll") for (int p = 0; p < 5; ++p) {                                        \
         acc[p][0] = mfma16(S##w[2 * p], S##a[p], acc[p][0]); acc[p][1] = mfma16(S##w[2 * p + 1], S##a[p], acc[p][1]); \
@@ -331,7 +345,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
 #undef E0_LD
 #undef E0_MMA
             {   // input channel 128 (Nyquist bin): K = 4 MFMAs whose k = 1..3 slots are zero on both operands
-                const f32x4 an = RX[T_ROW_NYQ * QS16 + nq], bn = RX[(T_ROW_NYQ + 4) * QS16 + nq];
+                const f32x4 an = RX[T_ROW_NYQ * QSD + nq], bn = RX[(T_ROW_NYQ + 4) * QSD + nq];
                 const f32x4 wa0 = WL(ws + 80), wa1 = WL(ws + 81), wb0 = WL(ws + 82), wb1 = WL(ws + 83);
                 e1b[0] = WL(ws_e1); e1b[1] = WL(ws_e1 + 1);
                 E1w[0] = WL(ws_e1 + 2); E1w[1] = WL(ws_e1 + 3);
@@ -355,10 +369,10 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
                 const f32x4 y2 = (acc[1][rt] + acc[2][rt]) - y0 - y4;
                 const f32x4 t2 = (acc[3][rt] - y0) - 4.0f * y2 - 16.0f * y4;
                 const f32x4 y3 = t2 * (1.0f / 6.0f) - bb * (1.0f / 3.0f);
-                f32x4 *o = RE + (8 * w + 4 * rt) * QS16 + nq;
+                f32x4 *o = RE + (8 * w + 4 * rt) * QSD + nq;
                 o[0] = relu4((bb - y3) + bias);
-                o[32 * QS16] = relu4(y2 + bias);
-                o[64 * QS16] = relu4(y3 + bias);
+                o[32 * QSD] = relu4(y2 + bias);
+                o[64 * QSD] = relu4(y3 + bias);
             }
         }
         __syncthreads();   // (3) enc0 out
@@ -369,7 +383,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
             const int nt = w & 1, tp = w >> 1;
             const int ws = ws_e1 + 2;
             f32x4 acc[2] = {e1b[0], e1b[1]};
-#define E1_ROW(it) (RE + ((tp + ((it) >> 3)) * 32 + 4 * ((it) & 7)) * QS16 + nq)
+#define E1_ROW(it) (RE + ((tp + ((it) >> 3)) * 32 + 4 * ((it) & 7)) * QSD + nq)
             f32x4 Aw[2] = {E1w[0], E1w[1]}, Bw[2], Aa = *E1_ROW(0), Ba;
             for (int it = 0; it < 16; it += 2) {
                 Bw[0] = WL(ws + 2 * (it + 1)); Bw[1] = WL(ws + 2 * (it + 1) + 1); Ba = *E1_ROW(it + 1); SB();
@@ -388,7 +402,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
             }
 #undef E1_ROW
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) RX[(16 * tp + 8 * nt + 4 * rt) * QS16 + nq] = relu4(acc[rt]);
+            for (int rt = 0; rt < 2; ++rt) RX[(16 * tp + 8 * nt + 4 * rt) * QSD + nq] = relu4(acc[rt]);
         }
         __syncthreads();   // (4) enc1 out in rows 0..31
 
@@ -404,12 +418,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
 #pragma unroll
             for (int k = 2; k < 8; ++k) wv[k] = WL(ws + k);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) av[j] = RX[(16 * kh + 4 * j) * QS16 + nq];
+            for (int j = 0; j < 4; ++j) av[j] = RX[(16 * kh + 4 * j) * QSD + nq];
             SB();
 #pragma unroll
             for (int j = 0; j < 4; ++j) { acc[0] = mfma16(wv[2 * j], av[j], acc[0]); acc[1] = mfma16(wv[2 * j + 1], av[j], acc[1]); }
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) RE[(16 * kh + 8 * (w & 1) + 4 * rt) * QS16 + nq] = acc[rt];
+            for (int rt = 0; rt < 2; ++rt) RE[(16 * kh + 8 * (w & 1) + 4 * rt) * QSD + nq] = acc[rt];
         }
         __syncthreads();   // (5) enc2 partials
 
@@ -424,7 +438,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
             for (int k = 2; k < 8; ++k) wv[k] = WL(ws + k);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x4 a = RE[(4 * j) * QS16 + nq], b2 = RE[(16 + 4 * j) * QS16 + nq];
+                const f32x4 a = RE[(4 * j) * QSD + nq], b2 = RE[(16 + 4 * j) * QSD + nq];
                 av[j] = relu4(f32x4{a.x + b2.x, a.y + b2.y, a.z + b2.z, a.w + b2.w});
             }
 #pragma unroll
@@ -433,7 +447,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
 #pragma unroll
             for (int j = 0; j < 4; ++j) { acc[0] = mfma16(wv[2 * j], av[j], acc[0]); acc[1] = mfma16(wv[2 * j + 1], av[j], acc[1]); }
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) RX[(8 * w + 4 * rt) * QS16 + nq] = relu4(acc[rt]);
+            for (int rt = 0; rt < 2; ++rt) RX[(8 * w + 4 * rt) * QSD + nq] = relu4(acc[rt]);
         }
         __syncthreads();   // (6) LSTM input x in rows 0..31
 
@@ -443,7 +457,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
             f32x4 Aw[8], Bw[8], Aa = RX[nq], Ba, hw[2];
 #pragma unroll
             for (int k = 0; k < 8; ++k) Aw[k] = Lw[k];
-#define L_LD(S, it) _Pragma("unroll") for (int k = 0; k < 8; ++k) S##w[k] = WL(ws + 8 * (it) + k); S##a = RX[(4 * (it)) * QS16 + nq];
+#define L_LD(S, it) _Pragma("unroll") for (int k = 0; k < 8; ++k) S##w[k] = WL(ws + 8 * (it) + k); S##a = RX[(4 * (it)) * QSD + nq];
 #define L_MMA(S) _Pragma("unroll") for (int k = 0; k < 8; ++k) G[k] = mfma16(S##w[k], S##a, G[k]);
             for (int it = 0; it < 8; it += 2) {
                 L_LD(B, it + 1) SB();
@@ -467,7 +481,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     part_ += hwv.k * fmaxf(hn.k, 0.f);
                 CELL(x) CELL(y) CELL(z) CELL(w)
 #undef CELL
-                RH[(8 * w + 4 * rt) * QS16 + nq] = hn;
+                RH[(8 * w + 4 * rt) * QSD + nq] = hn;
                 if (t == T - 1 && live) {
                     *reinterpret_cast<f32x4 *>(P.state + (size_t)slot * 256 + 32 * w + 16 * rt + 4 * kq) = hn;
                     *reinterpret_cast<f32x4 *>(P.state + (size_t)slot * 256 + 128 + 32 * w + 16 * rt + 4 * kq) = cn;
