@@ -223,7 +223,7 @@ def main() -> int:
         engines, streams, probs, events = [], [], [], []
         for v in versions:
             with open(weights_io.packaged_blob_path(v), "rb") as f:
-                e = Engine(f.read(), model_version=v, device_id=local_rank, max_streams=nb)
+                e = Engine(f.read(), model_version=v, device_id=local_rank, max_streams=nb, shared_gpu=len(versions) > 1)
             e.open_streams(nb)                        # slots 0..nb-1, zero state, default thresholds
             engines.append(e)
             streams.append(torch.cuda.Stream())

@@ -82,6 +82,7 @@ struct vad_engine {
     size_t wbytes16 = 0;
     uint32_t sect16[vadk::NWAVES][16] = {};
     int tile_policy = 0;                     // 0 = by batch size, 16 / 32 = forced (vad_debug_set_tile)
+    bool shared_gpu = false;                 // VAD_ENGINE_SHARED_GPU: keep to 32-stream tiles (n / 32 CUs), leave the rest to the co-tenant
     int sample_rate = 16000;
     int frame_samples = VAD_FRAME_SAMPLES;   // samples per model step (512; Silero V5's 8 kHz sub-model: 256)
     // batched slot control (open / reset / thresholds): one pinned block up, one kernel
@@ -249,7 +250,7 @@ int check_slots(vad_engine *e, const int64_t *slots, int64_t n) {
 
 int launch(vad_engine *e, const vadk::StepParams &p, hipStream_t s) {
     hipError_t r = hipErrorInvalidValue;
-    const bool t16 = e->d_wstream16 && (e->tile_policy == 16 || (e->tile_policy == 0 && p.n <= vad_engine::T16_MAX_STREAMS));
+    const bool t16 = e->d_wstream16 && (e->tile_policy == 16 || (e->tile_policy == 0 && !e->shared_gpu && p.n <= vad_engine::T16_MAX_STREAMS));
     if (e->version == 5 && t16) {
         vadk::StepParams p16 = p;
         p16.wstream = e->d_wstream16;
@@ -407,6 +408,7 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
     e->device = desc->device_id;
     e->max_streams = desc->max_streams;
     e->sample_rate = desc->sample_rate;
+    e->shared_gpu = (desc->flags & VAD_ENGINE_SHARED_GPU) != 0;
     e->frame_samples = (desc->model_version == 5 && want_8k) ? vadk::v5::FRAME_8K : VAD_FRAME_SAMPLES;
     auto bail = [&](hipError_t hr, const char *what) {
         g_create_error = std::string("Failed to load model: ") + what + ": " + hipGetErrorString(hr);

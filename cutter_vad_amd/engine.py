@@ -33,12 +33,12 @@ class Engine:
     """
 
     def __init__(self, weights: bytes, model_version: int = 5, device_id: int = 0, max_streams: int = 8192,
-                 sample_rate: int = 16000):
+                 sample_rate: int = 16000, shared_gpu: bool = False):
         self._lib = _ffi.lib()
         self._h = C.c_void_p()
         self._weights = weights  # keep alive during create
         desc = _ffi.EngineDesc(C.sizeof(_ffi.EngineDesc), model_version, C.cast(C.c_char_p(weights), C.c_void_p),
-                               len(weights), device_id, max_streams, sample_rate, 0)
+                               len(weights), device_id, max_streams, sample_rate, 1 if shared_gpu else 0)  # VAD_ENGINE_SHARED_GPU
         rc = self._lib.vad_engine_create(C.byref(desc), C.byref(self._h))
         if rc != _ffi.VAD_OK:
             self._h = C.c_void_p()

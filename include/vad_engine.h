@@ -80,8 +80,13 @@ typedef struct vad_engine_desc {
     int32_t sample_rate;        /* the graph's `sr` input (core/silero_model.py:491): 16000, or - with the blob of the graph's 8 kHz
                                    sub-model - V4: 8000 / 24000 / 48000 (same 512-sample frames), V5: 8000 (native 8 kHz audio in
                                    256-sample frames: every [512] below reads [vad_info.frame_samples]) */
-    uint32_t flags;             /* reserved, 0 */
+    uint32_t flags;             /* VAD_ENGINE_* bits */
 } vad_engine_desc;
+/* Another engine's kernels run on this GPU at the same time (e.g. a Silero V4 and a V5 pool side by side: BASELINE configs[4]).
+ * A Silero V5 16 kHz engine normally serves calls of <= 4 096 streams on 16-stream tiles, which spreads them over up to all 256 CUs
+ * (28 us instead of 47 us per step) - and leaves no CU to a co-tenant.  With this flag it keeps to 32-stream tiles: a call of n
+ * streams occupies n / 32 CUs and the other engine's workgroups run beside it. */
+#define VAD_ENGINE_SHARED_GPU 1u
 
 typedef struct vad_info {
     uint32_t struct_size;

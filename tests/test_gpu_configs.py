@@ -64,7 +64,9 @@ def test_config4_share_v4_and_v5_engines_concurrent_on_two_hip_streams():
     frames = make_streams(2 * B, T, seed=1234)
     dev = torch.device("cuda:0")
     d_frames = torch.from_numpy(frames).to(dev)                       # [2B, T, 512]
-    with Engine(_blob(5), model_version=5, max_streams=B) as e5, Engine(_blob(4), model_version=4, max_streams=B) as e4:
+    # VAD_ENGINE_SHARED_GPU: V5 keeps to 32-stream tiles (4 096 streams = 128 CUs) so that V4's 128 workgroups run beside it
+    with Engine(_blob(5), model_version=5, max_streams=B, shared_gpu=True) as e5, \
+            Engine(_blob(4), model_version=4, max_streams=B, shared_gpu=True) as e4:
         e5.open_streams(B)
         e4.open_streams(B)
         s5, s4 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
@@ -90,7 +92,7 @@ def test_config4_share_v4_and_v5_engines_concurrent_on_two_hip_streams():
     assert np.abs(got4[pick] - ref4).max() <= TOL[4]
     # alone, through the host-pointer API: bit-identical probabilities and recurrent state
     for v, got, st, x in ((5, got5, st5, frames[:B]), (4, got4, st4, frames[B:])):
-        with Engine(_blob(v), model_version=v, max_streams=B) as solo:
+        with Engine(_blob(v), model_version=v, max_streams=B, shared_gpu=True) as solo:     # same kernel shape as above
             slots = solo.open_streams(B)
             alone = np.stack([solo.step(slots, x[:, t]) for t in range(T)], axis=1)
             assert np.array_equal(alone, got), v

@@ -129,7 +129,8 @@ def config3_pipelined():
 
 def config4_per_gpu():
     B = 4096
-    e5, e4 = Engine(blob(5), max_streams=B), Engine(blob(4), model_version=4, max_streams=B)
+    # two engines share the GPU: VAD_ENGINE_SHARED_GPU keeps V5 on 32-stream tiles (128 CUs), V4's 128 tiles run beside it
+    e5, e4 = Engine(blob(5), max_streams=B, shared_gpu=True), Engine(blob(4), model_version=4, max_streams=B, shared_gpu=True)
     e5.open_streams(B)
     e4.open_streams(B)
     ring = (0.1 * torch.randn(16, 2 * B, 512, device="cuda")).contiguous()
