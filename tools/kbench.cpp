@@ -21,6 +21,13 @@
 #include "../cutter_vad_amd/csrc/vad_layout.h"
 
 extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream_t stream);
+#ifdef KB_TILE16      // tools/kbench16.sh: the 16-stream tile kernel (link silero_v5_t16.hip instead of silero_v5.hip)
+extern "C" hipError_t vadk_launch_silero_v5_t16(const vadk::StepParams *p, hipStream_t stream);
+#define vadk_launch_silero_v5 vadk_launch_silero_v5_t16
+#define PACK vadk::pack_silero_v5_t16
+#else
+#define PACK vadk::pack_silero_v5
+#endif
 
 #define CK(x)                                                                      \
     do {                                                                           \
@@ -45,7 +52,7 @@ int main(int argc, char **argv) {
     fclose(f);
     vadk::PackedWeights pw;
     std::string err;
-    if (!vadk::pack_silero_v5(blob.data(), blob.size(), pw, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    if (!PACK(blob.data(), blob.size(), pw, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
 
     vadk::StepParams p{};
     float *d_w, *d_state, *d_frames, *d_probs;
