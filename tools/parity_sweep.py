@@ -32,24 +32,30 @@ def main():
     frames = make_streams(n, T, seed=4242)
     nthreads = min(16, os.cpu_count() or 1)
     res = []
-    for v, sr in ((5, 16000), (4, 16000), (4, 8000)):
+    # (model, sr, forced tile shape): V5 on both tile shapes; V5's 8 kHz sub-model sees the same audio as 256-sample frames
+    for v, sr, tile in ((5, 16000, 32), (5, 16000, 16), (5, 8000, 0), (4, 16000, 0), (4, 8000, 0)):
         blob = open(weights_io.packaged_blob_path(v, sr), "rb").read()
         o64, o32 = oracle.OracleModel(blob, "f64"), oracle.OracleModel(blob, "f32")
+        L = o64.frame_samples
+        fr = frames if L == 512 else frames.reshape(n, -1, 256)[:, :T]
         with Engine(blob, model_version=v, max_streams=n, sample_rate=sr) as eng:
+            if tile:
+                eng.set_tile(tile)
             slots = eng.open_streams(n)
             s64, s32 = np.zeros((n, 256), np.float32), np.zeros((n, 256), np.float32)
             dk, do = np.empty((n, T)), np.empty((n, T))
             for t in range(T):
-                x = oracle.denoise(frames[:, t]).reshape(n, 512)
-                got = eng.step(slots, frames[:, t])
+                x = oracle.denoise(fr[:, t]).reshape(n, L)
+                got = eng.step(slots, np.ascontiguousarray(fr[:, t]))
                 ref = om_step(o64, x, s64, nthreads)
                 r32 = om_step(o32, x, s32, nthreads)
                 dk[:, t] = np.abs(got.astype(np.float64) - ref)
                 do[:, t] = np.abs(r32.astype(np.float64) - ref)
                 if t % 32 == 31:
-                    print(f"v{v}/{sr}: frame {t + 1}/{T}", flush=True)
+                    print(f"v{v}/{sr}/tile{tile}: frame {t + 1}/{T}", flush=True)
         worst = np.dstack(np.unravel_index(np.argsort(dk, axis=None)[::-1][:8], dk.shape))[0]
-        row = {"version": v, "sample_rate": sr, "frames": n * T, "hip_vs_f64": stats(dk), "oracle_f32_vs_f64": stats(do),
+        row = {"version": v, "sample_rate": sr, "streams_per_tile": tile or 32, "frame_samples": L, "frames": n * T,
+               "hip_vs_f64": stats(dk), "oracle_f32_vs_f64": stats(do),
                "hip_worst": [{"stream": int(i), "frame": int(t), "dp": float(dk[i, t])} for i, t in worst]}
         res.append(row)
         print(json.dumps(row), flush=True)
