@@ -179,6 +179,7 @@ struct vad_engine {
     int64_t steps = 0, frames = 0;
     hipDeviceProp_t prop{};
     mutable std::mutex mu;
+    mutable std::mutex err_mu;        // `err` is written under `mu` by most entry points and under `tick_mu` by vad_tick_push
     mutable std::string err;
 
     int fail(int code, const char *fmt, ...) const {
@@ -187,6 +188,7 @@ struct vad_engine {
         va_start(ap, fmt);
         vsnprintf(buf, sizeof buf, fmt, ap);
         va_end(ap);
+        std::lock_guard<std::mutex> lk(err_mu);
         err = buf;
         return code;
     }
@@ -350,7 +352,7 @@ extern "C" {
 const char *vad_last_create_error(void) { return g_create_error.c_str(); }
 const char *vad_last_error(const vad_engine *e) {
     if (!e) return "null engine";
-    std::lock_guard<std::mutex> lk(e->mu);      // other threads may be writing e->err: hand out a thread-local copy
+    std::lock_guard<std::mutex> lk(e->err_mu);  // other threads may be writing e->err: hand out a thread-local copy
     g_error_copy = e->err;
     return g_error_copy.c_str();
 }
