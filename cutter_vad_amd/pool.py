@@ -129,10 +129,8 @@ class StreamBatch:
     def add(self, n: int = 1, config: Optional[VADConfig] = None) -> np.ndarray:
         cfg = config or self.config
         new = self.engine.open_streams(n)
-        for s in new:
-            self.engine.set_thresholds(int(s), cfg.vad_start_probability, cfg.vad_end_probability,
-                                       cfg.voice_start_ratio, cfg.voice_end_ratio, cfg.voice_start_frame_count,
-                                       cfg.voice_end_frame_count)
+        self.engine.set_thresholds_many(new, (cfg.vad_start_probability, cfg.vad_end_probability, cfg.voice_start_ratio,
+                                              cfg.voice_end_ratio, cfg.voice_start_frame_count, cfg.voice_end_frame_count))
         self.slots.extend(int(s) for s in new)
         return new
 
@@ -145,6 +143,15 @@ class StreamBatch:
         s = np.asarray(self.slots if slots is None else slots, dtype=np.int64)
         thr = 0.01 if self.config.enable_denoising else None
         return self.engine.step_events(s, frames, denoise=thr)
+
+    def step_rates(self, segments, slots: Optional[Sequence[int]] = None):
+        """One tick for streams whose audio arrives at 8 / 16 / 24 / 48 kHz (``VADConfig.auto_convert_sample_rate``; the
+        reference's hook is a ``pass``, vad_wrapper.py:621-624): ``segments`` = [(chunks [n_k, 512 * sr_k / 16000], sr_k), ...]
+        in the order of ``slots``.  Resample + step chained on the GPU (``vad_step_rates``) ->
+        ``(probs, events, seg_frames)``."""
+        s = np.asarray(self.slots if slots is None else slots, dtype=np.int64)
+        thr = 0.01 if self.config.enable_denoising else None
+        return self.engine.step_rates(segments, s, denoise=thr)
 
     def close(self) -> None:
         for s in list(self.slots):

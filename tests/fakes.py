@@ -63,6 +63,11 @@ class FakeEngine:
         self.thr[int(s)] = tuple(t)
         self.sm[int(s)] = oracle.StateMachine(*t)
 
+    def set_thresholds_many(self, slots, thresholds):
+        rows = [thresholds] * len(slots) if np.isscalar(thresholds[0]) else list(thresholds)
+        for s, t in zip(slots, rows):
+            self.set_thresholds(int(s), *t)
+
     def get_state(self, s):
         return self.state[int(s)].copy()
 

@@ -234,3 +234,28 @@ def test_async_wrapper_on_the_real_engine_equals_the_sync_wrapper():
     assert [g for g in got if g == "S" or g[0] == "E"] == [x for x in want if x == "S" or x[0] == "E"]
     assert sum(1 for g in got if g != "S" and g[0] == "C") == sum(1 for x in want if x != "S" and x[0] == "C")
     assert any(g != "S" and g[0] == "E" for g in got)
+
+
+def test_stream_batch_steps_mixed_rate_streams():
+    """StreamBatch.step_rates: the multi-stream caller's form of configs[3] (8 / 24 / 48 kHz chunks -> GPU resample -> V5)."""
+    from cutter_vad_amd import StreamBatch, VADConfig
+    from cutter_vad_amd import weights_io
+    from oracle import oracle
+    from tests.signals import make_streams
+    rates = ((8000, 256), (24000, 768), (48000, 1536))
+    per, T = 40, 6
+    base = make_streams(3 * per, 3 * T, seed=77).reshape(3 * per, -1)
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        om = oracle.OracleModel(f.read(), "f64")
+    batch = StreamBatch(VADConfig())
+    try:
+        batch.add(3 * per)
+        st = np.zeros((3 * per, 256), np.float32)
+        for t in range(T):
+            segs = [(np.ascontiguousarray(base[k * per:(k + 1) * per, t * n_in:(t + 1) * n_in]), sr) for k, (sr, n_in) in enumerate(rates)]
+            p, ev, seg = batch.step_rates(segs)
+            x16 = np.stack([oracle.resample(a[i], 512) for a, _ in segs for i in range(per)]).astype(np.float32)
+            ref = om.step_batch(oracle.denoise(x16).reshape(3 * per, 512), st, nthreads=8)
+            assert np.abs(p - ref).max() <= 5e-5 and ev.shape == (3 * per,)
+    finally:
+        batch.close()
