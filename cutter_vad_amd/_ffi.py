@@ -137,6 +137,8 @@ SIGNATURES = {
     "vad_debug_resample_operator": (C.c_int, [C.c_int32, _f32p, C.c_size_t]),
     "vad_debug_pack_resample": (C.c_int, [C.c_int32, _f32p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
                                           C.POINTER(C.c_uint32)]),
+    "vad_debug_pack_resample_t16": (C.c_int, [C.c_int32, _f32p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
+                                              C.POINTER(C.c_uint32)]),
     "vad_debug_sm_replay": (C.c_int, [_vp, C.c_int64, _f32p, C.c_int64, _u8p, _i32p]),
     "vad_engine_synchronize": (C.c_int, [_vp]),
     "vad_debug_set_tile": (C.c_int, [_vp, C.c_int32]),

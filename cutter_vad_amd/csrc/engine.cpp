@@ -30,6 +30,7 @@
 extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_silero_v4(const vadk::StepParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_silero_v5_t16(const vadk::StepParams *p, hipStream_t stream);
+extern "C" hipError_t vadk_launch_silero_v5_t16_rates(const vadk::StepParams *p, const vadk::RateParams *r, hipStream_t stream);
 extern "C" hipError_t vadk_launch_resample(const vadk::ResampleParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_slot_control(vadk::SmSlot *sm, float *state, const int32_t *d_slots, int n, int op,
                                                const vadk::SmSlot *def, const vad_thresholds *d_thr, int nthr, hipStream_t stream);
@@ -169,6 +170,7 @@ struct vad_engine {
         uint32_t row128_block = 0;
     };
     std::vector<ResampleOp> resample_ops;   // built lazily, one per input rate
+    std::vector<ResampleOp> resample_ops16; // the same operators packed for the fused resample -> step kernel (16-stream tiles)
     float *d_rs_in = nullptr;  size_t d_rs_in_cap = 0;
     float *d_rs_out = nullptr; size_t d_rs_out_cap = 0;
     std::vector<uint8_t> open;
@@ -500,6 +502,8 @@ void vad_engine_destroy(vad_engine *e) {
     if (e->h_small_out) (void)hipHostFree(e->h_small_out);
     for (void *b : e->host_blocks) (void)hipHostFree(b);
     for (auto &op : e->resample_ops)
+        if (op.d_w) (void)hipFree(op.d_w);
+    for (auto &op : e->resample_ops16)
         if (op.d_w) (void)hipFree(op.d_w);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -833,8 +837,9 @@ int resample_chunk_len(int sr_in) {
     }
 }
 
-int get_resample_op(vad_engine *e, int n_in, vad_engine::ResampleOp **out) {
-    for (auto &op : e->resample_ops)
+int get_resample_op(vad_engine *e, int n_in, vad_engine::ResampleOp **out, bool t16 = false) {
+    auto &ops = t16 ? e->resample_ops16 : e->resample_ops;
+    for (auto &op : ops)
         if (op.n_in == n_in) {
             *out = &op;
             return VAD_OK;
@@ -843,7 +848,8 @@ int get_resample_op(vad_engine *e, int n_in, vad_engine::ResampleOp **out) {
     std::string perr;
     vad_engine::ResampleOp op;
     op.n_in = n_in;
-    op.tile_blocks = vadk::pack_resample_operator(n_in, packed, &op.row128_block, perr);
+    op.tile_blocks = t16 ? vadk::pack_resample_operator_t16(n_in, packed, &op.row128_block, perr)
+                         : vadk::pack_resample_operator(n_in, packed, &op.row128_block, perr);
     if (op.tile_blocks == 0) return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio: %s", perr.c_str());
     op.bytes = packed.size() * sizeof(float);
     hipError_t r = hipMalloc((void **)&op.d_w, op.bytes);
@@ -853,8 +859,8 @@ int get_resample_op(vad_engine *e, int n_in, vad_engine::ResampleOp **out) {
         (void)hipFree(op.d_w);
         return e->hip_fail(r, "hipMemcpy(resample operator)");
     }
-    e->resample_ops.push_back(op);
-    *out = &e->resample_ops.back();
+    ops.push_back(op);
+    *out = &ops.back();
     return VAD_OK;
 }
 
@@ -957,6 +963,58 @@ int step_rates_enqueue(vad_engine *e, int32_t nseg, const float *const *d_in, co
     if (int rc = check_call_size(e, total, 1, VAD_FMT_F32)) return rc;
     if (total == 0) return VAD_OK;
     if (!d_probs) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: null buffer");
+    // Silero V5, at most 4 096 streams: ONE launch - every 16-stream tile resamples its own chunks into LDS and steps the
+    // model from there (silero_v5_t16.hip, RS instantiation); the 16 kHz frames never exist in HBM
+    if (e->version == 5 && e->d_wstream16 && !e->shared_gpu && e->tile_policy != 32 && total <= vad_engine::T16_MAX_STREAMS &&
+        nseg <= vadk::RATE_MAX_SEGS) {
+        vadk::RateParams rp{};
+        int32_t tiles = 0, stream0 = 0, ns = 0;
+        for (int k = 0; k < nseg; ++k) {
+            if (n[k] == 0) continue;
+            vadk::RateSeg &sg = rp.seg[ns];
+            if (sr_in[k] == 16000) {
+                sg.wstream = nullptr;
+                sg.n_in = VAD_FRAME_SAMPLES;
+            } else {
+                const int want = resample_chunk_len(sr_in[k]);
+                if (want == 0)
+                    return e->fail(VAD_ERR_UNSUPPORTED, "Failed to resample audio from %dHz to 16000Hz: supported input rates are 8000, 16000, 24000, 48000", sr_in[k]);
+                vad_engine::ResampleOp *op = nullptr;
+                if (int rc = get_resample_op(e, want, &op, true)) return rc;
+                sg.wstream = op->d_w;
+                sg.wstream_bytes = (uint32_t)op->bytes;
+                sg.wave_blocks = op->tile_blocks;
+                sg.row128_block = op->row128_block;
+                sg.n_in = want;
+            }
+            sg.in = d_in[k];
+            sg.n = (int32_t)n[k];
+            sg.stream0 = stream0;
+            rp.tile_start[ns++] = tiles;
+            tiles += (int32_t)((n[k] + 15) / 16);
+            stream0 += (int32_t)n[k];
+        }
+        rp.nseg = ns;
+        rp.tile_start[ns] = tiles;
+        vadk::StepParams p = e->base;
+        p.wstream = e->d_wstream16;
+        p.wstream_bytes = (uint32_t)e->wbytes16;
+        std::memcpy(p.sect, e->sect16, sizeof p.sect);
+        p.slots = d_slots;
+        p.frames = nullptr;
+        p.probs = d_probs;
+        p.events = d_events;
+        p.seg_frames = d_seg;
+        p.n = (int32_t)total;
+        p.T = 1;
+        p.fmt = VAD_FMT_F32;
+        p.thresh = thr;
+        hipError_t r = vadk_launch_silero_v5_t16_rates(&p, &rp, s);
+        if (r != hipSuccess) return e->hip_fail(r, "kernel launch");
+        e->steps += 1;
+        e->frames += total;
+        return VAD_OK;
+    }
     // the 16 kHz frames of the tick: [total][512] f32, engine-owned, written by the resampler and read by the model launch
     // right behind it on the same HIP stream - they never leave the GPU
     if (int rc = ensure(e, e->d_rs_out, e->d_rs_out_cap, sizeof(float) * VAD_FRAME_SAMPLES * (size_t)total)) return rc;
@@ -1340,6 +1398,31 @@ int vad_debug_pack_resample(int32_t n_in, float *out, size_t out_floats, size_t 
     if (out) {
         if (out_floats < packed.size()) {
             g_create_error = "vad_debug_pack_resample: output buffer too small";
+            return VAD_ERR_INVALID_ARG;
+        }
+        std::memcpy(out, packed.data(), packed.size() * sizeof(float));
+    }
+    return VAD_OK;
+}
+
+int vad_debug_pack_resample_t16(int32_t n_in, float *out, size_t out_floats, size_t *n_floats, uint32_t *wave_blocks,
+                                uint32_t *row128_block) {
+    g_create_error.clear();
+    if (n_in < 256 || n_in % 256 || !n_floats || !wave_blocks || !row128_block) {
+        g_create_error = "vad_debug_pack_resample_t16: n_in must be a positive multiple of 256";
+        return VAD_ERR_INVALID_ARG;
+    }
+    std::vector<float> packed;
+    std::string perr;
+    *wave_blocks = vadk::pack_resample_operator_t16(n_in, packed, row128_block, perr);
+    if (*wave_blocks == 0) {
+        g_create_error = perr;
+        return VAD_ERR_INVALID_ARG;
+    }
+    *n_floats = packed.size();
+    if (out) {
+        if (out_floats < packed.size()) {
+            g_create_error = "vad_debug_pack_resample_t16: output buffer too small";
             return VAD_ERR_INVALID_ARG;
         }
         std::memcpy(out, packed.data(), packed.size() * sizeof(float));

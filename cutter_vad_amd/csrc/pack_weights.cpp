@@ -529,6 +529,66 @@ uint32_t pack_resample_operator(int n_in, std::vector<float> &out, uint32_t *row
     return per_tile;
 }
 
+// The same folded operator for the fused resample -> Silero V5 kernel on 16-stream tiles (silero_v5_t16.hip, RS = true):
+// 16 x 16 x 4 MFMA tiles, wave w owns output rows o = 32 w .. 32 w + 31 (two row tiles rt) of all four parts.  Per wave:
+//   4 vector blocks (D layout): RE[o][Q] / 2 for rt 0, 1, then RO[o][Q] / 2 for rt 0, 1;
+//   per k-iteration (16 values of j): the blocks SE rt0, SE rt1, AE rt0, AE rt1, SO rt0, SO rt1, AO rt0, AO rt1;
+// after the four waves the plain floats of row 128 as in pack_resample_operator.  Returns the blocks per wave.
+uint32_t pack_resample_operator_t16(int n_in, std::vector<float> &out, uint32_t *row128_block, std::string &err) {
+    std::vector<double> R;
+    build_resample_operator_d(n_in, R);
+    const int n = n_in, H = n / 2, Q = n / 4;
+    if (n % 256) {
+        err = "resample chunk length must be a multiple of 256 samples";
+        return 0;
+    }
+    auto Rv = [&](int o, int i) { return R[(size_t)(o & 511) * n + (i % n)]; };
+    double worst = 0;
+    for (int o = 0; o < 512; ++o)
+        for (int i = 0; i < n; ++i) {
+            worst = std::max(worst, std::fabs(Rv(o, i) - Rv(512 - o, n - i)));
+            worst = std::max(worst, std::fabs(Rv(o, i) - Rv(o + 256, i + H)));
+        }
+    if (worst > 1e-12) {
+        err = "resample operator lacks the symmetries the folded kernel relies on";
+        return 0;
+    }
+    auto RE = [&](int o, int i) { return Rv(o, i) + Rv(o, i + H); };
+    auto RO = [&](int o, int i) { return Rv(o, i) - Rv(o, i + H); };
+    auto G = [&](int part, int o, int j) -> float {
+        switch (part) {
+            case 0: return (float)(j == 0 ? 0.5 * RE(o, 0) : 0.25 * (RE(o, j) + RE(o, H - j)));   // GSE
+            case 1: return (float)(j == 0 ? 0.0 : 0.25 * (RE(o, j) - RE(o, H - j)));             // GAE
+            case 2: return (float)(j == 0 ? 0.0 : 0.25 * (RO(o, j) + RO(o, H - j)));             // GSO
+            default: return (float)(j == 0 ? 0.5 * RO(o, 0) : 0.25 * (RO(o, j) - RO(o, H - j)));  // GAO
+        }
+    };
+    StreamBuilder sb;
+    for (int w = 0; w < 4; ++w) {
+        for (int rt = 0; rt < 2; ++rt) sb.vector_block16([&](int c) { return (float)(0.5 * RE(32 * w + 16 * rt + c, Q)); });
+        for (int rt = 0; rt < 2; ++rt) sb.vector_block16([&](int c) { return (float)(0.5 * RO(32 * w + 16 * rt + c, Q)); });
+        for (int j = 0; j < Q / 16; ++j)
+            for (int part = 0; part < 4; ++part)
+                for (int rt = 0; rt < 2; ++rt)
+                    sb.weight_block16([&](int r, int k) { return G(part, 32 * w + 16 * rt + r, k); }, j);
+    }
+    const uint32_t per_wave = sb.blocks() / 4;
+    *row128_block = sb.blocks();
+    std::vector<float> row(2 * (size_t)Q + 2);
+    for (int j = 0; j < Q; ++j) {
+        row[j] = G(0, 128, j);
+        row[Q + j] = G(2, 128, j);
+    }
+    row[2 * Q] = (float)(0.5 * RE(128, Q));
+    row[2 * Q + 1] = (float)(0.5 * RO(128, Q));
+    for (size_t j0 = 0; j0 < row.size(); j0 += BLK_FLOATS) {
+        float *b = sb.new_block();
+        for (size_t j = j0; j < j0 + BLK_FLOATS && j < row.size(); ++j) b[j - j0] = row[j];
+    }
+    out = std::move(sb.data);
+    return per_wave;
+}
+
 bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::string &err) {
     using namespace v4;
     Blob B;

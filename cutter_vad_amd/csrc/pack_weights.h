@@ -29,5 +29,7 @@ bool pack_silero_v5_t16(const void *blob, size_t len, PackedWeights &out, std::s
 void build_resample_operator(int n_in, std::vector<float> &R);
 // radix-2 + mirror-folded packing of that operator (pack_weights.cpp); returns the blocks per row tile, 0 on failure
 uint32_t pack_resample_operator(int n_in, std::vector<float> &out, uint32_t *row128_block, std::string &err);
+// the same operator packed for the fused resample -> V5 kernel on 16-stream tiles; returns the blocks per wave, 0 on failure
+uint32_t pack_resample_operator_t16(int n_in, std::vector<float> &out, uint32_t *row128_block, std::string &err);
 
 }  // namespace vadk

@@ -46,6 +46,14 @@ constexpr int T_ROWS_H = 32;
 static_assert(T_ROWS_X * QSD >= 192 * QSL, "the loader view must end before h");
 constexpr int T_LDS_F4 = (T_ROWS_X + T_ROWS_H) * QSD + 16 + 12 + 36 + 16 + 96;   // + head partials [4][16], |X128| [3][16], fold corrections [3][3][16], sink [64], state machines [16] x 96 B
 static_assert(T_LDS_F4 * 16 <= 80 * 1024, "stays under half a CU's LDS");
+// RS instantiation (fused resample -> step): the tile's 16 kHz frames live in LDS behind everything else, [16 streams][129 quads]
+// (128 + 1 of padding: the recombination stores scalars down a column of streams); the resampler's folded input chunks
+// (2 buffers x {ue, ve, uo, vo} x 16 quad rows, loader stride) are staged in the activation region, which is idle until the
+// frame loop starts
+constexpr int FQ = 129;
+constexpr int RS_CH_ROWS = 16;
+constexpr int RS_BUF = 4 * RS_CH_ROWS * QSL;
+static_assert(2 * RS_BUF <= T_ROWS_X * QSD, "resampler staging must fit the activation region");
 
 __device__ __forceinline__ f32x4 mfma16(f32x4 w, f32x4 a, f32x4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a.x, acc, 0, 0, 0);
@@ -57,10 +65,14 @@ __device__ __forceinline__ f32x4 mfma16(f32x4 w, f32x4 a, f32x4 acc) {
 
 }  // namespace
 
-template <bool F32IN>
-__global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams P) {
+// RS: one tick for streams at other input rates (vad_step_rates): the tile first resamples its 16 chunks to 16 kHz into LDS -
+// AudioUtils.resample_audio's Fourier method as the folded operator of resample.hip, on 16 x 16 x 4 tiles - and the frame loop
+// ingests them from there: no second launch, no HBM round trip of the 16 kHz frames.  T = 1, float32 input.
+template <bool F32IN, bool RS>
+__global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams P, const RateParams R) {
     using namespace vadk::v5;
-    __shared__ f32x4 lds[T_LDS_F4];
+    static_assert(!RS || F32IN, "resampled frames are float32");
+    __shared__ f32x4 lds[T_LDS_F4 + (RS ? MT16 * FQ : 0)];
     f32x4 *const RX = lds;
     f32x4 *const RE = lds + T_ROW_E * QSD;
     f32x4 *const RH = lds + T_ROWS_X * QSD;
@@ -77,9 +89,18 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     const int kq = lane >> 4;                     // channel group (B operand) = row quad of the D tile
     const int nq = kq * QSD + n;                  // lane's offset inside a group of 4 quad rows (dense view)
     const int nqL = kq * QSL + n;                 // the same in the loader view
-    const int tile0 = blockIdx.x * MT16;
+    // RS: which segment (input rate) does this tile serve?  block-uniform: scalar compares on kernel arguments
+    int sidx = 0;
+    if constexpr (RS) {
+#pragma unroll
+        for (int k = 1; k < RATE_MAX_SEGS; ++k)
+            if (k < R.nseg && (int)blockIdx.x >= R.tile_start[k]) sidx = k;
+    }
+    const int tis = RS ? (int)blockIdx.x - R.tile_start[sidx] : 0;        // tile within its segment
+    const int seg_n = RS ? R.seg[sidx].n : 0;
+    const int tile0 = RS ? R.seg[sidx].stream0 + tis * MT16 : (int)blockIdx.x * MT16;
     const int gf = tile0 + n;
-    const bool live = gf < P.n;
+    const bool live = RS ? tis * MT16 + n < seg_n : gf < P.n;
     const int slot = live ? (P.slots ? P.slots[gf] : gf) : 0;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wstream), 0, (int)P.wstream_bytes, 0x00020000);
     const int lane16 = lane * 16;
@@ -99,8 +120,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
     u32x4 xa_[4], xb_[4], xc_[4];                  // raw quads of the three columns
+    f32x4 *const F4 = lds + T_LDS_F4;              // RS: the tile's resampled frames
 #define X_ISSUE(c, XR, tt)                                                                                      \
-    {                                                                                                           \
+    if constexpr (RS) {                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                           \
+            XR[k] = __builtin_bit_cast(u32x4, F4[(tid >> 4) * FQ + 32 * (c) + q + 16 * k]);                     \
+    } else {                                                                                                    \
         const int fq = ((tile0 + (tid >> 4)) * T + (tt)) * 128 + 32 * (c) + q;                                  \
         _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                           \
             XR[k] = __builtin_amdgcn_raw_buffer_load_b128(frs, (fq + 16 * k) << qsh, 0, 0);                     \
@@ -136,6 +161,146 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
         for (int k = 0; k < 6; ++k) reinterpret_cast<f32x4 *>(smL + tid)[k] = smq[k];
     }
     const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];
+
+    if constexpr (RS) {
+        // ---- the tile's 16 chunks -> 512 samples at 16 kHz each, into F (resample.hip has the algebra; pack_resample_operator_t16
+        //      the operator layout): four folded inputs ue / ve / uo / vo of length Q = n_in / 4 against four 128-row operators
+        //      (se, ae, so, ao); wave w owns rows o = 32 w .. 32 w + 31 (two row tiles) of all four
+        const RateSeg S = R.seg[sidx];
+        float *const Ff = reinterpret_cast<float *>(F4);
+        const int ls0 = tis * MT16;                                   // first stream of the tile within the segment
+        if (S.wstream == nullptr) {                                   // already 16 kHz (resample_audio returns its input): copy
+            const __amdgpu_buffer_rsrc_t xrs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S.in), 0, (int)((unsigned)S.n * 2048u), 0x00020000);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = it * NTHREADS + tid, ms = idx >> 7, qd = idx & 127;
+                F4[ms * FQ + qd] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((ls0 + ms) * 128 + qd) * 16, 0, 0));
+            }
+        } else {
+            const int Q = S.n_in >> 2, nchunks = Q >> 6;
+            const __amdgpu_buffer_rsrc_t ors =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S.wstream), 0, (int)S.wstream_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t xrs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S.in), 0, (int)((unsigned)S.n * (unsigned)S.n_in * 4u), 0x00020000);
+#define OL(blk) ldw(ors, lane16, (blk))
+            const int wbase = w * (int)S.wave_blocks;
+            f32x4 acc[8];                                             // part p (se, ae, so, ao), row tile rt -> acc[2 p + rt]
+            {   // the sample each half-size product cannot pair, x[Q] +- x[Q + H], is a rank-1 term: accumulator init
+                const float xa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ((ls0 + n) * S.n_in + Q) * 4, 0, 0));
+                const float xb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ((ls0 + n) * S.n_in + 3 * Q) * 4, 0, 0));
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    acc[0 + rt] = OL(wbase + rt) * (xa + xb);
+                    acc[4 + rt] = OL(wbase + 2 + rt) * (xa - xb);
+                    acc[2 + rt] = acc[6 + rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            // chunk loader: 16 streams x 16 folded quads = one per thread (stream ms = tid >> 4, quad ql = tid & 15)
+            u32x4 xl[6];
+            const int cms = tid >> 4, cql = tid & 15;
+            auto load_chunk = [&](int c) {
+                const int qq = cql + 16 * c, base = (ls0 + cms) * Q;
+                xl[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + qq) * 16, 0, 0);
+                xl[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + qq + (Q >> 1)) * 16, 0, 0);
+                xl[2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (Q >> 1) - qq) * 16, 0, 0);
+                xl[3] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (Q >> 1) - qq - 1) * 16, 0, 0);
+                xl[4] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (qq == 0 ? 0 : Q - qq)) * 16, 0, 0);
+                xl[5] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + Q - qq - 1) * 16, 0, 0);
+            };
+            auto store_chunk = [&](int c, int buf) {
+                const f32x4 a = __builtin_bit_cast(f32x4, xl[0]), cc = __builtin_bit_cast(f32x4, xl[1]);
+                const f32x4 b0 = __builtin_bit_cast(f32x4, xl[2]), b1 = __builtin_bit_cast(f32x4, xl[3]);
+                const f32x4 d0 = __builtin_bit_cast(f32x4, xl[4]), d1 = __builtin_bit_cast(f32x4, xl[5]);
+                const f32x4 b = f32x4{b0.x, b1.w, b1.z, b1.y}, d = f32x4{d0.x, d1.w, d1.z, d1.y};
+                const f32x4 pe = a + cc, me = a - cc, qe = b + d, qo = b - d;
+                f32x4 ue = pe + qe, ve = pe - qe, uo = me + qo, vo = me - qo;
+                if (cql + 16 * c == 0) { ue.x = pe.x; ve.x = 0.f; uo.x = 0.f; vo.x = me.x; }     // j = 0 has no partner
+                f32x4 *dst = lds + buf * RS_BUF + cql * QSL + cms;
+                dst[0] = ue;
+                dst[RS_CH_ROWS * QSL] = ve;
+                dst[2 * RS_CH_ROWS * QSL] = uo;
+                dst[3 * RS_CH_ROWS * QSL] = vo;
+            };
+            // output rows 128 / 384 on the VALU: thread = (stream tid & 15, part tid >> 4); parts 0..7 dot ue with GSE[128],
+            // 8..15 uo with GSO[128], two quads of every chunk each
+            float r128 = 0.f;
+            const int rpart = tid >> 4, pr = rpart & 7, psel = rpart >> 3;
+            constexpr int D = 4;                                      // operator blocks run D k-iterations ahead, across chunks
+            f32x4 wq[D][8], xq[4];
+            int ws = wbase + 4;
+#define R_LDW(slot, j) _Pragma("unroll") for (int k = 0; k < 8; ++k) wq[slot][k] = OL(ws + 8 * (j) + k);
+#pragma unroll
+            for (int d = 0; d < D - 1; ++d) { R_LDW(d, d) }
+            load_chunk(0);
+            store_chunk(0, 0);
+            __syncthreads();
+            for (int c = 0; c < nchunks; ++c) {
+                const f32x4 *X = lds + (c & 1) * RS_BUF;
+                asm volatile("" : "+s"(ws));
+                f32x4 g128[2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    R_LDW((j + D - 1) % D, j + D - 1)                 // past j = 3: the next chunk's blocks (the stream is contiguous)
+                    if (j == 0) {
+                        if (c + 1 < nchunks) load_chunk(c + 1);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            g128[i] = ldw(ors, (psel * (Q >> 2) + 16 * c + 2 * pr + i) * 16, (int)S.row128_block);
+                    }
+#pragma unroll
+                    for (int p4 = 0; p4 < 4; ++p4) xq[p4] = X[(p4 * RS_CH_ROWS + 4 * j) * QSL + nqL];
+                    SB();
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] = mfma16(wq[j % D][k], xq[k >> 1], acc[k]);
+                    SB();
+                }
+                ws += 32;
+                {
+                    const int ms = tid & 15;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const f32x4 uu = X[(psel * 2 * RS_CH_ROWS + 2 * pr + i) * QSL + ms];
+                        r128 += g128[i].x * uu.x + g128[i].y * uu.y + g128[i].z * uu.z + g128[i].w * uu.w;
+                    }
+                }
+                if (c + 1 < nchunks) store_chunk(c + 1, (c + 1) & 1);
+                __syncthreads();
+            }
+#undef R_LDW
+            // recombine: y[o] = se+ae+so+ao, y[o+256] = se+ae-so-ao, y[256-o] = se-ae+so-ao, y[512-o] = se-ae-so+ao
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int row = 32 * w + 16 * rt + 4 * kq;
+                const f32x4 se = acc[0 + rt], ae = acc[2 + rt], so = acc[4 + rt], ao = acc[6 + rt];
+                const f32x4 pe = se + ae, me = se - ae, pO = so + ao, mO = so - ao;
+                F4[n * FQ + (row >> 2)] = pe + pO;
+                F4[n * FQ + 64 + (row >> 2)] = pe - pO;
+                const f32x4 lo = me + mO, hi = me - mO;
+                float *o = Ff + n * (4 * FQ);
+                if (row != 0) { o[256 - row] = lo.x; o[512 - row] = hi.x; }     // o = 0: y[256] and y[0] are written above
+                o[255 - row] = lo.y; o[511 - row] = hi.y;
+                o[254 - row] = lo.z; o[510 - row] = hi.z;
+                o[253 - row] = lo.w; o[509 - row] = hi.w;
+            }
+            headp[rpart * 16 + (tid & 15)] = r128;                   // [16 parts][16 streams]: headp .. fcor are idle before the frame loop
+            __syncthreads();
+            if (tid < MT16) {
+                float e = 0.f, od = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { e += headp[k * 16 + tid]; od += headp[(8 + k) * 16 + tid]; }
+                const float xq1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ((ls0 + tid) * S.n_in + Q) * 4, 0, 0));
+                const float xq3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ((ls0 + tid) * S.n_in + 3 * Q) * 4, 0, 0));
+                const f32x4 mid = ldw(ors, (Q >> 1) * 16, (int)S.row128_block);       // floats 2Q, 2Q + 1: RE[128][Q] / 2, RO[128][Q] / 2
+                e += mid.x * (xq1 + xq3);
+                od += mid.y * (xq1 - xq3);
+                Ff[tid * (4 * FQ) + 128] = e + od;
+                Ff[tid * (4 * FQ) + 384] = e - od;
+            }
+#undef OL
+        }
+        __syncthreads();                                              // F complete; the staging area is free for the frame loop
+    }
 
     for (int t = 0; t < T; ++t) {
         int ws_stft = o_stft, ws_e0 = o_e0, ws_e1 = o_e1, ws_e2 = o_e2, ws_e3 = o_e3, ws_l = o_l;
@@ -518,9 +683,19 @@ extern "C" hipError_t vadk_launch_silero_v5_t16(const vadk::StepParams *p, hipSt
     (void)hipGetLastError();
     const int tiles = (p->n + MT16 - 1) / MT16;
     if (tiles <= 0) return hipSuccess;
+    const vadk::RateParams none{};
     if (p->fmt == 0)
-        hipLaunchKernelGGL(silero_v5_step16<true>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+        hipLaunchKernelGGL((silero_v5_step16<true, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, none);
     else
-        hipLaunchKernelGGL(silero_v5_step16<false>, dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+        hipLaunchKernelGGL((silero_v5_step16<false, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, none);
+    return hipGetLastError();
+}
+
+// one tick for streams at several input rates: resample + step fused, one launch (p->T must be 1, p->n = all streams)
+extern "C" hipError_t vadk_launch_silero_v5_t16_rates(const vadk::StepParams *p, const vadk::RateParams *r, hipStream_t stream) {
+    (void)hipGetLastError();
+    const int tiles = r->tile_start[r->nseg];
+    if (tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL((silero_v5_step16<true, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, *r);
     return hipGetLastError();
 }

@@ -181,4 +181,22 @@ struct ResampleParams {
     int32_t tile_start[RESAMPLE_MAX_SEGS + 1];
 };
 
+// fused resample -> Silero V5 step on 16-stream tiles (csrc/silero_v5_t16.hip, RS instantiation): one launch for a tick whose
+// streams arrive at different rates.  Segment k = n streams of one input rate, served by 16-stream tiles tile_start[k] ..
+// tile_start[k+1]-1; stream0 = index of its first stream in the call's slots / probs / events arrays.
+struct RateSeg {
+    const float *wstream;     // pack_resample_operator_t16; nullptr: the segment is 16 kHz already (`in` holds 512-sample frames)
+    uint32_t wstream_bytes;
+    uint32_t wave_blocks;     // operator blocks per wave
+    uint32_t row128_block;
+    int32_t n, n_in, stream0;
+    const float *in;          // [n][n_in]
+};
+constexpr int RATE_MAX_SEGS = 8;
+struct RateParams {
+    RateSeg seg[RATE_MAX_SEGS];
+    int32_t nseg;
+    int32_t tile_start[RATE_MAX_SEGS + 1];
+};
+
 }  // namespace vadk

@@ -295,8 +295,10 @@ VAD_API int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *o
  * (utils/audio.py:19-55); this entry point is that path, on the GPU: segment k holds n[k] chunks of one tick at sr_in[k]
  * (256 samples @ 8 kHz, 768 @ 24 kHz, 1536 @ 48 kHz - one 512-sample 16 kHz frame each; 512 @ 16 kHz passes through, as
  * resample_audio does at :39-40); all segments are resampled in ONE launch into engine-owned HBM and every stream advances one
- * frame in ONE model launch right behind it on the same HIP stream - the 16 kHz frames never travel.  slots / probs / events /
- * seg_frames are the concatenation of the segments, in order.  16 kHz engines only (Silero V5, or V4's 16 kHz sub-model).
+ * frame in ONE model launch right behind it on the same HIP stream - the 16 kHz frames never travel.  A Silero V5 engine serves
+ * ticks of at most 4 096 streams with ONE fused launch instead: every 16-stream tile resamples its own chunks into LDS and steps
+ * the model from there (results equal the two-launch form to rounding).  slots / probs / events / seg_frames are the
+ * concatenation of the segments, in order.  16 kHz engines only (Silero V5, or V4's 16 kHz sub-model).
  * The device form is asynchronous like vad_step_device and follows its slot rules; calls on one engine must use one stream.
  */
 VAD_API int vad_step_rates_device(vad_engine *e, int32_t nseg, const float *const *d_in, const int64_t *n, const int32_t *sr_in,
@@ -328,6 +330,11 @@ VAD_API int vad_debug_resample_operator(int32_t n_in, float *R, size_t r_floats)
  */
 VAD_API int vad_debug_pack_resample(int32_t n_in, float *out, size_t out_floats, size_t *n_floats,
                                     uint32_t *tile_blocks, uint32_t *row128_block);
+
+/* the same operator as the fused resample -> step kernel streams it (16 x 16 x 4 tiles: pack_resample_operator_t16);
+ * wave_blocks = 1 KiB blocks per wave (4 vector blocks + 8 per 16-sample k-iteration) */
+VAD_API int vad_debug_pack_resample_t16(int32_t n_in, float *out, size_t out_floats, size_t *n_floats,
+                                        uint32_t *wave_blocks, uint32_t *row128_block);
 
 /*
  * Diagnostic: replay a scripted probability sequence through ONE slot's device-side state

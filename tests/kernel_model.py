@@ -697,3 +697,49 @@ def v5_step_t16(W, sect, x, hc, gate=0.01):
             z += (hw[:, None] * np.maximum(hn, 0)).sum(0)
     prob = sig(z + W[sect[0][S_HEADB]][0, 0])
     return prob.astype(np.float32), np.concatenate([h_new, c_new], axis=1).astype(np.float32)
+
+
+def packed_resample_t16(n_in: int):
+    lib = _ffi.lib()
+    n, wb, r128 = C.c_size_t(), C.c_uint32(), C.c_uint32()
+    assert lib.vad_debug_pack_resample_t16(n_in, None, 0, C.byref(n), C.byref(wb), C.byref(r128)) == 0
+    out = np.empty(n.value, np.float32)
+    assert lib.vad_debug_pack_resample_t16(n_in, out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(n), C.byref(wb),
+                                           C.byref(r128)) == 0
+    return out.reshape(-1, 64, 4), int(wb.value), int(r128.value)
+
+
+def resample_t16(W, wave_blocks, row128_block, x):
+    """x [16, n_in] -> y [16, 512]: the RS prologue of silero_v5_t16.hip over pack_resample_operator_t16's stream (float64)."""
+    x = x.astype(np.float64)
+    n_in = x.shape[1]
+    H, Q = n_in // 2, n_in // 4
+    xe, xo = x[:, :H] + x[:, H:], x[:, :H] - x[:, H:]
+    j = np.arange(Q)
+    rev = (H - j) % H
+    ue, ve, uo, vo = xe[:, j] + xe[:, rev], xe[:, j] - xe[:, rev], xo[:, j] + xo[:, rev], xo[:, j] - xo[:, rev]
+    ue[:, 0], ve[:, 0], uo[:, 0], vo[:, 0] = xe[:, 0], 0.0, 0.0, xo[:, 0]
+    parts = [a.reshape(16, Q // 4, 4).transpose(1, 0, 2) for a in (ue, ve, uo, vo)]      # quad rows [Q/4, 16 streams, 4]
+    y = np.zeros((16, 512))
+    for w in range(4):
+        wb = w * wave_blocks
+        for rt in range(2):
+            acc = [np.zeros((16, 16)) for _ in range(4)]
+            acc[0] += _vec16(W[wb + rt])[:, None] * xe[:, Q][None, :]
+            acc[2] += _vec16(W[wb + 2 + rt])[:, None] * xo[:, Q][None, :]
+            for g in range(Q // 16):
+                for p in range(4):
+                    acc[p] += _mfma16(W[wb + 4 + 8 * g + 2 * p + rt], _rows16(parts[p], 4 * g))
+            se, ae, so, ao = acc
+            for r in range(16):
+                o = 32 * w + 16 * rt + r
+                y[:, o] = (se + ae + so + ao)[r]
+                y[:, o + 256] = (se + ae - so - ao)[r]
+                if o:
+                    y[:, 256 - o] = (se - ae + so - ao)[r]
+                    y[:, 512 - o] = (se - ae - so + ao)[r]
+    row = W[row128_block:].reshape(-1).astype(np.float64)
+    e = ue @ row[:Q] + row[2 * Q] * xe[:, Q]
+    od = uo @ row[Q:2 * Q] + row[2 * Q + 1] * xo[:, Q]
+    y[:, 128], y[:, 384] = e + od, e - od
+    return y

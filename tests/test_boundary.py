@@ -132,6 +132,19 @@ def test_packed_layout_for_the_16_stream_tile_kernel_reproduces_the_oracle():
             assert np.abs(hc - hc_o).max() <= 1e-4
 
 
+@pytest.mark.parametrize("n_in", [256, 768, 1536])
+def test_fused_resampler_operator_packing_reproduces_scipy(n_in):
+    """pack_resample_operator_t16 through the model of the fused kernel's resample prologue == scipy.signal.resample."""
+    import scipy.signal
+    from tests import kernel_model as KM
+    W, wave_blocks, row128 = KM.packed_resample_t16(n_in)
+    assert wave_blocks == 4 + 8 * (n_in // 4 // 16)
+    x = (0.4 * np.random.default_rng(n_in).standard_normal((16, n_in))).astype(np.float32)
+    y = KM.resample_t16(W, wave_blocks, row128, x)
+    ref = np.stack([scipy.signal.resample(r.astype(np.float64), 512) for r in x])
+    assert np.abs(y - ref).max() <= 2e-6
+
+
 def test_weights_blob_roundtrip_and_reference_arity_rule(tmp_path):
     with open(weights_io.packaged_blob_path(5), "rb") as f:
         blob = f.read()

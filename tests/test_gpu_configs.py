@@ -128,11 +128,28 @@ def test_config3_mixed_input_rates_one_product_call():
                             for i in pick]).astype(np.float32)
             ref = om.step_batch(oracle.denoise(x16).reshape(pick.size, 512), st, nthreads=8)
             assert np.abs(p[pick] - ref).max() <= 5e-5, t            # bar 1e-4; the resampler adds <= 1e-5 on the samples
-            # the same tick as two calls per segment on another engine: identical bits
+            # the same tick as separate resample and step calls on another engine: the fused launch (16 x 16 x 4 tiles in both the
+            # resampler and the model) equals it to rounding; with 32-stream tiles pinned the product call is the two-launch
+            # chain itself and the bits are identical
             f16 = np.concatenate([two.resample(a, sr) if sr != 16000 else a for a, sr in segs])
             p2, ev2, _ = two.step_events(slots2, f16)
-            assert np.array_equal(p, p2) and np.array_equal(ev, ev2)
+            assert np.abs(p - p2).max() <= 5e-6 and (ev == ev2).mean() > 0.999
             d_x.append(segs)
+        eng.reset(slots)
+        two.reset(slots2)
+        eng.set_tile(32)
+        two.set_tile(32)
+        for t in range(T):
+            p, ev, _ = eng.step_rates(d_x[t], slots)
+            f16 = np.concatenate([two.resample(a, sr) if sr != 16000 else a for a, sr in d_x[t]])
+            p2, ev2, _ = two.step_events(slots2, f16)
+            assert np.array_equal(p, p2) and np.array_equal(ev, ev2)
+        eng.set_tile(0)
+        two.set_tile(0)
+        fused = []
+        eng.reset(slots)
+        for t in range(T):
+            fused.append(eng.step_rates(d_x[t], slots)[0])
         # device pointers, asynchronous: replay the 5 ticks from zero state
         eng.reset(slots)
         dev = torch.device("cuda:0")
@@ -148,10 +165,8 @@ def test_config3_mixed_input_rates_one_product_call():
             torch.cuda.synchronize()
             eng.step_rates_device(d_segs, d_p[t].data_ptr(), stream=ts.cuda_stream)
         ts.synchronize()
-        two.reset(slots2)
-        for t in range(T):
-            f16 = np.concatenate([two.resample(a, sr) if sr != 16000 else a for a, sr in d_x[t]])
-            assert np.array_equal(d_p[t].cpu().numpy(), two.step(slots2, f16)), t
+        for t in range(T):                      # the asynchronous device form runs the same fused launch: same bits as the host form
+            assert np.array_equal(d_p[t].cpu().numpy(), fused[t]), t
         with pytest.raises(Exception, match="must hold 768"):
             eng.step_rates([(np.zeros((2, 700), np.float32), 24000)], slots[:2])
         with pytest.raises(Exception, match="supported input rates"):
