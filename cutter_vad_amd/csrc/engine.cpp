@@ -83,6 +83,7 @@ struct vad_engine {
     size_t wbytes16 = 0;
     uint32_t sect16[vadk::NWAVES][16] = {};
     int tile_policy = 0;                     // 0 = by batch size, 16 / 32 = forced (vad_debug_set_tile)
+    bool rates_fused = true;                 // vad_debug_set_tile(-1 / -2): two-launch / fused form of vad_step_rates (benchmarks)
     bool shared_gpu = false;                 // VAD_ENGINE_SHARED_GPU: keep to 32-stream tiles (n / 32 CUs), leave the rest to the co-tenant
     int sample_rate = 16000;
     int frame_samples = VAD_FRAME_SAMPLES;   // samples per model step (512; Silero V5's 8 kHz sub-model: 256)
@@ -966,7 +967,7 @@ int step_rates_enqueue(vad_engine *e, int32_t nseg, const float *const *d_in, co
     // Silero V5, at most 4 096 streams: ONE launch - every 16-stream tile resamples its own chunks into LDS and steps the
     // model from there (silero_v5_t16.hip, RS instantiation); the 16 kHz frames never exist in HBM
     if (e->version == 5 && e->d_wstream16 && !e->shared_gpu && e->tile_policy != 32 && total <= vad_engine::T16_MAX_STREAMS &&
-        nseg <= vadk::RATE_MAX_SEGS) {
+        nseg <= vadk::RATE_MAX_SEGS && e->rates_fused) {
         vadk::RateParams rp{};
         int32_t tiles = 0, stream0 = 0, ns = 0;
         for (int k = 0; k < nseg; ++k) {
@@ -1459,6 +1460,10 @@ int vad_debug_pack_weights(int32_t model_version, const void *weights, size_t we
 int vad_debug_set_tile(vad_engine *e, int32_t streams_per_tile) {
     if (!e) return VAD_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
+    if (streams_per_tile == -1 || streams_per_tile == -2) {       // vad_step_rates: -1 = resample launch + model launch, -2 = fused (default)
+        e->rates_fused = streams_per_tile == -2;
+        return VAD_OK;
+    }
     if (streams_per_tile != 0 && streams_per_tile != 16 && streams_per_tile != 32)
         return e->fail(VAD_ERR_INVALID_ARG, "tile: 0 (by batch size), 16 or 32");
     if (streams_per_tile == 16 && !e->d_wstream16)

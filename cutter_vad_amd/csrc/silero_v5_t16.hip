@@ -46,14 +46,15 @@ constexpr int T_ROWS_H = 32;
 static_assert(T_ROWS_X * QSD >= 192 * QSL, "the loader view must end before h");
 constexpr int T_LDS_F4 = (T_ROWS_X + T_ROWS_H) * QSD + 16 + 12 + 36 + 16 + 96;   // + head partials [4][16], |X128| [3][16], fold corrections [3][3][16], sink [64], state machines [16] x 96 B
 static_assert(T_LDS_F4 * 16 <= 80 * 1024, "stays under half a CU's LDS");
-// RS instantiation (fused resample -> step): the tile's 16 kHz frames live in LDS behind everything else, [16 streams][129 quads]
-// (128 + 1 of padding: the recombination stores scalars down a column of streams); the resampler's folded input chunks
-// (2 buffers x {ue, ve, uo, vo} x 16 quad rows, loader stride) are staged in the activation region, which is idle until the
-// frame loop starts
+// RS instantiation (fused resample -> step): no LDS of its own.  The resampler's folded input chunks (2 buffers x {ue, ve, uo, vo}
+// x 16 quad rows, loader stride) are staged in the activation region, which is idle until the frame loop starts; the tile's 16 kHz
+// frames F [16 streams][129 quads] (128 + 1 of padding: the recombination stores scalars down a column of streams) then take the
+// same place - the frame loop reads all three columns of F into registers BEFORE its first barrier, and the folds that overwrite
+// the region come after it.
 constexpr int FQ = 129;
 constexpr int RS_CH_ROWS = 16;
 constexpr int RS_BUF = 4 * RS_CH_ROWS * QSL;
-static_assert(2 * RS_BUF <= T_ROWS_X * QSD, "resampler staging must fit the activation region");
+static_assert(2 * RS_BUF <= 192 * QSL && MT16 * FQ <= 192 * QSL, "resampler staging and F must fit the loader view");
 
 __device__ __forceinline__ f32x4 mfma16(f32x4 w, f32x4 a, f32x4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a.x, acc, 0, 0, 0);
@@ -69,10 +70,12 @@ __device__ __forceinline__ f32x4 mfma16(f32x4 w, f32x4 a, f32x4 acc) {
 // AudioUtils.resample_audio's Fourier method as the folded operator of resample.hip, on 16 x 16 x 4 tiles - and the frame loop
 // ingests them from there: no second launch, no HBM round trip of the 16 kHz frames.  T = 1, float32 input.
 template <bool F32IN, bool RS>
-__global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams P, const RateParams R) {
+// (RS may have a few more tiles than CUs - segments are padded to whole tiles - so it is built for two workgroups per CU: the
+// stragglers then run beside other tiles instead of after them)
+__global__ void __launch_bounds__(NTHREADS, RS ? 2 : 1) silero_v5_step16(const StepParams P, const RateParams R) {
     using namespace vadk::v5;
     static_assert(!RS || F32IN, "resampled frames are float32");
-    __shared__ f32x4 lds[T_LDS_F4 + (RS ? MT16 * FQ : 0)];
+    __shared__ f32x4 lds[T_LDS_F4];
     f32x4 *const RX = lds;
     f32x4 *const RE = lds + T_ROW_E * QSD;
     f32x4 *const RH = lds + T_ROWS_X * QSD;
@@ -120,7 +123,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
     u32x4 xa_[4], xb_[4], xc_[4];                  // raw quads of the three columns
-    f32x4 *const F4 = lds + T_LDS_F4;              // RS: the tile's resampled frames
+    f32x4 *const F4 = lds;                         // RS: the tile's resampled frames (alias of the loader view, see FQ)
 #define X_ISSUE(c, XR, tt)                                                                                      \
     if constexpr (RS) {                                                                                         \
         _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                           \
@@ -373,11 +376,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
             H_LDW(wA, 0)
             SB();
             H_LDW(wB, 1) X_ISSUE(0, xa_, t) X_ISSUE(1, xb_, t) SB();
+            if constexpr (RS) { X_ISSUE(2, xc_, t) SB(); }     // F is dead once every wave has passed the barrier below
             __syncthreads();   // (0) h_{t-1} visible (t > 0: follows barrier (8))
 #pragma unroll
             for (int k = 0; k < 8; ++k) G[k] = nb[k];
             H_MMA(wA, 0) SB();
-            H_LDW(wA, 2) X_ISSUE(2, xc_, t) SB(); H_MMA(wB, 1) SB();
+            H_LDW(wA, 2) if constexpr (!RS) { X_ISSUE(2, xc_, t) } SB(); H_MMA(wB, 1) SB();
             H_LDW(wB, 3) SB(); H_MMA(wA, 2) X_FOLD(0, xa_) H_MIX SB();
             H_LDW(wA, 4) SB(); H_MMA(wB, 3) SB();
             H_LDW(wB, 5) SB(); H_MMA(wA, 4) X_FOLD(1, xb_) H_MIX SB();

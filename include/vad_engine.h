@@ -349,7 +349,8 @@ VAD_API int vad_debug_sm_replay(vad_engine *e, int64_t slot, const float *probs,
 /*
  * Diagnostic: which kernel shape serves the step calls of a Silero V5 16 kHz engine.  0 (default) = by batch size: calls with
  * at most 4 096 streams run on 16-stream tiles (twice as many workgroups, half as long each), larger ones on 32-stream tiles;
- * 16 / 32 force one shape (the test-suite checks that both give the same bits; tools/bench_configs.py times them).
+ * 16 / 32 force one shape (the test-suite checks that both give the same results; tools/bench_configs.py times them).
+ * -1 / -2: vad_step_rates as two launches (resample, then model) / as the fused launch (default), for the same comparison.
  */
 VAD_API int vad_debug_set_tile(vad_engine *e, int32_t streams_per_tile);
 
