@@ -966,8 +966,10 @@ int step_rates_enqueue(vad_engine *e, int32_t nseg, const float *const *d_in, co
     if (!d_probs) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: null buffer");
     // Silero V5, at most 4 096 streams: ONE launch - every 16-stream tile resamples its own chunks into LDS and steps the
     // model from there (silero_v5_t16.hip, RS instantiation); the 16 kHz frames never exist in HBM
-    if (e->version == 5 && e->d_wstream16 && !e->shared_gpu && e->tile_policy != 32 && total <= vad_engine::T16_MAX_STREAMS &&
-        nseg <= vadk::RATE_MAX_SEGS && e->rates_fused) {
+    int64_t tiles16 = 0;                       // segments are padded to whole 16-stream tiles
+    for (int k = 0; k < nseg; ++k) tiles16 += (n[k] + 15) / 16;
+    if (e->version == 5 && e->d_wstream16 && !e->shared_gpu && e->tile_policy != 32 && nseg <= vadk::RATE_MAX_SEGS && e->rates_fused &&
+        tiles16 <= e->prop.multiProcessorCount) {      // at most one tile per CU: a second round of tiles would cost a whole tile time
         vadk::RateParams rp{};
         int32_t tiles = 0, stream0 = 0, ns = 0;
         for (int k = 0; k < nseg; ++k) {

@@ -296,8 +296,9 @@ VAD_API int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *o
  * (256 samples @ 8 kHz, 768 @ 24 kHz, 1536 @ 48 kHz - one 512-sample 16 kHz frame each; 512 @ 16 kHz passes through, as
  * resample_audio does at :39-40); all segments are resampled in ONE launch into engine-owned HBM and every stream advances one
  * frame in ONE model launch right behind it on the same HIP stream - the 16 kHz frames never travel.  A Silero V5 engine serves
- * ticks of at most 4 096 streams with ONE fused launch instead: every 16-stream tile resamples its own chunks into LDS and steps
- * the model from there (results equal the two-launch form to rounding).  slots / probs / events / seg_frames are the
+ * ticks that fit one 16-stream tile per CU (each segment padded to whole tiles: at most 256 tiles, ~4 000 streams) with ONE
+ * fused launch instead: every tile resamples its own chunks into LDS and steps the model from there (results equal the
+ * two-launch form to rounding).  slots / probs / events / seg_frames are the
  * concatenation of the segments, in order.  16 kHz engines only (Silero V5, or V4's 16 kHz sub-model).
  * The device form is asynchronous like vad_step_device and follows its slot rules; calls on one engine must use one stream.
  */

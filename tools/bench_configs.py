@@ -71,9 +71,9 @@ def tile_shapes():
     return out
 
 
-def config3():
+def config3(per=None):
     B = 4096
-    per = B // 3
+    per = per or B // 3
     eng = Engine(blob(5), max_streams=B)
     eng.open_streams(B)
     rates = ((8000, 256), (24000, 768), (48000, 1536))
@@ -91,9 +91,16 @@ def config3():
     eng.set_tile(-1)                  # the two-launch form of the same call: resample kernel, then the model kernel
     dt2 = timed(step, [ts])
     eng.close()
-    return {"config": "configs[3]: batch=4095 (3 x 1365) mixed 8/24/48 kHz -> vad_step_rates_device (ONE fused launch: every 16-stream tile "
-                      "resamples its chunks into LDS and steps from there)", "us_per_step": dt * 1e6, "frames_per_s": 3 * per / dt,
-            "us_per_step_two_launches": dt2 * 1e6}
+    tiles = 3 * ((per + 15) // 16)
+    return {"config": f"configs[3]: batch={3 * per} (3 x {per}) mixed 8/24/48 kHz -> vad_step_rates_device; {tiles} 16-stream tiles: "
+                      + ("ONE fused launch (every tile resamples its chunks into LDS and steps from there)" if tiles <= 256 else
+                         "more tiles than CUs -> resample launch + model launch"),
+            "us_per_step": dt * 1e6, "frames_per_s": 3 * per / dt, "us_per_step_two_launches_forced": dt2 * 1e6}
+
+
+def config3_255_tiles():
+    """configs[3] with the three thirds rounded to whole tiles (3 x 1 360 = 4 080 streams = 255 tiles): the fused launch"""
+    return config3(1360)
 
 
 def config3_pipelined():
@@ -273,5 +280,5 @@ if __name__ == "__main__":
         print(json.dumps(r), flush=True)
     for r in resampler_alone():
         print(json.dumps(r), flush=True)
-    for fn in (config1, config3, config3_pipelined, config4_per_gpu, v4_alone, v4_8k):
+    for fn in (config1, config3, config3_255_tiles, config3_pipelined, config4_per_gpu, v4_alone, v4_8k):
         print(json.dumps(fn()), flush=True)
