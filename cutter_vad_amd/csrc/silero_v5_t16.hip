@@ -201,9 +201,11 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
                 }
             }
             // chunk loader: 16 streams x 16 folded quads = one per thread (stream ms = tid >> 4, quad ql = tid & 15)
-            u32x4 xl[6];
+            // (input chunks are requested TWO chunks ahead - two register sets - so that a chunk's HBM round trip has a whole
+            // chunk of MFMAs, ~1.7 us, more to hide under than it needs)
+            u32x4 xlA[6], xlB[6];
             const int cms = tid >> 4, cql = tid & 15;
-            auto load_chunk = [&](int c) {
+            auto load_chunk = [&](int c, u32x4 *xl) {
                 const int qq = cql + 16 * c, base = (ls0 + cms) * Q;
                 xl[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + qq) * 16, 0, 0);
                 xl[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + qq + (Q >> 1)) * 16, 0, 0);
@@ -212,7 +214,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
                 xl[4] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (qq == 0 ? 0 : Q - qq)) * 16, 0, 0);
                 xl[5] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + Q - qq - 1) * 16, 0, 0);
             };
-            auto store_chunk = [&](int c, int buf) {
+            auto store_chunk = [&](int c, int buf, const u32x4 *xl) {
                 const f32x4 a = __builtin_bit_cast(f32x4, xl[0]), cc = __builtin_bit_cast(f32x4, xl[1]);
                 const f32x4 b0 = __builtin_bit_cast(f32x4, xl[2]), b1 = __builtin_bit_cast(f32x4, xl[3]);
                 const f32x4 d0 = __builtin_bit_cast(f32x4, xl[4]), d1 = __builtin_bit_cast(f32x4, xl[5]);
@@ -236,41 +238,45 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
 #define R_LDW(slot, j) _Pragma("unroll") for (int k = 0; k < 8; ++k) wq[slot][k] = OL(ws + 8 * (j) + k);
 #pragma unroll
             for (int d = 0; d < D - 1; ++d) { R_LDW(d, d) }
-            load_chunk(0);
-            store_chunk(0, 0);
+            load_chunk(0, xlA);
+            store_chunk(0, 0, xlA);
+            if (nchunks > 1) load_chunk(1, xlB);
             __syncthreads();
-            for (int c = 0; c < nchunks; ++c) {
-                const f32x4 *X = lds + (c & 1) * RS_BUF;
-                asm volatile("" : "+s"(ws));
-                f32x4 g128[2];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    R_LDW((j + D - 1) % D, j + D - 1)                 // past j = 3: the next chunk's blocks (the stream is contiguous)
-                    if (j == 0) {
-                        if (c + 1 < nchunks) load_chunk(c + 1);
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            g128[i] = ldw(ors, (psel * (Q >> 2) + 16 * c + 2 * pr + i) * 16, (int)S.row128_block);
-                    }
-#pragma unroll
-                    for (int p4 = 0; p4 < 4; ++p4) xq[p4] = X[(p4 * RS_CH_ROWS + 4 * j) * QSL + nqL];
-                    SB();
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[k] = mfma16(wq[j % D][k], xq[k >> 1], acc[k]);
-                    SB();
-                }
-                ws += 32;
-                {
-                    const int ms = tid & 15;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const f32x4 uu = X[(psel * 2 * RS_CH_ROWS + 2 * pr + i) * QSL + ms];
-                        r128 += g128[i].x * uu.x + g128[i].y * uu.y + g128[i].z * uu.z + g128[i].w * uu.w;
-                    }
-                }
-                if (c + 1 < nchunks) store_chunk(c + 1, (c + 1) & 1);
-                __syncthreads();
+            // chunk c: the MFMAs read staging buffer c & 1; chunk c + 1 (already requested, in `XS`) is folded into the other buffer
+            // at the end; chunk c + 2 is requested into `XL` at the start
+#define RS_CHUNK(c, XS, XL)                                                                                     \
+            {                                                                                                   \
+                const f32x4 *X = lds + ((c) & 1) * RS_BUF;                                                      \
+                asm volatile("" : "+s"(ws));                                                                    \
+                f32x4 g128[2];                                                                                  \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
+                    R_LDW((j + D - 1) % D, j + D - 1)   /* past j = 3: the next chunk's blocks (the stream is contiguous) */ \
+                    if (j == 0) {                                                                               \
+                        if ((c) + 2 < nchunks) load_chunk((c) + 2, XL);                                         \
+                        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                           \
+                            g128[i] = ldw(ors, (psel * (Q >> 2) + 16 * (c) + 2 * pr + i) * 16, (int)S.row128_block); \
+                    }                                                                                           \
+                    _Pragma("unroll") for (int p4 = 0; p4 < 4; ++p4) xq[p4] = X[(p4 * RS_CH_ROWS + 4 * j) * QSL + nqL]; \
+                    SB();                                                                                       \
+                    _Pragma("unroll") for (int k = 0; k < 8; ++k) acc[k] = mfma16(wq[j % D][k], xq[k >> 1], acc[k]); \
+                    SB();                                                                                       \
+                }                                                                                               \
+                ws += 32;                                                                                       \
+                {                                                                                               \
+                    const int ms = tid & 15;                                                                    \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
+                        const f32x4 uu = X[(psel * 2 * RS_CH_ROWS + 2 * pr + i) * QSL + ms];                    \
+                        r128 += g128[i].x * uu.x + g128[i].y * uu.y + g128[i].z * uu.z + g128[i].w * uu.w;      \
+                    }                                                                                           \
+                }                                                                                               \
+                if ((c) + 1 < nchunks) store_chunk((c) + 1, ((c) + 1) & 1, XS);                                 \
+                __syncthreads();                                                                                \
             }
+            for (int c = 0; c < nchunks; c += 2) {
+                RS_CHUNK(c, xlB, xlA)
+                if (c + 1 < nchunks) RS_CHUNK(c + 1, xlA, xlB)
+            }
+#undef RS_CHUNK
 #undef R_LDW
             // recombine: y[o] = se+ae+so+ao, y[o+256] = se+ae-so-ao, y[256-o] = se-ae+so-ao, y[512-o] = se-ae-so+ao
 #pragma unroll
