@@ -203,12 +203,12 @@ def test_resample_operator_matches_scipy_and_reference_fixture():
     assert lib.vad_debug_resample_operator(100, None, 0) == _ffi.VAD_ERR_INVALID_ARG
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="c_abi_min"):
     import subprocess
     pkg = os.path.join(ROOT, "cutter_vad_amd")
-    exe = str(tmp_path / "c_abi_min")
+    exe = str(tmp_path / name)
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "c_abi_min.c"), "-L", pkg, "-lvad_engine", f"-Wl,-rpath,{pkg}", "-o", exe])
+                           os.path.join(ROOT, "examples", name + ".c"), "-L", pkg, "-lvad_engine", f"-Wl,-rpath,{pkg}", "-lm", "-o", exe])
     return exe
 
 
@@ -218,6 +218,7 @@ def test_header_is_plain_c_and_a_c_caller_fails_loudly_without_gpu(tmp_path):
     import subprocess
     import torch
     exe = _build_c_example(tmp_path)
+    _build_c_example(tmp_path, "c_abi_serve")        # the ABI v2 serving loop compiles as pedantic C99 too
     if torch.cuda.is_available():
         pytest.skip("GPU present: the run itself is covered by tests/test_gpu_v5.py")
     r = subprocess.run([exe, weights_io.packaged_blob_path(5)], capture_output=True, text=True)
