@@ -84,8 +84,8 @@ class TickResult(C.Structure):
         ("probs", C.POINTER(C.c_float)),
         ("events", C.POINTER(C.c_uint8)),
         ("seg_frames", C.POINTER(C.c_int32)),
-        ("group_start", C.c_int64 * 7),
-        ("group_frames", C.c_void_p * 6),
+        ("group_start", C.c_int64 * 13),
+        ("group_frames", C.c_void_p * 12),
         ("nsamples", C.POINTER(C.c_int32)),
         ("host_us", C.c_float * 3),
     ]
@@ -117,6 +117,7 @@ SIGNATURES = {
     "vad_step_submit": (C.c_int, [_vp, _i64p, C.c_int64, C.c_int32, _vp, C.c_int, C.c_float, _i64p]),
     "vad_step_collect": (C.c_int, [_vp, C.c_int64, _f32p, _u8p, _i32p]),
     "vad_tick_push": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, C.c_int, C.c_int]),
+    "vad_tick_push_rate": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, C.c_int, C.c_int, C.c_int32]),
     "vad_tick_cancel": (C.c_int, [_vp, C.c_int64]),
     "vad_tick_push_many": (C.c_int, [_vp, _i64p, C.c_int64, _vp, C.c_int32, C.c_int, C.c_int]),
     "vad_tick_enable_segments": (C.c_int, [_vp, C.c_int]),

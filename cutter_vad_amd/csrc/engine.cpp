@@ -103,7 +103,19 @@ struct vad_engine {
     // tick assembler (vad_tick_push / vad_tick_run): producers write a slot's next frame straight into the page-locked
     // staging row of the coming tick, grouped by (frame format, gate on/off) = the launches of that tick; double-buffered so
     // that frames keep arriving while a tick runs.  A slot's further frames wait in `tick_overflow` (one frame per slot and tick).
-    static constexpr int TICK_GROUPS = 6;            // group = frame_fmt * 2 + gate_on
+    // groups 0..5 = frame_fmt * 2 + gate_on: frames at the engine's own rate, staged in their wire format;
+    // groups 6..11 = 6 + 3 * gate_on + {0: 8 kHz, 1: 24 kHz, 2: 48 kHz}: chunks at another input rate (vad_tick_push_rate), staged
+    // as float32 [n_in] and resampled on the GPU inside the tick (vad_step_rates' path)
+    static constexpr int TICK_GROUPS = VAD_TICK_GROUPS;
+    static int tick_group_len(int group, int frame_samples) {
+        static const int rate_len[3] = {256, 768, 1536};
+        return group < 6 ? frame_samples : rate_len[(group - 6) % 3];
+    }
+    static int tick_group_rate(int group) {
+        static const int rate[3] = {8000, 24000, 48000};
+        return rate[(group - 6) % 3];
+    }
+    static size_t tick_sample_bytes(int group) { return (group >= 2 && group < 6) ? 2 : 4; }
     struct TickBuf {
         uint8_t *h = nullptr;                        // pinned: [cap] rows of frame bytes, then [cap] int32 slots, then [cap] int32 lengths
         int64_t cap = 0, count = 0;
@@ -125,14 +137,14 @@ struct vad_engine {
     // The audio stays in its wire format (int16 stays int16: half the bytes, a memcpy per frame) as runs of (group, samples,
     // gate threshold); it becomes float32 - scaled with a true division and gated - when the finished segment is taken.
     struct SegAudio {
-        struct Run { int group; float thr; int64_t samples; };
+        struct Run { int group; float thr; int64_t samples; };      // group as in the tick: tells sample type, int16 scale, gate
         std::vector<uint8_t> raw;
         std::vector<Run> runs;
         int64_t samples = 0;
         void clear() { raw.clear(); runs.clear(); samples = 0; }
         void swap(SegAudio &o) { raw.swap(o.raw); runs.swap(o.runs); std::swap(samples, o.samples); }
         void append(int group, float thr, const uint8_t *src, size_t cnt) {
-            const size_t bytes = cnt * (group >= 2 ? 2 : 4), at = raw.size();
+            const size_t bytes = cnt * ((group >= 2 && group < 6) ? 2 : 4), at = raw.size();
             if (raw.capacity() < at + bytes) raw.reserve(std::max<size_t>(2 * raw.capacity(), at + bytes + 32768));   // ~1 s of int16 audio ahead
             raw.resize(at + bytes);
             std::memcpy(raw.data() + at, src, bytes);
@@ -144,16 +156,17 @@ struct vad_engine {
             const uint8_t *src = raw.data();
             for (const Run &r : runs) {
                 const size_t cnt = (size_t)r.samples;
-                if (r.group < 2) std::memcpy(o, src, cnt * 4);
+                const bool i16 = r.group >= 2 && r.group < 6;
+                if (!i16) std::memcpy(o, src, cnt * 4);
                 else {
                     const float sc = r.group < 4 ? 32767.0f : 32768.0f;     // np.int16 -> float32 / 32767.0 (true division)
                     const int16_t *q = reinterpret_cast<const int16_t *>(src);
                     for (size_t k = 0; k < cnt; ++k) o[k] = (float)q[k] / sc;
                 }
-                if (r.group & 1)                                             // utils/audio.py:117-118
+                if (r.group < 6 ? (r.group & 1) : (r.group >= 9))          // the group's gate: utils/audio.py:117-118
                     for (size_t k = 0; k < cnt; ++k) o[k] = std::fabs(o[k]) > r.thr ? o[k] : 0.f;
                 o += cnt;
-                src += cnt * (r.group >= 2 ? 2 : 4);
+                src += cnt * (i16 ? 2 : 4);
             }
         }
     };
@@ -1118,8 +1131,9 @@ namespace {
 // one frame of `slot` into the staging of the coming tick (tick_mu held)
 int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int group) {
     vad_engine::TickBuf &tb = e->tick_buf[e->tick_cur][group];
-    const size_t ss = group >= 2 ? 2 : 4;                       // bytes per sample: groups 0,1 = float32
-    const size_t rb = ss * (size_t)e->frame_samples;
+    const size_t ss = vad_engine::tick_sample_bytes(group);
+    const int flen = vad_engine::tick_group_len(group, e->frame_samples);
+    const size_t rb = ss * (size_t)flen;
     if (tb.count == tb.cap) {
         const int64_t cap = std::min<int64_t>(e->max_streams, std::max<int64_t>(256, 2 * tb.cap));
         if (cap <= tb.cap) return e->fail(VAD_ERR_INVALID_ARG, "tick: more pending frames than slots");
@@ -1138,11 +1152,11 @@ int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsample
         tb.row_bytes = rb;
     }
     // SileroVADModel._prepare_audio_input (core/silero_model.py:464-468): right-zero-pad short frames, truncate long ones
-    const size_t take = std::min<size_t>((size_t)nsamples, (size_t)e->frame_samples) * ss;
+    const size_t take = std::min<size_t>((size_t)nsamples, (size_t)flen) * ss;
     uint8_t *dst = tb.row(tb.count);
     std::memcpy(dst, samples, take);
     if (take < rb) std::memset(dst + take, 0, rb - take);
-    if (e->tick_segments && nsamples > e->frame_samples) {      // the model sees the head; a segment keeps the whole frame
+    if (e->tick_segments && nsamples > flen) {                  // the model sees the head; a segment keeps the whole frame
         const uint8_t *src = static_cast<const uint8_t *>(samples);
         e->tick_tails[slot].emplace_back(src + take, src + ss * (size_t)nsamples);
     }
@@ -1170,6 +1184,41 @@ int vad_tick_push(vad_engine *e, int64_t slot, const void *samples, int32_t nsam
     const int32_t keep = e->tick_segments ? nsamples : std::min<int32_t>(nsamples, e->frame_samples);
     const uint8_t *src = static_cast<const uint8_t *>(samples);
     q.push_back(vad_engine::TickPending{std::vector<uint8_t>(src, src + ss * (size_t)keep), nsamples, group});
+    return VAD_OK;
+}
+
+int vad_tick_push_rate(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int gate_on, int32_t sr_in) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    if (sr_in == e->sample_rate) return vad_tick_push(e, slot, samples, nsamples, frame_fmt, gate_on);
+    std::lock_guard<std::mutex> lk(e->tick_mu);
+    if (!samples || nsamples < 1 || frame_fmt < VAD_FMT_F32 || frame_fmt > VAD_FMT_I16_32768)
+        return e->fail(VAD_ERR_INVALID_ARG, "tick: null frame, empty frame or unknown format");
+    if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
+        return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
+    if (e->frame_samples != VAD_FRAME_SAMPLES || e->sample_rate != 16000)
+        return e->fail(VAD_ERR_UNSUPPORTED, "Failed to resample audio: resampled streams need a 16 kHz engine");
+    const int ri = sr_in == 8000 ? 0 : sr_in == 24000 ? 1 : sr_in == 48000 ? 2 : -1;
+    if (ri < 0)
+        return e->fail(VAD_ERR_UNSUPPORTED, "Failed to resample audio from %dHz to 16000Hz: supported input rates are 8000, 24000, 48000", sr_in);
+    const int group = 6 + 3 * (gate_on ? 1 : 0) + ri;
+    const int want = vad_engine::tick_group_len(group, e->frame_samples);
+    if (nsamples != want)
+        return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio from %dHz to 16000Hz: a chunk must hold %d samples, got %d", sr_in, want, nsamples);
+    // staged as float32 (the resampler's input type): int16 wire frames are scaled here, with numpy's true division
+    thread_local std::vector<float> cvt;
+    const float *src = static_cast<const float *>(samples);
+    if (frame_fmt != VAD_FMT_F32) {
+        cvt.resize((size_t)nsamples);
+        const float sc = frame_fmt == VAD_FMT_I16_32767 ? 32767.0f : 32768.0f;
+        const int16_t *q = static_cast<const int16_t *>(samples);
+        for (int32_t k = 0; k < nsamples; ++k) cvt[(size_t)k] = (float)q[k] / sc;
+        src = cvt.data();
+    }
+    if (e->tick_gen[(size_t)slot] != e->tick_generation) return tick_place(e, slot, src, nsamples, group);
+    auto &q = e->tick_overflow[slot];
+    if (q.size() >= 256) return e->fail(VAD_ERR_BUSY, "tick: slot %lld has 256 frames waiting - is vad_tick_run being called?", (long long)slot);
+    const uint8_t *b = reinterpret_cast<const uint8_t *>(src);
+    q.push_back(vad_engine::TickPending{std::vector<uint8_t>(b, b + 4 * (size_t)nsamples), nsamples, group});
     return VAD_OK;
 }
 
@@ -1247,7 +1296,7 @@ int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
         }
         for (auto it = e->tick_overflow.begin(); it != e->tick_overflow.end();) {
             vad_engine::TickPending &p = it->second.front();
-            if (int rc = tick_place(e, it->first, p.data.data(), (int32_t)(p.data.size() / (p.group >= 2 ? 2 : 4)), p.group)) return rc;
+            if (int rc = tick_place(e, it->first, p.data.data(), (int32_t)(p.data.size() / vad_engine::tick_sample_bytes(p.group)), p.group)) return rc;
             e->tick_buf[e->tick_cur][p.group].lens()[e->tick_buf[e->tick_cur][p.group].count - 1] = p.nsamples;
             it->second.pop_front();
             it = it->second.empty() ? e->tick_overflow.erase(it) : std::next(it);
@@ -1299,12 +1348,18 @@ int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
         }
     HIP_TRY(e, hipMemcpyAsync(e->d_tick_out + o_s32, h_s32, sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, e->stream));
     size_t foff = 0;
+    const float *d_rate_in[vad_engine::TICK_GROUPS] = {};
     for (int g = 0; g < vad_engine::TICK_GROUPS; ++g) {        // one launch per (format, gate) group: one in practice
         const int64_t cnt = tbs[g].count;
         if (!cnt) continue;
         const size_t fbytes = (size_t)cnt * tbs[g].row_bytes;
         uint8_t *d_fr = static_cast<uint8_t *>(e->d_tick_frames) + foff;
         HIP_TRY(e, hipMemcpyAsync(d_fr, tbs[g].h, fbytes, hipMemcpyHostToDevice, e->stream));
+        foff += (fbytes + 255) & ~(size_t)255;
+        if (g >= 6) {               // chunks at another rate: stepped below, all rates of a gate value in one vad_step_rates tick
+            d_rate_in[g] = reinterpret_cast<const float *>(d_fr);
+            continue;
+        }
         vadk::StepParams p = e->base;
         p.slots = reinterpret_cast<const int32_t *>(e->d_tick_out + o_s32) + out->group_start[g];
         p.frames = d_fr;
@@ -1316,7 +1371,25 @@ int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
         p.fmt = g / 2;
         p.thresh = (g & 1) ? denoise_thresh : -1.0f;
         if (int rc = launch(e, p, e->stream)) return rc;
-        foff += (fbytes + 255) & ~(size_t)255;
+    }
+    for (int gate = 0; gate < 2; ++gate) {
+        const int g0 = 6 + 3 * gate;
+        const float *seg_in[3];
+        int64_t seg_n[3];
+        int32_t seg_sr[3];
+        int ns = 0;
+        for (int ri = 0; ri < 3; ++ri)
+            if (tbs[g0 + ri].count) {
+                seg_in[ns] = d_rate_in[g0 + ri];
+                seg_n[ns] = tbs[g0 + ri].count;
+                seg_sr[ns++] = vad_engine::tick_group_rate(g0 + ri);
+            }
+        if (!ns) continue;
+        const int64_t at = out->group_start[g0];               // the gate's rate groups are adjacent in the result arrays
+        if (int rc = step_rates_enqueue(e, ns, seg_in, seg_n, seg_sr, reinterpret_cast<const int32_t *>(e->d_tick_out + o_s32) + at,
+                                        gate ? denoise_thresh : -1.0f, reinterpret_cast<float *>(e->d_tick_out + o_probs) + at,
+                                        e->d_tick_out + o_ev + at, reinterpret_cast<int32_t *>(e->d_tick_out + o_seg) + at, e->stream))
+            return rc;
     }
     HIP_TRY(e, hipMemcpyAsync(e->h_tick_out + o_probs, e->d_tick_out + o_probs, o_s32 - o_probs, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -1340,7 +1413,8 @@ int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
                 const int ev = out->events[i];
                 const bool above = (double)out->probs[i] >= e->h_start_prob[sl];
                 const int32_t L = tbs[g].lens()[r];
-                const bool is_long = L > e->frame_samples;
+                const int flen = vad_engine::tick_group_len(g, e->frame_samples);
+                const bool is_long = L > flen;
                 std::deque<std::vector<uint8_t>> *tails = is_long ? &e->tick_tails[(int64_t)sl] : nullptr;
                 if (!st.active && !above) {                                            // idle stream: nothing is kept (:873-874)
                     st.pre.clear();
@@ -1348,9 +1422,9 @@ int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
                     continue;
                 }
                 vad_engine::SegAudio &dst = st.active ? st.seg : st.pre;               // :891 / :838-839
-                dst.append(g, denoise_thresh, tbs[g].row(r), (size_t)std::min<int32_t>(L, e->frame_samples));
+                dst.append(g, denoise_thresh, tbs[g].row(r), (size_t)std::min<int32_t>(L, flen));
                 if (tails && !tails->empty()) {
-                    dst.append(g, denoise_thresh, tails->front().data(), tails->front().size() / (g < 2 ? 4 : 2));
+                    dst.append(g, denoise_thresh, tails->front().data(), tails->front().size() / vad_engine::tick_sample_bytes(g));
                     tails->pop_front();
                 }
                 if (!st.active) {

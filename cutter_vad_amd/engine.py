@@ -19,6 +19,9 @@ from . import _ffi
 from .core.exceptions import AudioProcessingError, ModelInitializationError, VADError
 
 _FMT = {np.dtype(np.float32): _ffi.VAD_FMT_F32, np.dtype(np.int16): _ffi.VAD_FMT_I16_32767}
+TICK_GROUPS = 12                      # include/vad_engine.h VAD_TICK_GROUPS
+TICK_RATES = (8000, 24000, 48000)     # tick groups 6.. : 6 + 3 * gate_on + index into this
+TICK_RATE_CHUNK = (256, 768, 1536)    # samples of such a chunk = one 16 kHz frame's worth
 
 
 def _ptr(a: np.ndarray, ty):
@@ -230,21 +233,25 @@ class Engine:
                                                     d_events or None, d_seg or None, stream or None))
 
     # ------------------------------------------------------------------ tick assembler (shared-pool serving)
-    def tick_push(self, slot: int, frame, gate_on: bool = True, i16_scale: int = 32767) -> None:
+    def tick_push(self, slot: int, frame, gate_on: bool = True, i16_scale: int = 32767, sample_rate: Optional[int] = None) -> None:
         """Queue one frame for ``slot`` (``vad_tick_push``): ``bytes`` = little-endian int16 PCM as it came off the wire,
         or a float32 array.  Written straight into the coming tick's page-locked staging; padded / truncated to the
-        model's frame length."""
+        model's frame length.  ``sample_rate`` other than the engine's (8000 / 24000 / 48000 on a 16 kHz engine): the chunk
+        that yields one frame, resampled on the GPU inside the tick (``vad_tick_push_rate``)."""
+        i16_fmt = _ffi.VAD_FMT_I16_32768 if i16_scale == 32768 else _ffi.VAD_FMT_I16_32767
         if isinstance(frame, (bytes, bytearray, memoryview)):
-            fmt = _ffi.VAD_FMT_I16_32768 if i16_scale == 32768 else _ffi.VAD_FMT_I16_32767
-            self._check(self._lib.vad_tick_push(self._h, int(slot), bytes(frame), len(frame) // 2, fmt, int(gate_on)))
-            return
-        f = np.ascontiguousarray(frame)
-        if f.dtype == np.int16:
-            fmt = _ffi.VAD_FMT_I16_32768 if i16_scale == 32768 else _ffi.VAD_FMT_I16_32767
+            buf, count, fmt = bytes(frame), len(frame) // 2, i16_fmt
         else:
-            f = np.ascontiguousarray(f, np.float32)
-            fmt = _ffi.VAD_FMT_F32
-        self._check(self._lib.vad_tick_push(self._h, int(slot), f.ctypes.data_as(C.c_void_p), f.size, fmt, int(gate_on)))
+            f = np.ascontiguousarray(frame)
+            fmt = i16_fmt
+            if f.dtype != np.int16:
+                f = np.ascontiguousarray(f, np.float32)
+                fmt = _ffi.VAD_FMT_F32
+            buf, count = f.ctypes.data_as(C.c_void_p), f.size
+        if sample_rate is None or int(sample_rate) == self.sample_rate:
+            self._check(self._lib.vad_tick_push(self._h, int(slot), buf, count, fmt, int(gate_on)))
+        else:
+            self._check(self._lib.vad_tick_push_rate(self._h, int(slot), buf, count, fmt, int(gate_on), int(sample_rate)))
 
     def tick_push_many(self, slots, frames, gate_on: bool = True, i16_scale: int = 32767) -> None:
         """frames [n, L] (float32 or int16), one per listed slot (``vad_tick_push_many``)."""
@@ -277,9 +284,10 @@ class Engine:
     def tick_run(self, denoise: float = 0.01):
         """Advance every slot with a pending frame by one frame (``vad_tick_run``) ->
         ``(slots, probs, events, seg_frames, group_start, frames, nsamples)``: arrays over the stepped streams (views of
-        engine-owned page-locked memory, valid until the next ``tick_run``), ``group_start`` [7], ``frames[g]`` = the staged
-        audio of group g = fmt * 2 + gate_on as an array [count, frame] (float32 for g < 2, int16 above) or None, and
-        ``nsamples`` = the length each frame had when it was pushed."""
+        engine-owned page-locked memory, valid until the next ``tick_run``), ``group_start`` [13], ``frames[g]`` = the staged
+        audio of group g as an array [count, frame] or None - g = fmt * 2 + gate_on for g < 6 (float32 for g < 2, int16
+        above), g = 6 + 3 * gate_on + {0: 8 kHz, 1: 24 kHz, 2: 48 kHz} for chunks at another rate (float32 [count, 256 / 768 /
+        1536]) - and ``nsamples`` = the length each frame had when it was pushed."""
         r = _ffi.TickResult()
         r.struct_size = C.sizeof(_ffi.TickResult)
         self._check(self._lib.vad_tick_run(self._h, float(denoise), C.byref(r)))
@@ -288,19 +296,20 @@ class Engine:
         gs = np.array(list(r.group_start), np.int64)
         if n == 0:
             e = np.empty(0)
-            return (e.astype(np.int64), e.astype(np.float32), e.astype(np.uint8), e.astype(np.int32), gs, [None] * 6,
+            return (e.astype(np.int64), e.astype(np.float32), e.astype(np.uint8), e.astype(np.int32), gs, [None] * TICK_GROUPS,
                     e.astype(np.int32))
         as_arr = np.ctypeslib.as_array
         slots, probs = as_arr(r.slots, (n,)), as_arr(r.probs, (n,))
         events, seg = as_arr(r.events, (n,)), as_arr(r.seg_frames, (n,))
         frames = []
-        for g in range(6):
+        for g in range(TICK_GROUPS):
             cnt = int(gs[g + 1] - gs[g])
             if cnt == 0 or not r.group_frames[g]:
                 frames.append(None)
                 continue
-            ct = C.c_float if g < 2 else C.c_int16
-            frames.append(as_arr(C.cast(r.group_frames[g], C.POINTER(ct)), (cnt, self.frame_samples)))
+            ct = C.c_int16 if 2 <= g < 6 else C.c_float
+            flen = self.frame_samples if g < 6 else TICK_RATE_CHUNK[(g - 6) % 3]
+            frames.append(as_arr(C.cast(r.group_frames[g], C.POINTER(ct)), (cnt, flen)))
         return slots, probs, events, seg, gs, frames, as_arr(r.nsamples, (n,))
 
     # ------------------------------------------------------------------ pipelined host ingest

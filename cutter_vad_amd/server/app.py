@@ -232,7 +232,9 @@ class ClientSession:
         self.outbox.put_nowait(None)
 
 
-def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0.010) -> FastAPI:
+def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0.010, convert_rates: bool = False) -> FastAPI:
+    """``convert_rates``: clients that announce 8 / 24 / 48 kHz with 32 ms frames are resampled on the GPU inside the pool's
+    tick (SharedStreamPool); off, such a client gets the reference's per-frame error."""
     state: Dict[str, Any] = {"pool": pool, "clients": {}, "ticker": None}
 
     @contextlib.asynccontextmanager
@@ -247,7 +249,7 @@ def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0
 
     def get_pool() -> SharedStreamPool:
         if state["pool"] is None:
-            state["pool"] = SharedStreamPool(tick_interval=tick_interval)
+            state["pool"] = SharedStreamPool(tick_interval=tick_interval, convert_rates=convert_rates)
         return state["pool"]
 
     async def ticker() -> None:

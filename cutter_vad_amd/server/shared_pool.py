@@ -22,6 +22,13 @@ a frame straight into the coming tick's staging row, ``tick`` gets back arrays o
 those arrays at once; the segments' audio (pre-roll, open segment) is kept by the engine's tick as well
 (``vad_tick_enable_segments``), so a session is touched individually only on START, on END, or while it talks if it asked
 for ``voice_continue`` payloads.
+
+``convert_rates=True`` (opt-in; Silero V5 pools at 16 kHz): a session whose config names 8 / 24 / 48 kHz with
+``auto_convert_sample_rate`` sends chunks of ``512 * sample_rate / 16000`` samples (32 ms) at its own rate; the tick resamples
+them on the GPU (``AudioUtils.resample_audio`` = scipy's Fourier method, utils/audio.py:46-49, as one operator per rate) and
+steps them in the same launch (``vad_tick_push_rate``).  The reference declares that conversion but leaves the hook empty
+(vad_wrapper.py:621-624) and its V5 graph fails on such frames; with the flag off this pool fails the same way.  Segments
+and ``voice_continue`` payloads carry the audio at the rate it arrived in.
 """
 
 from __future__ import annotations
@@ -37,6 +44,7 @@ from .. import _ffi, weights_io
 from ..core.config import SileroModelVersion, VADConfig
 from ..core.exceptions import AudioProcessingError, CallbackError
 from ..core.silero_model import SileroVADModel
+from ..engine import TICK_RATES
 from ..pool import EnginePool, default_pool, resolve_model_path
 from ..utils.audio import AudioUtils
 from ..utils.wav_writer import WAVWriter
@@ -48,7 +56,7 @@ class PooledSession:
     """One client stream: a slot of the shared engine + the host half of its voice segments."""
 
     __slots__ = ("pool", "slot", "config", "long_frames", "on_start", "on_end", "on_continue", "on_error", "closed",
-                 "wav_writer", "user")
+                 "wav_writer", "user", "rate")
 
     def __init__(self, pool: "SharedStreamPool", slot: int, config: VADConfig) -> None:
         self.pool = pool
@@ -63,6 +71,7 @@ class PooledSession:
         self.wav_writer = WAVWriter(sample_rate=config.output_wav_sample_rate, bit_depth=config.output_wav_bit_depth,
                                     channels=1)
         self.user = None
+        self.rate: Optional[int] = pool._input_rate(config)      # None: frames at the engine's rate; else resampled in the tick
 
     # the per-session scalars live in the pool's arrays (indexed by slot) so that a tick can work on all of them at once
     @property
@@ -99,12 +108,13 @@ class PooledSession:
 class SharedStreamPool:
     def __init__(self, model_version: SileroModelVersion = SileroModelVersion.V5, device_id: Optional[int] = None,
                  max_streams: Optional[int] = None, pool: Optional[EnginePool] = None,
-                 tick_interval: float = 0.010, sample_rate: int = 16000) -> None:
+                 tick_interval: float = 0.010, sample_rate: int = 16000, convert_rates: bool = False) -> None:
         vi = 4 if model_version == SileroModelVersion.V4 else 5
         self.frame = weights_io.frame_samples(vi, sample_rate)     # 512; 256 on Silero V5's 8 kHz sub-model
         SileroVADModel._check_rate(sample_rate, model_version, self.frame)
         self._base = VADConfig(model_version=model_version, sample_rate=sample_rate, buffer_size=self.frame)
         self._k8 = weights_io.is_8k_variant(vi, sample_rate)
+        self.convert_rates = bool(convert_rates) and vi == 5 and int(sample_rate) == 16000
         self._pool = pool or default_pool()
         self.engine = self._pool.engine_for(resolve_model_path(self._base), model_version, device_id, max_streams,
                                             sample_rate)
@@ -170,7 +180,21 @@ class SharedStreamPool:
             self._by_slot[slot] = s
         return s
 
+    def _input_rate(self, cfg: VADConfig) -> Optional[int]:
+        """The rate a session's chunks are resampled from inside the tick, None if it sends the engine's own frames."""
+        sr = int(cfg.sample_rate)
+        if self.convert_rates and cfg.auto_convert_sample_rate and sr in TICK_RATES:
+            return sr
+        return None
+
     def _check_session_rate(self, cfg: VADConfig) -> None:
+        sr = self._input_rate(cfg)
+        if sr is not None:
+            want = FRAME * sr // 16000
+            if int(cfg.buffer_size) != want:
+                raise AudioProcessingError(f"Failed to resample audio from {sr}Hz to 16000Hz: a chunk must hold {want} samples "
+                                           f"(32 ms), the session's buffer_size is {int(cfg.buffer_size)}")
+            return
         # V5 + a rate other than 16 kHz: the reference's graph fails on every frame (SURVEY a9); V4: the pool's engine is
         # one of the graph's two sub-models, a session must ask for the same one
         SileroVADModel._check_rate(cfg.sample_rate, cfg.model_version, self.frame)
@@ -203,6 +227,7 @@ class SharedStreamPool:
                                        config.voice_start_ratio, config.voice_end_ratio, config.voice_start_frame_count,
                                        config.voice_end_frame_count)
             s.config = config
+            s.rate = self._input_rate(config)
             with self._lock:
                 self._init_slot(s.slot, config)
             s.wav_writer = WAVWriter(sample_rate=config.output_wav_sample_rate, bit_depth=config.output_wav_bit_depth,
@@ -227,8 +252,8 @@ class SharedStreamPool:
         with self._lock:
             if s.closed:
                 raise AudioProcessingError("session is closed")
-            self.engine.tick_push(s.slot, x, bool(self._gate[s.slot]))
-            if x.size > self.frame:                 # only voice_continue payloads need the whole frame here (the engine keeps its own)
+            self.engine.tick_push(s.slot, x, bool(self._gate[s.slot]), sample_rate=s.rate)
+            if x.size > self.frame and s.rate is None:   # only voice_continue payloads need the whole frame here (the engine keeps its own)
                 s.long_frames.append(x)
 
     def submit_pcm16(self, s: PooledSession, data: bytes) -> None:
@@ -241,8 +266,8 @@ class SharedStreamPool:
         with self._lock:
             if s.closed:
                 raise AudioProcessingError("session is closed")
-            self.engine.tick_push(s.slot, data, bool(self._gate[s.slot]))
-            if len(data) > 2 * self.frame:
+            self.engine.tick_push(s.slot, data, bool(self._gate[s.slot]), sample_rate=s.rate)
+            if len(data) > 2 * self.frame and s.rate is None:
                 s.long_frames.append(np.frombuffer(data, dtype="<i2").astype(np.float32) / np.float32(32767.0))
 
     # ------------------------------------------------------------------ the tick
@@ -264,7 +289,8 @@ class SharedStreamPool:
             n = int(slots.size)
             if n == 0:
                 return 0
-            self.launches += sum(1 for g in range(6) if gs[g + 1] > gs[g])
+            # launches: one per (format, gate) group; the resampled groups of a gate value share one
+            self.launches += sum(1 for g in range(6) if gs[g + 1] > gs[g]) + int(gs[9] > gs[6]) + int(gs[12] > gs[9])
             self.ticks += 1
             self.frames += n
             self._lastp[slots] = p
@@ -274,7 +300,9 @@ class SharedStreamPool:
             ended = (ev & _ffi.VAD_EV_END) != 0
             self._active[slots] = (was_active | started) & ~ended
             wants = self._cont[slots] & was_active          # voice_continue payloads: only for sessions that registered one
-            busy = np.nonzero(started | ended | wants | (nsamp > self.frame))[0]
+            long = nsamp > self.frame
+            long[int(gs[6]):] = False                       # chunks at another rate always have their exact length
+            busy = np.nonzero(started | ended | wants | long)[0]
             if busy.size == 0:                      # idle and silently talking sessions cost no Python at all
                 return n
             grp = np.searchsorted(gs[1:], busy, side="right")
@@ -284,7 +312,7 @@ class SharedStreamPool:
                     continue
                 try:
                     L = int(nsamp[i])
-                    whole = s.long_frames.popleft() if (L > self.frame and s.long_frames) else None
+                    whole = s.long_frames.popleft() if (long[i] and s.long_frames) else None
                     if started[i]:
                         self._call(s.on_start, "voice_start")
                     wav = None
@@ -297,8 +325,8 @@ class SharedStreamPool:
                     if wants[i] and s.on_continue is not None:
                         if whole is None:
                             x = frames[g][i - int(gs[g])][:L]
-                            whole = x.astype(np.float32) / np.float32(32767.0 if g < 4 else 32768.0) if g >= 2 else x.copy()
-                        if g & 1:
+                            whole = x.astype(np.float32) / np.float32(32767.0 if g < 4 else 32768.0) if 2 <= g < 6 else x.copy()
+                        if (g & 1) if g < 6 else g >= 9:
                             whole = AudioUtils.denoise_audio(whole)
                         self._call(s.on_continue, "voice_continue", whole.tobytes())
                 except Exception as e:

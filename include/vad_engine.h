@@ -258,7 +258,13 @@ VAD_API int vad_resample_multi_device(vad_engine *e, int32_t nseg, const float *
  *       (what segment assembly keeps).  All pointers are engine-owned and stay valid until the next vad_tick_run.
  *       Pushes may continue while a tick runs (double-buffered staging).  `thr` is the gate threshold of the gate_on groups.
  *   vad_tick_cancel(e, slot)   drops the slot's pending frames (call before vad_stream_close of a slot that may have some).
+ *   vad_tick_push_rate(e, slot, samples, nsamples, fmt, gate_on, sr_in)   the same for a client whose audio arrives at 8 / 24 /
+ *       48 kHz (VADConfig.auto_convert_sample_rate; nsamples must be the chunk that yields one 16 kHz frame: 256 / 768 / 1536):
+ *       the chunk is staged as float32 in group 6 + 3 * gate_on + {0, 1, 2}; vad_tick_run resamples those groups on the GPU and
+ *       steps them like vad_step_rates (one fused launch when it fits); group_frames[g] then holds the chunks at their own rate
+ *       [count][nsamples] float32 - what the segment keeps.  16 kHz engines only.
  */
+#define VAD_TICK_GROUPS 12
 typedef struct vad_tick_result {
     uint32_t struct_size;          /* sizeof(vad_tick_result) */
     int64_t n;
@@ -266,12 +272,14 @@ typedef struct vad_tick_result {
     const float *probs;
     const uint8_t *events;
     const int32_t *seg_frames;
-    int64_t group_start[7];
-    const void *group_frames[6];
+    int64_t group_start[VAD_TICK_GROUPS + 1];
+    const void *group_frames[VAD_TICK_GROUPS];
     const int32_t *nsamples;       /* samples the caller pushed for entry i (before padding / truncation to the frame length) */
     float host_us[3];              /* where this tick's wall time went: buffer swap + queued frames | copies + launches + wait | segment assembly */
 } vad_tick_result;
 VAD_API int vad_tick_push(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int gate_on);
+VAD_API int vad_tick_push_rate(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int gate_on,
+                               int32_t sr_in);
 /* the same frame length / format / gate for n slots: frames [n][nsamples] (a front end that batches its sockets' frames) */
 VAD_API int vad_tick_push_many(vad_engine *e, const int64_t *slots, int64_t n, const void *frames, int32_t nsamples,
                                int frame_fmt, int gate_on);

@@ -107,7 +107,9 @@ class FakeEngine:
     #      order, one step_events call per (format, gate) group
     frame_samples = 512
 
-    def tick_push(self, slot, frame, gate_on=True, i16_scale=32767):
+    sample_rate = 16000
+
+    def tick_push(self, slot, frame, gate_on=True, i16_scale=32767, sample_rate=None):
         q = self.__dict__.setdefault("_tickq", {})
         if isinstance(frame, (bytes, bytearray, memoryview)):
             x = np.frombuffer(bytes(frame), dtype="<i2")
@@ -117,7 +119,16 @@ class FakeEngine:
             fmt = 0
         if len(q.setdefault(int(slot), [])) >= 257:
             raise RuntimeError("tick: 256 frames waiting")
-        q[int(slot)].append((fmt * 2 + int(bool(gate_on)), x))
+        g = fmt * 2 + int(bool(gate_on))
+        if sample_rate is not None and int(sample_rate) != self.sample_rate:      # vad_tick_push_rate
+            ri = (8000, 24000, 48000).index(int(sample_rate))
+            if x.size != (256, 768, 1536)[ri]:
+                raise RuntimeError(f"Failed to resample audio from {sample_rate}Hz to 16000Hz: a chunk must hold "
+                                   f"{(256, 768, 1536)[ri]} samples, got {x.size}")
+            if fmt:
+                x = x.astype(np.float32) / np.float32(32768.0 if fmt == 2 else 32767.0)
+            g = 6 + 3 * int(bool(gate_on)) + ri
+        q[int(slot)].append((g, x))
 
     def tick_cancel(self, slot):
         self.__dict__.setdefault("_tickq", {}).pop(int(slot), None)
@@ -136,8 +147,8 @@ class FakeEngine:
     def _assemble(self, slot, g, x, p, ev, denoise):
         """the host half of _process_voice_state on the frame as pushed (vad_tick_enable_segments)"""
         st = self.__dict__.setdefault("_seg", {}).setdefault(int(slot), dict(active=False, pre=[], seg=[], done=None))
-        k = x.astype(np.float32) / np.float32(32768.0 if g >= 4 else 32767.0) if g >= 2 else x.astype(np.float32)
-        if g & 1:
+        k = x.astype(np.float32) / np.float32(32768.0 if g >= 4 else 32767.0) if 2 <= g < 6 else x.astype(np.float32)
+        if (g & 1) if g < 6 else g >= 9:
             k = np.where(np.abs(k) > np.float32(denoise), k, np.float32(0.0)).astype(np.float32)
         if not st["active"]:
             st["pre"] = st["pre"] + [k] if float(p) >= self.thr[int(slot)][0] else []
@@ -151,22 +162,27 @@ class FakeEngine:
     def tick_run(self, denoise=0.01):
         q = self.__dict__.setdefault("_tickq", {})
         F = self.frame_samples
-        groups = {g: [] for g in range(6)}
+        groups = {g: [] for g in range(12)}
         for slot in list(q):
             g, x = q[slot].pop(0)
             if not q[slot]:
                 del q[slot]
             groups[g].append((slot, x))
-        slots, probs, events, segs, ns, frames, gs = [], [], [], [], [], [None] * 6, [0]
-        for g in range(6):
+        slots, probs, events, segs, ns, frames, gs = [], [], [], [], [], [None] * 12, [0]
+        for g in range(12):
             rows = groups[g]
             if rows:
-                arr = np.zeros((len(rows), F), np.int16 if g >= 2 else np.float32)
+                Fg = F if g < 6 else (256, 768, 1536)[(g - 6) % 3]
+                arr = np.zeros((len(rows), Fg), np.int16 if 2 <= g < 6 else np.float32)
                 for i, (_, x) in enumerate(rows):
-                    m = min(x.size, F)
+                    m = min(x.size, Fg)
                     arr[i, :m] = x[:m]
                 sl = [r[0] for r in rows]
-                p, ev, sg = self.step_events(sl, arr, denoise if g & 1 else None, 32768 if g >= 4 else 32767)
+                if g < 6:
+                    p, ev, sg = self.step_events(sl, arr, denoise if g & 1 else None, 32768 if g >= 4 else 32767)
+                else:           # resample (scipy's Fourier method, as the oracle restates it) -> gate -> model
+                    x16 = np.stack([oracle.resample(r, 512) for r in arr])
+                    p, ev, sg = self.step_events(sl, x16, denoise if g >= 9 else None)
                 slots += sl
                 probs += list(p)
                 events += list(ev)

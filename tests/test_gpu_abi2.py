@@ -221,6 +221,63 @@ def test_tick_assembler_matches_direct_steps_and_keeps_the_segments(eng):
             eng.close_stream(int(s_))
 
 
+def test_tick_rate_groups_equal_step_rates(eng):
+    """vad_tick_push_rate: chunks at 8 / 24 / 48 kHz staged next to ordinary frames; vad_tick_run steps them exactly like
+    vad_step_rates on the same chunks (bit for bit: same segments, same launch), overflow frames wait their turn, wrong
+    lengths and rates are refused at the push."""
+    from cutter_vad_amd.engine import Engine
+    rates = ((8000, 256), (24000, 768), (48000, 1536))
+    per, T = 40, 4
+    base = make_streams(3 * per + 16, 3 * (T + 1), seed=77).reshape(3 * per + 16, -1)
+    slots = eng.open_streams(3 * per + 16)
+    with Engine(_blob(5), model_version=5, max_streams=256) as ref:
+        rs = ref.open_streams(3 * per)
+        r16 = ref.open_streams(16)
+        lag = []
+        try:
+            for t in range(T):
+                segs = []
+                for k, (sr, n_in) in enumerate(rates):
+                    a = np.ascontiguousarray(base[k * per:(k + 1) * per, t * n_in:(t + 1) * n_in])
+                    segs.append((a, sr))
+                    for i in range(per):
+                        eng.tick_push(int(slots[k * per + i]), a[i], gate_on=True, sample_rate=sr)
+                x16 = np.ascontiguousarray(base[3 * per:, t * 512:(t + 1) * 512])
+                for i in range(16):
+                    eng.tick_push(int(slots[3 * per + i]), x16[i], gate_on=True)
+                lag.append(segs[2][0][0].copy())
+                if t == 1:          # a second chunk for one 48 kHz stream: from now on that stream runs one tick behind
+                    extra = np.ascontiguousarray(base[2 * per, T * 1536:(T + 1) * 1536])
+                    eng.tick_push(int(slots[2 * per]), extra, gate_on=True, sample_rate=48000)
+                    lag.append(extra)
+                segs[2][0][0] = lag.pop(0)                                        # what this tick steps for that stream
+                s, p, ev, seg, gs, frames, ns = eng.tick_run(0.01)
+                assert [int(gs[g + 1] - gs[g]) for g in range(12)] == [0, 16] + [0] * 7 + [per] * 3
+                assert s.tolist() == slots[3 * per:].tolist() + slots[:3 * per].tolist()
+                assert frames[11].shape == (per, 1536) and ns[-1] == 1536
+                assert np.array_equal(frames[11], segs[2][0])
+                rp, rev, rseg = ref.step_rates(segs, rs, denoise=0.01)
+                p16, ev16, _ = ref.step_events(r16, x16, denoise=0.01)
+                assert np.array_equal(p[16:], rp) and np.array_equal(ev[16:], rev) and np.array_equal(seg[16:], rseg), t
+                assert np.array_equal(p[:16], p16) and np.array_equal(ev[:16], ev16)
+            assert eng.tick_run(0.01)[0].tolist() == [int(slots[2 * per])]       # the frame that was still waiting
+            with pytest.raises(Exception, match="must hold 768 samples"):
+                eng.tick_push(int(slots[0]), np.zeros(700, np.float32), sample_rate=24000)
+            with pytest.raises(Exception, match="supported input rates"):
+                eng.tick_push(int(slots[0]), np.zeros(441, np.float32), sample_rate=44100)
+            # int16 wire chunks are scaled with numpy's true division before the resampler sees them
+            q = np.round(base[0, :256] * 32767).astype("<i2")
+            eng.reset(slots[:2])
+            eng.tick_push(int(slots[0]), q.tobytes(), gate_on=False, sample_rate=8000)
+            eng.tick_push(int(slots[1]), q.astype(np.float32) / np.float32(32767.0), gate_on=False, sample_rate=8000)
+            _, p, *_ = eng.tick_run(0.01)
+            assert p[0] == p[1]
+        finally:
+            for s_ in slots:
+                eng.tick_cancel(int(s_))
+                eng.close_stream(int(s_))
+
+
 def test_c99_serving_loop_runs_the_tick_and_the_pipeline(tmp_path):
     """examples/c_abi_serve.c: a serving loop written against include/vad_engine.h alone - vad_tick_push_many / vad_tick_run /
     vad_tick_take_segment for 48 clients, then the same frames through vad_step_submit / vad_step_collect; the program itself

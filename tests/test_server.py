@@ -188,3 +188,87 @@ def test_wire_protocol_over_asgi():
             assert m["event"] == "ERROR" and m["message"].startswith("Audio processing error:")
         assert client.get("/stats").json()["launches"] >= 5
     assert pool.session_count == 0
+
+
+def test_sessions_at_other_rates_are_resampled_inside_the_tick():
+    """convert_rates: 8 / 24 / 48 kHz clients on a 16 kHz V5 pool (VADConfig.auto_convert_sample_rate, the hook the reference
+    leaves empty: vad_wrapper.py:621-624).  Chunks of 32 ms at the client's rate; the model sees scipy's Fourier resample."""
+    from oracle import oracle
+    eng = FakeEngine(fn=lambda fr: 0.9 if np.abs(fr).max() > 0.3 else 0.05)
+    pool = SharedStreamPool(pool=FakePool(eng), convert_rates=True)
+    common = dict(vad_start_probability=0.4, vad_end_probability=0.3, voice_start_frame_count=2, voice_end_frame_count=2)
+    rng = np.random.default_rng(5)
+    logs, sessions = {}, {}
+    for sr, n_in in ((8000, 256), (24000, 768), (48000, 1536), (16000, 512)):
+        s = pool.open_session(VADConfig(sample_rate=sr, buffer_size=n_in, **common))
+        assert s.rate == (None if sr == 16000 else sr)
+        logs[sr] = []
+        s.set_callbacks(lambda sr=sr: logs[sr].append("S"), lambda wav, sr=sr: logs[sr].append(("E", len(wav))),
+                        lambda pcm, sr=sr: logs[sr].append(("C", len(pcm))))
+        sessions[sr] = (s, n_in)
+    t = np.arange(1536 * 8) / 48000.0
+    tone48 = (0.6 * np.sin(2 * np.pi * 300.0 * t)).astype(np.float32)
+    sent = {}
+    for sr, (s, n_in) in sessions.items():
+        tone = tone48[::48000 // sr]                              # the same 300 Hz tone at every rate
+        chunks = [np.zeros(n_in, np.float32)] + [tone[k * n_in:(k + 1) * n_in] for k in range(3)] + [np.zeros(n_in, np.float32)] * 3
+        sent[sr] = chunks
+        for k, c in enumerate(chunks):
+            if sr == 24000 and k % 2:                             # int16 wire frames resample too
+                s.submit_pcm16((c * 32767).astype("<i2").tobytes())
+            else:
+                s.submit(c)
+    assert pool.drain() == 4 * 7
+    # every client heard the same thing: START on the 2nd loud chunk, END on the 2nd quiet one; payloads at the client's rate
+    for sr, (s, n_in) in sessions.items():
+        assert logs[sr] == ["S", ("C", 4 * n_in), ("C", 4 * n_in), ("E", 44 + 2 * n_in * 5), ("C", 4 * n_in)], (sr, logs[sr])
+    # what the model saw for the 48 kHz client's first loud chunk is the oracle's resample of it
+    want = oracle.resample(sent[48000][1], 512)
+    seen = [f for f in eng.frames_seen if f.shape[0] >= 1 and f.shape[1] == 512]
+    assert any(np.array_equal(want, row) for f in seen for row in f)     # (the scripted engine records frames before the gate)
+    assert pool.stats()["launches"] < pool.stats()["frames"]
+    # a chunk of the wrong length is the session's error, not the pool's
+    with pytest.raises(Exception, match="Failed to resample"):
+        sessions[48000][0].submit(np.zeros(1440, np.float32))
+    with pytest.raises(AudioProcessingError, match="buffer_size"):
+        pool.open_session(VADConfig(sample_rate=48000, buffer_size=1440))
+    pool.close()
+    # without the flag such a session fails like the reference's V5 graph does (SURVEY a9)
+    plain = SharedStreamPool(pool=FakePool(FakeEngine(fn=lambda fr: 0.0)))
+    with pytest.raises(AudioProcessingError, match="8 kHz graph branch"):
+        plain.open_session(VADConfig(sample_rate=48000, buffer_size=1536))
+    plain.close()
+
+
+def test_websocket_client_at_48_khz_with_32_ms_frames():
+    """create_app(convert_rates=True): a client announcing 48 kHz / 32 ms frames is resampled inside the pool's tick; with 30 ms
+    frames (1440 samples, not one model frame's worth) it hears the reason on every frame, like any other per-frame failure."""
+    from fastapi.testclient import TestClient
+    from cutter_vad_amd.server.app import create_app
+    eng = FakeEngine(fn=lambda fr: 0.9 if np.abs(fr).max() > 0.3 else 0.05)
+    app = create_app(SharedStreamPool(pool=FakePool(eng), convert_rates=True), tick_interval=0.002)
+    t = np.arange(1536) / 48000.0
+    loud = (0.6 * np.sin(2 * np.pi * 300.0 * t) * 32767).astype("<i2").tobytes()
+
+    def recv_until(ws, kind, limit=200):
+        for _ in range(limit):
+            m = json.loads(ws.receive_text())
+            if m["event"] == kind:
+                return m
+        raise AssertionError(f"no {kind}")
+
+    with TestClient(app) as client:
+        with client.websocket_connect("/vad?sample_rate=48000&frame_duration_ms=32&start_frame_count=2&end_frame_count=2") as ws:
+            assert json.loads(ws.receive_text())["event"] == "INFO"
+            for _ in range(3):
+                ws.send_bytes(loud)
+            assert recv_until(ws, "VOICE_START")["segment_index"] == 0
+            for _ in range(3):
+                ws.send_bytes(b"\0" * len(loud))
+            assert recv_until(ws, "VOICE_END")["segment_index"] == 0
+        assert any(f.shape[1] == 512 and np.abs(f).max() > 0.5 for f in eng.frames_seen)
+        with client.websocket_connect("/vad?sample_rate=48000&frame_duration_ms=30") as ws:
+            assert json.loads(ws.receive_text())["event"] == "INFO"
+            ws.send_bytes(b"\0" * 2880)
+            m = recv_until(ws, "ERROR")
+            assert "Failed to resample audio from 48000Hz" in m["message"] and "1536" in m["message"]
