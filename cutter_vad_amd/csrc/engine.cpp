@@ -30,6 +30,7 @@
 extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_silero_v4(const vadk::StepParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_silero_v5_t16(const vadk::StepParams *p, hipStream_t stream);
+extern "C" hipError_t vadk_launch_silero_v4_t16(const vadk::StepParams *p, int one_per_cu, hipStream_t stream);
 extern "C" hipError_t vadk_launch_silero_v5_t16_rates(const vadk::StepParams *p, const vadk::RateParams *r, hipStream_t stream);
 extern "C" hipError_t vadk_launch_resample(const vadk::ResampleParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_slot_control(vadk::SmSlot *sm, float *state, const int32_t *d_slots, int n, int op,
@@ -269,7 +270,16 @@ int check_slots(vad_engine *e, const int64_t *slots, int64_t n) {
 int launch(vad_engine *e, const vadk::StepParams &p, hipStream_t s) {
     hipError_t r = hipErrorInvalidValue;
     const bool t16 = e->d_wstream16 && (e->tile_policy == 16 || (e->tile_policy == 0 && !e->shared_gpu && p.n <= vad_engine::T16_MAX_STREAMS));
-    if (e->version == 5 && t16) {
+    if (e->version == 4 && e->d_wstream16 && e->tile_policy != 32) {
+        // Silero V4: 16-stream tiles, two workgroups per CU (each fills the other's waits) - one per CU while the call has no
+        // more tiles than the GPU has CUs, so that a small batch spreads out instead of pairing up
+        vadk::StepParams p16 = p;
+        p16.wstream = e->d_wstream16;
+        p16.wstream_bytes = (uint32_t)e->wbytes16;
+        std::memcpy(p16.sect, e->sect16, sizeof p16.sect);
+        const int tiles16 = (p.n + 15) / 16;
+        r = vadk_launch_silero_v4_t16(&p16, (!e->shared_gpu && tiles16 <= e->prop.multiProcessorCount) ? 1 : 0, s);
+    } else if (e->version == 5 && t16) {
         vadk::StepParams p16 = p;
         p16.wstream = e->d_wstream16;
         p16.wstream_bytes = (uint32_t)e->wbytes16;
@@ -448,9 +458,11 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
     if ((r = hipMalloc((void **)&e->d_wstream, e->wbytes)) != hipSuccess) return bail(r, "hipMalloc(weights)");
     if ((r = hipMemcpy(e->d_wstream, pw.data.data(), e->wbytes, hipMemcpyHostToDevice)) != hipSuccess)
         return bail(r, "hipMemcpy(weights)");
-    if (desc->model_version == 5 && !want_8k) {
+    if (desc->model_version == 4 || !want_8k) {          // every model but V5's 8 kHz sub-model has a 16-stream tile kernel
         vadk::PackedWeights pw16;
-        if (!vadk::pack_silero_v5_t16(desc->weights, desc->weights_len, pw16, perr)) {
+        const bool ok16 = desc->model_version == 4 ? vadk::pack_silero_v4_t16(desc->weights, desc->weights_len, pw16, perr)
+                                                   : vadk::pack_silero_v5_t16(desc->weights, desc->weights_len, pw16, perr);
+        if (!ok16) {
             g_create_error = perr;
             vad_engine_destroy(e);
             return VAD_ERR_BAD_WEIGHTS;
@@ -1512,10 +1524,11 @@ int vad_debug_pack_weights(int32_t model_version, const void *weights, size_t we
     g_create_error.clear();
     vadk::PackedWeights pw;
     std::string perr;
-    // model_version 516: Silero V5 packed for the 16-stream tile kernel (tests/kernel_model.py models both packings)
+    // model_version 516 / 416: Silero V5 / V4 packed for the 16-stream tile kernels (tests/kernel_model.py models both packings)
     const bool ok = model_version == 5     ? vadk::pack_silero_v5(weights, weights_len, pw, perr)
                     : model_version == 516 ? vadk::pack_silero_v5_t16(weights, weights_len, pw, perr)
                     : model_version == 4   ? vadk::pack_silero_v4(weights, weights_len, pw, perr)
+                    : model_version == 416 ? vadk::pack_silero_v4_t16(weights, weights_len, pw, perr)
                                            : false;
     if (!ok) {
         g_create_error = perr.empty() ? "Failed to load model: model_version must be 4 or 5" : perr;
@@ -1543,7 +1556,7 @@ int vad_debug_set_tile(vad_engine *e, int32_t streams_per_tile) {
     if (streams_per_tile != 0 && streams_per_tile != 16 && streams_per_tile != 32)
         return e->fail(VAD_ERR_INVALID_ARG, "tile: 0 (by batch size), 16 or 32");
     if (streams_per_tile == 16 && !e->d_wstream16)
-        return e->fail(VAD_ERR_UNSUPPORTED, "the 16-stream tile kernel exists for Silero V5 at 16 kHz only");
+        return e->fail(VAD_ERR_UNSUPPORTED, "Silero V5's 8 kHz sub-model has no 16-stream tile kernel");
     e->tile_policy = streams_per_tile;
     return VAD_OK;
 }

@@ -589,39 +589,46 @@ uint32_t pack_resample_operator_t16(int n_in, std::vector<float> &out, uint32_t 
     return per_wave;
 }
 
-bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::string &err) {
-    using namespace v4;
-    Blob B;
+namespace {
+// the tensors of a Silero V4 blob (either sub-model), by role
+struct V4Tensors {
+    const float *stft, *filt;
+    const float *dww[4], *dwb[4], *pww[4], *pwb[4], *pjw[4], *pjb[4], *sw[4], *sbias[4];
+    const float *lwi[2], *lwh[2], *lbi[2], *lbh[2], *head_w, *head_b;
+    int variant;
+};
+constexpr int V4_CI[4] = {258, 16, 32, 32}, V4_CO[4] = {16, 32, 32, 64}, V4_SC[4] = {16, 32, 32, 64};
+
+bool load_v4(const void *blob, size_t len, Blob &B, V4Tensors &t, std::string &err) {
     if (!open_blob(blob, len, B, err)) return false;
     if (B.version != 4) {
         err = "Failed to load model: weight blob is not Silero V4";
         return false;
     }
-    static const int ci[4] = {258, 16, 32, 32}, co[4] = {16, 32, 32, 64}, sc[4] = {16, 32, 32, 64};
-    const float *stft = B.get("stft.basis", 258 * 256), *filt = B.get("norm.filter", 7);
-    const float *dww[4], *dwb[4], *pww[4], *pwb[4], *pjw[4] = {nullptr, nullptr, nullptr, nullptr}, *pjb[4] = {nullptr, nullptr, nullptr, nullptr};
-    const float *sw[4], *sbias[4];
+    t = V4Tensors{};
+    t.stft = B.get("stft.basis", 258 * 256);
+    t.filt = B.get("norm.filter", 7);
     char nm[32];
     for (int i = 0; i < 4; ++i) {
-        std::snprintf(nm, sizeof nm, "l%d.dw.w", i); dww[i] = B.get(nm, (uint64_t)ci[i] * 5);
-        std::snprintf(nm, sizeof nm, "l%d.dw.b", i); dwb[i] = B.get(nm, ci[i]);
-        std::snprintf(nm, sizeof nm, "l%d.pw.w", i); pww[i] = B.get(nm, (uint64_t)co[i] * ci[i]);
-        std::snprintf(nm, sizeof nm, "l%d.pw.b", i); pwb[i] = B.get(nm, co[i]);
+        std::snprintf(nm, sizeof nm, "l%d.dw.w", i); t.dww[i] = B.get(nm, (uint64_t)V4_CI[i] * 5);
+        std::snprintf(nm, sizeof nm, "l%d.dw.b", i); t.dwb[i] = B.get(nm, V4_CI[i]);
+        std::snprintf(nm, sizeof nm, "l%d.pw.w", i); t.pww[i] = B.get(nm, (uint64_t)V4_CO[i] * V4_CI[i]);
+        std::snprintf(nm, sizeof nm, "l%d.pw.b", i); t.pwb[i] = B.get(nm, V4_CO[i]);
         if (i != 2) {
-            std::snprintf(nm, sizeof nm, "l%d.proj.w", i); pjw[i] = B.get(nm, (uint64_t)co[i] * ci[i]);
-            std::snprintf(nm, sizeof nm, "l%d.proj.b", i); pjb[i] = B.get(nm, co[i]);
+            std::snprintf(nm, sizeof nm, "l%d.proj.w", i); t.pjw[i] = B.get(nm, (uint64_t)V4_CO[i] * V4_CI[i]);
+            std::snprintf(nm, sizeof nm, "l%d.proj.b", i); t.pjb[i] = B.get(nm, V4_CO[i]);
         }
-        std::snprintf(nm, sizeof nm, "s%d.w", i); sw[i] = B.get(nm, (uint64_t)sc[i] * sc[i]);
-        std::snprintf(nm, sizeof nm, "s%d.b", i); sbias[i] = B.get(nm, sc[i]);
+        std::snprintf(nm, sizeof nm, "s%d.w", i); t.sw[i] = B.get(nm, (uint64_t)V4_SC[i] * V4_SC[i]);
+        std::snprintf(nm, sizeof nm, "s%d.b", i); t.sbias[i] = B.get(nm, V4_SC[i]);
     }
-    const float *lwi[2], *lwh[2], *lbi[2], *lbh[2];
     for (int l = 0; l < 2; ++l) {
-        std::snprintf(nm, sizeof nm, "lstm%d.w_ih", l); lwi[l] = B.get(nm, 256 * 64);
-        std::snprintf(nm, sizeof nm, "lstm%d.w_hh", l); lwh[l] = B.get(nm, 256 * 64);
-        std::snprintf(nm, sizeof nm, "lstm%d.b_ih", l); lbi[l] = B.get(nm, 256);
-        std::snprintf(nm, sizeof nm, "lstm%d.b_hh", l); lbh[l] = B.get(nm, 256);
+        std::snprintf(nm, sizeof nm, "lstm%d.w_ih", l); t.lwi[l] = B.get(nm, 256 * 64);
+        std::snprintf(nm, sizeof nm, "lstm%d.w_hh", l); t.lwh[l] = B.get(nm, 256 * 64);
+        std::snprintf(nm, sizeof nm, "lstm%d.b_ih", l); t.lbi[l] = B.get(nm, 256);
+        std::snprintf(nm, sizeof nm, "lstm%d.b_hh", l); t.lbh[l] = B.get(nm, 256);
     }
-    const float *head_w = B.get("head.w", 64), *head_b = B.get("head.b", 1);
+    t.head_w = B.get("head.w", 64);
+    t.head_b = B.get("head.b", 1);
     if (!err.empty()) return false;
     {   // optional: meta.variant = 8000 marks the graph's else-branch (weights_io._extract_v4)
         std::string none;
@@ -629,62 +636,84 @@ bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::strin
         B.err = &none;
         const float *var = B.get("meta.variant", 1);
         B.err = keep;
-        out.variant = (var && var[0] == 8000.0f) ? 1 : 0;
+        t.variant = (var && var[0] == 8000.0f) ? 1 : 0;
     }
-    if (!check_stft_symmetry(stft, err)) return false;
-    if (!check_windowed_dft(stft, err)) return false;
-    // the STFT kernel emits its 128 regular bins in the even/odd order of the 4-way folded DFT (v5::bin_of_channel);
-    // the first layer's per-channel tables and weight columns follow that order.  Channel 128 (Nyquist) stays.
-    auto bin = [](int c) { return c < 128 ? v5::bin_of_channel(c) : c; };
+    if (!check_stft_symmetry(t.stft, err)) return false;
+    if (!check_windowed_dft(t.stft, err)) return false;
+    return true;
+}
 
-    StreamBuilder sb;
-    uint32_t sec[S_COUNT] = {};
-    // depthwise taps (k = 0..4) + bias (k = 5) per channel quad as float4 rows: row = (q * 6 + k), value i = channel 4q + i
-    auto dw_table = [&](const float *w5, const float *b, int C, int c0, int nquads) {
-        const uint32_t first = sb.blocks();
-        std::vector<float> tab((size_t)nquads * 6 * 4, 0.f);
-        for (int q = 0; q < nquads; ++q)
+// the STFT kernels emit their 128 regular bins in the even/odd order of the 4-way folded DFT (v5::bin_of_channel);
+// the first layer's per-channel tables and weight columns follow that order.  Channel 128 (Nyquist) stays.
+inline int v4_bin(int c) { return c < 128 ? v5::bin_of_channel(c) : c; }
+
+// depthwise taps (k = 0..4) + bias (k = 5) per channel quad as float4 rows: row = (q * 6 + k), value i = channel 4q + i
+uint32_t v4_dw_table(StreamBuilder &sb, const float *w5, const float *b, int C, int nquads) {
+    const uint32_t first = sb.blocks();
+    std::vector<float> tab((size_t)nquads * 6 * 4, 0.f);
+    for (int q = 0; q < nquads; ++q)
+        for (int k = 0; k < 6; ++k)
+            for (int i = 0; i < 4; ++i) {
+                const int c = 4 * q + i;
+                if (c < C) tab[((size_t)q * 6 + k) * 4 + i] = k < 5 ? w5[(size_t)c * 5 + k] : b[c];
+            }
+    for (size_t off = 0; off < tab.size(); off += BLK_FLOATS) {
+        float *blk = sb.new_block();
+        std::memcpy(blk, tab.data() + off, sizeof(float) * std::min<size_t>(BLK_FLOATS, tab.size() - off));
+    }
+    return first;
+}
+
+// S_DW0 and S_L0, shared by both tile shapes (the first layer runs on 16 x 16 x 4 tiles in either kernel).
+// S_DW0: part 0 = magnitude channels 0..128 (34 quads), part 1 = normalised channels 129..257, then the 7-tap filter.
+// S_L0: 16 outputs.  Bias block, then the Nyquist channel's four weight columns (pw|mag, proj|mag, pw|norm, proj|norm; that
+// channel is contracted on the VALU), then per k-iteration of 16 channels the same four operands.
+void v4_first_layer(StreamBuilder &sb, const V4Tensors &t, uint32_t *sec) {
+    using namespace v4;
+    sec[S_DW0] = sb.blocks();
+    std::vector<float> tab((size_t)(2 * 34 * 6 + 2) * 4, 0.f);
+    for (int p = 0; p < 2; ++p)
+        for (int q = 0; q < 34; ++q)
             for (int k = 0; k < 6; ++k)
                 for (int i = 0; i < 4; ++i) {
                     const int c = 4 * q + i;
-                    if (c < C) tab[((size_t)q * 6 + k) * 4 + i] = k < 5 ? w5[(size_t)(c0 + c) * 5 + k] : b[c0 + c];
+                    if (c < 129)
+                        tab[(((size_t)p * 34 + q) * 6 + k) * 4 + i] =
+                            k < 5 ? t.dww[0][(size_t)(129 * p + v4_bin(c)) * 5 + k] : t.dwb[0][129 * p + v4_bin(c)];
                 }
-        for (size_t off = 0; off < tab.size(); off += BLK_FLOATS) {
-            float *blk = sb.new_block();
-            std::memcpy(blk, tab.data() + off, sizeof(float) * std::min<size_t>(BLK_FLOATS, tab.size() - off));
-        }
-        return first;
-    };
-    // S_DW0: part 0 = magnitude channels 0..128 (34 quads), part 1 = normalised channels 129..257, then the 7-tap filter
-    {
-        sec[S_DW0] = sb.blocks();
-        std::vector<float> tab((size_t)(2 * 34 * 6 + 2) * 4, 0.f);
-        for (int p = 0; p < 2; ++p)
-            for (int q = 0; q < 34; ++q)
-                for (int k = 0; k < 6; ++k)
-                    for (int i = 0; i < 4; ++i) {
-                        const int c = 4 * q + i;
-                        if (c < 129) tab[(((size_t)p * 34 + q) * 6 + k) * 4 + i] = k < 5 ? dww[0][(size_t)(129 * p + bin(c)) * 5 + k] : dwb[0][129 * p + bin(c)];
-                    }
-        for (int k = 0; k < 7; ++k) tab[(size_t)(2 * 34 * 6) * 4 + k] = filt[k];
-        for (size_t off = 0; off < tab.size(); off += BLK_FLOATS) {
-            float *blk = sb.new_block();
-            std::memcpy(blk, tab.data() + off, sizeof(float) * std::min<size_t>(BLK_FLOATS, tab.size() - off));
-        }
+    for (int k = 0; k < 7; ++k) tab[(size_t)(2 * 34 * 6) * 4 + k] = t.filt[k];
+    for (size_t off = 0; off < tab.size(); off += BLK_FLOATS) {
+        float *blk = sb.new_block();
+        std::memcpy(blk, tab.data() + off, sizeof(float) * std::min<size_t>(BLK_FLOATS, tab.size() - off));
     }
-    // S_L0: 16 outputs as 16x16x4 tiles.  Bias block, then the Nyquist channel's four weight columns (pw|mag, proj|mag,
-    // pw|norm, proj|norm; that channel is contracted on the VALU), then per k-iteration of 16 channels the same four operands
     sec[S_L0] = sb.blocks();
-    sb.vector_block16([&](int r) { return pwb[0][r] + pjb[0][r]; });
+    sb.vector_block16([&](int r) { return t.pwb[0][r] + t.pjb[0][r]; });
     for (int p = 0; p < 2; ++p) {
-        sb.vector_block16([&](int r) { return pww[0][(size_t)r * 258 + 129 * p + bin(128)]; });
-        sb.vector_block16([&](int r) { return pjw[0][(size_t)r * 258 + 129 * p + bin(128)]; });
+        sb.vector_block16([&](int r) { return t.pww[0][(size_t)r * 258 + 129 * p + v4_bin(128)]; });
+        sb.vector_block16([&](int r) { return t.pjw[0][(size_t)r * 258 + 129 * p + v4_bin(128)]; });
     }
     for (int j = 0; j < 8; ++j)
         for (int p = 0; p < 2; ++p) {
-            sb.weight_block16([&](int r, int c) { return pww[0][(size_t)r * 258 + 129 * p + bin(c)]; }, j);
-            sb.weight_block16([&](int r, int c) { return pjw[0][(size_t)r * 258 + 129 * p + bin(c)]; }, j);
+            sb.weight_block16([&](int r, int c) { return t.pww[0][(size_t)r * 258 + 129 * p + v4_bin(c)]; }, j);
+            sb.weight_block16([&](int r, int c) { return t.pjw[0][(size_t)r * 258 + 129 * p + v4_bin(c)]; }, j);
         }
+}
+}  // namespace
+
+bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::string &err) {
+    using namespace v4;
+    Blob B;
+    V4Tensors t;
+    if (!load_v4(blob, len, B, t, err)) return false;
+    out.variant = t.variant;
+    const float *const stft = t.stft;
+    const float *const *dww = t.dww, *const *dwb = t.dwb, *const *pww = t.pww, *const *pwb = t.pwb, *const *pjw = t.pjw, *const *pjb = t.pjb;
+    const float *const *sw = t.sw, *const *sbias = t.sbias, *const *lwi = t.lwi, *const *lwh = t.lwh, *const *lbi = t.lbi, *const *lbh = t.lbh;
+    const float *const head_w = t.head_w, *const head_b = t.head_b;
+    StreamBuilder sb;
+    uint32_t sec[S_COUNT] = {};
+    auto dw_table = [&](const float *w5, const float *b, int C, int, int nquads) { return v4_dw_table(sb, w5, b, C, nquads); };
+    v4_first_layer(sb, t, sec);
     // S_S0: 16 -> 16 (rows 0..15)
     sec[S_S0] = sb.blocks();
     sb.vector_blocks([&](int c) { return c < 16 ? sbias[0][c] : 0.f; });
@@ -749,6 +778,108 @@ bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::strin
         out.sect[w][S_LSTM1] = lstm_sec[1][w];
         out.sect[w][S_STFT] = sb.blocks();
         pack_dft4_wave(sb, w);
+    }
+    out.data = std::move(sb.data);
+    return true;
+}
+
+// ---- Silero V4 for the 16-stream tile kernel (csrc/silero_v4_t16.hip) ----------------------------------------------------------
+// Every contraction on v_mfma_f32_16x16x4_f32 (blocks as in pack_silero_v5_t16: weight_block16 = 16 rows x 16 channels, a
+// per-channel vector of a 16-row tile = one vector_block16).  A layer with C outputs has C / 16 row tiles rt; sections that every
+// wave reads are packed once:
+//   S_DW0, S_L0 : as pack_silero_v4 (the first layer runs on these tiles there, too)
+//   S_S0  : bias, W                                   (16 -> 16, K = 16)
+//   S_L1  : dw table, then per rt (2): bias, pw, proj (16 -> 32)
+//   S_S1  : per rt (2): bias, 2 k-iterations          (32 -> 32)
+//   S_L2  : dw table, per rt (2): bias, 2 k-it pw     (32 -> 32, identity residual)
+//   S_S2  : per rt (2): bias, 2 k-it
+//   S_L3  : dw table, per rt (4): bias, pw 2 k-it, proj 2 k-it   (32 -> 64)
+//   S_S3  : per rt (4): bias, 4 k-it                  (64 -> 64)
+//   S_LSTM{0,1} : per wave w (hidden units 16 w .. 16 w + 15): bias of gates i, f, g, o (4 blocks), then 8 k-iterations (0..3
+//                 contract the layer input, 4..7 h_{t-1}) x 4 gates - the D layout puts the four gates of a unit into one lane
+//   S_HEADB : head bias, then the head weights of wave w's units (block 1 + w);  S_NYQ : window;  S_STFT : as V5's t16 stream
+bool pack_silero_v4_t16(const void *blob, size_t len, PackedWeights &out, std::string &err) {
+    using namespace v4;
+    Blob B;
+    V4Tensors t;
+    if (!load_v4(blob, len, B, t, err)) return false;
+    out.variant = t.variant;
+    StreamBuilder sb;
+    uint32_t sec[S_COUNT] = {};
+    v4_first_layer(sb, t, sec);
+    auto bias16 = [&](const float *a, const float *b2, int rt) {
+        sb.vector_block16([&](int c) { return a[16 * rt + c] + (b2 ? b2[16 * rt + c] : 0.f); });
+    };
+    auto mat16 = [&](const float *W, int K, int rt, int j) {
+        sb.weight_block16([&](int r, int c) { return W[(size_t)(16 * rt + r) * K + c]; }, j);
+    };
+    sec[S_S0] = sb.blocks();
+    bias16(t.sbias[0], nullptr, 0);
+    mat16(t.sw[0], 16, 0, 0);
+    sec[S_L1] = v4_dw_table(sb, t.dww[1], t.dwb[1], 16, 4);
+    for (int rt = 0; rt < 2; ++rt) {
+        bias16(t.pwb[1], t.pjb[1], rt);
+        mat16(t.pww[1], 16, rt, 0);
+        mat16(t.pjw[1], 16, rt, 0);
+    }
+    sec[S_S1] = sb.blocks();
+    for (int rt = 0; rt < 2; ++rt) {
+        bias16(t.sbias[1], nullptr, rt);
+        for (int j = 0; j < 2; ++j) mat16(t.sw[1], 32, rt, j);
+    }
+    sec[S_L2] = v4_dw_table(sb, t.dww[2], t.dwb[2], 32, 8);
+    for (int rt = 0; rt < 2; ++rt) {
+        bias16(t.pwb[2], nullptr, rt);
+        for (int j = 0; j < 2; ++j) mat16(t.pww[2], 32, rt, j);
+    }
+    sec[S_S2] = sb.blocks();
+    for (int rt = 0; rt < 2; ++rt) {
+        bias16(t.sbias[2], nullptr, rt);
+        for (int j = 0; j < 2; ++j) mat16(t.sw[2], 32, rt, j);
+    }
+    sec[S_L3] = v4_dw_table(sb, t.dww[3], t.dwb[3], 32, 8);
+    for (int rt = 0; rt < 4; ++rt) {
+        bias16(t.pwb[3], t.pjb[3], rt);
+        for (int j = 0; j < 2; ++j) mat16(t.pww[3], 32, rt, j);
+        for (int j = 0; j < 2; ++j) mat16(t.pjw[3], 32, rt, j);
+    }
+    sec[S_S3] = sb.blocks();
+    for (int rt = 0; rt < 4; ++rt) {
+        bias16(t.sbias[3], nullptr, rt);
+        for (int j = 0; j < 4; ++j) mat16(t.sw[3], 64, rt, j);
+    }
+    uint32_t lstm_sec[2][NWAVES];
+    for (int l = 0; l < 2; ++l)
+        for (int w = 0; w < NWAVES; ++w) {
+            lstm_sec[l][w] = sb.blocks();
+            for (int q = 0; q < 4; ++q)
+                sb.vector_block16([&](int c) { const int r = q * 64 + 16 * w + c; return t.lbi[l][r] + t.lbh[l][r]; });
+            for (int j = 0; j < 8; ++j)
+                for (int q = 0; q < 4; ++q) {
+                    const float *wsrc = j < 4 ? t.lwi[l] : t.lwh[l];
+                    sb.weight_block16([&](int r, int c) { return wsrc[(size_t)(q * 64 + 16 * w + r) * 64 + c]; }, j & 3);
+                }
+        }
+    sec[S_HEADB] = sb.blocks();
+    sb.new_block()[0] = t.head_b[0];
+    for (int w = 0; w < NWAVES; ++w) sb.vector_block16([&](int c) { return t.head_w[16 * w + c]; });
+    sec[S_NYQ] = sb.blocks();
+    std::memcpy(sb.new_block(), t.stft, 256 * sizeof(float));
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int w = 0; w < NWAVES; ++w) {
+        for (int k = 0; k < S_COUNT; ++k) out.sect[w][k] = sec[k];
+        out.sect[w][S_LSTM0] = lstm_sec[0][w];
+        out.sect[w][S_LSTM1] = lstm_sec[1][w];
+        // STFT: per k-iteration (n = 16 j .. 16 j + 15): cos rt0, cos rt1, -sin rt0, -sin rt1 (bins bin_of_channel(32 w + 16 rt + r))
+        out.sect[w][S_STFT] = sb.blocks();
+        for (int j = 0; j < 4; ++j)
+            for (int part = 0; part < 2; ++part)
+                for (int rt = 0; rt < 2; ++rt)
+                    sb.weight_block16([&](int r, int n) {
+                        const int k = v5::bin_of_channel(32 * w + 16 * rt + r);
+                        const double ph = two_pi * (double)((k * n) & 255) / 256.0;
+                        return n == 0 ? 0.f : (float)(part == 0 ? std::cos(ph) : -std::sin(ph));
+                    }, j);
     }
     out.data = std::move(sb.data);
     return true;

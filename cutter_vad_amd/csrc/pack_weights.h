@@ -21,6 +21,8 @@ struct PackedWeights {
 // ModelInitializationError text, core/silero_model.py:330-334).
 bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::string &err);
 bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::string &err);
+// Silero V4 (either sub-model) repacked for the 16-stream tile kernel (csrc/silero_v4_t16.hip)
+bool pack_silero_v4_t16(const void *blob, size_t len, PackedWeights &out, std::string &err);
 // Silero V5 16 kHz repacked for the 16-stream tile kernel (16 x 16 x 4 MFMA tiles; csrc/silero_v5_t16.hip)
 bool pack_silero_v5_t16(const void *blob, size_t len, PackedWeights &out, std::string &err);
 

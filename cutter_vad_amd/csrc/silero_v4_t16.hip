@@ -1,0 +1,775 @@
+// Silero-VAD V4 step kernel on 16-STREAM tiles, two workgroups per CU (gfx950).
+//
+// silero_v4.hip carries 32 streams per workgroup with one wave per SIMD (it needs all 512 registers to park the magnitudes
+// and 158 KB of LDS), and 57 % of its cycles are waits that a single wave cannot hide: seven thin phases between barriers, the
+// frame's HBM round trip, dependent LDS / L2 round trips.  This kernel is the same network and the same
+// algebra (reflect-padded frame in LDS, 4-way folded DFT, the two real bins in float64, K-split first layer on 16 x 16 x 4
+// tiles, LSTM waves owning all four gates of 16 units) on v_mfma_f32_16x16x4_f32 throughout: a workgroup carries 16 streams in
+// under 80 KB of LDS and 256 registers per wave, so TWO workgroups share a CU and each fills the other's waits.
+//
+// Fragment convention as in silero_v5_t16.hip: lane l = (n = l & 15, kq = l >> 4); A: W[row n][k = kq]; B: X[k = kq][stream n];
+// D: lane (stream n, rq = kq) holds rows 4 rq .. 4 rq + 3 of the 16-row tile = one LDS quad.  A k-iteration contracts 16
+// channels: lane (n, kq) reads activation quad row 4 j + kq (one ds_read_b128 = the B operands of 4 MFMAs).
+// LDS quad row = 16 streams x float4, dense stride QSD = 16; the folded STFT operands are written transposed by the fold (16
+// lanes of a stream write 16 rows) and use the padded stride QSL = 17.
+// Weight stream: pack_silero_v4_t16 (pack_weights.cpp); tests/kernel_model.py::v4_step_t16 is the NumPy model of this file's
+// indexing.
+#include <hip/hip_runtime.h>
+#include "vad_layout.h"
+#include "sm_device.h"
+#include "vadk_device.h"
+
+using namespace vadk;
+using namespace vadk::dev;
+
+// -DVADK_STAMPS (tools/kbench4.cpp -DKB_TILE16): s_memtime at phase boundaries, [block][wave][32]
+#ifdef VADK_STAMPS
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        if (lane == 0) P.stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + (k)] = clock64();          \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+namespace {
+
+constexpr int MT16 = 16;
+constexpr int QSL = 17;
+constexpr int QSD = 16;
+// STFT part: reflect-padded frame [16][176 quads] | folded operands of two columns [128 rows][QSL] | window [64] | small
+constexpr int XPQ = 176;
+constexpr int U_XS = MT16 * XPQ;
+constexpr int U_UV = 128 * QSL;
+constexpr int U_WT = 64;
+constexpr int U_SMALL = 40;                       // nyqv [2][16], dcv [2][16], fcor [2][3][16] floats
+constexpr int K1_F4 = U_XS + U_UV + U_WT + U_SMALL;
+static_assert((U_XS + U_UV) % 16 == 0, "window table must start on a 16-quad boundary (XOR-swizzled reads)");
+// tail: rows as in vad_layout.h v4 (33 t + q magnitudes, R_A16, R_Y*, R_H*), dense stride
+constexpr int T_ROWS = vadk::v4::MAG_ROWS + 16;
+constexpr int T_MISC_FLOATS = 16 + 8 * 16 + 2 * 4 * 16;      // mm [16], colmean [8][16], head partials [2 steps][4 waves][16]
+constexpr int K2_F4 = T_ROWS * QSD + T_MISC_FLOATS / 4 + 128;   // + partial log sums [4 waves][8 columns][16]
+constexpr int T16_LDS_F4 = K1_F4 > K2_F4 ? K1_F4 : K2_F4;
+static_assert(T16_LDS_F4 * 16 <= 80 * 1024, "two workgroups per CU");
+
+__device__ __forceinline__ f32x4 ldt(__amdgpu_buffer_rsrc_t rs, int row, int blk) {   // table row (float4) of a VALU table
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, row * 16, blk * 1024, 0));
+}
+
+__device__ __forceinline__ f32x4 mfma16(f32x4 w, f32x4 a, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a.w, acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) {
+    return f32x4{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
+}
+
+// a double moved across lanes by a DPP control (quad_perm / row_half_mirror) on its two halves
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ float log1p20(float mag) {   // log(1 + mag * 2^20): Mul, Add, Log of the graph
+    return __builtin_amdgcn_logf(1.0f + mag * 1048576.0f) * 0.69314718055994531f;
+}
+__device__ __forceinline__ float lognorm(float mag, float mm) { return log1p20(mag) - mm; }
+
+}  // namespace
+
+// K8: the graph's 8 kHz sub-model (silero_v4.hip has the differences: third stride conv has stride 1, two columns through block 3,
+// two LSTM time steps, mean of the two sigmoids)
+template <bool K8>
+__global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams P, const int tframe) {
+    using namespace vadk::v4;
+    __shared__ f32x4 lds[T16_LDS_F4];
+    f32x4 *const XP = lds;
+    f32x4 *const UV = lds + U_XS;
+    f32x4 *const WT = UV + U_UV;
+    float *const nyqv = reinterpret_cast<float *>(WT + U_WT);    // [2][16] |X128| of the two columns in flight
+    float *const dcv = nyqv + 32;                                 // [2][16] X0 (signed)
+    float *const fcor = dcv + 32;                                 // [2 columns][y128, a64, b64][16 streams]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const int nq = kq * QSD + n, nqL = kq * QSL + n;
+    const int tile0 = blockIdx.x * MT16;
+    const int T = P.T;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wstream), 0, (int)P.wstream_bytes, 0x00020000);
+    const int lane16 = lane * 16;
+    const int o_stft = (int)P.sect[w][S_STFT];
+#define WL(blk) ldw(wrs, lane16, (blk))
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // the tail's view of the same LDS
+    f32x4 *const RX = lds;
+    float *const misc = reinterpret_cast<float *>(lds + T_ROWS * QSD);
+    float *const mmv = misc;                  // [16]
+    float *const colmean = misc + 16;         // [8][16]
+    float *const headp = misc + 16 + 128;     // [2][4][16]
+    float *const colpart = misc + T_MISC_FLOATS;   // [4 waves][8 columns][16 streams]
+    const int gf = tile0 + n;                 // tid & 15 == n: one slot lookup serves h, c and the state machine
+    const bool live = gf < P.n;
+    const int slot = live ? (P.slots ? P.slots[gf] : gf) : 0;
+
+    STAMP(0);
+    // ---- raw frame -> LDS (gate + int16 scaling fused): 16 streams x 128 quads, 8 per thread, all requested before the first use;
+    //      the buffer descriptor's range check zero-fills the streams past n
+    {
+        const float thr = P.thresh;
+        const bool f32in = P.fmt == 0;
+        const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
+        if (f32in) {
+            u32x4 xv[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = it * NTHREADS + tid;
+                xv[it] = __builtin_amdgcn_raw_buffer_load_b128(frs, (((tile0 + (idx >> 7)) * T + tframe) * 128 + (idx & 127)) * 16, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = it * NTHREADS + tid;
+                XP[(idx >> 7) * XPQ + 24 + (idx & 127)] = gate4(__builtin_bit_cast(f32x4, xv[it]), thr);
+            }
+        } else {
+            const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
+            u32x2 sv[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = it * NTHREADS + tid;
+                sv[it] = __builtin_amdgcn_raw_buffer_load_b64(frs, (((tile0 + (idx >> 7)) * T + tframe) * 128 + (idx & 127)) * 8, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = it * NTHREADS + tid;
+                const int s0 = (int)(short)(sv[it].x & 0xffffu), s1 = (int)(short)(sv[it].x >> 16);
+                const int s2 = (int)(short)(sv[it].y & 0xffffu), s3 = (int)(short)(sv[it].y >> 16);
+                XP[(idx >> 7) * XPQ + 24 + (idx & 127)] = gate4(f32x4{(float)s0 / sc, (float)s1 / sc, (float)s2 / sc, (float)s3 / sc}, thr);
+            }
+        }
+    }
+    if (tid < U_WT) WT[tid] = ldw(wrs, tid * 16, (int)P.sect[0][S_NYQ]);
+    __syncthreads();
+    // mirrored edges (numpy 'reflect', 96 + 96): as silero_v4.hip
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int idx = it * NTHREADS + tid;          // 16 streams x 48 edge quads
+        const int ms = idx / 48, k = idx - ms * 48;
+        f32x4 *row = XP + ms * XPQ;
+        if (k < 24) {
+            const f32x4 lo = row[48 - k], hi = row[47 - k];
+            row[k] = f32x4{lo.x, hi.w, hi.z, hi.y};
+        } else {
+            const int Q = 128 + k;
+            const f32x4 p = row[303 - Q], pm = row[302 - Q];
+            row[Q] = f32x4{p.z, p.y, p.x, pm.w};
+        }
+    }
+    __syncthreads();
+    STAMP(1);
+
+    // window of the stored basis for this thread's fold position n = 4 fq .. 4 fq + 3
+    const int fq = tid & 15, fms = tid >> 4;
+    const int o_win = (int)P.sect[w][S_NYQ];
+    const f32x4 W1 = ldw(wrs, fq * 16, o_win), W3 = ldw(wrs, (32 + fq) * 16, o_win);
+    const float w64 = ldw(wrs, 16 * 16, o_win).x;                 // w[64] = w[192]
+
+    f32x4 mg[8][2];                                  // |X| of this wave's 32 bins (two row tiles), 8 columns
+    float nyq[4];                                    // threads < 32: |X[128]| of column 2 grp + (tid >> 4), stream n
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {              // STFT columns 2 grp, 2 grp + 1 (hop 64 on the padded frame)
+        int ws = o_stft;
+        asm volatile("" : "+s"(ws));
+        // ---- window + 4-way fold: stream fms, n = 4 fq + i, one column per pass (silero_v4.hip has the algebra)
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            const int Q0 = 16 * (2 * grp + cp);
+            const f32x4 *xs = XP + fms * XPQ + Q0;
+            const f32x4 xA = xs[fq], xC = xs[32 + fq];
+            const f32x4 r1a = xs[32 - fq], r1b = xs[31 - fq];
+            const f32x4 r2a = xs[fq == 0 ? 63 : 64 - fq], r2b = xs[63 - fq];
+            const f32x4 y1 = f32x4{xA.x * W1.x, xA.y * W1.y, xA.z * W1.z, xA.w * W1.w};
+            const f32x4 y3 = f32x4{xC.x * W3.x, xC.y * W3.y, xC.z * W3.z, xC.w * W3.w};
+            const f32x4 y2 = f32x4{r1a.x * W3.x, r1b.w * W3.y, r1b.z * W3.z, r1b.y * W3.w};
+            const f32x4 y4 = f32x4{r2a.x * W1.x, r2b.w * W1.y, r2b.z * W1.z, r2b.y * W1.w};
+            const f32x4 s14 = f32x4{y1.x + y4.x, y1.y + y4.y, y1.z + y4.z, y1.w + y4.w};
+            const f32x4 d14 = f32x4{y1.x - y4.x, y1.y - y4.y, y1.z - y4.z, y1.w - y4.w};
+            const f32x4 s23 = f32x4{y2.x + y3.x, y2.y + y3.y, y2.z + y3.z, y2.w + y3.w};
+            const f32x4 d23 = f32x4{y2.x - y3.x, y2.y - y3.y, y2.z - y3.z, y2.w - y3.w};
+            f32x4 pe = f32x4{s14.x + s23.x, s14.y + s23.y, s14.z + s23.z, s14.w + s23.w};
+            f32x4 po = f32x4{s14.x - s23.x, s14.y - s23.y, s14.z - s23.z, s14.w - s23.w};
+            f32x4 qe = f32x4{d14.x - d23.x, d14.y - d23.y, d14.z - d23.z, d14.w - d23.w};
+            f32x4 qo = f32x4{d14.x + d23.x, d14.y + d23.y, d14.z + d23.z, d14.w + d23.w};
+            if (fq == 0) {
+                pe.x = po.x = qe.x = qo.x = 0.f;
+                const float y64 = xs[16].x * w64, y192 = xs[48].x * w64;
+                fcor[(cp * 3 + 0) * 16 + fms] = y3.x;           // y[128]
+                fcor[(cp * 3 + 1) * 16 + fms] = y64 + y192;     // a64
+                fcor[(cp * 3 + 2) * 16 + fms] = y64 - y192;     // b64
+            }
+            st2(&UV[(64 * cp + fq) * QSL + fms], pe);
+            st2(&UV[(64 * cp + 16 + fq) * QSL + fms], po);
+            st2(&UV[(64 * cp + 32 + fq) * QSL + fms], qe);
+            st2(&UV[(64 * cp + 48 + fq) * QSL + fms], qo);
+        }
+        // ---- the two REAL bins, k = 0 and k = 128, in float64 straight from the samples (DESIGN.md §3 "Numerics"): X0 = E + O,
+        //      X128 = E - O with E / O = sum over even / odd n of w[n] xp[n].  32 (column, stream) pairs, 8 lanes each; lane (blk,
+        //      half) sums quads 16 blk + 8 half .. + 7, order XOR-swizzled so that 16 neighbouring lanes read 16 different banks
+        {
+            const int pair = tid >> 3, p8 = tid & 7;
+            const int cp = pair >> 4, ms = pair & 15;
+            const int blk = p8 >> 1, half = p8 & 1;
+            const unsigned sw = (unsigned)(4 * (ms & 1) + blk);
+            const unsigned bx = (((unsigned)(ms * XPQ + 16 * (2 * grp + cp) + 16 * blk + 8 * half)) ^ sw) << 4;   // byte offsets; bases are multiples of 8 quads
+            const unsigned bw = (((unsigned)(U_XS + U_UV + 16 * blk + 8 * half)) ^ sw) << 4;
+            const char *const lb = reinterpret_cast<const char *>(lds);
+            double e0 = 0., e1 = 0., o0 = 0., o1 = 0.;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(lb + (bx ^ (unsigned)(i << 4)));
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(lb + (bw ^ (unsigned)(i << 4)));
+                e0 = __builtin_fma((double)wv.x, (double)xv.x, e0);
+                o0 = __builtin_fma((double)wv.y, (double)xv.y, o0);
+                e1 = __builtin_fma((double)wv.z, (double)xv.z, e1);
+                o1 = __builtin_fma((double)wv.w, (double)xv.w, o1);
+            }
+            double e = e0 + e1, o = o0 + o1;
+            e += dpp_f64<0xB1>(e); o += dpp_f64<0xB1>(o);      // quad_perm [1,0,3,2]
+            e += dpp_f64<0x4E>(e); o += dpp_f64<0x4E>(o);      // quad_perm [2,3,0,1]
+            e += dpp_f64<0x141>(e); o += dpp_f64<0x141>(o);    // row_half_mirror: the other quad of the group of 8
+            if (p8 == 0) {
+                dcv[cp * 16 + ms] = (float)(e + o);
+                nyqv[cp * 16 + ms] = fabsf((float)(e - o));
+            }
+        }
+        f32x4 Aw[4], Bw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Aw[k] = WL(ws + k);
+        SB();
+        if (grp == 0) STAMP(2);
+        __syncthreads();
+        if (grp == 0) STAMP(3);
+        // ---- MFMA: wave w = bins bin_of_channel(32 w + 16 rt + r): cos on pe | po, -sin on qe | qo (even | odd bins), two columns,
+        //      K = 64; the accumulators start from the rank-1 terms of n = 0, 64, 128 (register i of a D quad is tile row 4 rq + i)
+        f32x4 are[2][2], aim[2][2];
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            const float y128 = fcor[(cp * 3 + 0) * 16 + n], a64 = fcor[(cp * 3 + 1) * 16 + n], b64 = fcor[(cp * 3 + 2) * 16 + n];
+            const float rp = w < 2 ? y128 + a64 : -y128, rm = w < 2 ? y128 - a64 : -y128;
+            const float ip = w < 2 ? 0.f : -b64, im_ = w < 2 ? 0.f : b64;
+            are[cp][0] = are[cp][1] = f32x4{rp, rm, rp, rm};
+            aim[cp][0] = aim[cp][1] = f32x4{ip, im_, ip, im_};
+        }
+        {
+            const int rR = w < 2 ? 0 : 16, rI = w < 2 ? 32 : 48;
+            const f32x4 *const XR = UV + rR * QSL + nqL, *const XI = UV + rI * QSL + nqL;
+            f32x4 Au[2], Av[2], Bu[2], Bv[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { Au[c] = XR[(64 * c) * QSL]; Av[c] = XI[(64 * c) * QSL]; }
+#define S_LD(S, jj)                                                                        \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) S##w[k] = WL(ws + 4 * (jj) + k);         \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) { S##u[c] = XR[(64 * c + 4 * (jj)) * QSL]; S##v[c] = XI[(64 * c + 4 * (jj)) * QSL]; }
+#define S_MMA(S)                                                                           \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                        \
+        are[c][0] = mfma16(S##w[0], S##u[c], are[c][0]); are[c][1] = mfma16(S##w[1], S##u[c], are[c][1]);   \
+        aim[c][0] = mfma16(S##w[2], S##v[c], aim[c][0]); aim[c][1] = mfma16(S##w[3], S##v[c], aim[c][1]);   \
+    }
+            for (int j = 0; j < 4; j += 2) {
+                S_LD(B, j + 1) SB();
+                S_MMA(A) SB();
+                const int jn = j + 2 < 4 ? j + 2 : 2;
+                S_LD(A, jn) SB();
+                S_MMA(B) SB();
+            }
+#undef S_LD
+#undef S_MMA
+        }
+        if (grp == 0) STAMP(4);
+        {   // bin 0 (wave 0, row tile 0, tile row 0 = component 0 of the lanes kq = 0) takes the float64 sum; its im is identically 0
+            const bool own0 = (w == 0) & (kq == 0);
+            const float d0 = dcv[n], d1 = dcv[16 + n];
+            are[0][0].x = own0 ? d0 : are[0][0].x;
+            are[1][0].x = own0 ? d1 : are[1][0].x;
+        }
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const f32x4 r = are[cp][rt], i = aim[cp][rt];
+                mg[2 * grp + cp][rt] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
+            }
+        nyq[grp] = nyqv[((tid >> 4) & 1) * 16 + n];
+        if (grp == 0) STAMP(5);
+        __syncthreads();       // every wave done with UV / fcor / dcv before the next fold overwrites them
+        if (grp == 0) STAMP(6);
+        if (grp == 3) STAMP(7);
+    }
+
+    // =================================================================================================
+    //  tail: the LDS is re-used with the second layout from here on
+    // =================================================================================================
+    // state of this lane's stream, requested now and used after the first layer / in the cells
+    f32x4 hprev[2], cprev[2];
+    {
+        const float *st = P.state + (size_t)slot * 256;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const f32x4 v = reinterpret_cast<const f32x4 *>(st)[(tid >> 4) * 2 + qq];     // h of both layers: 32 quads per stream
+            hprev[qq] = live ? v : zero4;
+        }
+#pragma unroll
+        for (int layer = 0; layer < 2; ++layer) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(st + 128 + 64 * layer + 16 * w + 4 * kq);   // c of units 16 w + 4 kq + i
+            cprev[layer] = live ? v : zero4;
+        }
+    }
+    // ---- P0 + P1: magnitudes registers -> LDS rows (33 t + 8 w + 4 rt + kq), and the per-column mean of the log-spectrum on the way
+#pragma unroll
+    for (int tc = 0; tc < 8; ++tc) {
+        float s = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const f32x4 v = mg[tc][rt];
+            RX[(MAG_Q * tc + 8 * w + 4 * rt) * QSD + nq] = v;
+            s += (log1p20(v.x) + log1p20(v.y)) + (log1p20(v.z) + log1p20(v.w));
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (kq == 0) colpart[(w * 8 + tc) * 16 + n] = s;
+    }
+    if (tid < 32) {
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) RX[(MAG_Q * (2 * grp + (tid >> 4)) + 32) * QSD + n] = f32x4{nyq[grp], 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int ms = tid & 15, tc = tid >> 4;
+        const float s = ((colpart[tc * 16 + ms] + colpart[(8 + tc) * 16 + ms]) + (colpart[(16 + tc) * 16 + ms] + colpart[(24 + tc) * 16 + ms])) +
+                        log1p20(RX[(MAG_Q * tc + 32) * QSD + ms].x);
+        colmean[tc * 16 + ms] = s * (1.0f / 129.0f);
+    }
+    __syncthreads();
+    if (tid < MT16) {
+        const int o_dw0 = (int)P.sect[0][S_DW0];
+        const f32x4 f0 = ldt(wrs, 2 * 34 * 6, o_dw0), f1 = ldt(wrs, 2 * 34 * 6 + 1, o_dw0);
+        const float filt[7] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z};
+        float mp[14];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) mp[3 + t] = colmean[t * 16 + tid];
+        mp[0] = mp[3 + 3]; mp[1] = mp[3 + 2]; mp[2] = mp[3 + 1];          // reverse(mean[1:4])
+        mp[11] = mp[3 + 6]; mp[12] = mp[3 + 5]; mp[13] = mp[3 + 4];       // reverse(mean[-4:-1])
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) s = fmaf(filt[k], mp[t + k], s);
+            acc += s;
+        }
+        mmv[tid] = acc * 0.125f;
+    }
+    __syncthreads();
+    STAMP(17);
+
+    // ---- P2: first layer (258 -> 16 channels), all four kept output columns in every wave, K split over the waves: wave w
+    //      contracts the channel quads 16 j + 4 kq of j = w and w + 4; the Nyquist channel is a rank-1 VALU term (output column w in
+    //      wave w); the four partial tiles per column meet in LDS once the magnitude rows are dead (silero_v4.hip, P2)
+    f32x4 p3b, p3w;
+    {
+        int o_dw0 = (int)P.sect[w][S_DW0], o_l0 = (int)P.sect[w][S_L0];
+        asm volatile("" : "+s"(o_dw0), "+s"(o_l0));
+        f32x4 acc[4];
+        {
+            const f32x4 b0 = WL(o_l0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = w == 0 ? b0 : zero4;       // the bias enters once
+        }
+        const int ws = o_l0 + 5;
+        const float mm = mmv[n];
+        f32x4 tn[12], wn[4];         // Nyquist channel: quad 32 of the tables (component 0), its four weight columns in the D layout
+        tn[0] = ldt(wrs, 32 * 6 + 5, o_dw0); tn[1] = ldt(wrs, (34 + 32) * 6 + 5, o_dw0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { tn[2 + 2 * k] = ldt(wrs, 32 * 6 + k, o_dw0); tn[3 + 2 * k] = ldt(wrs, (34 + 32) * 6 + k, o_dw0); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wn[k] = WL(o_l0 + 1 + k);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int q_ = 4 * (w + 4 * it) + kq;
+            f32x4 tb[12], wq[4];
+            tb[0] = ldt(wrs, q_ * 6 + 5, o_dw0); tb[1] = ldt(wrs, (34 + q_) * 6 + 5, o_dw0);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                tb[2 + 2 * k] = ldt(wrs, q_ * 6 + k, o_dw0);
+                tb[3 + 2 * k] = ldt(wrs, (34 + q_) * 6 + k, o_dw0);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wq[k] = WL(ws + 4 * (w + 4 * it) + k);
+            f32x4 mgc[8], spc[8];
+#pragma unroll
+            for (int tc = 0; tc < 8; ++tc) mgc[tc] = RX[(MAG_Q * tc + 4 * (w + 4 * it)) * QSD + nq];
+#pragma unroll
+            for (int tc = 0; tc < 8; ++tc)
+                spc[tc] = f32x4{lognorm(mgc[tc].x, mm), lognorm(mgc[tc].y, mm), lognorm(mgc[tc].z, mm), lognorm(mgc[tc].w, mm)};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 dm = tb[0], dn = tb[1];        // depthwise k5 p2 around input column 2c: biases, then the taps
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int tc = 2 * c + k - 2;
+                    if (tc >= 0 && tc < 8) {
+                        dm = fma4(tb[2 + 2 * k], mgc[tc], dm);
+                        dn = fma4(tb[3 + 2 * k], spc[tc], dn);
+                    }
+                }
+                dm = relu4(dm);
+                dn = relu4(dn);
+                f32x4 a_ = acc[c];
+                a_ = mfma16(wq[0], dm, a_);
+                a_ = mfma16(wq[1], mgc[2 * c], a_);
+                a_ = mfma16(wq[2], dn, a_);
+                a_ = mfma16(wq[3], spc[2 * c], a_);
+                acc[c] = a_;
+            }
+        }
+        {   // Nyquist channel of output column w (input column 2w): scalars per stream, rank-1 into this lane's output quad
+            float dm = tn[0].x, dn = tn[1].x, xm = 0.f, xn = 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int tc = 2 * w + k - 2;
+                if (tc >= 0 && tc < 8) {             // wave-uniform
+                    const float mgv = RX[(MAG_Q * tc + 32) * QSD + n].x;
+                    const float sp = lognorm(mgv, mm);
+                    dm = fmaf(tn[2 + 2 * k].x, mgv, dm);
+                    dn = fmaf(tn[3 + 2 * k].x, sp, dn);
+                    if (k == 2) { xm = mgv; xn = sp; }
+                }
+            }
+            dm = fmaxf(dm, 0.f);
+            dn = fmaxf(dn, 0.f);
+            const f32x4 r1 = wn[0] * dm + wn[1] * xm + wn[2] * dn + wn[3] * xn;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c == w) acc[c] = acc[c] + r1;
+        }
+        {
+            const int o_ = (int)P.sect[w][S_S0];
+            p3b = WL(o_); p3w = WL(o_ + 1);
+        }
+        STAMP(18);
+        __syncthreads();   // every wave is done with the magnitude rows: they now carry the partial tiles
+#pragma unroll
+        for (int c = 0; c < 4; ++c) RX[((w * 4 + c) * 4) * QSD + nq] = acc[c];       // PART[wave][column][output quad][stream]
+        __syncthreads();
+        {
+            const int cq = tid >> 4, ms = tid & 15;   // (column, channel quad), stream
+            const f32x4 p0 = RX[cq * QSD + ms], p1 = RX[(16 + cq) * QSD + ms], p2 = RX[(32 + cq) * QSD + ms], p3 = RX[(48 + cq) * QSD + ms];
+            RX[(R_A16 + cq) * QSD + ms] = relu4((p0 + p1) + (p2 + p3));
+        }
+    }
+    __syncthreads();   // the magnitude rows are free from here on
+    STAMP(20);
+
+    // previous h of both LSTM layers -> rows R_H0.. (32 quads per stream)
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) RX[(R_H0 + (tid >> 4) * 2 + qq) * QSD + (tid & 15)] = hprev[qq];
+
+    // ---- P3: s0 1x1 16 -> 16 on the 4 kept columns; wave w = column w -------------------------------------------------------
+    f32x4 p4t[6], p4w[6];
+    {
+        const int o_ = (int)P.sect[w][S_L1];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p4t[k] = ldt(wrs, kq * 6 + k, o_);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p4w[k] = WL(o_ + 1 + k);
+        SB();
+        const f32x4 acc = mfma16(p3w, RX[(R_A16 + 4 * w) * QSD + nq], p3b);
+        RX[(R_Y0 + 4 * w) * QSD + nq] = relu4(acc);
+    }
+    __syncthreads();
+
+    // ---- P4: block 1 (16 -> 32): dw k5 over the 4 columns (VALU) -> pw, + proj(y); wave w = column w, two row tiles ------------
+    f32x4 p5w[3];
+    {
+        f32x4 d = p4t[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int tc = w + k - 2;
+            if (tc >= 0 && tc < 4) d = fma4(p4t[k], RX[(R_Y0 + 4 * tc) * QSD + nq], d);
+        }
+        d = relu4(d);
+        const f32x4 y = RX[(R_Y0 + 4 * w) * QSD + nq];
+        {
+            const int o_ = (int)P.sect[w][S_S1] + 3 * (w & 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p5w[k] = WL(o_ + k);
+        }
+        SB();
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            f32x4 acc = p4w[3 * rt];
+            acc = mfma16(p4w[3 * rt + 1], d, acc);
+            acc = mfma16(p4w[3 * rt + 2], y, acc);
+            RX[(R_Y1 + 8 * w + 4 * rt) * QSD + nq] = relu4(acc);
+        }
+    }
+    __syncthreads();
+
+    STAMP(21);
+    // ---- P5: s1 1x1 32 -> 32, stride 2: columns 0 and 2; wave w = (column w >> 1, row tile w & 1) -------------------------------
+    const int col2 = w >> 1, rt2 = w & 1;
+    f32x4 p6t[12], p6w[3];
+    {
+        const int o_ = (int)P.sect[w][S_L2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) p6t[6 * j + k] = ldt(wrs, (4 * j + kq) * 6 + k, o_);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p6w[k] = WL(o_ + 1 + 3 * rt2 + k);
+        SB();
+        const int r = R_Y1 + 8 * (2 * col2);
+        f32x4 acc = p5w[0];
+        acc = mfma16(p5w[1], RX[(r + 0) * QSD + nq], acc);
+        acc = mfma16(p5w[2], RX[(r + 4) * QSD + nq], acc);
+        RX[(R_Y2 + 8 * col2 + 4 * rt2) * QSD + nq] = relu4(acc);
+    }
+    __syncthreads();
+
+    // ---- P6: block 2 (32 -> 32, identity residual) on 2 columns; wave w = (column, row tile) -------------------------------------
+    f32x4 p7w[3];
+    {
+        f32x4 d[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            d[j] = p6t[6 * j + 5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int tc = col2 + k - 2;
+                if (tc >= 0 && tc < 2) d[j] = fma4(p6t[6 * j + k], RX[(R_Y2 + 8 * tc + 4 * j) * QSD + nq], d[j]);
+            }
+            d[j] = relu4(d[j]);
+        }
+        {
+            const int o_ = (int)P.sect[w][S_S2] + 3 * (K8 ? rt2 : (w & 1));
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p7w[k] = WL(o_ + k);
+        }
+        SB();
+        f32x4 acc = p6w[0];
+        acc = mfma16(p6w[1], d[0], acc);
+        acc = mfma16(p6w[2], d[1], acc);
+        // + identity residual: output channels 16 rt + 4 kq + i = input quad 4 rt + kq of the same column
+        const f32x4 r = RX[(R_Y2 + 8 * col2 + 4 * rt2) * QSD + nq];
+        RX[(R_Y3 + 8 * col2 + 4 * rt2) * QSD + nq] = relu4(acc + r);
+    }
+    __syncthreads();
+
+    STAMP(22);
+    // ---- P7: s2 1x1 32 -> 32.  16 kHz: stride 2 -> column 0, waves 0, 1 = row tile.  8 kHz: stride 1, wave w = (column, row tile) ----
+    f32x4 p8t[6], p8w[5];
+    {
+        const int o_ = (int)P.sect[w][S_L3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            p8t[3 * j] = ldt(wrs, (4 * j + kq) * 6 + 2, o_);
+            p8t[3 * j + 1] = ldt(wrs, (4 * j + kq) * 6 + 5, o_);
+            p8t[3 * j + 2] = zero4;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) p8w[k] = WL(o_ + 1 + 5 * w + k);
+        SB();
+        if (K8 || w < 2) {
+            const int c7 = K8 ? col2 : 0, r7 = K8 ? rt2 : w;
+            const int rin = R_Y3 + 8 * c7, rout = K8 ? R8_Y4 + 8 * c7 : R_Y4;
+            f32x4 acc = p7w[0];
+            acc = mfma16(p7w[1], RX[(rin + 0) * QSD + nq], acc);
+            acc = mfma16(p7w[2], RX[(rin + 4) * QSD + nq], acc);
+            RX[(rout + 4 * r7) * QSD + nq] = relu4(acc);
+        }
+    }
+    __syncthreads();
+
+    // ---- P8: block 3 (32 -> 64); wave w = row tile w.  16 kHz: one column (dw: centre tap only).  8 kHz: two columns (dw taps
+    //      2,3 on column 0 and 1,2 on column 1) ------------------------------------------------------------------------------------
+    constexpr int NC = K8 ? 2 : 1;
+    f32x4 p9w[5];
+    {
+        {
+            const int o_ = (int)P.sect[w][S_S3] + 5 * w;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) p9w[k] = WL(o_ + k);
+        }
+        f32x4 y[NC][2], d[NC][2];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) y[c][j] = RX[((K8 ? R8_Y4 + 8 * c : R_Y4) + 4 * j) * QSD + nq];
+        if constexpr (K8) {
+            const int o_ = (int)P.sect[w][S_L3];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 t1 = ldt(wrs, (4 * j + kq) * 6 + 1, o_), t3 = ldt(wrs, (4 * j + kq) * 6 + 3, o_);
+                // out[col] = b + w[2] in[col] + w[2 + (oth - col)] in[oth]
+                d[0][j] = relu4(fma4(t3, y[1][j], fma4(p8t[3 * j], y[0][j], p8t[3 * j + 1])));
+                d[1][j] = relu4(fma4(t1, y[0][j], fma4(p8t[3 * j], y[1][j], p8t[3 * j + 1])));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) d[0][j] = relu4(fma4(p8t[3 * j], y[0][j], p8t[3 * j + 1]));
+        }
+        SB();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            f32x4 acc = p8w[0];
+            acc = mfma16(p8w[1], d[c][0], acc);
+            acc = mfma16(p8w[2], d[c][1], acc);
+            acc = mfma16(p8w[3], y[c][0], acc);
+            acc = mfma16(p8w[4], y[c][1], acc);
+            RX[((K8 ? R8_Y5 + 16 * c : R_Y5) + 4 * w) * QSD + nq] = relu4(acc);
+        }
+    }
+    __syncthreads();
+
+    // ---- P9: s3 1x1 64 -> 64; wave w = row tile w (8 kHz: both columns) ----------------------------------------------------------
+    f32x4 smq[6];
+    const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];
+    const f32x4 hw = WL((int)P.sect[w][S_HEADB] + 1 + w);
+    f32x4 lbq[4];                                    // gate biases of the first cell
+    {
+        const int ob = (int)P.sect[w][S_LSTM0];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lbq[k] = WL(ob + k);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) smq[k] = reinterpret_cast<const f32x4 *>(P.sm + slot)[k];
+        SB();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int rin = K8 ? R8_Y5 + 16 * c : R_Y5;
+            f32x4 acc = p9w[0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = mfma16(p9w[1 + j], RX[(rin + 4 * j) * QSD + nq], acc);
+            RX[((K8 ? R8_Y6 + 16 * c : R_Y6) + 4 * w) * QSD + nq] = relu4(acc);
+        }
+    }
+    __syncthreads();
+
+    STAMP(23);
+    // ---- P10/P11: two stacked LSTM(64) cells, T3 time steps (1, or 2 for the 8 kHz sub-model).  Wave w owns hidden units
+    //      16 w .. 16 w + 15: four 16-row tiles = gates i, f, g, o, full K = 128 (layer input | h_{t-1}) = 8 k-iterations; the D
+    //      layout puts the four gates of a unit into the same lane - every wave finishes its own cells, one barrier per cell.
+    constexpr int T3 = K8 ? 2 : 1;
+    constexpr int R_H0M = R8_Y5;                    // 8 kHz only: layer 0's h after the SECOND step (R_H0N is still being read)
+#pragma unroll
+    for (int step = 0; step < T3; ++step) {
+        float part = 0.f;
+#pragma unroll
+        for (int layer = 0; layer < 2; ++layer) {
+            const int ob = (int)P.sect[w][layer == 0 ? S_LSTM0 : S_LSTM1];
+            f32x4 G[4] = {lbq[0], lbq[1], lbq[2], lbq[3]};
+            const int rx = layer == 0 ? (K8 ? R8_Y6 + 16 * step : R_Y6) : (step == 0 ? R_H0N : R_H0M);
+            const int rh = layer == 0 ? (step == 0 ? R_H0 : R_H0N) : (step == 0 ? R_H1 : R_H1N);
+            const f32x4 *const xsrc = RX + rx * QSD + nq, *const hsrc = RX + rh * QSD + nq;
+#define LS_ROW(it) (((it) < 4 ? xsrc : hsrc)[(4 * ((it) & 3)) * QSD])
+#define LS_LD(S, it) _Pragma("unroll") for (int k = 0; k < 4; ++k) S##w[k] = WL(ob + 4 + 4 * (it) + k); S##a = LS_ROW(it);
+#define LS_MMA(S) _Pragma("unroll") for (int k = 0; k < 4; ++k) G[k] = mfma16(S##w[k], S##a, G[k]);
+            f32x4 Aw[4], Bw[4], Aa, Ba;
+            LS_LD(A, 0)
+#pragma unroll
+            for (int it = 0; it < 8; it += 2) {
+                LS_LD(B, it + 1) SB();
+                LS_MMA(A) SB();
+                const int itn = it + 2 < 8 ? it + 2 : 6;
+                LS_LD(A, itn) SB();
+                LS_MMA(B) SB();
+            }
+#undef LS_ROW
+#undef LS_LD
+#undef LS_MMA
+            // the next cell's biases fly during this cell's update
+            if (layer == 0 || step + 1 < T3) {
+                const int obn = (int)P.sect[w][layer == 0 ? S_LSTM1 : S_LSTM0];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lbq[k] = WL(obn + k);
+                SB();
+            }
+            {
+                float *st = P.state + (size_t)slot * 256;
+                const f32x4 i4 = G[0], f4 = G[1], c4g = G[2], o4 = G[3];
+                const int unit = 16 * w + 4 * kq;
+                const f32x4 cp = cprev[layer];
+                f32x4 cn, hn;
+#define CELL(k)                                                             \
+    cn.k = sigmoidf_(f4.k) * cp.k + sigmoidf_(i4.k) * tanhf_(c4g.k);      \
+    hn.k = sigmoidf_(o4.k) * tanhf_(cn.k);
+                CELL(x) CELL(y) CELL(z) CELL(w)
+#undef CELL
+                cprev[layer] = cn;
+                if (step == T3 - 1 && live) {
+                    *reinterpret_cast<f32x4 *>(st + 128 + 64 * layer + unit) = cn;
+                    *reinterpret_cast<f32x4 *>(st + 64 * layer + unit) = hn;
+                }
+                if (layer == 0) {
+                    RX[((step == 0 ? R_H0N : R_H0M) + 4 * w) * QSD + nq] = hn;
+                } else {
+                    if (step + 1 < T3) RX[(R_H1N + 4 * w) * QSD + nq] = hn;
+                    part += hw.x * fmaxf(hn.x, 0.f) + hw.y * fmaxf(hn.y, 0.f) + hw.z * fmaxf(hn.z, 0.f) + hw.w * fmaxf(hn.w, 0.f);
+                }
+            }
+            __syncthreads();
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (kq == 0) headp[step * 64 + w * 16 + n] = part;
+    }
+    STAMP(24);
+    __syncthreads();
+
+    // ---- head + state machine ------------------------------------------------------------------------
+    if (tid < MT16 && live) {
+        float p = sigmoidf_(hb + ((headp[tid] + headp[16 + tid]) + (headp[32 + tid] + headp[48 + tid])));
+        if (K8)     // ReduceMean over the two time steps
+            p = (p + sigmoidf_(hb + ((headp[64 + tid] + headp[80 + tid]) + (headp[96 + tid] + headp[112 + tid])))) * 0.5f;
+        p = fminf(p, 1.0f);
+        P.probs[(size_t)(tile0 + tid) * T + tframe] = p;
+        SmSlot sm;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) reinterpret_cast<f32x4 *>(&sm)[k] = smq[k];
+        int seg = 0;
+        const int ev = sm_step(sm, p, &seg);
+        P.sm[slot] = sm;
+        if (P.events) P.events[(size_t)(tile0 + tid) * T + tframe] = (uint8_t)ev;
+        if (P.seg_frames) {
+            if (ev & 2) P.seg_frames[tile0 + tid] = seg;
+            else if (tframe == 0) P.seg_frames[tile0 + tid] = 0;
+        }
+    }
+    STAMP(25);
+#undef WL
+}
+
+// host-callable launcher: the T frames of a call run as T launches on one stream (state lives in HBM between them).
+// one_per_cu: pad the launch with dynamic LDS so that a CU takes ONE workgroup - a call with at most one tile per CU spreads over
+// twice as many CUs instead of pairing its tiles up (the dispatcher fills a CU before it moves on)
+extern "C" hipError_t vadk_launch_silero_v4_t16(const vadk::StepParams *p, int one_per_cu, hipStream_t stream) {
+    (void)hipGetLastError();
+    const int tiles = (p->n + MT16 - 1) / MT16;
+    if (tiles <= 0) return hipSuccess;
+    const unsigned pad = one_per_cu ? 8u * 1024u : 0u;
+    for (int t = 0; t < p->T; ++t) {
+        if (p->variant == 1)
+            hipLaunchKernelGGL(silero_v4_step16<true>, dim3(tiles), dim3(vadk::NTHREADS), pad, stream, *p, t);
+        else
+            hipLaunchKernelGGL(silero_v4_step16<false>, dim3(tiles), dim3(vadk::NTHREADS), pad, stream, *p, t);
+    }
+    return hipGetLastError();
+}

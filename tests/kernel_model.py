@@ -743,3 +743,227 @@ def resample_t16(W, wave_blocks, row128_block, x):
     od = uo @ row[Q:2 * Q] + row[2 * Q + 1] * xo[:, Q]
     y[:, 128], y[:, 384] = e + od, e - od
     return y
+
+
+# ======================================================================================
+#  Silero V4 on 16-stream tiles: model of silero_v4_t16.hip over pack_silero_v4_t16's streams
+# ======================================================================================
+def v4_step_t16(W, sect, x, hc, gate=0.01, k8=False):
+    """x [16,512] f32, hc [16,256] (h0 h1 c0 c1) -> (prob [16], new hc); float64 contractions; mirrors silero_v4_t16.hip:
+    same rows, block offsets and wave roles.  k8: the graph's 8 kHz sub-model (two columns through block 3, two LSTM steps)."""
+    S = V4
+    x = x.astype(np.float64)
+    if gate is not None and gate >= 0:
+        x = np.where(np.abs(x) > gate, x, 0.0)
+    xp = np.pad(x, ((0, 0), (96, 96)), mode="reflect")                    # [16, 704]
+    wtab = W[sect[0][S["S_NYQ"]]].reshape(-1)[:256].astype(np.float64)
+    RX = np.zeros((280, 16, 4))
+    n = np.arange(64)
+    sgn = np.where(np.arange(16) % 2 == 0, 1.0, -1.0)[:, None]
+    for grp in range(4):
+        UV = np.zeros((128, 16, 4))
+        fcor = np.zeros((2, 3, 16))
+        for cp in range(2):
+            t = 2 * grp + cp
+            y = xp[:, 64 * t:64 * t + 256] * wtab[None, :]
+            y1, y2, y3, y4 = y[:, n], y[:, 128 - n], y[:, 128 + n], y[:, (256 - n) % 256]
+            for k, arr in enumerate((y1 + y4 + y2 + y3, y1 + y4 - y2 - y3, y1 - y4 - y2 + y3, y1 - y4 + y2 - y3)):
+                arr = arr.copy()
+                arr[:, 0] = 0.0
+                UV[64 * cp + 16 * k:64 * cp + 16 * k + 16] = arr.reshape(16, 16, 4).transpose(1, 0, 2)
+            fcor[cp] = y[:, 128], y[:, 64] + y[:, 192], y[:, 64] - y[:, 192]
+            e, o = y[:, 0::2].sum(1), y[:, 1::2].sum(1)                      # the two real bins straight from the samples (float64)
+            RX[33 * t + 32, :, 0] = np.abs(e - o)
+            dc = e + o
+            for w in range(4):
+                ws = sect[w][S["S_STFT"]]
+                rR, rI = (0, 32) if w < 2 else (16, 48)
+                for rt in range(2):
+                    are, aim = np.zeros((16, 16)), np.zeros((16, 16))
+                    for j in range(4):
+                        are += _mfma16(W[ws + 4 * j + rt], _rows16(UV, 64 * cp + rR + 4 * j))
+                        aim += _mfma16(W[ws + 4 * j + 2 + rt], _rows16(UV, 64 * cp + rI + 4 * j))
+                    y128, a64, b64 = fcor[cp, 0][None, :], fcor[cp, 1][None, :], fcor[cp, 2][None, :]
+                    re, im = (are + y128 + sgn * a64, aim) if w < 2 else (are - y128, aim - sgn * b64)
+                    if w == 0 and rt == 0:
+                        re[0] = dc
+                    _store16(RX, 33 * t + 8 * w + 4 * rt, np.sqrt(re ** 2 + im ** 2), relu=False)
+    lg = lambda mg: np.log(1.0 + mg * 1048576.0)
+    o_dw0 = sect[0][S["S_DW0"]]
+    colmean = np.zeros((8, 16))
+    for t in range(8):
+        sp = lg(RX[33 * t:33 * t + 33])
+        colmean[t] = (sp[:32].sum(axis=(0, 2)) + sp[32, :, 0]) / 129.0
+    f0, f1 = _table_row(W, o_dw0, 2 * 34 * 6), _table_row(W, o_dw0, 2 * 34 * 6 + 1)
+    filt = np.concatenate([f0, f1[:3]])
+    mp = np.concatenate([colmean[[3, 2, 1]], colmean, colmean[[6, 5, 4]]])
+    mm = np.mean([sum(filt[k] * mp[t + k] for k in range(7)) for t in range(8)], axis=0)   # [16]
+    # P2 first layer (as in the 32-stream kernel, one stream half)
+    o_l0 = sect[0][S["S_L0"]]
+    ws = o_l0 + 5
+    vec = lambda blk: np.repeat(_vec16(W[blk])[:, None], 16, 1)                # bias tile [16 rows, 16 streams]
+    part = np.zeros((4, 4, 16, 16))               # [wave][column][channel][stream]
+    part[0] += vec(o_l0)[None]
+    wn = [_vec16(W[o_l0 + 1 + k]) for k in range(4)]
+    for w in range(4):
+        for it in range(2):
+            j = w + 4 * it
+            for c in range(4):
+                frag = {k: np.zeros((64, 4)) for k in ("dm", "xm", "dn", "xn")}
+                for kq in range(4):
+                    q = 4 * j + kq
+                    dm = np.repeat(_table_row(W, o_dw0, q * 6 + 5)[None], 16, 0)
+                    dn = np.repeat(_table_row(W, o_dw0, (34 + q) * 6 + 5)[None], 16, 0)
+                    for k in range(5):
+                        tc = 2 * c + k - 2
+                        if 0 <= tc < 8:
+                            mg = RX[33 * tc + q]
+                            dm = dm + _table_row(W, o_dw0, q * 6 + k)[None] * mg
+                            dn = dn + _table_row(W, o_dw0, (34 + q) * 6 + k)[None] * (lg(mg) - mm[:, None])
+                    sl = slice(16 * kq, 16 * kq + 16)
+                    mg0 = RX[33 * 2 * c + q]
+                    frag["dm"][sl], frag["xm"][sl] = np.maximum(dm, 0), mg0
+                    frag["dn"][sl], frag["xn"][sl] = np.maximum(dn, 0), lg(mg0) - mm[:, None]
+                for i, k in enumerate(("dm", "xm", "dn", "xn")):
+                    part[w, c] += _mfma16(W[ws + 4 * j + i], frag[k])
+        dm = np.full(16, _table_row(W, o_dw0, 32 * 6 + 5)[0])
+        dn = np.full(16, _table_row(W, o_dw0, (34 + 32) * 6 + 5)[0])
+        for k in range(5):
+            tc = 2 * w + k - 2
+            if 0 <= tc < 8:
+                mg = RX[33 * tc + 32][:, 0]
+                dm = dm + _table_row(W, o_dw0, 32 * 6 + k)[0] * mg
+                dn = dn + _table_row(W, o_dw0, (34 + 32) * 6 + k)[0] * (lg(mg) - mm)
+        xm = RX[33 * 2 * w + 32][:, 0]
+        xn = lg(xm) - mm
+        part[w, w] += (np.outer(wn[0], np.maximum(dm, 0)) + np.outer(wn[1], xm) + np.outer(wn[2], np.maximum(dn, 0)) +
+                       np.outer(wn[3], xn))
+    first = np.maximum(part.sum(axis=0), 0)       # [column][16 channels][16 streams]
+    R_A16 = 264
+    for c in range(4):
+        _store16(RX, R_A16 + 4 * c, first[c], relu=False)
+    R_Y0, R_Y1, R_Y2, R_Y3, R_Y4, R_Y5, R_Y6 = 0, 16, 48, 64, 80, 88, 104
+    R_H0, R_H1, R_H0N, R_H1N = 120, 136, 152, 96
+    R8_Y4, R8_Y5, R8_Y6, R_H0M = 80, 0, 32, 0
+    RX[R_H0:R_H0 + 32] = hc[:, :128].astype(np.float64).reshape(16, 32, 4).transpose(1, 0, 2)
+
+    def dwq(tab_blk, q, taps):
+        d = np.repeat(_table_row(W, tab_blk, q * 6 + 5)[None], 16, 0)
+        for k, quad in taps:
+            d = d + _table_row(W, tab_blk, q * 6 + k)[None] * quad
+        return np.maximum(d, 0)
+
+    def dwfrag(tab_blk, j, taps_of):                # fragment of k-iteration j: lane (n, kq) = channel quad 4 j + kq
+        return np.concatenate([dwq(tab_blk, 4 * j + kq, taps_of(4 * j + kq)) for kq in range(4)], axis=0)
+
+    # P3: s0, wave w = column w
+    o = sect[0][S["S_S0"]]
+    res = {w: vec(o) + _mfma16(W[o + 1], _rows16(RX, R_A16 + 4 * w)) for w in range(4)}
+    for w in range(4):
+        _store16(RX, R_Y0 + 4 * w, res[w])
+    # P4: block 1 (16 -> 32), wave w = column w, two row tiles
+    o = sect[0][S["S_L1"]]
+    res = {}
+    for w in range(4):
+        d = dwfrag(o, 0, lambda q: [(k, RX[R_Y0 + 4 * (w + k - 2) + q]) for k in range(5) if 0 <= w + k - 2 < 4])
+        y = _rows16(RX, R_Y0 + 4 * w)
+        for rt in range(2):
+            b = o + 1 + 3 * rt
+            res[w, rt] = vec(b) + _mfma16(W[b + 1], d) + _mfma16(W[b + 2], y)
+    for (w, rt), acc in res.items():
+        _store16(RX, R_Y1 + 8 * w + 4 * rt, acc)
+    # P5: s1 on columns 0 and 2; wave w = (column w >> 1, row tile w & 1)
+    o = sect[0][S["S_S1"]]
+    res = {}
+    for w in range(4):
+        col, rt = w >> 1, w & 1
+        b = o + 3 * rt
+        res[w] = vec(b) + sum(_mfma16(W[b + 1 + j], _rows16(RX, R_Y1 + 8 * (2 * col) + 4 * j)) for j in range(2))
+    for w in range(4):
+        _store16(RX, R_Y2 + 8 * (w >> 1) + 4 * (w & 1), res[w])
+    # P6: block 2 (identity residual)
+    o = sect[0][S["S_L2"]]
+    res = {}
+    for w in range(4):
+        col, rt = w >> 1, w & 1
+        b = o + 1 + 3 * rt
+        acc = vec(b)
+        for j in range(2):
+            acc = acc + _mfma16(W[b + 1 + j], dwfrag(o, j, lambda q: [(k, RX[R_Y2 + 8 * (col + k - 2) + q]) for k in range(5) if 0 <= col + k - 2 < 2]))
+        resid = np.concatenate([RX[R_Y2 + 8 * col + 4 * rt + rq].T for rq in range(4)], axis=0)     # [16 ch, 16 streams]
+        res[w] = acc + resid
+    for w in range(4):
+        _store16(RX, R_Y3 + 8 * (w >> 1) + 4 * (w & 1), res[w])
+    # P7: s2.  16 kHz: stride 2 -> column 0, waves 0, 1 = row tile; 8 kHz: stride 1, wave w = (column, row tile)
+    o = sect[0][S["S_S2"]]
+    res = {}
+    for w in range(4 if k8 else 2):
+        col, rt = (w >> 1, w & 1) if k8 else (0, w)
+        b = o + 3 * rt
+        res[w] = vec(b) + sum(_mfma16(W[b + 1 + j], _rows16(RX, R_Y3 + 8 * col + 4 * j)) for j in range(2))
+    for w, acc in res.items():
+        col, rt = (w >> 1, w & 1) if k8 else (0, w)
+        _store16(RX, (R8_Y4 + 8 * col if k8 else R_Y4) + 4 * rt, acc)
+    # P8: block 3 (32 -> 64), wave w = row tile w; 8 kHz: both columns
+    o = sect[0][S["S_L3"]]
+    ncol = 2 if k8 else 1
+    res = {}
+    for w in range(4):
+        b = o + 1 + 5 * w
+        for col in range(ncol):
+            base = R8_Y4 + 8 * col if k8 else R_Y4
+            acc = vec(b)
+            for j in range(2):
+                if k8:
+                    oth = 1 - col
+                    d = dwfrag(o, j, lambda q: [(2, RX[R8_Y4 + 8 * col + q]), (2 + (oth - col), RX[R8_Y4 + 8 * oth + q])])
+                else:
+                    d = dwfrag(o, j, lambda q: [(2, RX[R_Y4 + q])])
+                acc = acc + _mfma16(W[b + 1 + j], d) + _mfma16(W[b + 3 + j], _rows16(RX, base + 4 * j))
+            res[w, col] = acc
+    for (w, col), acc in res.items():
+        _store16(RX, (R8_Y5 + 16 * col if k8 else R_Y5) + 4 * w, acc)
+    # P9: s3 (64 -> 64), wave w = row tile w
+    o = sect[0][S["S_S3"]]
+    res = {}
+    for w in range(4):
+        b = o + 5 * w
+        for col in range(ncol):
+            base = R8_Y5 + 16 * col if k8 else R_Y5
+            res[w, col] = vec(b) + sum(_mfma16(W[b + 1 + j], _rows16(RX, base + 4 * j)) for j in range(4))
+    for (w, col), acc in res.items():
+        _store16(RX, (R8_Y6 + 16 * col if k8 else R_Y6) + 4 * w, acc)
+    # LSTMs: wave w = units 16 w .. 16 w + 15, gates i, f, g, o as four 16-row tiles
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    new = hc.astype(np.float64).copy()
+    cst = [hc[:, 128:192].astype(np.float64).T.copy(), hc[:, 192:256].astype(np.float64).T.copy()]     # [64 units, 16 streams]
+    oh = sect[0][S["S_HEADB"]]
+    probs = []
+    for step in range(2 if k8 else 1):
+        z = np.zeros(16)
+        for layer in range(2):
+            xin = ((R8_Y6 + 16 * step) if k8 else R_Y6) if layer == 0 else (R_H0N if step == 0 else R_H0M)
+            hin = (R_H0 if step == 0 else R_H0N) if layer == 0 else (R_H1 if step == 0 else R_H1N)
+            hn_all = np.zeros((64, 16))
+            for w in range(4):
+                ob = sect[w][S["S_LSTM0" if layer == 0 else "S_LSTM1"]]
+                g = [vec(ob + q) for q in range(4)]
+                for j in range(8):
+                    a = _rows16(RX, (xin if j < 4 else hin) + 4 * (j & 3))
+                    for q in range(4):
+                        g[q] = g[q] + _mfma16(W[ob + 4 + 4 * j + q], a)
+                sl = slice(16 * w, 16 * w + 16)
+                cn = sig(g[1]) * cst[layer][sl] + sig(g[0]) * np.tanh(g[2])
+                hn = sig(g[3]) * np.tanh(cn)
+                cst[layer][sl] = cn
+                hn_all[sl] = hn
+                new[:, 128 + 64 * layer + 16 * w:128 + 64 * layer + 16 * w + 16] = cn.T
+                new[:, 64 * layer + 16 * w:64 * layer + 16 * w + 16] = hn.T
+                if layer == 1:
+                    z += (_vec16(W[oh + 1 + w])[:, None] * np.maximum(hn, 0)).sum(0)
+            dst = (R_H0N if step == 0 else R_H0M) if layer == 0 else R_H1N
+            if layer == 0 or step == 0:
+                RX[dst:dst + 16] = hn_all.T.reshape(16, 16, 4).transpose(1, 0, 2)
+        probs.append(sig(z + W[oh][0, 0]))
+    prob = np.mean(probs, axis=0)
+    return prob.astype(np.float32), new.astype(np.float32)

@@ -258,3 +258,24 @@ def test_packed_layout_reproduces_the_oracle_v4():
             po = om.step_batch(oracle.denoise(x[:, t]).reshape(32, 512), hc_o)
             assert np.abs(p - po).max() <= 5e-6
             assert np.abs(hc - hc_o).max() <= 1e-4
+
+
+@pytest.mark.parametrize("sr", [16000, 8000])
+def test_packed_layout_of_the_v4_16_stream_tile_kernel_reproduces_the_oracle(sr):
+    """pack_silero_v4_t16's streams, read with silero_v4_t16.hip's indexing (tests/kernel_model.py), == oracle; both sub-models."""
+    from oracle import oracle
+    from tests import kernel_model as KM
+    from tests.signals import make_streams
+    with open(weights_io.packaged_blob_path(4, sr), "rb") as f:
+        blob = f.read()
+    W, sect = KM.packed_streams(416, blob)
+    om = oracle.OracleModel(blob, "f64")
+    x = make_streams(16, 2, seed=8)
+    hc = np.zeros((16, 256), np.float32)
+    hc_o = hc.copy()
+    with np.errstate(over="ignore"):
+        for t in range(2):
+            p, hc = KM.v4_step_t16(W, sect, x[:, t], hc, gate=0.01, k8=sr != 16000)
+            po = om.step_batch(oracle.denoise(x[:, t]).reshape(16, 512), hc_o)
+            assert np.abs(p - po).max() <= 5e-6
+            assert np.abs(hc - hc_o).max() <= 1e-4

@@ -171,6 +171,28 @@ def v4_alone():
             "frac_of_fp32_peak_at_1.38_MFLOP_per_frame": 1.38e6 * B / dt / 157.3e12}
 
 
+def v4_tile_shapes():
+    """V4 (both sub-models), device-resident, both tile shapes (vad_debug_set_tile): the 32-stream kernel with one wave per SIMD
+    against 16-stream tiles, two workgroups per CU."""
+    out = []
+    for sr in (16000, 8000):
+        for B in (256, 1024, 2048, 4096, 8192):
+            eng = Engine(open(weights_io.packaged_blob_path(4, sr), "rb").read(), model_version=4, max_streams=B, sample_rate=sr)
+            eng.open_streams(B)
+            ring = (0.1 * torch.randn(16, B, 512, device="cuda")).contiguous()
+            probs = torch.empty(B, device="cuda")
+            ts = torch.cuda.Stream()
+            row = {"config": f"batch={B}, V4 {sr} Hz sub-model, device-resident", "streams": B}
+            for tile in (32, 16):
+                eng.set_tile(tile)
+                dt = timed(lambda i: eng.step_device(B, ring[i % 16].data_ptr(), probs.data_ptr(), stream=ts.cuda_stream), [ts])
+                row[f"us_per_step_tile{tile}"] = dt * 1e6
+                row[f"frames_per_s_tile{tile}"] = B / dt
+            eng.close()
+            out.append(row)
+    return out
+
+
 def resampler_alone():
     """vadk_resample_512 alone: 4096 chunks per launch, device-resident, per input rate."""
     B = 4096

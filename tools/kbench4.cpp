@@ -16,6 +16,18 @@
 #include "../cutter_vad_amd/csrc/vad_layout.h"
 
 extern "C" hipError_t vadk_launch_silero_v4(const vadk::StepParams *p, hipStream_t stream);
+#ifdef KB_TILE16      // the 16-stream tile kernel (silero_v4_t16.hip); KB_ONE_PER_CU: one workgroup per CU
+extern "C" hipError_t vadk_launch_silero_v4_t16(const vadk::StepParams *p, int one_per_cu, hipStream_t stream);
+#ifndef KB_ONE_PER_CU
+#define KB_ONE_PER_CU 0
+#endif
+#define vadk_launch_silero_v4(p, s) vadk_launch_silero_v4_t16((p), KB_ONE_PER_CU, (s))
+#define KB_MT 16
+#define KB_PACK vadk::pack_silero_v4_t16
+#else
+#define KB_MT vadk::MT
+#define KB_PACK vadk::pack_silero_v4
+#endif
 
 #define CK(x)                                                                      \
     do {                                                                           \
@@ -39,8 +51,8 @@ int main(int argc, char **argv) {
     fclose(f);
     vadk::PackedWeights pw;
     std::string err;
-    if (!vadk::pack_silero_v4(blob.data(), blob.size(), pw, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
-    const int tiles = (B + vadk::MT - 1) / vadk::MT;
+    if (!KB_PACK(blob.data(), blob.size(), pw, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    const int tiles = (B + KB_MT - 1) / KB_MT;
     vadk::StepParams p{};
     float *d_w, *d_state, *d_frames, *d_probs;
     vadk::SmSlot *d_sm;
