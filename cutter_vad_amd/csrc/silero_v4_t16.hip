@@ -49,6 +49,7 @@ static_assert((U_XS + U_UV) % 16 == 0, "window table must start on a 16-quad bou
 constexpr int T_ROWS = vadk::v4::MAG_ROWS + 16;
 constexpr int T_MISC_FLOATS = 16 + 8 * 16 + 2 * 4 * 16;      // mm [16], colmean [8][16], head partials [2 steps][4 waves][16]
 constexpr int K2_F4 = T_ROWS * QSD + T_MISC_FLOATS / 4 + 128;   // + partial log sums [4 waves][8 columns][16]
+constexpr int R_NY = 64;                          // tail: |X128| [8 columns][16 streams] as floats in rows 64, 65 (past the partial tiles)
 constexpr int T16_LDS_F4 = K1_F4 > K2_F4 ? K1_F4 : K2_F4;
 static_assert(T16_LDS_F4 * 16 <= 80 * 1024, "two workgroups per CU");
 
@@ -80,7 +81,7 @@ __device__ __forceinline__ double dpp_f64(double v) {
 __device__ __forceinline__ float log1p20(float mag) {   // log(1 + mag * 2^20): Mul, Add, Log of the graph
     return __builtin_amdgcn_logf(1.0f + mag * 1048576.0f) * 0.69314718055994531f;
 }
-__device__ __forceinline__ float lognorm(float mag, float mm) { return log1p20(mag) - mm; }
+__device__ __forceinline__ float lognorm(float mag, float mm) { return log1p20(mag) - mm; }     // minus the adaptive-normalisation mean
 
 }  // namespace
 
@@ -318,13 +319,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
     // =================================================================================================
     //  tail: the LDS is re-used with the second layout from here on
     // =================================================================================================
-    // state of this lane's stream, requested now and used after the first layer / in the cells
-    f32x4 hprev[2], cprev[2];
+    // state of this lane's stream: h_{t-1} of both layers -> rows R_H0.. (32 quads per stream; nothing else lives there in this
+    // kernel's tail), c_{t-1} of this lane's units -> registers
+    f32x4 cprev[2];
     {
         const float *st = P.state + (size_t)slot * 256;
+        f32x4 hprev[2];
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
-            const f32x4 v = reinterpret_cast<const f32x4 *>(st)[(tid >> 4) * 2 + qq];     // h of both layers: 32 quads per stream
+            const f32x4 v = reinterpret_cast<const f32x4 *>(st)[(tid >> 4) * 2 + qq];
             hprev[qq] = live ? v : zero4;
         }
 #pragma unroll
@@ -332,30 +335,36 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
             const f32x4 v = *reinterpret_cast<const f32x4 *>(st + 128 + 64 * layer + 16 * w + 4 * kq);   // c of units 16 w + 4 kq + i
             cprev[layer] = live ? v : zero4;
         }
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) RX[(R_H0 + (tid >> 4) * 2 + qq) * QSD + (tid & 15)] = hprev[qq];
     }
-    // ---- P0 + P1: magnitudes registers -> LDS rows (33 t + 8 w + 4 rt + kq), and the per-column mean of the log-spectrum on the way
+    // ---- P0 + P1: the log-spectrum of this wave's bins (kept in registers next to the magnitudes: the first layer below contracts
+    //      exactly the channel quads a wave produced, so neither ever travels through LDS) and its per-column means
+    f32x4 lg[8][2];
 #pragma unroll
     for (int tc = 0; tc < 8; ++tc) {
         float s = 0.f;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const f32x4 v = mg[tc][rt];
-            RX[(MAG_Q * tc + 8 * w + 4 * rt) * QSD + nq] = v;
-            s += (log1p20(v.x) + log1p20(v.y)) + (log1p20(v.z) + log1p20(v.w));
+            const f32x4 l = f32x4{log1p20(v.x), log1p20(v.y), log1p20(v.z), log1p20(v.w)};
+            lg[tc][rt] = l;
+            s += (l.x + l.y) + (l.z + l.w);
         }
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
         if (kq == 0) colpart[(w * 8 + tc) * 16 + n] = s;
     }
+    float *const nyqm = reinterpret_cast<float *>(RX + R_NY * QSD);     // [8 columns][16 streams] |X128|
     if (tid < 32) {
 #pragma unroll
-        for (int grp = 0; grp < 4; ++grp) RX[(MAG_Q * (2 * grp + (tid >> 4)) + 32) * QSD + n] = f32x4{nyq[grp], 0.f, 0.f, 0.f};
+        for (int grp = 0; grp < 4; ++grp) nyqm[(2 * grp + (tid >> 4)) * 16 + n] = nyq[grp];
     }
     __syncthreads();
     if (tid < 128) {
         const int ms = tid & 15, tc = tid >> 4;
         const float s = ((colpart[tc * 16 + ms] + colpart[(8 + tc) * 16 + ms]) + (colpart[(16 + tc) * 16 + ms] + colpart[(24 + tc) * 16 + ms])) +
-                        log1p20(RX[(MAG_Q * tc + 32) * QSD + ms].x);
+                        log1p20(nyqm[tc * 16 + ms]);
         colmean[tc * 16 + ms] = s * (1.0f / 129.0f);
     }
     __syncthreads();
@@ -382,8 +391,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
     STAMP(17);
 
     // ---- P2: first layer (258 -> 16 channels), all four kept output columns in every wave, K split over the waves: wave w
-    //      contracts the channel quads 16 j + 4 kq of j = w and w + 4; the Nyquist channel is a rank-1 VALU term (output column w in
-    //      wave w); the four partial tiles per column meet in LDS once the magnitude rows are dead (silero_v4.hip, P2)
+    //      contracts the k-iterations j = 2 w, 2 w + 1 - the 32 bins it produced itself, straight from its registers; the Nyquist
+    //      channel is a rank-1 VALU term (output column w in wave w); the four partial tiles per column meet in LDS (silero_v4.hip, P2)
     f32x4 p3b, p3w;
     {
         int o_dw0 = (int)P.sect[w][S_DW0], o_l0 = (int)P.sect[w][S_L0];
@@ -404,7 +413,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
         for (int k = 0; k < 4; ++k) wn[k] = WL(o_l0 + 1 + k);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            const int q_ = 4 * (w + 4 * it) + kq;
+            const int q_ = 4 * (2 * w + it) + kq;
             f32x4 tb[12], wq[4];
             tb[0] = ldt(wrs, q_ * 6 + 5, o_dw0); tb[1] = ldt(wrs, (34 + q_) * 6 + 5, o_dw0);
 #pragma unroll
@@ -413,13 +422,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
                 tb[3 + 2 * k] = ldt(wrs, (34 + q_) * 6 + k, o_dw0);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wq[k] = WL(ws + 4 * (w + 4 * it) + k);
+            for (int k = 0; k < 4; ++k) wq[k] = WL(ws + 4 * (2 * w + it) + k);
             f32x4 mgc[8], spc[8];
 #pragma unroll
-            for (int tc = 0; tc < 8; ++tc) mgc[tc] = RX[(MAG_Q * tc + 4 * (w + 4 * it)) * QSD + nq];
-#pragma unroll
-            for (int tc = 0; tc < 8; ++tc)
-                spc[tc] = f32x4{lognorm(mgc[tc].x, mm), lognorm(mgc[tc].y, mm), lognorm(mgc[tc].z, mm), lognorm(mgc[tc].w, mm)};
+            for (int tc = 0; tc < 8; ++tc) {
+                mgc[tc] = mg[tc][it];
+                const f32x4 l = lg[tc][it];
+                spc[tc] = f32x4{l.x - mm, l.y - mm, l.z - mm, l.w - mm};       // Sub of the graph: the adaptive normalisation
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 f32x4 dm = tb[0], dn = tb[1];        // depthwise k5 p2 around input column 2c: biases, then the taps
@@ -447,7 +457,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
             for (int k = 0; k < 5; ++k) {
                 const int tc = 2 * w + k - 2;
                 if (tc >= 0 && tc < 8) {             // wave-uniform
-                    const float mgv = RX[(MAG_Q * tc + 32) * QSD + n].x;
+                    const float mgv = nyqm[tc * 16 + n];
                     const float sp = lognorm(mgv, mm);
                     dm = fmaf(tn[2 + 2 * k].x, mgv, dm);
                     dn = fmaf(tn[3 + 2 * k].x, sp, dn);
@@ -466,9 +476,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
             p3b = WL(o_); p3w = WL(o_ + 1);
         }
         STAMP(18);
-        __syncthreads();   // every wave is done with the magnitude rows: they now carry the partial tiles
 #pragma unroll
-        for (int c = 0; c < 4; ++c) RX[((w * 4 + c) * 4) * QSD + nq] = acc[c];       // PART[wave][column][output quad][stream]
+        for (int c = 0; c < 4; ++c) RX[((w * 4 + c) * 4) * QSD + nq] = acc[c];       // PART[wave][column][output quad][stream], rows 0..63
         __syncthreads();
         {
             const int cq = tid >> 4, ms = tid & 15;   // (column, channel quad), stream
@@ -476,12 +485,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
             RX[(R_A16 + cq) * QSD + ms] = relu4((p0 + p1) + (p2 + p3));
         }
     }
-    __syncthreads();   // the magnitude rows are free from here on
+    __syncthreads();
     STAMP(20);
-
-    // previous h of both LSTM layers -> rows R_H0.. (32 quads per stream)
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) RX[(R_H0 + (tid >> 4) * 2 + qq) * QSD + (tid & 15)] = hprev[qq];
 
     // ---- P3: s0 1x1 16 -> 16 on the 4 kept columns; wave w = column w -------------------------------------------------------
     f32x4 p4t[6], p4w[6];

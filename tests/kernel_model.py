@@ -807,7 +807,7 @@ def v4_step_t16(W, sect, x, hc, gate=0.01, k8=False):
     wn = [_vec16(W[o_l0 + 1 + k]) for k in range(4)]
     for w in range(4):
         for it in range(2):
-            j = w + 4 * it
+            j = 2 * w + it                         # the bins the wave produced itself (registers in the kernel)
             for c in range(4):
                 frag = {k: np.zeros((64, 4)) for k in ("dm", "xm", "dn", "xn")}
                 for kq in range(4):

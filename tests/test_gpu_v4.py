@@ -1,4 +1,5 @@
-"""GPU parity of the Silero V4 path (a8): silero_v4_step through the C ABI vs the oracle."""
+"""GPU parity of the Silero V4 path (a8) through the C ABI vs the oracle - both kernel shapes: 16-stream tiles with two workgroups
+per CU (silero_v4_t16.hip, the engine's choice) and 32-stream tiles (silero_v4.hip, pinned with vad_debug_set_tile)."""
 
 import numpy as np
 import pytest
@@ -27,10 +28,11 @@ def om(blob):
     return oracle.OracleModel(blob, "f64")
 
 
-@pytest.fixture(scope="module")
-def engine(blob):
+@pytest.fixture(scope="module", params=[0, 32], ids=["tile16", "tile32"])
+def engine(blob, request):
     from cutter_vad_amd.engine import Engine
     e = Engine(blob, model_version=4, max_streams=2048)
+    e.set_tile(request.param)
     yield e
     e.close()
 
@@ -132,15 +134,43 @@ def test_wrapper_with_v4(engine):
 
 
 # ------------------------------------------------------------------ a9: the 8 kHz sub-model (every sr != 16000)
-@pytest.fixture(scope="module")
-def setup8k():
+@pytest.fixture(scope="module", params=[0, 32], ids=["tile16", "tile32"])
+def setup8k(request):
     from cutter_vad_amd.engine import Engine
     from oracle import oracle
     with open(weights_io.packaged_blob_path(4, 8000), "rb") as f:
         blob = f.read()
     e = Engine(blob, model_version=4, max_streams=512, sample_rate=8000)
+    e.set_tile(request.param)
     yield e, oracle.OracleModel(blob, "f64")
     e.close()
+
+
+@pytest.mark.parametrize("sr", [16000, 8000])
+def test_the_two_tile_shapes_agree_to_rounding_and_each_is_position_independent(sr):
+    """16- and 32-stream tiles evaluate the same sums in different orders: equal to rounding (2e-5 on V4's log-spectrum input, both
+    within the bar of the oracle), and inside one shape a stream's bits do not depend on the batch it travels in - including the
+    calls small enough to run one workgroup per CU (the launch is padded with dynamic LDS, the arithmetic is the same)."""
+    from cutter_vad_amd.engine import Engine
+    with open(weights_io.packaged_blob_path(4, sr), "rb") as f:
+        blob = f.read()
+    n, T = 4500, 4                                    # 282 tiles of 16: more than one per CU
+    frames = make_streams(n, T, seed=4016)
+    with Engine(blob, model_version=4, max_streams=n, sample_rate=sr) as eng:
+        slots = eng.open_streams(n)
+        runs = {}
+        for tile in (16, 32):
+            eng.set_tile(tile)
+            eng.reset(slots)
+            runs[tile] = np.stack([eng.step(slots, frames[:, t]) for t in range(T)], axis=1)
+        assert np.abs(runs[16] - runs[32]).max() <= 2e-5
+        eng.set_tile(16)
+        sub = np.arange(1000, 1045)                   # 45 streams: 3 tiles, one per CU
+        eng.reset(slots[:45])
+        small = np.stack([eng.step(slots[:45], frames[sub, t]) for t in range(T)], axis=1)
+        assert np.array_equal(small, runs[16][sub])
+        with pytest.raises(Exception):
+            eng.set_tile(7)
 
 
 @pytest.mark.parametrize("n", [1, 33, 200])
