@@ -123,67 +123,75 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
     const int slot = live ? (P.slots ? P.slots[gf] : gf) : 0;
 
     STAMP(0);
-    // ---- raw frame -> LDS (gate + int16 scaling fused): 16 streams x 128 quads, 8 per thread, all requested before the first use;
-    //      the buffer descriptor's range check zero-fills the streams past n
-    {
-        const float thr = P.thresh;
-        const bool f32in = P.fmt == 0;
-        const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
-        if (f32in) {
-            u32x4 xv[8];
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int idx = it * NTHREADS + tid;
-                xv[it] = __builtin_amdgcn_raw_buffer_load_b128(frs, (((tile0 + (idx >> 7)) * T + tframe) * 128 + (idx & 127)) * 16, 0, 0);
-            }
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int idx = it * NTHREADS + tid;
-                XP[(idx >> 7) * XPQ + 24 + (idx & 127)] = gate4(__builtin_bit_cast(f32x4, xv[it]), thr);
-            }
-        } else {
-            const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
-            u32x2 sv[8];
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int idx = it * NTHREADS + tid;
-                sv[it] = __builtin_amdgcn_raw_buffer_load_b64(frs, (((tile0 + (idx >> 7)) * T + tframe) * 128 + (idx & 127)) * 8, 0, 0);
-            }
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int idx = it * NTHREADS + tid;
-                const int s0 = (int)(short)(sv[it].x & 0xffffu), s1 = (int)(short)(sv[it].x >> 16);
-                const int s2 = (int)(short)(sv[it].y & 0xffffu), s3 = (int)(short)(sv[it].y >> 16);
-                XP[(idx >> 7) * XPQ + 24 + (idx & 127)] = gate4(f32x4{(float)s0 / sc, (float)s1 / sc, (float)s2 / sc, (float)s3 / sc}, thr);
-            }
-        }
-    }
-    if (tid < U_WT) WT[tid] = ldw(wrs, tid * 16, (int)P.sect[0][S_NYQ]);
-    __syncthreads();
-    // mirrored edges (numpy 'reflect', 96 + 96): as silero_v4.hip
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-        const int idx = it * NTHREADS + tid;          // 16 streams x 48 edge quads
-        const int ms = idx / 48, k = idx - ms * 48;
-        f32x4 *row = XP + ms * XPQ;
-        if (k < 24) {
-            const f32x4 lo = row[48 - k], hi = row[47 - k];
-            row[k] = f32x4{lo.x, hi.w, hi.z, hi.y};
-        } else {
-            const int Q = 128 + k;
-            const f32x4 p = row[303 - Q], pm = row[302 - Q];
-            row[Q] = f32x4{p.z, p.y, p.x, pm.w};
-        }
-    }
-    __syncthreads();
-    STAMP(1);
-
-    // window of the stored basis for this thread's fold position n = 4 fq .. 4 fq + 3
+    // window of the stored basis for this thread's fold position n = 4 fq .. 4 fq + 3, and the window table for the float64 sums:
+    // requested BEFORE the frame (a wave's loads return in order - behind the frame they would arrive with its last byte)
     const int fq = tid & 15, fms = tid >> 4;
     const int o_win = (int)P.sect[w][S_NYQ];
     const f32x4 W1 = ldw(wrs, fq * 16, o_win), W3 = ldw(wrs, (32 + fq) * 16, o_win);
     const float w64 = ldw(wrs, 16 * 16, o_win).x;                 // w[64] = w[192]
+    const f32x4 wtq = ldw(wrs, (tid & 63) * 16, o_win);
+    f32x4 S0w[16];                                   // ... and so are the DFT blocks of the first column pair (4 k-iterations x 4)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) S0w[k] = WL(o_stft + k);
+    // ---- raw frame -> LDS (gate + int16 scaling fused): 16 streams x 128 quads, 8 per thread; piece `it` = quads 16 it .. 16 it + 15
+    //      of every stream.  The first column pair needs only pieces 0..3 (+ the left mirror): they are requested first, stored and
+    //      folded while 4..7 - requested when 0..3 have arrived, so that HBM serves every workgroup's first half first - are on
+    //      their way; those are stored under the MFMAs of column pairs 0 and 1 (-0.6 us per 8 192 streams).
+    //      The buffer descriptor's range check zero-fills the streams past n.
+    const float thr = P.thresh;
+    const bool f32in = P.fmt == 0;
+    const float isc = P.fmt == 1 ? 32767.0f : 32768.0f;
+    u32x4 xv[8];
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
+    const int xq0 = ((tile0 + fms) * T + tframe) * 128 + fq;
+#define X_ISSUE(lo, hi)                                                                                     \
+    if (f32in) {                                                                                            \
+        _Pragma("unroll") for (int it = (lo); it < (hi); ++it)                                              \
+            xv[it] = __builtin_amdgcn_raw_buffer_load_b128(frs, (xq0 + 16 * it) * 16, 0, 0);                \
+    } else {                                                                                                \
+        _Pragma("unroll") for (int it = (lo); it < (hi); ++it) {                                            \
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(frs, (xq0 + 16 * it) * 8, 0, 0);           \
+            xv[it] = u32x4{v.x, v.y, 0u, 0u};                                                               \
+        }                                                                                                   \
+    }
+    X_ISSUE(0, 4)
+#define X_PUT(it)                                                                                           \
+    {                                                                                                       \
+        f32x4 v_ = __builtin_bit_cast(f32x4, xv[it]);                                                       \
+        if (!f32in) {                                                                                       \
+            const int s0 = (int)(short)(xv[it].x & 0xffffu), s1 = (int)(short)(xv[it].x >> 16);             \
+            const int s2 = (int)(short)(xv[it].y & 0xffffu), s3 = (int)(short)(xv[it].y >> 16);             \
+            v_ = f32x4{(float)s0 / isc, (float)s1 / isc, (float)s2 / isc, (float)s3 / isc};                 \
+        }                                                                                                   \
+        XP[fms * XPQ + 24 + 16 * (it) + fq] = gate4(v_, thr);                                               \
+    }
+    if (tid < U_WT) WT[tid] = wtq;
+    X_PUT(0) X_PUT(1) X_PUT(2) X_PUT(3)
+    SB();
+    X_ISSUE(4, 8)          // asked for only now: HBM serves every workgroup's first half first
+    __syncthreads();
+    // mirrored edges (numpy 'reflect', 96 + 96; silero_v4.hip has the index algebra): the left one now, the right one once pieces
+    // 6, 7 are in (16 streams x 24 quads each)
+#define X_MIRROR(right)                                                                                     \
+    _Pragma("unroll") for (int it_ = 0; it_ < 2; ++it_) {                                                   \
+        const int idx = it_ * NTHREADS + tid;                                                               \
+        if (idx < MT16 * 24) {                                                                              \
+            const int ms = idx / 24, k = idx - ms * 24;                                                     \
+            f32x4 *row = XP + ms * XPQ;                                                                     \
+            if (!(right)) {                                                                                 \
+                const f32x4 lo = row[48 - k], hi = row[47 - k];                                             \
+                row[k] = f32x4{lo.x, hi.w, hi.z, hi.y};                                                     \
+            } else {                                                                                        \
+                const int Q = 152 + k;                                                                      \
+                const f32x4 p = row[303 - Q], pm = row[302 - Q];                                            \
+                row[Q] = f32x4{p.z, p.y, p.x, pm.w};                                                        \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+    X_MIRROR(false)
+    __syncthreads();
+    STAMP(1);
 
     f32x4 mg[8][2];                                  // |X| of this wave's 32 bins (two row tiles), 8 columns
     float nyq[4];                                    // threads < 32: |X[128]| of column 2 grp + (tid >> 4), stream n
@@ -191,6 +199,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
     for (int grp = 0; grp < 4; ++grp) {              // STFT columns 2 grp, 2 grp + 1 (hop 64 on the padded frame)
         int ws = o_stft;
         asm volatile("" : "+s"(ws));
+        if (grp == 2) X_MIRROR(true)      // pieces 6, 7 were stored before the barrier that ended column pair 1; read by pair 3's fold
         // ---- window + 4-way fold: stream fms, n = 4 fq + i, one column per pass (silero_v4.hip has the algebra)
 #pragma unroll
         for (int cp = 0; cp < 2; ++cp) {
@@ -255,7 +264,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
         }
         f32x4 Aw[4], Bw[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) Aw[k] = WL(ws + k);
+        for (int k = 0; k < 4; ++k) Aw[k] = grp == 0 ? S0w[k] : WL(ws + k);
         SB();
         if (grp == 0) STAMP(2);
         __syncthreads();
@@ -278,13 +287,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
 #pragma unroll
             for (int c = 0; c < 2; ++c) { Au[c] = XR[(64 * c) * QSL]; Av[c] = XI[(64 * c) * QSL]; }
 #define S_LD(S, jj)                                                                        \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) S##w[k] = WL(ws + 4 * (jj) + k);         \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) S##w[k] = grp == 0 ? S0w[4 * (jj) + k] : WL(ws + 4 * (jj) + k);   \
     _Pragma("unroll") for (int c = 0; c < 2; ++c) { S##u[c] = XR[(64 * c + 4 * (jj)) * QSL]; S##v[c] = XI[(64 * c + 4 * (jj)) * QSL]; }
 #define S_MMA(S)                                                                           \
     _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                        \
         are[c][0] = mfma16(S##w[0], S##u[c], are[c][0]); are[c][1] = mfma16(S##w[1], S##u[c], are[c][1]);   \
         aim[c][0] = mfma16(S##w[2], S##v[c], aim[c][0]); aim[c][1] = mfma16(S##w[3], S##v[c], aim[c][1]);   \
     }
+#pragma unroll
             for (int j = 0; j < 4; j += 2) {
                 S_LD(B, j + 1) SB();
                 S_MMA(A) SB();
@@ -310,12 +320,17 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
                 mg[2 * grp + cp][rt] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
             }
         nyq[grp] = nyqv[((tid >> 4) & 1) * 16 + n];
+        if (grp == 0) { X_PUT(4) X_PUT(5) }
+        if (grp == 1) { X_PUT(6) X_PUT(7) }
         if (grp == 0) STAMP(5);
         __syncthreads();       // every wave done with UV / fcor / dcv before the next fold overwrites them
         if (grp == 0) STAMP(6);
         if (grp == 3) STAMP(7);
     }
 
+#undef X_PUT
+#undef X_ISSUE
+#undef X_MIRROR
     // =================================================================================================
     //  tail: the LDS is re-used with the second layout from here on
     // =================================================================================================

@@ -116,7 +116,7 @@ int main(int argc, char **argv) {
             if (!have) continue;
             if (prev >= 0) {
                 double acc = 0; int cnt = 0;
-                for (int b = 0; b < tiles; ++b) if (S(b, w, k) && S(b, w, prev)) { acc += (double)(S(b, w, k) - S(b, w, prev)); ++cnt; }
+                for (int b = 0; b < tiles; ++b) if (S(b, w, k) && S(b, w, prev)) { acc += (double)(long long)(S(b, w, k) - S(b, w, prev)); ++cnt; }
                 if (cnt) printf(" %d>%d=%.0f", prev, k, acc / cnt);
             }
             prev = k;
