@@ -85,7 +85,8 @@ typedef struct vad_engine_desc {
 /* Another engine's kernels run on this GPU at the same time (e.g. a Silero V4 and a V5 pool side by side: BASELINE configs[4]).
  * A Silero V5 16 kHz engine normally serves calls of <= 4 096 streams on 16-stream tiles, which spreads them over up to all 256 CUs
  * (28 us instead of 47 us per step) - and leaves no CU to a co-tenant.  With this flag it keeps to 32-stream tiles: a call of n
- * streams occupies n / 32 CUs and the other engine's workgroups run beside it. */
+ * streams occupies n / 32 CUs and the other engine's workgroups run beside it.  A Silero V4 engine (16-stream tiles) then always
+ * places two workgroups on a CU instead of spreading a small call over one CU per tile: n / 32 CUs as well. */
 #define VAD_ENGINE_SHARED_GPU 1u
 
 typedef struct vad_info {
@@ -356,9 +357,10 @@ VAD_API int vad_debug_sm_replay(vad_engine *e, int64_t slot, const float *probs,
                                 int32_t *seg_frames_out);
 
 /*
- * Diagnostic: which kernel shape serves the step calls of a Silero V5 16 kHz engine.  0 (default) = by batch size: calls with
- * at most 4 096 streams run on 16-stream tiles (twice as many workgroups, half as long each), larger ones on 32-stream tiles;
- * 16 / 32 force one shape (the test-suite checks that both give the same results; tools/bench_configs.py times them).
+ * Diagnostic: which kernel shape serves the step calls.  0 (default) = the engine's choice - Silero V5 at 16 kHz: calls with at
+ * most 4 096 streams run on 16-stream tiles (twice as many workgroups, half as long each), larger ones on 32-stream tiles; Silero
+ * V4 (both sub-models): always 16-stream tiles, two workgroups per CU.  16 / 32 force one shape (the test-suite checks that both
+ * give the same results to rounding; tools/bench_configs.py times them).  V5's 8 kHz sub-model has 32-stream tiles only.
  * -1 / -2: vad_step_rates as two launches (resample, then model) / as the fused launch (default), for the same comparison.
  */
 VAD_API int vad_debug_set_tile(vad_engine *e, int32_t streams_per_tile);

@@ -78,7 +78,56 @@ def run_batched(n, ticks=40):
             "real_time_factor": (n * ticks / (t_sub + t_tick)) / (n * 1000 / 30), "events": counts}
 
 
+def run_rates(n, ticks=40):
+    """n sessions, a quarter each at 8 / 16 / 24 / 48 kHz (SharedStreamPool(convert_rates=True)): every tick carries 32 ms int16
+    chunks at the client's rate, resampled on the GPU inside the tick (vad_tick_push_rate)."""
+    pool = SharedStreamPool(max_streams=8192, convert_rates=True)
+    rates = (8000, 16000, 24000, 48000)
+    sessions, counts = [], {"start": 0, "end": 0}
+    for k in range(n):
+        sr = rates[k % 4]
+        s = pool.open_session(VADConfig(sample_rate=sr, buffer_size=512 * sr // 16000, vad_start_probability=0.4,
+                                        vad_end_probability=0.3, voice_start_frame_count=6, voice_end_frame_count=12))
+        s.set_callbacks(lambda: counts.__setitem__("start", counts["start"] + 1),
+                        lambda wav: counts.__setitem__("end", counts["end"] + 1), None)
+        sessions.append(s)
+    x = make_streams(64, 3 * (ticks + 5), seed=9).reshape(64, -1)
+    pcm = np.clip(x * 32767.0, -32768, 32767).astype("<i2")
+    wire = []
+    for t in range(ticks + 5):
+        row = []
+        for k in range(n):
+            L = 512 * rates[k % 4] // 16000
+            row.append(pcm[k % 64, t * L:(t + 1) * L].tobytes())
+        wire.append(row)
+    t_sub = t_tick = 0.0
+    c_us = [0.0, 0.0, 0.0]
+    for t in range(ticks + 5):
+        a = time.perf_counter()
+        for k, s in enumerate(sessions):
+            s.submit_pcm16(wire[t][k])
+        b = time.perf_counter()
+        pool.tick()
+        c = time.perf_counter()
+        if t >= 5:
+            t_sub += b - a
+            t_tick += c - b
+            for k in range(3):
+                c_us[k] += pool.engine.last_tick_us[k]
+    st = pool.stats()
+    pool.close()
+    return {"sessions": n, "ingest": "submit_pcm16, a quarter each at 8 / 16 / 24 / 48 kHz (32 ms chunks)",
+            "tick_in_C_us": {"swap": c_us[0] / ticks, "gpu": c_us[1] / ticks, "segments": c_us[2] / ticks},
+            "submit_ms_per_tick": t_sub / ticks * 1e3, "tick_ms": t_tick / ticks * 1e3, "launches_per_tick": st["launches"] / st["ticks"],
+            "frames_per_s_host_inclusive": n * ticks / (t_sub + t_tick),
+            "real_time_factor": (n * ticks / (t_sub + t_tick)) / (n * 1000 / 32), "events": counts}
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "rates":
+        for n in (2048, 8192):
+            print(json.dumps(run_rates(n)), flush=True)
+        sys.exit(0)
     for n in (256, 2048, 8192):
         print(json.dumps(run(n)), flush=True)
     print(json.dumps(run_batched(8192)), flush=True)
