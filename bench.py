@@ -327,7 +327,7 @@ def main() -> int:
                     traffic = None
             out["roofline"] = {
                 "bound": "mfma",
-                "kernel": "silero_v5_step" if not mixed else "silero_v5_step + silero_v4_step (concurrent)",
+                "kernel": "silero_v5_step" if not mixed else "silero_v5_step + silero_v4_step16 (concurrent)",
                 "achieved": achieved / 1e12,
                 "peak": PEAK_FP32_MFMA / 1e12,
                 "unit": "TFLOP/s",

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (repo root, GPU box): tools/profile_configs.sh <tag>   -> gpurun_out/<tag>_configs_kernel_stats.csv
 # rocprofv3 --kernel-trace --stats over the non-headline configs (V4, V4 8 kHz, batch 1 024, mixed-rate resample + V5, resampler alone):
-# per-kernel average durations of silero_v4_step / vadk_resample_512 / silero_v5_step to set beside tools/bench_configs.py.
+# per-kernel average durations of silero_v4_step16 / vadk_resample_512 / silero_v5_step[16] to set beside tools/bench_configs.py.
 set -e
 TAG=$1
 OUT=$PWD/gpurun_out
