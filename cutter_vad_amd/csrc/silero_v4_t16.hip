@@ -6,6 +6,9 @@
 // algebra (reflect-padded frame in LDS, 4-way folded DFT, the two real bins in float64, K-split first layer on 16 x 16 x 4
 // tiles, LSTM waves owning all four gates of 16 units) on v_mfma_f32_16x16x4_f32 throughout: a workgroup carries 16 streams in
 // under 80 KB of LDS and 256 registers per wave, so TWO workgroups share a CU and each fills the other's waits.
+// Measured: 62.1 -> 50.8 us per 8 192 streams, 59.8 -> 31.6 us per 4 096 (one workgroup per CU); the MFMA pipe is
+// busy 53 % of the CU-busy cycles (43 %), and the pair of workgroups issues MFMA + VALU work in ~85 % of them - what is left is
+// instruction count and the ~8.5 k idle cycles at the start of every launch (kernel arguments, first half of the frame).
 //
 // Fragment convention as in silero_v5_t16.hip: lane l = (n = l & 15, kq = l >> 4); A: W[row n][k = kq]; B: X[k = kq][stream n];
 // D: lane (stream n, rq = kq) holds rows 4 rq .. 4 rq + 3 of the 16-row tile = one LDS quad.  A k-iteration contracts 16

@@ -229,6 +229,19 @@ def v4_8k():
     return {"config": "batch=8192, V4 8 kHz sub-model (a9; two LSTM steps per frame)", "us_per_step": dt * 1e6, "frames_per_s": B / dt}
 
 
+def v5_8k():
+    """Silero V5's 8 kHz sub-model: native 8 kHz audio in 256-sample frames (32 ms as well), 32-stream tiles."""
+    B = 8192
+    eng = Engine(open(weights_io.packaged_blob_path(5, 8000), "rb").read(), model_version=5, max_streams=B, sample_rate=8000)
+    eng.open_streams(B)
+    ring = (0.1 * torch.randn(16, B, 256, device="cuda")).contiguous()
+    probs = torch.empty(B, device="cuda")
+    ts = torch.cuda.Stream()
+    dt = timed(lambda i: eng.step_device(B, ring[i % 16].data_ptr(), probs.data_ptr(), stream=ts.cuda_stream), [ts])
+    eng.close()
+    return {"config": "batch=8192, V5 8 kHz sub-model (256-sample frames)", "us_per_step": dt * 1e6, "frames_per_s": B / dt}
+
+
 def single_stream_wrapper():
     """configs[0]: ONE stream through the drop-in VADWrapper (host framing + one launch + sync + callbacks per chunk)."""
     import time
