@@ -242,6 +242,27 @@ def v5_8k():
     return {"config": "batch=8192, V5 8 kHz sub-model (256-sample frames)", "us_per_step": dt * 1e6, "frames_per_s": B / dt}
 
 
+def int16_ingest():
+    """Device-resident int16 frames (the wire format of the serving path) against float32 ones, V5 and V4, 8 192 streams."""
+    from cutter_vad_amd import _ffi
+    out = []
+    B = 8192
+    for v in (5, 4):
+        eng = Engine(blob(v), model_version=v, max_streams=B)
+        eng.open_streams(B)
+        f32 = (0.1 * torch.randn(16, B, 512, device="cuda")).contiguous()
+        i16 = (f32 * 32767.0).round().clamp(-32768, 32767).to(torch.int16).contiguous()
+        probs = torch.empty(B, device="cuda")
+        ts = torch.cuda.Stream()
+        row = {"config": f"batch={B}, V{v}, device-resident frames, float32 vs int16 (/32767) ingest"}
+        for name, ring, fmt in (("f32", f32, _ffi.VAD_FMT_F32), ("i16", i16, _ffi.VAD_FMT_I16_32767)):
+            dt = timed(lambda i: eng.step_device(B, ring[i % 16].data_ptr(), probs.data_ptr(), fmt=fmt, stream=ts.cuda_stream), [ts])
+            row[f"us_per_step_{name}"] = dt * 1e6
+        eng.close()
+        out.append(row)
+    return out
+
+
 def single_stream_wrapper():
     """configs[0]: ONE stream through the drop-in VADWrapper (host framing + one launch + sync + callbacks per chunk)."""
     import time
