@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P
                 XP[(idx >> 7) * XPQ + 24 + (idx & 127)] = gate4(__builtin_bit_cast(f32x4, xv[it]), thr);
             }
         } else {
-            const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
+            const float sc = P.fmt == 1 ? 32767.0f : 32768.0f, rsc = 1.0f / sc;
             u32x2 sv[16];
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v4_step(const StepParams P
                 const int idx = it * NTHREADS + tid;
                 const int s0 = (int)(short)(sv[it].x & 0xffffu), s1 = (int)(short)(sv[it].x >> 16);
                 const int s2 = (int)(short)(sv[it].y & 0xffffu), s3 = (int)(short)(sv[it].y >> 16);
-                XP[(idx >> 7) * XPQ + 24 + (idx & 127)] = gate4(f32x4{(float)s0 / sc, (float)s1 / sc, (float)s2 / sc, (float)s3 / sc}, thr);
+                XP[(idx >> 7) * XPQ + 24 + (idx & 127)] = gate4(f32x4{i16_div(s0, sc, rsc), i16_div(s1, sc, rsc), i16_div(s2, sc, rsc), i16_div(s3, sc, rsc)}, thr);
             }
         }
     }

@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
     //      The buffer descriptor's range check zero-fills the streams past n.
     const float thr = P.thresh;
     const bool f32in = P.fmt == 0;
-    const float isc = P.fmt == 1 ? 32767.0f : 32768.0f;
+    const float isc = P.fmt == 1 ? 32767.0f : 32768.0f, risc = 1.0f / isc;
     u32x4 xv[8];
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
         if (!f32in) {                                                                                       \
             const int s0 = (int)(short)(xv[it].x & 0xffffu), s1 = (int)(short)(xv[it].x >> 16);             \
             const int s2 = (int)(short)(xv[it].y & 0xffffu), s3 = (int)(short)(xv[it].y >> 16);             \
-            v_ = f32x4{(float)s0 / isc, (float)s1 / isc, (float)s2 / isc, (float)s3 / isc};                 \
+            v_ = f32x4{i16_div(s0, isc, risc), i16_div(s1, isc, risc), i16_div(s2, isc, risc), i16_div(s3, isc, risc)};   \
         }                                                                                                   \
         XP[fms * XPQ + 24 + 16 * (it) + fq] = gate4(v_, thr);                                               \
     }

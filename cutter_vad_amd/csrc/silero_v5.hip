@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
     const bool q0 = q == 0;
     constexpr bool f32in = F32IN;
     constexpr int qsh = f32in ? 4 : 3;             // log2(bytes per 4-sample quad)
-    const float sc = P.fmt == 1 ? 32767.0f : 32768.0f;
+    const float sc = P.fmt == 1 ? 32767.0f : 32768.0f, rsc = 1.0f / sc;
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * ((f32in ? 2048u : 1024u) >> (K8 ? 1 : 0))), 0x00020000);
     u32x4 xa_[8], xb_[8];                          // raw quads of a column (both 16-stream halves), as bits
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
                 if constexpr (!f32in) {
                     const int s0 = (int)(short)(b.x & 0xffffu), s1 = (int)(short)(b.x >> 16);
                     const int s2 = (int)(short)(b.y & 0xffffu), s3 = (int)(short)(b.y >> 16);
-                    v = f32x4{(float)s0 / sc, (float)s1 / sc, (float)s2 / sc, (float)s3 / sc};
+                    v = f32x4{i16_div(s0, sc, rsc), i16_div(s1, sc, rsc), i16_div(s2, sc, rsc), i16_div(s3, sc, rsc)};
                 }
                 return gate4(v, thr);
             };

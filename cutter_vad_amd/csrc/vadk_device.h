@@ -90,6 +90,17 @@ __device__ __forceinline__ f32x4 ldw(__amdgpu_buffer_rsrc_t rs, int voff, int bl
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, blk * 1024, 0));
 }
 
+// (float) s / d for an int16 s and d = 32767 or 32768, bit for bit the IEEE quotient that numpy's true division gives
+// (vad_websocket_server.py:341): q = s * r with r = float(1 / d), then one Newton correction in two fmas.  Exhaustively equal over
+// all 65 536 values of s (tools/i16_division_check.py, tests/test_host_logic.py); 3 instructions instead of the ~10 of the
+// v_div_scale / v_rcp / v_div_fmas / v_div_fixup sequence - 64 samples per thread in the V5 kernel.
+__device__ __forceinline__ float i16_div(int s, float d, float r) {
+    const float x = (float)s;
+    const float q = x * r;
+    const float e = __builtin_fmaf(-q, d, x);
+    return __builtin_fmaf(e, r, q);
+}
+
 __device__ __forceinline__ f32x4 gate4(f32x4 v, float thr) {
     // utils/audio.py:117-118: np.where(np.abs(x) > thr, x, 0.0); thr < 0 disables the gate
     // branch-free (a uniform branch here would split the caller's basic block and defeat its instruction interleave)

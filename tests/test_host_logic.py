@@ -438,3 +438,16 @@ def test_v5_at_8k_runs_native_256_sample_frames_and_refuses_what_the_reference_c
     proc48, _ = _processor([0.5], sample_rate=SampleRate(48000), buffer_size=256)
     with pytest.raises(AudioProcessingError, match="Model prediction failed"):
         proc48.process_frame(np.zeros(256, np.float32))
+
+
+def test_int16_scaling_by_reciprocal_and_one_correction_is_the_ieee_quotient():
+    """The kernels' int16 ingest (vadk_device.h: i16_div) replaces x / 32767.0f by a multiply and two fmas: equal to numpy's true
+    division for EVERY int16 value (exhaustive, exact rational emulation of the float32 operations), for both wire scales."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("i16chk", os.path.join(os.path.dirname(__file__), "..", "tools", "i16_division_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, plain = mod.mismatches(32767.0)
+    assert bad == 0 and plain > 0          # the correction is needed: a bare multiply by 1/32767 is off by an ulp on 1 536 values
+    assert mod.mismatches(32768.0) == (0, 0)
