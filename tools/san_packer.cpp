@@ -14,6 +14,16 @@ int main(int argc, char **argv) {
         vadk::PackedWeights pw;
         bool ok = std::string(argv[i]).find("v5") != std::string::npos ? vadk::pack_silero_v5(b.data(), b.size(), pw, err) : vadk::pack_silero_v4(b.data(), b.size(), pw, err);
         printf("%s: %d %zu %s\n", argv[i], (int)ok, pw.data.size(), err.c_str());
+        {   // the 16-stream tile packings of the same blob (V5's exists for the 16 kHz sub-model only)
+            vadk::PackedWeights p16; std::string e16;
+            const bool v5 = std::string(argv[i]).find("v5") != std::string::npos;
+            const bool ok16 = v5 ? vadk::pack_silero_v5_t16(b.data(), b.size(), p16, e16) : vadk::pack_silero_v4_t16(b.data(), b.size(), p16, e16);
+            printf("  t16: %d %zu %s\n", (int)ok16, p16.data.size(), e16.c_str());
+            for (size_t cut : {(size_t)0, (size_t)64, b.size() / 2, b.size() - 1}) {
+                vadk::PackedWeights q; std::string e2;
+                if (v5 ? vadk::pack_silero_v5_t16(b.data(), cut, q, e2) : vadk::pack_silero_v4_t16(b.data(), cut, q, e2)) printf("  t16 cut %zu unexpectedly ok\n", cut);
+            }
+        }
         // truncated / corrupted blobs must fail cleanly
         for (size_t cut : {(size_t)0, (size_t)7, (size_t)64, b.size() / 2, b.size() - 1}) {
             vadk::PackedWeights q; std::string e2;
@@ -34,6 +44,9 @@ int main(int argc, char **argv) {
         std::vector<float> out; uint32_t r128 = 0;
         uint32_t tb = vadk::pack_resample_operator(n, out, &r128, err);
         printf("resample %d: %u %u %zu\n", n, tb, r128, out.size());
+        std::vector<float> o16; uint32_t r16 = 0;
+        uint32_t wb = vadk::pack_resample_operator_t16(n, o16, &r16, err);
+        printf("resample t16 %d: %u %u %zu\n", n, wb, r16, o16.size());
     }
     return 0;
 }
