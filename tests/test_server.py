@@ -272,3 +272,35 @@ def test_websocket_client_at_48_khz_with_32_ms_frames():
             ws.send_bytes(b"\0" * 2880)
             m = recv_until(ws, "ERROR")
             assert "Failed to resample audio from 48000Hz" in m["message"] and "1536" in m["message"]
+
+
+def test_reconfigure_moves_a_session_between_native_and_resampled_ingest():
+    """A CONFIG message may change a client's sample rate (vad_websocket_server.py:300-318 rebuilds the wrapper): the pooled
+    session switches between engine-rate frames and resampled chunks, starts from a clean state, and chunks of the old length
+    are refused with the reason."""
+    eng = FakeEngine(fn=lambda fr: 0.9 if np.abs(fr).max() > 0.3 else 0.05)
+    pool = SharedStreamPool(pool=FakePool(eng), convert_rates=True)
+    thr = dict(vad_start_probability=0.4, vad_end_probability=0.3, voice_start_frame_count=1, voice_end_frame_count=2)
+    s = pool.open_session(VADConfig(buffer_size=512, **thr))
+    got = []
+    s.set_callbacks(lambda: got.append("S"), lambda wav: got.append(("E", len(wav))))
+    assert s.rate is None
+    s.submit(np.full(512, 0.5, np.float32))
+    assert pool.tick() == 1 and got == ["S"] and s.is_voice_active()
+    pool.reconfigure(s, VADConfig(sample_rate=48000, buffer_size=1536, **thr))
+    assert s.rate == 48000 and not s.is_voice_active()
+    with pytest.raises(Exception, match="Failed to resample"):
+        s.submit(np.full(512, 0.5, np.float32))
+    t = np.arange(1536) / 48000.0
+    s.submit((0.6 * np.sin(2 * np.pi * 300.0 * t)).astype(np.float32))
+    s.submit(np.zeros(1536, np.float32))
+    s.submit(np.zeros(1536, np.float32))
+    assert pool.drain() == 3
+    assert got == ["S", "S", ("E", 44 + 2 * 1536 * 3)]
+    pool.reconfigure(s, VADConfig(buffer_size=480, **thr))
+    assert s.rate is None
+    s.submit(np.full(480, 0.5, np.float32))
+    assert pool.tick() == 1 and got[-1] == "S"
+    with pytest.raises(AudioProcessingError, match="buffer_size"):
+        pool.reconfigure(s, VADConfig(sample_rate=24000, buffer_size=512, **thr))
+    pool.close()
