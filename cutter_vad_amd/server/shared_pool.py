@@ -230,6 +230,9 @@ class SharedStreamPool:
             s.rate = self._input_rate(config)
             with self._lock:
                 self._init_slot(s.slot, config)
+                # the session keeps its callbacks across a reconfigure (the app binds them once, at open): so does the flag
+                # that makes the tick deliver voice_continue payloads to it
+                self._cont[s.slot] = s.on_continue is not None
             s.wav_writer = WAVWriter(sample_rate=config.output_wav_sample_rate, bit_depth=config.output_wav_bit_depth,
                                      channels=1)
 

@@ -74,6 +74,14 @@ def test_one_launch_per_tick_and_reference_semantics():
     assert pool.session_count == 4 and eng.closed == [sessions[0].slot]
     pool.reconfigure(sessions[2], VADConfig(**{**cfg, "voice_start_frame_count": 1}))
     assert not sessions[2].is_voice_active() and eng.thr[sessions[2].slot][4] == 1
+    # the callbacks bound at open survive a reconfigure, voice_continue included (the app binds them once per client)
+    after = []
+    sessions[2].set_callbacks(lambda: after.append("S"), lambda wav: after.append("E"), lambda pcm: after.append("C"))
+    pool.reconfigure(sessions[2], VADConfig(**{**cfg, "voice_start_frame_count": 1}))
+    for f in [LOUD] * 3 + [QUIET] * 3:
+        sessions[2].submit(f)
+    pool.drain()
+    assert after == ["S", "C", "C", "C", "C", "E", "C"]
     pool.close()
     assert pool.session_count == 0
 
@@ -172,6 +180,8 @@ def test_wire_protocol_over_asgi():
             ws.send_bytes((np.full(320, 0.5) * 32767).astype("<i2").tobytes())          # 20 ms frames now
             seen = recv_until(ws, "VOICE_START")
             assert seen[-1]["segment_index"] == 1
+            ws.send_bytes((np.full(320, 0.5) * 32767).astype("<i2").tobytes())
+            assert recv_until(ws, "VOICE_CONTINUE")[-1]["event"] == "VOICE_CONTINUE"   # still delivered after a second CONFIG
             ws.send_text("{not json")
             assert recv_until(ws, "ERROR")[-1]["message"].startswith("Invalid JSON")
             ws.send_text(json.dumps({"type": "NOPE"}))
