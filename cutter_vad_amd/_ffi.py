@@ -135,7 +135,10 @@ SIGNATURES = {
                                          C.POINTER(C.c_uint32)]),
     "vad_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vad_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vad_resample_generic": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, _f32p]),
+    "vad_resample_generic_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, _vp]),
     "vad_debug_resample_operator": (C.c_int, [C.c_int32, _f32p, C.c_size_t]),
+    "vad_debug_resample_generic_entries": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_size_t]),
     "vad_debug_pack_resample": (C.c_int, [C.c_int32, _f32p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
                                           C.POINTER(C.c_uint32)]),
     "vad_debug_pack_resample_t16": (C.c_int, [C.c_int32, _f32p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),

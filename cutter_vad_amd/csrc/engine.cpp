@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "pack_weights.h"
+#include "resample_generic.h"
 #include "vad_layout.h"
 
 extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream_t stream);
@@ -188,6 +189,21 @@ struct vad_engine {
     std::vector<ResampleOp> resample_ops16; // the same operators packed for the fused resample -> step kernel (16-stream tiles)
     float *d_rs_in = nullptr;  size_t d_rs_in_cap = 0;
     float *d_rs_out = nullptr; size_t d_rs_out_cap = 0;
+    // generic whole-array resampler (vad_resample_generic): the float64 tables of the last few (n_in, n_out) shapes, on the device
+    struct RsgEntry {
+        int64_t n_in = 0, n_out = 0, a = 0, b = 0, L = 0, P = 0;
+        int32_t corrected = 0;
+        double *d_tn = nullptr, *d_tm = nullptr;
+        size_t bytes = 0;
+        uint64_t used = 0;
+    };
+    static constexpr size_t RSG_CACHE_ENTRIES = 8;
+    static constexpr size_t RSG_CACHE_BYTES = 512u << 20;
+    std::vector<RsgEntry> rsg_cache;
+    uint64_t rsg_clock = 0;
+    double *d_rsg_partial = nullptr; size_t d_rsg_partial_cap = 0;
+    void *d_rsg_in = nullptr;  size_t d_rsg_in_cap = 0;
+    float *d_rsg_out = nullptr; size_t d_rsg_out_cap = 0;
     std::vector<uint8_t> open;
     std::vector<int64_t> free_list;
     std::vector<uint32_t> stamp;   // duplicate detection per step
@@ -531,6 +547,13 @@ void vad_engine_destroy(vad_engine *e) {
         if (op.d_w) (void)hipFree(op.d_w);
     for (auto &op : e->resample_ops16)
         if (op.d_w) (void)hipFree(op.d_w);
+    for (auto &c : e->rsg_cache) {
+        if (c.d_tn) (void)hipFree(c.d_tn);
+        if (c.d_tm) (void)hipFree(c.d_tm);
+    }
+    if (e->d_rsg_partial) (void)hipFree(e->d_rsg_partial);
+    if (e->d_rsg_in) (void)hipFree(e->d_rsg_in);
+    if (e->d_rsg_out) (void)hipFree(e->d_rsg_out);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -971,6 +994,154 @@ int vad_resample_multi_device(vad_engine *e, int32_t nseg, const float *const *d
     p.tile_start[nseg] = tiles;
     hipError_t r = vadk_launch_resample(&p, stream ? static_cast<hipStream_t>(stream) : e->stream);
     if (r != hipSuccess) return e->hip_fail(r, "resample kernel launch");
+    return VAD_OK;
+}
+
+// ---- AudioUtils.resample_audio for any (length, rates): whole-array Fourier resampling, operator evaluated on the fly -----
+namespace {
+
+int rsg_check(vad_engine *e, int64_t rows, int64_t n_in, int64_t n_out) {
+    if (rows < 0 || n_in < 1 || n_out < 1 || n_in > vadk::RSG_MAX_LEN || n_out > vadk::RSG_MAX_LEN)
+        return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio: rows >= 0 and 1 <= n_in, n_out < 2^31 (rows = %lld, n_in = %lld, n_out = %lld)",
+                       (long long)rows, (long long)n_in, (long long)n_out);
+    const unsigned __int128 entries = (unsigned __int128)(rows ? rows : 1) * (unsigned __int128)n_in * (unsigned __int128)n_out;
+    if (entries > (unsigned __int128)vadk::RSG_MAX_ENTRIES)
+        return e->fail(VAD_ERR_UNSUPPORTED, "Failed to resample audio: %lld arrays of %lld -> %lld samples are more than the 2^42 operator entries "
+                       "one call evaluates; resample in pieces", (long long)rows, (long long)n_in, (long long)n_out);
+    return VAD_OK;
+}
+
+int rsg_tables(vad_engine *e, int64_t n_in, int64_t n_out, vad_engine::RsgEntry **out) {
+    for (auto &c : e->rsg_cache)
+        if (c.n_in == n_in && c.n_out == n_out) {
+            c.used = ++e->rsg_clock;
+            *out = &c;
+            return VAD_OK;
+        }
+    vadk::RsgTables t;
+    std::string perr;
+    if (!vadk::build_rsg_tables(n_in, n_out, t, perr)) return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio: %s", perr.c_str());
+    vad_engine::RsgEntry c;
+    c.n_in = n_in; c.n_out = n_out; c.a = t.a; c.b = t.b; c.L = t.L; c.P = t.P; c.corrected = t.corrected;
+    const size_t bn = t.tn.size() * sizeof(double), bm = t.tm.size() * sizeof(double);
+    c.bytes = bn + bm;
+    // make room: the least recently used shapes go first
+    auto total = [&] { size_t b = 0; for (auto &x : e->rsg_cache) b += x.bytes; return b; };
+    while (!e->rsg_cache.empty() && (e->rsg_cache.size() >= vad_engine::RSG_CACHE_ENTRIES || total() + c.bytes > vad_engine::RSG_CACHE_BYTES)) {
+        auto lru = std::min_element(e->rsg_cache.begin(), e->rsg_cache.end(), [](const auto &x, const auto &y) { return x.used < y.used; });
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        (void)hipFree(lru->d_tn);
+        (void)hipFree(lru->d_tm);
+        e->rsg_cache.erase(lru);
+    }
+    hipError_t r = hipMalloc((void **)&c.d_tn, bn);
+    if (r != hipSuccess) return e->hip_fail(r, "hipMalloc(resample tables)");
+    r = hipMalloc((void **)&c.d_tm, bm);
+    if (r == hipSuccess) r = hipMemcpy(c.d_tn, t.tn.data(), bn, hipMemcpyHostToDevice);
+    if (r == hipSuccess) r = hipMemcpy(c.d_tm, t.tm.data(), bm, hipMemcpyHostToDevice);
+    if (r != hipSuccess) {
+        (void)hipFree(c.d_tn);
+        if (c.d_tm) (void)hipFree(c.d_tm);
+        return e->hip_fail(r, "hipMalloc / hipMemcpy(resample tables)");
+    }
+    c.used = ++e->rsg_clock;
+    e->rsg_cache.push_back(c);
+    *out = &e->rsg_cache.back();
+    return VAD_OK;
+}
+
+// device buffers in, device buffer out; launches cover (rows chunk) x (output range) pieces of at most 2^34 entries each
+int rsg_run(vad_engine *e, const void *d_in, int in_f64, int64_t rows, int64_t n_in, int64_t n_out, float *d_out, hipStream_t s) {
+    vad_engine::RsgEntry *c = nullptr;
+    if (int rc = rsg_tables(e, n_in, n_out, &c)) return rc;
+    constexpr int64_t BUDGET = 1ll << 34;
+    const int64_t tiles_all = (n_out + 63) / 64;
+    const int64_t per_tile = n_in * 64;                              // entries of one 64-output tile of one array
+    int64_t rows_per = std::max<int64_t>(1, std::min<int64_t>({rows, 65535, BUDGET / std::max<int64_t>(1, per_tile * tiles_all)}));
+    int64_t tiles_per = rows_per > 1 ? tiles_all : std::max<int64_t>(1, std::min<int64_t>(tiles_all, BUDGET / per_tile));
+    const size_t esz = in_f64 ? 8 : 4;
+    for (int64_t r0 = 0; r0 < rows; r0 += rows_per) {
+        const int64_t rc = std::min(rows_per, rows - r0);
+        for (int64_t t0 = 0; t0 < tiles_all; t0 += tiles_per) {
+            const int64_t tc = std::min(tiles_per, tiles_all - t0);
+            vadk::RsgParams p{};
+            p.x = static_cast<const uint8_t *>(d_in) + (size_t)r0 * (size_t)n_in * esz;
+            p.y = d_out + (size_t)r0 * (size_t)n_out;
+            p.tn = c->d_tn; p.tm = c->d_tm;
+            p.n_in = n_in; p.n_out = n_out; p.a = c->a; p.b = c->b; p.L = c->L;
+            p.m_begin = t0 * 64;
+            p.m_end = std::min(n_out, (t0 + tc) * 64);
+            p.rows = (int32_t)rc;
+            // enough waves to fill the chip: slices of n per output tile, at least 64 samples each
+            int64_t ns = std::max<int64_t>(1, std::min<int64_t>((4096 + tc * rc - 1) / (tc * rc), std::max<int64_t>(1, n_in / 64)));
+            const int64_t sl = (n_in + ns - 1) / ns;
+            ns = (n_in + sl - 1) / sl;
+            p.nslice = (int32_t)ns;
+            p.slice_len = (int32_t)sl;
+            p.x_f64 = in_f64 ? 1 : 0;
+            p.corrected = c->corrected;
+            p.peak = (double)(c->P - c->corrected);
+            p.inv_n_in = 1.0 / (double)n_in;
+            if (int rc2 = ensure(e, e->d_rsg_partial, e->d_rsg_partial_cap, sizeof(double) * (size_t)ns * (size_t)rc * (size_t)(p.m_end - p.m_begin))) {
+                return rc2;
+            }
+            p.partial = e->d_rsg_partial;
+            hipError_t r = vadk_launch_rsg_partial(&p, s);
+            if (r == hipSuccess) r = vadk_launch_rsg_finish(&p, s);
+            if (r != hipSuccess) return e->hip_fail(r, "resample kernel launch");
+        }
+    }
+    return VAD_OK;
+}
+
+}  // namespace
+
+int vad_resample_generic(vad_engine *e, const void *in, int in_f64, int64_t rows, int64_t n_in, int64_t n_out, float *out) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (int rc = rsg_check(e, rows, n_in, n_out)) return rc;
+    if (rows > 0 && (!in || !out)) return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio: null buffer");
+    if (rows == 0) return VAD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    const size_t ib = (in_f64 ? 8u : 4u) * (size_t)rows * (size_t)n_in, ob = sizeof(float) * (size_t)rows * (size_t)n_out;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));          // the shared partial / staging buffers may still be in use by an earlier call
+    if (int rc = ensure(e, e->d_rsg_in, e->d_rsg_in_cap, ib)) return rc;
+    if (int rc = ensure(e, e->d_rsg_out, e->d_rsg_out_cap, ob)) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->d_rsg_in, in, ib, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (int rc = rsg_run(e, e->d_rsg_in, in_f64, rows, n_in, n_out, e->d_rsg_out, e->stream)) return rc;
+    HIP_TRY(e, hipMemcpyAsync(out, e->d_rsg_out, ob, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return VAD_OK;
+}
+
+int vad_resample_generic_device(vad_engine *e, const void *d_in, int in_f64, int64_t rows, int64_t n_in, int64_t n_out, float *d_out) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (int rc = rsg_check(e, rows, n_in, n_out)) return rc;
+    if (rows > 0 && (!d_in || !d_out)) return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio: null buffer");
+    if (rows == 0) return VAD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (int rc = rsg_run(e, d_in, in_f64, rows, n_in, n_out, d_out, e->stream)) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));          // synchronous: d_out is complete on return
+    return VAD_OK;
+}
+
+int vad_debug_resample_generic_entries(int64_t n_in, int64_t n_out, int64_t m0, int64_t m1, double *R, size_t r_doubles) {
+    g_create_error.clear();
+    if (m0 < 0 || m1 < m0 || m1 > n_out || !R || r_doubles < (size_t)(m1 - m0) * (size_t)n_in) {
+        g_create_error = "vad_debug_resample_generic_entries: 0 <= m0 <= m1 <= n_out and R must hold (m1 - m0) * n_in doubles";
+        return VAD_ERR_INVALID_ARG;
+    }
+    vadk::RsgTables t;
+    std::string perr;
+    if (!vadk::build_rsg_tables(n_in, n_out, t, perr)) {
+        g_create_error = "vad_debug_resample_generic_entries: " + perr;
+        return VAD_ERR_INVALID_ARG;
+    }
+    for (int64_t m = m0; m < m1; ++m)
+        for (int64_t n = 0; n < n_in; ++n) R[(size_t)(m - m0) * (size_t)n_in + (size_t)n] = vadk::rsg_entry(t, m, n);
     return VAD_OK;
 }
 

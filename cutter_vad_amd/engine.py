@@ -402,3 +402,16 @@ class Engine:
         self._check(self._lib.vad_resample(self._h, _ptr(x, C.c_float), x.shape[0], x.shape[1], int(sr_in),
                                            _ptr(out, C.c_float)))
         return out
+
+    def resample_generic(self, arrays, n_out: int) -> np.ndarray:
+        """arrays [rows, n_in] (float32, or float64 for double-precision input) -> [rows, n_out] float32: each row through
+        ``scipy.signal.resample(row, n_out)`` as a whole (``vad_resample_generic``; any lengths)."""
+        x = np.ascontiguousarray(arrays)
+        if x.dtype != np.float64:
+            x = np.ascontiguousarray(x, np.float32)
+        if x.ndim != 2:
+            raise AudioProcessingError(f"Failed to resample audio: expected [rows, n_in], got {x.shape}")
+        out = np.empty((x.shape[0], max(int(n_out), 0)), np.float32)
+        self._check(self._lib.vad_resample_generic(self._h, x.ctypes.data_as(C.c_void_p), int(x.dtype == np.float64), x.shape[0],
+                                                   x.shape[1], int(n_out), _ptr(out, C.c_float)))
+        return out

@@ -94,27 +94,55 @@ class AudioUtils:
 
     @staticmethod
     def resample_audio(audio_data: np.ndarray, original_rate: int, target_rate: int) -> np.ndarray:
-        """audio.py:19-55 (``scipy.signal.resample``, Fourier method), on the GPU.
+        """audio.py:19-55: ``scipy.signal.resample(audio_data, int(len(audio_data) * target_rate / original_rate))`` of the
+        WHOLE array (Fourier method) as float32 - on the GPU, for every input the reference accepts: any length, any pair of
+        rates, [N] or [N, C] (axis 0), float / integer / bool dtypes (complex input: the reference keeps the real part of the
+        complex resample, which is the resample of the real part).
 
-        Chunking convention of this build (the reference defines none, it never calls this on
-        its path — vad_wrapper.py:621-624 is ``pass``): the signal is resampled in independent
-        chunks that each yield 512 output samples at 16 kHz (256 / 768 / 1536 input samples at
-        8 / 24 / 48 kHz).  A whole-array call with exactly one chunk is therefore identical to
-        the reference; other lengths must be a whole number of chunks."""
-        if original_rate == target_rate:
-            return audio_data
+        A 1-D float32 array that is exactly one streaming chunk (256 / 768 / 1536 samples at 8 / 24 / 48 kHz -> 512 at
+        16 kHz) takes the MFMA kernel the serving tick uses (``vad_resample``); everything else the generic kernel
+        (``vad_resample_generic``: the Fourier operator evaluated in float64, never stored).  Both are the same function of
+        the input up to float32 rounding (tests: <= 1e-5 against scipy).  Arrays beyond the generic kernel's size limit
+        (len * out_len * columns > 2^42) are refused with AudioProcessingError - never cut into pieces, which would give a
+        different answer from the reference's."""
         try:
-            if target_rate != 16000 or original_rate not in _CHUNK_IN:
-                raise ValueError("the HIP resampler converts 8/24/48 kHz to 16 kHz")
-            n_in = _CHUNK_IN[original_rate]
-            x = np.ascontiguousarray(audio_data, dtype=np.float32)
-            if x.ndim != 1 or x.size == 0 or x.size % n_in:
-                raise ValueError(f"length must be a positive multiple of {n_in} samples at {original_rate} Hz")
-            from ..pool import default_pool
-            return default_pool().resample(x.reshape(-1, n_in), original_rate).reshape(-1)
-        except AudioProcessingError:
-            raise
+            if original_rate == target_rate:
+                return audio_data
+            ratio = target_rate / original_rate
+            resampled_length = int(len(audio_data) * ratio)
+            return _fourier_resample(np.asarray(audio_data), resampled_length)
         except Exception as e:
+            if isinstance(e, AudioProcessingError) and "Failed to resample audio" in str(e):
+                raise
             raise AudioProcessingError(
                 f"Failed to resample audio from {original_rate}Hz to {target_rate}Hz: {e}",
                 f"Input shape: {getattr(audio_data, 'shape', None)}, dtype: {getattr(audio_data, 'dtype', None)}")
+
+
+def _fourier_resample(x: np.ndarray, num: int) -> np.ndarray:
+    """``scipy.signal.resample(x, num).astype(np.float32)`` along axis 0, window=None (audio.py:46-49)."""
+    if num < 0:
+        raise ValueError("negative dimensions are not allowed")                # numpy's, from scipy's np.zeros(newshape)
+    n = x.shape[0]
+    if n == 0:
+        raise ValueError("invalid number of data points (0) specified")        # scipy.fft's, from rfft of an empty axis
+    if np.iscomplexobj(x):
+        x = x.real
+    tail = x.shape[1:]
+    # scipy transforms float32 (and float16) input in single precision, everything else real in double: the kernel takes both
+    wide = x.dtype not in (np.float32, np.float16)
+    rows = np.array(np.moveaxis(x, 0, -1).reshape(-1, n), np.float64 if wide else np.float32, order="C")     # [columns, n], a copy
+    # a NaN / Inf anywhere reaches every output sample of its column through the transform
+    bad = ~np.isfinite(rows).all(axis=1)
+    rows[bad] = 0
+    if num == 0:
+        y = np.zeros((rows.shape[0], 1), np.float32)          # scipy's irfft hands back ONE sample per column, times num / len = 0
+    elif x.ndim == 1 and not wide and num == 512 and n in _CHUNK_IN.values():
+        from ..pool import default_pool
+        rate = next(sr for sr, k in _CHUNK_IN.items() if k == n)
+        y = default_pool().any_engine().resample(rows, rate)
+    else:
+        from ..pool import default_pool
+        y = default_pool().any_engine().resample_generic(rows, num)
+    y[bad] = np.nan
+    return np.ascontiguousarray(np.moveaxis(y.reshape(tail + (y.shape[1],)), -1, 0))

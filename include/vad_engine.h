@@ -244,6 +244,23 @@ VAD_API int vad_resample_multi_device(vad_engine *e, int32_t nseg, const float *
                                       const int32_t *n_in, const int32_t *sr_in, float *const *d_out, void *stream);
 
 /*
+ * AudioUtils.resample_audio for EVERY input the reference function accepts (utils/audio.py:39-49): the whole array goes through
+ * scipy.signal.resample(x, int(len(x) * target_rate / original_rate)) - any length, any pair of rates.  The caller computes
+ * n_out exactly as the reference does (Python float arithmetic, utils/audio.py:43-46); only the two lengths enter the maths.
+ * in [rows][n_in] float32 (in_f64 = 0) or float64 (in_f64 = 1: scipy transforms float64 / integer arrays in double precision)
+ * -> out [rows][n_out] float32 (the reference's .astype(np.float32), :49); rows = independent arrays of one length (the
+ * columns of an [N, C] array: scipy resamples along axis 0).  The operator is evaluated in float64 on the GPU, never stored
+ * (csrc/resample_generic.hip).  Limits: n_in, n_out in 1 .. 2^31 - 1 and rows * n_in * n_out <= 2^42 (VAD_ERR_UNSUPPORTED
+ * beyond; measured 0.5e12 entries / s on an MI355X: 1.5 ms for one second of 48 kHz audio to 16 kHz, 0.14 s for ten seconds, ~8 s at
+ * the cap = 75 s of 48 kHz audio - the work is O(n_in * n_out), an FFT's is not; longer arrays must be cut by the caller - the
+ * result of a cut array is NOT the reference's, which is why the engine refuses instead of cutting).
+ * The _device form takes device pointers and is synchronous as well (the result is complete on return).
+ */
+VAD_API int vad_resample_generic(vad_engine *e, const void *in, int in_f64, int64_t rows, int64_t n_in, int64_t n_out, float *out);
+VAD_API int vad_resample_generic_device(vad_engine *e, const void *d_in, int in_f64, int64_t rows, int64_t n_in, int64_t n_out,
+                                        float *d_out);
+
+/*
  * Tick assembler: the serving loop's side of vad_step_events, in C.  The reference runs the model inside every websocket's
  * receive loop, one client and one frame at a time (websocket_service/server/vad_websocket_server.py:326-382); a shared-pool
  * server instead collects the frames that arrived since the last tick and advances all those streams together:
@@ -332,6 +349,9 @@ VAD_API int vad_debug_pack_weights(int32_t model_version, const void *weights, s
  * applies for chunks of n_in samples; the CPU test-suite checks R @ x against scipy.signal.resample.
  */
 VAD_API int vad_debug_resample_operator(int32_t n_in, float *R, size_t r_floats);
+/* rows m0 .. m1-1 of the operator vad_resample_generic applies, R[(m - m0) * n_in + n] in float64, evaluated on the HOST with the
+ * arithmetic of the kernel (same tables, same small-angle rule): the CPU test-suite checks R @ x against scipy for awkward shapes */
+VAD_API int vad_debug_resample_generic_entries(int64_t n_in, int64_t n_out, int64_t m0, int64_t m1, double *R, size_t r_doubles);
 
 /*
  * Diagnostic (no GPU needed): the folded, MFMA-packed form of that operator exactly as the kernel

@@ -64,3 +64,33 @@ def model_cases_8k(speech_i16):
     short = (0.2 * np.random.default_rng(4243).standard_normal((8, 200))).astype(np.float32)
     c["short200_padded"] = np.pad(short, ((0, 0), (0, 56)))
     return c
+
+
+def resample_generic_inputs():
+    """(name, array, original_rate, target_rate): whole arrays for ``AudioUtils.resample_audio`` outside the three streaming
+    chunk shapes.  The first case is the reference's own test (/root/reference/tests/test_audio_utils.py:67-82)."""
+    def rn(seed, shape, dtype=np.float32, scale=0.5):
+        return (scale * np.random.default_rng(seed).standard_normal(shape)).astype(dtype)
+    t = np.linspace(0, 0.1, 100, False)
+    cases = [
+        ("ref_test_sine_1000_500", np.sin(2 * np.pi * 50 * t).astype(np.float32), 1000, 500),
+        ("odd_1001_44100_16000", rn(1, 1001), 44100, 16000),
+        ("odd_997_16000_44100", rn(2, 997), 16000, 44100),
+        ("tenth_second_44100_16000", rn(3, 4410), 44100, 16000),
+        ("three_chunks_48000_16000", rn(4, 4608), 48000, 16000),
+        ("two_chunks_8000_16000", rn(5, 512), 8000, 16000),
+        ("stereo_300x2_48000_16000", rn(6, (300, 2)), 48000, 16000),
+        ("int16_480_24000_16000", (rn(7, 480, np.float64) * 20000).astype(np.int16), 24000, 16000),
+        ("float64_777_22050_16000", rn(8, 777, np.float64), 22050, 16000),
+        ("up_odd_255_8000_16000", rn(9, 255), 8000, 16000),
+        ("up_even_256_8000_24000", rn(10, 256), 8000, 24000),
+        ("near_equal_1234_16000_15990", rn(11, 1234), 16000, 15990),
+        ("equal_len_even_10_16000_17599", rn(12, 10), 16000, 17599),
+        ("tiny_3_48000_16000", rn(13, 3), 48000, 16000),
+        ("tiny_2_16000_48000", rn(14, 2), 16000, 48000),
+        ("single_1_48000_16000", rn(15, 1), 48000, 16000),
+        ("down_even_out_1000_16000_8000", rn(16, 1000), 16000, 8000),
+        ("prime_4093_48000_44100", rn(17, 4093), 48000, 44100),
+        ("list_input_64_32000_16000", [float(v) for v in rn(18, 64, np.float64)], 32000, 16000),
+    ]
+    return cases

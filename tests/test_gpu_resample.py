@@ -84,16 +84,81 @@ def test_mixed_rates_in_one_launch(engine):
 
 
 def test_audio_utils_resample_goes_through_the_engine(engine):
-    from cutter_vad_amd import AudioProcessingError, AudioUtils
+    from cutter_vad_amd import AudioUtils
     import scipy.signal
     x = (0.5 * np.random.default_rng(11).standard_normal(1536)).astype(np.float32)
     y = AudioUtils.resample_audio(x, 48000, 16000)
     assert y.shape == (512,) and y.dtype == np.float32
     assert np.abs(y - scipy.signal.resample(x, 512).astype(np.float32)).max() <= TOL
-    y2 = AudioUtils.resample_audio(np.concatenate([x, x]), 48000, 16000)   # two independent chunks
-    assert np.abs(y2[:512] - y).max() == 0 and np.abs(y2[512:] - y).max() == 0
-    with pytest.raises(AudioProcessingError, match="Failed to resample audio from 48000Hz to 16000Hz"):
-        AudioUtils.resample_audio(x[:1000], 48000, 16000)
+    # more than one chunk: the WHOLE array through one transform, as the reference does it - not chunk by chunk
+    xx = np.concatenate([x, x[::-1], x])
+    y3 = AudioUtils.resample_audio(xx, 48000, 16000)
+    assert y3.shape == (1536,) and np.abs(y3 - scipy.signal.resample(xx, 1536).astype(np.float32)).max() <= TOL
+    assert np.abs(y3[:512] - y).max() > 1e-3          # and that is a different signal from three per-chunk resamples
+    # the one-chunk MFMA kernel and the generic kernel are the same function of the input
+    z = engine.resample_generic(x.reshape(1, -1), 512)[0]
+    assert np.abs(z - y).max() <= 2e-6
+
+
+def test_generic_resampler_matches_the_reference_function_on_any_shape(engine):
+    """AudioUtils.resample_audio on whole arrays of arbitrary length / rates / dtype: outputs of the reference's own function
+    (tests/golden/resample_generic.npz; case 1 is /root/reference/tests/test_audio_utils.py:67-82) and live scipy."""
+    import warnings
+    import scipy.signal
+    from cutter_vad_amd import AudioUtils
+    from tests.signals import resample_generic_inputs
+    g = np.load(os.path.join(GOLD, "resample_generic.npz"))
+    for name, x, r0, r1 in resample_generic_inputs():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = AudioUtils.resample_audio(x, r0, r1)
+            live = scipy.signal.resample(np.asarray(x), int(len(x) * (r1 / r0))).astype(np.float32)
+        want = g[name]
+        scale = max(1.0, float(np.abs(want).max()))
+        assert got.dtype == np.float32 and got.shape == want.shape, name
+        assert np.abs(got - want).max() <= TOL * scale and np.abs(got - live).max() <= TOL * scale, name
+    # the reference's own assertions on its own case
+    t = np.linspace(0, 0.1, 100, False)
+    r = AudioUtils.resample_audio(np.sin(2 * np.pi * 50 * t).astype(np.float32), 1000, 500)
+    assert abs(len(r) - 50) <= 1 and r.dtype == np.float32
+
+
+def test_generic_resampler_long_arrays_rows_and_launch_shapes(engine):
+    import scipy.signal
+    from cutter_vad_amd import AudioProcessingError, AudioUtils
+    rng = np.random.default_rng(77)
+    # one second of audio: 48 k -> 16 k (t = (3 m - n) / 48000) and 44.1 k -> 16 k (441 / 160: a 7 M-long period)
+    for n_in, r0 in ((48000, 48000), (44100, 44100)):
+        x = (0.3 * rng.standard_normal(n_in)).astype(np.float32)
+        y = AudioUtils.resample_audio(x, r0, 16000)
+        assert y.shape == (16000,) and np.abs(y - scipy.signal.resample(x, 16000).astype(np.float32)).max() <= TOL
+    # coprime lengths: every t is distinct, the closest to 0 are ~1e-9
+    x = (0.3 * rng.standard_normal(30011)).astype(np.float32)
+    y = engine.resample_generic(x.reshape(1, -1), 10007)[0]
+    assert np.abs(y - scipy.signal.resample(x, 10007).astype(np.float32)).max() <= TOL
+    # rows: many arrays of one shape in one call == one call each, bit for bit (fixed summation order), float64 input too
+    xs = (0.3 * rng.standard_normal((37, 1411))).astype(np.float32)
+    ys = engine.resample_generic(xs, 512)
+    assert ys.shape == (37, 512)
+    for i in (0, 17, 36):
+        assert np.array_equal(ys[i], engine.resample_generic(xs[i:i + 1], 512)[0])
+    assert np.abs(ys - scipy.signal.resample(xs, 512, axis=1).astype(np.float32)).max() <= TOL
+    xd = rng.standard_normal((3, 2000)) * 1e4
+    yd = engine.resample_generic(xd, 3000)
+    assert np.abs(yd - scipy.signal.resample(xd, 3000, axis=1).astype(np.float32)).max() <= 1e-6 * 1e4
+    # linearity and constants (DC gain 1)
+    a, b = xs[:4], xs[4:8]
+    assert np.abs(engine.resample_generic(a + 2 * b, 700) - (engine.resample_generic(a, 700) + 2 * engine.resample_generic(b, 700))).max() <= 2e-6
+    assert np.abs(engine.resample_generic(np.full((1, 999), 0.25, np.float32), 1234) - 0.25).max() <= 1e-6
+    # NaN / Inf in one column reach every output of that column and no other (what the transform does)
+    st = (0.3 * rng.standard_normal((300, 2))).astype(np.float32)
+    st[5, 1] = np.inf
+    ynan = AudioUtils.resample_audio(st, 48000, 16000)
+    assert np.isnan(ynan[:, 1]).all() and np.abs(ynan[:, 0] - scipy.signal.resample(st[:, 0], 100)).max() <= TOL
+    # beyond the size limit: refused, never cut into pieces
+    with pytest.raises(AudioProcessingError, match="2\\^42 operator entries"):
+        engine.resample_generic(np.zeros((1, 3_000_000), np.float32), 2_000_000)
+    assert np.array_equal(engine.resample_generic(np.zeros((0, 10), np.float32), 5), np.zeros((0, 5), np.float32))
 
 
 def test_config4_mixed_rates_resample_then_v5(engine):

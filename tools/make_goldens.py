@@ -316,8 +316,33 @@ def make_util_goldens(rtv):
     print("  utils: resample/framing/gate/wav written")
 
 
+def resample_generic_cases():
+    """(name, input array, original_rate, target_rate) of tests/golden/resample_generic.npz; inputs come from seeds, so
+    the fixture holds the reference's outputs only.  Shared with tests/signals.py users through this one definition."""
+    from tests.signals import resample_generic_inputs
+    return resample_generic_inputs()
+
+
+def make_resample_generic_goldens(rtv):
+    """AudioUtils.resample_audio (the reference's function, audio.py:19-55) on whole arrays of arbitrary length and rate."""
+    import warnings
+    from real_time_vad.utils.audio import AudioUtils
+    out = {}
+    for name, x, r0, r1 in resample_generic_cases():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            y = AudioUtils.resample_audio(x, r0, r1)
+        assert y.dtype == np.float32
+        out[name] = y
+    np.savez_compressed(os.path.join(OUT, "resample_generic.npz"), **out)
+    print(f"  resample_generic: {len(out)} cases written")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-resample-generic" in sys.argv:
+        make_resample_generic_goldens(import_reference())
+        return
     speech = load_speech_16k()
     if "--only-v4-8k" in sys.argv:
         make_v4_8k_goldens(speech)
@@ -338,6 +363,7 @@ def main():
     print("end-to-end golden (reference VADWrapper over onnx_interp):")
     make_e2e_golden(rtv, speech)
     make_util_goldens(rtv)
+    make_resample_generic_goldens(rtv)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f))} B")
 
