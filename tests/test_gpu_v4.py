@@ -14,6 +14,8 @@ TOL_S = 5e-4
 # happens to the two REAL bins (k = 0, 128) about once in 10^4 columns and practically never to a complex bin
 # (tools/v4_real_bins.py), so silero_v4.hip sums exactly those two in float64 and the fixed bar below holds; the sweep
 # in profiles/r02_parity_sweep.json (1 M frames) has the kernel closer to the f64 oracle than the oracle's own float32 build.
+# The one constructed input with exact nulls in COMPLEX bins (period-64 full-scale square wave) is held to the float32
+# yardstick on that input instead of a flat number: test_edge_inputs, profiles/r03_f32_yardsticks.json.
 
 
 @pytest.fixture(scope="module")
@@ -104,8 +106,8 @@ def test_multi_int16_gate_off_and_events(engine, om):
             engine.close_stream(s)
 
 
-def test_edge_inputs(engine, om):
-    T = 4
+def test_edge_inputs(engine, om, blob):
+    T = 8
     z = np.zeros((1, T, 512), np.float32)
     quiet = (0.005 * np.random.default_rng(5).standard_normal((1, T, 512))).astype(np.float32)
     imp = np.zeros((1, T, 512), np.float32)
@@ -117,8 +119,17 @@ def test_edge_inputs(engine, om):
         ref_p, _ = _oracle_run(om, frames, 0.01)
         got = np.stack([engine.step(slots, frames[:, t]) for t in range(T)], axis=1)
         assert np.abs(got[:3] - ref_p[:3]).max() <= TOL_P
-        # exact spectral nulls x 2^20 inside a log: any fp32 evaluation is order dependent here (Numerics)
-        assert np.abs(got[3] - ref_p[3]).max() <= 5e-3
+        # The period-64 full-scale square wave has EXACT nulls in complex spectral bins, which V4 multiplies by 2^20 inside a
+        # log: every float32 evaluation is order dependent there.  The bar is therefore the float32 yardstick on this very
+        # input, computed here: the oracle's own float32 build against its float64 build (recorded with PyTorch's float32
+        # operators next to it in profiles/r03_f32_yardsticks.json: oracle-f32 1.08e-3, torch-f32 8.8e-5, kernels 6.5e-4 /
+        # 7.7e-4 over these 8 frames).  The kernel may be at most twice as far from float64 as that build.
+        from oracle import oracle
+        o32 = oracle.OracleModel(blob, "f32")
+        ref32, _ = _oracle_run(o32, frames[3:], 0.01)
+        yard = float(np.abs(ref32[0] - ref_p[3]).max())
+        assert 1e-4 < yard < 5e-3                                   # the input does what the comment says
+        assert np.abs(got[3] - ref_p[3]).max() <= 2 * yard
     finally:
         for s in slots:
             engine.close_stream(s)
@@ -222,6 +233,17 @@ def test_8k_golden_and_wrapper_rate_selection(setup8k):
     try:
         got = np.array([eng.step([slot], sp[t:t + 1])[0] for t in range(240)])
         assert np.abs(got - g["speech_gate.probs"]).max() <= TOL_P
+        # exact complex-bin nulls, 8 kHz sub-model: bar = twice the float32 yardstick on the same input, as in test_edge_inputs
+        # (profiles/r03_f32_yardsticks.json: oracle-f32 4.2e-3, torch-f32 2.4e-3, kernels 3.6e-3 / 5.3e-3 over 8 frames)
+        from oracle import oracle
+        with open(weights_io.packaged_blob_path(4, 8000), "rb") as f:
+            o32 = oracle.OracleModel(f.read(), "f32")
+        sq = np.where(np.arange(512 * 8) % 64 < 32, 1.0, -1.0).astype(np.float32).reshape(1, 8, 512)
+        r64, _ = _oracle_run(setup8k[1], sq, 0.01)
+        r32, _ = _oracle_run(o32, sq, 0.01)
+        eng.reset([slot])
+        k = np.array([eng.step([slot], sq[:, t])[0] for t in range(8)])
+        assert np.abs(k - r64[0]).max() <= 2 * float(np.abs(r32 - r64).max())
     finally:
         eng.close_stream(slot)
     for rate in (8000, 48000):

@@ -65,8 +65,9 @@ def test_step_matches_oracle(engine, om, n):
             engine.close_stream(int(s))
 
 
-def test_interpreter_goldens_gate_int16_and_edges(engine, om):
+def test_interpreter_goldens_gate_int16_and_edges(engine, om, blob):
     from oracle import oracle
+    om32 = oracle.OracleModel(blob, "f32")
     g = np.load(os.path.join(GOLD, "model_v5_8k.npz"))
     pcm = np.load(os.path.join(GOLD, "speech16k_i16.npz"))["pcm"]
     cases = model_cases_8k(pcm)
@@ -76,8 +77,15 @@ def test_interpreter_goldens_gate_int16_and_edges(engine, om):
             engine.reset([s])
             got = np.array([engine.step([s], f[None], denoise=None)[0] for f in cases[name]], np.float32)   # cases are pre-gated
             assert np.abs(got - g[f"{name}.probs"]).max() <= TOL_P, name
-            ref_s = g[f"{name}.state"]                            # c reaches tens over 529 speech frames: relative bar
-            assert (np.abs(engine.get_state(s) - ref_s) <= 2e-4 * np.maximum(1.0, np.abs(ref_s))).all(), name
+            ref_s = g[f"{name}.state"]
+            # c is an unbounded accumulator (|c| reaches 140 over the 530 speech frames), so the state bar is relative - and it
+            # is tied to the float32 yardstick on the same input: twice what the oracle's own float32 build is off from its
+            # float64 build, at least 1e-5 (profiles/r03_f32_yardsticks.json: oracle-f32 6.1e-5, torch-f32 4.8e-6, kernel 3.5e-5)
+            st32 = np.zeros((1, 256), np.float32)
+            for f in cases[name]:
+                om32.step_batch(np.ascontiguousarray(f[None]), st32, nthreads=1)
+            rel = lambda a: np.abs(a - ref_s) / np.maximum(1.0, np.abs(ref_s))
+            assert rel(engine.get_state(s)).max() <= max(1e-5, 2 * float(rel(st32[0]).max())), name
         # the gate in the kernel == the gate of the fixture generator; no gate on the ungated speech
         engine.reset([s])
         sp = (pcm[::2].astype(np.float32) / np.float32(32767.0))[: 120 * 256].reshape(120, 256)
