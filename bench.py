@@ -58,10 +58,24 @@ CPU_STREAMS = 2048
 PREAMBLE_S = 0.4
 
 
-def synth_ring(first_stream: int, n: int) -> np.ndarray:
-    """BASELINE.md §4 generator -> [RING][n][512] float32 (one contiguous [n,512] batch per step)."""
+def synth_ring(first_stream: int, n: int, threads: int = 1) -> np.ndarray:
+    """BASELINE.md §4 generator -> [RING][n][512] float32 (one contiguous [n,512] batch per step).  Every stream has its own
+    seeded generator, so the streams are split over `threads` host threads (numpy's generators release the GIL): 8 ranks
+    starting together on one node each take their share of the cores instead of ~8 s of one core each."""
     from tests.signals import make_streams
-    return np.ascontiguousarray(make_streams(n, RING, seed=1234, first_stream=first_stream).transpose(1, 0, 2))
+    threads = max(1, min(int(threads), n // 256 or 1))
+    if threads == 1:
+        return np.ascontiguousarray(make_streams(n, RING, seed=1234, first_stream=first_stream).transpose(1, 0, 2))
+    from concurrent.futures import ThreadPoolExecutor
+    out = np.empty((RING, n, 512), np.float32)
+    edges = [n * k // threads for k in range(threads + 1)]
+
+    def part(k: int) -> None:
+        lo, hi = edges[k], edges[k + 1]
+        out[:, lo:hi] = make_streams(hi - lo, RING, seed=1234, first_stream=first_stream + lo).transpose(1, 0, 2)
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(part, range(threads)))
+    return out
 
 
 def usable_cores() -> int:
@@ -195,12 +209,34 @@ def main() -> int:
     # control-plane collectives.  The real multi-GPU run is one rank per GPU over RCCL.
     if os.environ.get("VAD_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
-    backend = "gloo" if fake else os.environ.get("VAD_BENCH_BACKEND", "nccl")              # "nccl" == RCCL on ROCm
+    prefer = "gloo" if fake and "VAD_BENCH_BACKEND" not in os.environ else os.environ.get("VAD_BENCH_BACKEND", "nccl")   # "nccl" == RCCL on ROCm
+    device = None
     if not fake:
         if local_rank >= torch.cuda.device_count():
             raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
         torch.cuda.set_device(local_rank)
-    dist = sharding.init_process_group(info, backend, torch.device("cuda", local_rank) if backend == "nccl" else None)
+        device = torch.device("cuda", local_rank)
+    # control plane: gloo always, RCCL on top when every rank's probe all-reduce works (sharding.ControlPlane); a failing RCCL
+    # never ends the job - the line says which one carried the barrier and the MAX
+    cp = sharding.ControlPlane(info, prefer, device)
+    # one rank per GPU, really: two ranks on one device would report n_gpus = N over fewer GPUs
+    # identity = what this rank asked for (device ordinal under its visibility masks), not a property the runtime reports:
+    # a runtime that reported one uuid for all GPUs must not be able to stop a legitimate run
+    masks = "|".join(os.environ.get(k, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    if not fake:
+        pr = torch.cuda.get_device_properties(local_rank)
+        ident = (socket.gethostname(), masks, local_rank)
+        shown = f"cuda:{local_rank} pci {getattr(pr, 'pci_bus_id', '?'):02x}" if isinstance(getattr(pr, "pci_bus_id", None), int) else f"cuda:{local_rank}"
+    else:
+        ident = (socket.gethostname(), masks, int(os.environ.get("VAD_BENCH_FAKE_DEVICE", local_rank)))
+        shown = f"fake:{ident[2]}"
+    dup = sharding.duplicate_devices(cp.gather(ident))
+    if dup and os.environ.get("VAD_BENCH_SINGLE_DEVICE") != "1":
+        if rank == 0:
+            sys.stderr.write(f"bench.py: ranks {dup[0][0]} and {dup[0][1]} map to the same GPU {dup[0][2]}; refusing to report "
+                             f"n_gpus = {world} for fewer devices (LOCAL_RANK -> device map)\n")
+        cp.close()
+        return 2
 
     B = args.streams
     first_stream, _ = sharding.stream_shard(world * B, world, rank)   # weak scaling: B streams per rank
@@ -213,7 +249,7 @@ def main() -> int:
         def run():
             for i in range(args.steps):
                 stepper.step(i)
-        elapsed = sharding.timed_region(dist, run, sync, device="cpu")
+        elapsed, own = sharding.timed_region_detail(cp, run, sync)
         preamble, ring_h, gpu_probs, versions = 0, None, None, [5]
     else:
         from cutter_vad_amd import weights_io
@@ -229,7 +265,7 @@ def main() -> int:
             streams.append(torch.cuda.Stream())
             probs.append(torch.empty(nb, device="cuda"))
             events.append(torch.empty(nb, dtype=torch.uint8, device="cuda"))
-        ring_h = synth_ring(first_stream, B)
+        ring_h = synth_ring(first_stream, B, threads=max(1, usable_cores() // world))
         ring = torch.from_numpy(ring_h).cuda()
         torch.cuda.synchronize()
         ptrs = [[ring[i, k * nb:(k + 1) * nb].data_ptr() for i in range(RING)] for k in range(len(versions))]
@@ -275,11 +311,15 @@ def main() -> int:
             join()
             e1.record(ts)
 
-        elapsed = sharding.timed_region(dist, run, torch.cuda.synchronize, device="cuda" if backend == "nccl" else "cpu")
+        elapsed, own = sharding.timed_region_detail(cp, run, torch.cuda.synchronize)
         kernel_s = [e0.elapsed_time(e1) * 1e-3 / args.steps]     # avg launch duration on the launch stream(s)
         for p in probs:
             assert bool(torch.isfinite(p).all()) and float(p.min()) >= 0.0 and float(p.max()) <= 1.0
 
+    # every rank's own figures, so that a straggler is visible behind the MAX
+    per_rank = cp.gather({"rank": rank, "device": shown,
+                          "kernel_us": None if kernel_s[0] is None else kernel_s[0] * 1e6,
+                          "ms_per_step": own / args.steps * 1e3, "frames_per_s": B * args.steps / own})
     if rank == 0:
         value = sharding.aggregate_rate(B, args.steps, world, elapsed)
         mixed = len(versions) > 1
@@ -309,7 +349,11 @@ def main() -> int:
                 "sharding": f"{world} independent per-GPU stream pools, no collective",
             },
             "preamble_steps": preamble,
+            "control_plane": cp.backend or "none (single process)",
+            "per_rank": per_rank,
         }
+        if cp.fallback_reason:
+            out["control_plane_fallback"] = cp.fallback_reason
         if fake:
             out["data"] = "none (VAD_BENCH_FAKE=1: CPU rehearsal of the launch path, not a measurement)"
             out["roofline"] = None
@@ -352,8 +396,7 @@ def main() -> int:
                 out["cpu_baseline"] = base_
                 out["parity"] = parity
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    cp.close()
     if not fake:
         for e in engines:
             e.close()

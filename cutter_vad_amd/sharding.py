@@ -58,8 +58,90 @@ def init_process_group(info: RankInfo, backend: str, device=None):
     return dist
 
 
+class ControlPlane:
+    """The only three things ranks ever say to each other: barrier, MAX of a number, gather of small records.
+
+    The default process group is ALWAYS gloo (it needs nothing but the rendezvous).  With ``prefer="nccl"`` an RCCL group over
+    the ranks' GPUs is created on top and probed with one all-reduce; every rank then reports over gloo whether its probe
+    worked, and only if ALL did is RCCL used for the barrier and the MAX.  Any failure (no GPU, two ranks on one device, an
+    RCCL that cannot initialise on this node) leaves the job on gloo, in the same process, with the reason kept in
+    ``fallback_reason`` - the measurement does not depend on the choice, there is no data-path collective either way."""
+
+    def __init__(self, info: RankInfo, prefer: str = "gloo", device=None, probe_timeout_s: float = 60.0) -> None:
+        self.info = info
+        self.backend: Optional[str] = None
+        self.fallback_reason: Optional[str] = None
+        self._dist = None
+        self._group = None
+        self._device = None
+        if info.world == 1:
+            return
+        import datetime
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=info.rank, world_size=info.world)
+        self._dist = dist
+        self.backend = "gloo"
+        if prefer != "nccl":
+            return
+        ok, why, group = 1, "", None
+        try:
+            os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")       # a stuck probe raises after the timeout instead of aborting the process
+            group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=probe_timeout_s))
+            t = torch.ones(1, device=device)
+            dist.all_reduce(t, group=group)
+            torch.cuda.synchronize()
+            if int(t.item()) != info.world:
+                raise RuntimeError(f"probe all-reduce returned {t.item()} for world size {info.world}")
+        except Exception as e:      # noqa: BLE001 - whatever RCCL throws, the job carries on over gloo
+            ok, why = 0, f"{type(e).__name__}: {e}".splitlines()[0][:300]
+        flags = [None] * info.world
+        dist.all_gather_object(flags, (ok, why))
+        if all(f[0] for f in flags):
+            self._group, self._device, self.backend = group, device, "nccl"
+        else:
+            bad = [(r, f[1]) for r, f in enumerate(flags) if not f[0]]
+            self.fallback_reason = f"rank {bad[0][0]}: {bad[0][1]}" + (f" (+{len(bad) - 1} more ranks)" if len(bad) > 1 else "")
+
+    @property
+    def active(self) -> bool:
+        return self._dist is not None
+
+    def barrier(self) -> None:
+        if self._dist is None:
+            return
+        if self._group is not None:
+            self._dist.barrier(group=self._group, device_ids=[self._device.index])
+        else:
+            self._dist.barrier()
+
+    def max(self, value: float) -> float:
+        if self._dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([value], dtype=torch.float64, device=self._device if self._group is not None else "cpu")
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self._group)
+        return float(t.item())
+
+    def gather(self, record) -> list:
+        """every rank's record on every rank, in rank order (gloo: small python objects)"""
+        if self._dist is None:
+            return [record]
+        out = [None] * self.info.world
+        self._dist.all_gather_object(out, record)
+        return out
+
+    def close(self) -> None:
+        if self._dist is not None:
+            self._dist.destroy_process_group()
+            self._dist = None
+
+
 def timed_region(dist, run: Callable[[], None], sync: Callable[[], None], device: Optional[str] = None) -> float:
-    """barrier + sync | run() | sync + barrier, then MAX of the wall time over ranks (seconds)."""
+    """barrier + sync | run() | sync + barrier, then MAX of the wall time over ranks (seconds).  ``dist``: None, an initialised
+    ``torch.distributed`` module, or a :class:`ControlPlane`."""
+    if isinstance(dist, ControlPlane):
+        return timed_region_detail(dist, run, sync)[0]
     import torch
     sync()
     if dist is not None:
@@ -75,6 +157,32 @@ def timed_region(dist, run: Callable[[], None], sync: Callable[[], None], device
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
+
+
+def timed_region_detail(cp: ControlPlane, run: Callable[[], None], sync: Callable[[], None]) -> Tuple[float, float]:
+    """-> (MAX over ranks, this rank's own) wall time of: sync, barrier, sync | run() | sync, barrier."""
+    sync()
+    cp.barrier()
+    sync()
+    t0 = time.perf_counter()
+    run()
+    sync()
+    own = time.perf_counter() - t0
+    cp.barrier()
+    return cp.max(own), own
+
+
+def duplicate_devices(records: list) -> list:
+    """records = [(host, device identity), ...] in rank order -> [(rank_a, rank_b, identity)] for every pair of ranks that
+    would step the same GPU (a wrong LOCAL_RANK -> device map halves the hardware under the reported n_gpus)."""
+    seen, dup = {}, []
+    for r, key in enumerate(records):
+        key = tuple(key)
+        if key in seen:
+            dup.append((seen[key], r, key))
+        else:
+            seen[key] = r
+    return dup
 
 
 def aggregate_rate(units_per_rank_per_step: int, steps: int, world: int, elapsed_max: float) -> float:

@@ -68,6 +68,36 @@ def test_two_gloo_ranks_share_nothing_but_the_clock(tmp_path):
     assert sharding.aggregate_rate(64, 5, world, r[0][2]) == pytest.approx(2 * 64 * 5 / r[0][2])
 
 
+def _cp_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    info = sharding.RankInfo.from_env()
+    cp = sharding.ControlPlane(info, "nccl", None)        # no GPU here: the RCCL probe fails on every rank -> gloo, same process
+    import time
+    total, own = sharding.timed_region_detail(cp, lambda: time.sleep(0.05 * (rank + 1)), lambda: None)
+    recs = cp.gather({"rank": rank, "own": own})
+    with open(os.path.join(out_dir, f"cp{rank}.txt"), "w") as f:
+        f.write(repr((cp.backend, cp.fallback_reason, total, own, [r["rank"] for r in recs], cp.max(float(rank)))))
+    cp.close()
+
+
+def test_control_plane_falls_back_to_gloo_in_process_when_rccl_cannot_start(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_cp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [eval(open(tmp_path / f"cp{k}.txt").read()) for k in range(world)]
+    for k, (backend, why, total, own, ranks, mx) in enumerate(got):
+        assert backend == "gloo" and "rank 0:" in why and "NCCL" in why          # every rank knows why, and agrees
+        assert ranks == [0, 1] and mx == 1.0
+        assert total >= own and total == got[0][2] and total >= 0.1             # MAX over ranks, identical everywhere
+    assert got[0][3] < got[1][3]                                                 # each rank also keeps its own time
+    one = sharding.ControlPlane(sharding.RankInfo(0, 0, 1), "nccl", None)        # a single process never opens a group
+    assert one.backend is None and not one.active and one.gather(5) == [5] and one.max(2.5) == 2.5
+    one.barrier()
+    one.close()
+    assert sharding.duplicate_devices([("h", "", 0), ("h", "", 1), ("h", "", 0)]) == [(0, 2, ("h", "", 0))]
+    assert sharding.duplicate_devices([("h", "0", 0), ("h", "1", 0)]) == []      # one visible GPU each: different devices
+
+
 def test_single_process_needs_no_process_group():
     assert sharding.init_process_group(sharding.RankInfo(0, 0, 1), "gloo") is None
     t = sharding.timed_region(None, lambda: None, lambda: None)
@@ -96,6 +126,20 @@ def test_bench_gpus_n_launches_n_ranks_itself_and_reports_n():
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["value"] == pytest.approx(2 * 8192 * 20 / (out["ms_per_step"] * 1e-3 * 20))
     assert out["ms_per_step"] >= 1.0 and "FAKE" in out["data"] and out["roofline"] is None
+    # a straggler is visible: one record per rank, the MAX is the line's time
+    assert out["control_plane"] == "gloo" and [r["rank"] for r in out["per_rank"]] == [0, 1]
+    assert max(r["ms_per_step"] for r in out["per_rank"]) == pytest.approx(out["ms_per_step"], rel=1e-6)
+    assert {r["device"] for r in out["per_rank"]} == {"fake:0", "fake:1"}
+
+
+def test_bench_survives_a_failing_rccl_and_refuses_two_ranks_on_one_device():
+    import json
+    r = _bench("--gpus", "2", "--steps", "5", "--warmup", "1", VAD_BENCH_FAKE="1", VAD_BENCH_BACKEND="nccl")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")][0]
+    assert out["n_gpus"] == 2 and out["control_plane"] == "gloo" and "NCCL" in out["control_plane_fallback"]
+    r = _bench("--gpus", "2", "--steps", "5", "--warmup", "1", VAD_BENCH_FAKE="1", VAD_BENCH_FAKE_DEVICE="0")
+    assert r.returncode != 0 and "map to the same GPU" in r.stderr and not [x for x in r.stdout.splitlines() if x.startswith("{")]
 
 
 def test_bench_refuses_to_run_fewer_gpus_than_asked():
