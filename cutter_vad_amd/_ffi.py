@@ -88,6 +88,7 @@ class TickResult(C.Structure):
         ("group_frames", C.c_void_p * 12),
         ("nsamples", C.POINTER(C.c_int32)),
         ("host_us", C.c_float * 3),
+        ("dropped", C.c_int64),
     ]
 
 
@@ -135,6 +136,10 @@ SIGNATURES = {
                                          C.POINTER(C.c_uint32)]),
     "vad_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vad_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vad_tick_pending": (C.c_int, [_vp, C.c_int64, _i64p]),
+    "vad_tick_push_status": (C.c_int, [_vp, _i64p, C.c_int64, _vp, C.c_int32, C.c_int, C.c_int, _i32p]),
+    "vad_tick_segment_save": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _i64p]),
+    "vad_tick_segment_restore": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64]),
     "vad_resample_generic": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, _f32p]),
     "vad_resample_generic_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, _vp]),
     "vad_debug_resample_operator": (C.c_int, [C.c_int32, _f32p, C.c_size_t]),

@@ -14,13 +14,18 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
+#include <cstdlib>
+#include <new>
 #include <chrono>
 #include <cstring>
 #include <deque>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -98,7 +103,7 @@ struct vad_engine {
         void *d_frames = nullptr; size_t d_frames_cap = 0;
         uint8_t *d_io = nullptr, *h_io = nullptr; size_t io_cap = 0;   // [slots i32 n | probs f32 n T | seg i32 n | events u8 n T]
         hipEvent_t copied = nullptr, done = nullptr, out = nullptr;
-        int64_t ticket = -1; int64_t n = 0; int32_t T = 0; bool busy = false;
+        int64_t ticket = -1; int64_t n = 0; int32_t T = 0; bool busy = false, collecting = false;
     } pipe[PIPE_DEPTH];
     hipStream_t copy_in = nullptr, copy_out = nullptr;
     int64_t next_ticket = 0;
@@ -119,60 +124,211 @@ struct vad_engine {
     }
     static size_t tick_sample_bytes(int group) { return (group >= 2 && group < 6) ? 2 : 4; }
     struct TickBuf {
-        uint8_t *h = nullptr;                        // pinned: [cap] rows of frame bytes, then [cap] int32 slots, then [cap] int32 lengths
+        uint8_t *h = nullptr;                        // pinned: [cap] rows of frame bytes, then [cap] int32 slots, [cap] int32 lengths, [cap] uint32 epochs
         int64_t cap = 0, count = 0;
         size_t row_bytes = 0;
         uint8_t *row(int64_t r) const { return h + (size_t)r * row_bytes; }
         int32_t *slots() const { return reinterpret_cast<int32_t *>(h + (size_t)cap * row_bytes); }
         int32_t *lens() const { return slots() + cap; }   // samples the caller pushed (before padding / truncation)
+        uint32_t *epochs() const { return reinterpret_cast<uint32_t *>(lens() + cap); }   // slot_epoch at push time: a row of a slot closed (and reopened) since is stale
+        void drop_row(int64_t r) {                   // the last row fills the hole
+            const int64_t last = count - 1;
+            if (r != last) {
+                std::memcpy(row(r), row(last), row_bytes);
+                slots()[r] = slots()[last];
+                lens()[r] = lens()[last];
+                epochs()[r] = epochs()[last];
+            }
+            count = last;
+        }
     };
     struct TickPending { std::vector<uint8_t> data; int32_t nsamples; int group; };   // the whole frame as pushed
-    std::mutex tick_mu;
+    std::mutex tick_mu;                              // lock order: mu, then tick_mu
     int tick_cur = 0;
     TickBuf tick_buf[2][TICK_GROUPS];
     std::vector<uint32_t> tick_gen;                  // per slot: == tick_generation <=> the slot has a frame in the coming tick
     uint32_t tick_generation = 1;
+    std::vector<uint32_t> slot_epoch;                // per slot: bumped by every open (written under mu + tick_mu)
     std::unordered_map<int64_t, std::deque<TickPending>> tick_overflow;
+    std::vector<int64_t> tick_overflow_order;        // the slots of tick_overflow in the order they started waiting: their frames are placed in this order
     std::unordered_map<int64_t, std::deque<std::vector<uint8_t>>> tick_tails;   // samples past the model's frame of over-long frames, push order
     // segment assembly on the host side of the tick (vad_tick_enable_segments): what SegmentAssembler / VADProcessor keep per
     // stream (core/silero_model.py:838-869, 891-895, 925-949) - pre-roll, the open segment, the finished one until taken
     // The audio stays in its wire format (int16 stays int16: half the bytes, a memcpy per frame) as runs of (group, samples,
     // gate threshold); it becomes float32 - scaled with a true division and gated - when the finished segment is taken.
+    // Storage: fixed 32 KB blocks from an arena (a free list over 8 MB chunks that were touched when they were allocated), so
+    // that the tick never reallocates and never page-faults while 8 192 talking streams append a frame each; the tick's
+    // assembly pass only PLANS the copies (destination block, offset, bytes) and a few threads then carry them out.
+    struct SegArena {
+        static constexpr size_t BLOCK = 32768, CHUNK_BLOCKS = 256;
+        std::vector<uint8_t *> chunks, free_blocks;
+        ~SegArena() { for (uint8_t *c : chunks) std::free(c); }
+        void grow() {
+            uint8_t *c = static_cast<uint8_t *>(std::malloc(BLOCK * CHUNK_BLOCKS));
+            if (!c) throw std::bad_alloc();
+            std::memset(c, 0, BLOCK * CHUNK_BLOCKS);          // fault the pages in now, not inside a tick
+            chunks.push_back(c);
+            for (size_t k = CHUNK_BLOCKS; k-- > 0;) free_blocks.push_back(c + k * BLOCK);
+        }
+        void reserve_blocks(size_t n) { while (free_blocks.size() < n) grow(); }
+        uint8_t *get() {
+            if (free_blocks.empty()) grow();
+            uint8_t *b = free_blocks.back();
+            free_blocks.pop_back();
+            return b;
+        }
+        void put(uint8_t *b) { free_blocks.push_back(b); }
+    };
+    struct SegCopy { uint8_t *dst; const uint8_t *src; uint32_t bytes; };
     struct SegAudio {
-        struct Run { int group; float thr; int64_t samples; };      // group as in the tick: tells sample type, int16 scale, gate
-        std::vector<uint8_t> raw;
+        struct Run { int32_t group; float thr; int64_t samples; };      // group as in the tick: tells sample type, int16 scale, gate
+        std::vector<uint8_t *> blocks;
+        size_t tail = SegArena::BLOCK;                                  // bytes used in the last block (BLOCK: none / full)
         std::vector<Run> runs;
         int64_t samples = 0;
-        void clear() { raw.clear(); runs.clear(); samples = 0; }
-        void swap(SegAudio &o) { raw.swap(o.raw); runs.swap(o.runs); std::swap(samples, o.samples); }
-        void append(int group, float thr, const uint8_t *src, size_t cnt) {
-            const size_t bytes = cnt * ((group >= 2 && group < 6) ? 2 : 4), at = raw.size();
-            if (raw.capacity() < at + bytes) raw.reserve(std::max<size_t>(2 * raw.capacity(), at + bytes + 32768));   // ~1 s of int16 audio ahead
-            raw.resize(at + bytes);
-            std::memcpy(raw.data() + at, src, bytes);
-            if (!runs.empty() && runs.back().group == group && runs.back().thr == thr) runs.back().samples += (int64_t)cnt;
+        static bool is_i16(int group) { return group >= 2 && group < 6; }
+        static bool gated(int group) { return group < 6 ? (group & 1) : (group >= 9); }
+        bool empty() const { return samples == 0; }
+        void clear(SegArena &a) {
+            for (uint8_t *b : blocks) a.put(b);
+            blocks.clear();
+            runs.clear();
+            tail = SegArena::BLOCK;
+            samples = 0;
+        }
+        void swap(SegAudio &o) { blocks.swap(o.blocks); runs.swap(o.runs); std::swap(samples, o.samples); std::swap(tail, o.tail); }
+        // appends cnt samples of `group`: plans the byte copies into `out` (or does them, out == nullptr)
+        void append(SegArena &a, int group, float thr, const uint8_t *src, size_t cnt, std::vector<SegCopy> *out) {
+            if (!cnt) return;
+            const size_t ss = is_i16(group) ? 2 : 4;
+            const bool same = !runs.empty() && runs.back().group == group && runs.back().thr == thr;
+            if (!same && ss == 4 && !blocks.empty()) tail = (tail + 3) & ~(size_t)3;     // a float32 run starts 4-aligned (the reader applies the same rule)
+            size_t bytes = cnt * ss;
+            while (bytes) {
+                if (tail >= SegArena::BLOCK) {
+                    blocks.push_back(a.get());
+                    tail = 0;
+                }
+                const size_t k = std::min(bytes, SegArena::BLOCK - tail);
+                if (out) out->push_back(SegCopy{blocks.back() + tail, src, (uint32_t)k});
+                else std::memcpy(blocks.back() + tail, src, k);
+                tail += k;
+                src += k;
+                bytes -= k;
+            }
+            if (same) runs.back().samples += (int64_t)cnt;
             else runs.push_back(Run{group, thr, (int64_t)cnt});
             samples += (int64_t)cnt;
         }
-        void to_float(float *o) const {
-            const uint8_t *src = raw.data();
+        // the stored bytes of every run in order: fn(run, pointer, samples in this piece); pieces never split a sample
+        template <class F>
+        void for_each_piece(F fn) const {
+            size_t bi = 0, off = 0;
             for (const Run &r : runs) {
-                const size_t cnt = (size_t)r.samples;
-                const bool i16 = r.group >= 2 && r.group < 6;
-                if (!i16) std::memcpy(o, src, cnt * 4);
+                const size_t ss = is_i16(r.group) ? 2 : 4;
+                if (ss == 4) off = (off + 3) & ~(size_t)3;
+                size_t left = (size_t)r.samples;
+                while (left) {
+                    if (off >= SegArena::BLOCK) { ++bi; off = 0; }
+                    const size_t k = std::min(left, (SegArena::BLOCK - off) / ss);
+                    fn(r, blocks[bi] + off, k);
+                    off += k * ss;
+                    left -= k;
+                }
+            }
+        }
+        void to_float(float *o) const {
+            for_each_piece([&](const Run &r, const uint8_t *src, size_t cnt) {
+                if (!is_i16(r.group)) std::memcpy(o, src, cnt * 4);
                 else {
                     const float sc = r.group < 4 ? 32767.0f : 32768.0f;     // np.int16 -> float32 / 32767.0 (true division)
                     const int16_t *q = reinterpret_cast<const int16_t *>(src);
                     for (size_t k = 0; k < cnt; ++k) o[k] = (float)q[k] / sc;
                 }
-                if (r.group < 6 ? (r.group & 1) : (r.group >= 9))          // the group's gate: utils/audio.py:117-118
+                if (gated(r.group))                                        // the group's gate: utils/audio.py:117-118
                     for (size_t k = 0; k < cnt; ++k) o[k] = std::fabs(o[k]) > r.thr ? o[k] : 0.f;
                 o += cnt;
-                src += cnt * (i16 ? 2 : 4);
-            }
+            });
+        }
+        size_t stored_bytes() const {
+            size_t b = 0;
+            for (const Run &r : runs) b += (size_t)r.samples * (is_i16(r.group) ? 2 : 4);
+            return b;
         }
     };
-    struct SegState { bool active = false; SegAudio pre, seg, done; };
+    struct SegState {
+        bool active = false;
+        SegAudio pre, seg, done;
+        void clear(SegArena &a) { active = false; pre.clear(a); seg.clear(a); done.clear(a); }
+    };
+    SegArena seg_arena;
+    std::vector<SegCopy> seg_copies;                 // the copies one tick planned
+    // the threads that carry out a tick's planned copies next to the calling one
+    struct CopyCrew {
+        std::vector<std::thread> th;
+        std::mutex m;
+        std::condition_variable cv_go, cv_done;
+        const SegCopy *items = nullptr;
+        size_t n = 0;
+        std::atomic<size_t> next{0};
+        uint64_t job = 0;
+        int busy = 0;
+        bool stop = false;
+        static void work(const SegCopy *it, size_t n, std::atomic<size_t> &next) {
+            for (;;) {
+                const size_t a = next.fetch_add(128, std::memory_order_relaxed);
+                if (a >= n) return;
+                const size_t b = std::min(n, a + 128);
+                for (size_t k = a; k < b; ++k) std::memcpy(it[k].dst, it[k].src, it[k].bytes);
+            }
+        }
+        void start(int threads) {
+            for (int t = 0; t < threads; ++t)
+                th.emplace_back([this] {
+                    uint64_t seen = 0;
+                    std::unique_lock<std::mutex> lk(m);
+                    for (;;) {
+                        cv_go.wait(lk, [&] { return stop || job != seen; });
+                        if (stop) return;
+                        seen = job;
+                        const SegCopy *it = items;
+                        const size_t cnt = n;
+                        lk.unlock();
+                        work(it, cnt, next);
+                        lk.lock();
+                        if (--busy == 0) cv_done.notify_one();
+                    }
+                });
+        }
+        void run(const SegCopy *it, size_t cnt) {
+            size_t bytes = 0;
+            for (size_t k = 0; k < cnt; ++k) bytes += it[k].bytes;
+            if (th.empty() || bytes < (256u << 10)) {
+                for (size_t k = 0; k < cnt; ++k) std::memcpy(it[k].dst, it[k].src, it[k].bytes);
+                return;
+            }
+            {
+                std::lock_guard<std::mutex> lk(m);
+                items = it;
+                n = cnt;
+                next.store(0, std::memory_order_relaxed);
+                busy = (int)th.size();
+                ++job;
+            }
+            cv_go.notify_all();
+            work(it, cnt, next);
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return busy == 0; });
+        }
+        ~CopyCrew() {
+            {
+                std::lock_guard<std::mutex> lk(m);
+                stop = true;
+            }
+            cv_go.notify_all();
+            for (auto &t : th) t.join();
+        }
+    } copy_crew;
     bool tick_segments = false;
     std::vector<SegState> seg_state;
     std::vector<double> h_start_prob;                // host copy of each slot's vad_start_probability (pre-roll rule :832-839)
@@ -508,6 +664,7 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
     e->open.assign((size_t)e->max_streams, 0);
     e->stamp.assign((size_t)e->max_streams, 0);
     e->tick_gen.assign((size_t)e->max_streams, 0);
+    e->slot_epoch.assign((size_t)e->max_streams, 0);
     e->h_start_prob.assign((size_t)e->max_streams, kDefaultSm.start_prob);
     e->free_list.reserve((size_t)e->max_streams);
     for (int64_t s = e->max_streams - 1; s >= 0; --s) e->free_list.push_back(s);
@@ -608,7 +765,7 @@ static int slot_control(vad_engine *e, const int64_t *slots, int64_t n, int op, 
             const size_t sl = (size_t)slots[i];
             if (op & 2) e->h_start_prob[sl] = kDefaultSm.start_prob;
             if (op & 8) e->h_start_prob[sl] = thr[nthr == 1 ? 0 : i].start_probability;
-            if ((op & (2 | 4)) && sl < e->seg_state.size()) e->seg_state[sl] = vad_engine::SegState();
+            if ((op & (2 | 4)) && sl < e->seg_state.size()) e->seg_state[sl].clear(e->seg_arena);
         }
     }
     HIP_TRY(e, hipMemcpyAsync(e->d_ctl, e->h_ctl, need, hipMemcpyHostToDevice, e->stream));
@@ -622,6 +779,23 @@ enum { CTL_ZERO_STATE = 1, CTL_DEFAULT_SM = 2, CTL_RESET_DYNAMIC = 4, CTL_SET_TH
 
 int vad_stream_open(vad_engine *e, int64_t *slot) { return vad_stream_open_many(e, 1, slot); }
 
+// everything the tick assembler holds for a slot: staged row, waiting frames, tails, segment audio (tick_mu held)
+static void tick_forget(vad_engine *e, int64_t slot) {
+    if (e->tick_overflow.erase(slot))
+        e->tick_overflow_order.erase(std::remove(e->tick_overflow_order.begin(), e->tick_overflow_order.end(), slot), e->tick_overflow_order.end());
+    e->tick_tails.erase(slot);
+    if ((size_t)slot < e->seg_state.size()) e->seg_state[(size_t)slot].clear(e->seg_arena);
+    if (e->tick_gen[(size_t)slot] == e->tick_generation) {
+        for (auto &tb : e->tick_buf[e->tick_cur])
+            for (int64_t r = 0; r < tb.count; ++r)
+                if (tb.slots()[r] == (int32_t)slot) {
+                    tb.drop_row(r);
+                    break;
+                }
+        e->tick_gen[(size_t)slot] = 0;
+    }
+}
+
 int vad_stream_open_many(vad_engine *e, int64_t n, int64_t *slots_out) {
     if (!e || n < 0 || (n > 0 && !slots_out)) return VAD_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
@@ -630,9 +804,16 @@ int vad_stream_open_many(vad_engine *e, int64_t n, int64_t *slots_out) {
                        e->open_count, (long long)n);
     for (int64_t i = 0; i < n; ++i) slots_out[i] = e->free_list[e->free_list.size() - 1 - (size_t)i];
     if (int rc = slot_control(e, slots_out, n, CTL_ZERO_STATE | CTL_DEFAULT_SM, nullptr, 0)) return rc;
-    for (int64_t i = 0; i < n; ++i) {
-        e->open[(size_t)e->free_list.back()] = 1;
-        e->free_list.pop_back();
+    {   // `open` is read by the tick's producers under tick_mu alone: written under both locks.  A recycled slot starts with
+        // nothing waiting, and a row it still has in a tick that is being run right now is recognised as stale by its epoch.
+        std::lock_guard<std::mutex> tl(e->tick_mu);
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t sl = e->free_list.back();
+            tick_forget(e, sl);
+            e->slot_epoch[(size_t)sl] += 1;
+            e->open[(size_t)sl] = 1;
+            e->free_list.pop_back();
+        }
     }
     e->open_count += (int)n;
     return VAD_OK;
@@ -643,7 +824,11 @@ int vad_stream_close(vad_engine *e, int64_t slot) {
     std::lock_guard<std::mutex> lk(e->mu);
     if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
         return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
-    e->open[(size_t)slot] = 0;
+    {
+        std::lock_guard<std::mutex> tl(e->tick_mu);
+        e->open[(size_t)slot] = 0;
+        tick_forget(e, slot);              // frames the client had waiting die with its stream
+    }
     e->open_count -= 1;
     e->free_list.push_back(slot);
     return VAD_OK;
@@ -714,6 +899,10 @@ int vad_stream_restore(vad_engine *e, int64_t slot, const void *buf, int64_t nby
                               hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->d_sm + slot, &s, sizeof s, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    {   // the tick's pre-roll rule reads the host copy of vad_start_probability
+        std::lock_guard<std::mutex> tl(e->tick_mu);
+        e->h_start_prob[(size_t)slot] = s.start_prob;
+    }
     return VAD_OK;
 }
 
@@ -818,11 +1007,23 @@ int vad_step_submit(vad_engine *e, const int64_t *slots, int64_t n, int32_t T, c
     int32_t *hs = reinterpret_cast<int32_t *>(pb.h_io);
     for (int64_t i = 0; i < n; ++i) hs[i] = (int32_t)slots[i];
     // in: slots + frames on the copy-in stream (true DMA when `frames` is page-locked: vad_host_alloc)
-    HIP_TRY(e, hipMemcpyAsync(pb.d_io, pb.h_io, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, e->copy_in));
-    HIP_TRY(e, hipMemcpyAsync(pb.d_frames, frames, fb, hipMemcpyHostToDevice, e->copy_in));
-    HIP_TRY(e, hipEventRecord(pb.copied, e->copy_in));
+    // from the first enqueued copy on, a failure must not leave `copy_in` reading the caller's frames (or this buffer) after
+    // the call returned: the error path waits for the copy stream before it reports
+    auto fail_after_copy = [&](int rc) {
+        (void)hipStreamSynchronize(e->copy_in);
+        (void)hipStreamSynchronize(e->stream);
+        return rc;
+    };
+#define HIP_TRY_PIPE(call)                                                          \
+    do {                                                                            \
+        hipError_t _r = (call);                                                     \
+        if (_r != hipSuccess) return fail_after_copy(e->hip_fail(_r, #call));       \
+    } while (0)
+    HIP_TRY_PIPE(hipMemcpyAsync(pb.d_io, pb.h_io, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, e->copy_in));
+    HIP_TRY_PIPE(hipMemcpyAsync(pb.d_frames, frames, fb, hipMemcpyHostToDevice, e->copy_in));
+    HIP_TRY_PIPE(hipEventRecord(pb.copied, e->copy_in));
     // compute: after the copy; kernels of successive tickets run in submission order on the engine's stream
-    HIP_TRY(e, hipStreamWaitEvent(e->stream, pb.copied, 0));
+    HIP_TRY_PIPE(hipStreamWaitEvent(e->stream, pb.copied, 0));
     vadk::StepParams p = e->base;
     p.slots = reinterpret_cast<const int32_t *>(pb.d_io);
     p.frames = pb.d_frames;
@@ -833,13 +1034,15 @@ int vad_step_submit(vad_engine *e, const int64_t *slots, int64_t n, int32_t T, c
     p.T = T;
     p.fmt = fmt;
     p.thresh = thr;
-    if (int rc = launch(e, p, e->stream)) return rc;
-    HIP_TRY(e, hipEventRecord(pb.done, e->stream));
+    if (int rc = launch(e, p, e->stream)) return fail_after_copy(rc);
+    HIP_TRY_PIPE(hipEventRecord(pb.done, e->stream));
     // out: probs | seg | events as one block on the copy-out stream
-    HIP_TRY(e, hipStreamWaitEvent(e->copy_out, pb.done, 0));
-    HIP_TRY(e, hipMemcpyAsync(pb.h_io + o_probs, pb.d_io + o_probs, io_bytes - o_probs, hipMemcpyDeviceToHost, e->copy_out));
-    HIP_TRY(e, hipEventRecord(pb.out, e->copy_out));
+    HIP_TRY_PIPE(hipStreamWaitEvent(e->copy_out, pb.done, 0));
+    HIP_TRY_PIPE(hipMemcpyAsync(pb.h_io + o_probs, pb.d_io + o_probs, io_bytes - o_probs, hipMemcpyDeviceToHost, e->copy_out));
+    HIP_TRY_PIPE(hipEventRecord(pb.out, e->copy_out));
+#undef HIP_TRY_PIPE
     pb.busy = true;
+    pb.collecting = false;
     pb.ticket = e->next_ticket;
     pb.n = n;
     pb.T = T;
@@ -855,15 +1058,17 @@ int vad_step_collect(vad_engine *e, int64_t ticket, float *probs_out, uint8_t *e
         std::lock_guard<std::mutex> lk(e->mu);
         if (ticket < 0) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: bad ticket");
         pb = &e->pipe[ticket % vad_engine::PIPE_DEPTH];
-        if (!pb->busy || pb->ticket != ticket)
+        if (!pb->busy || pb->ticket != ticket || pb->collecting)
             return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: ticket %lld is not outstanding", (long long)ticket);
         if (!probs_out) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: probs_out is null");
+        pb->collecting = true;         // a second collect of this ticket from another thread is refused, not raced
         out_ev = pb->out;
     }
     // wait WITHOUT the engine's mutex: another thread may submit the next ticket meanwhile (that is the overlap)
     hipError_t r = hipEventSynchronize(out_ev);
     std::lock_guard<std::mutex> lk(e->mu);
     pb->busy = false;
+    pb->collecting = false;
     if (r != hipSuccess) return e->hip_fail(r, "hipEventSynchronize(ticket)");
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t n = (size_t)pb->n, T = (size_t)pb->T;
@@ -1322,12 +1527,13 @@ int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsample
         if (cap <= tb.cap) return e->fail(VAD_ERR_INVALID_ARG, "tick: more pending frames than slots");
         uint8_t *nh = nullptr;
         hipError_t r = hipSetDevice(e->device);
-        if (r == hipSuccess) r = hipHostMalloc((void **)&nh, (size_t)cap * (rb + 2 * sizeof(int32_t)), hipHostMallocDefault);
+        if (r == hipSuccess) r = hipHostMalloc((void **)&nh, (size_t)cap * (rb + 3 * sizeof(int32_t)), hipHostMallocDefault);
         if (r != hipSuccess) return e->hip_fail(r, "hipHostMalloc(tick staging)");
         if (tb.count) {
             std::memcpy(nh, tb.h, (size_t)tb.count * rb);
             std::memcpy(nh + (size_t)cap * rb, tb.slots(), sizeof(int32_t) * (size_t)tb.count);
             std::memcpy(nh + (size_t)cap * (rb + sizeof(int32_t)), tb.lens(), sizeof(int32_t) * (size_t)tb.count);
+            std::memcpy(nh + (size_t)cap * (rb + 2 * sizeof(int32_t)), tb.epochs(), sizeof(int32_t) * (size_t)tb.count);
         }
         if (tb.h) (void)hipHostFree(tb.h);
         tb.h = nh;
@@ -1345,8 +1551,30 @@ int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsample
     }
     tb.slots()[tb.count] = (int32_t)slot;
     tb.lens()[tb.count] = nsamples;
+    tb.epochs()[tb.count] = e->slot_epoch[(size_t)slot];
     tb.count += 1;
     e->tick_gen[(size_t)slot] = e->tick_generation;
+    return VAD_OK;
+}
+
+// a frame at the engine's own rate (tick_mu held, arguments checked)
+int tick_push_locked(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int group) {
+    if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
+        return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
+    if (e->tick_gen[(size_t)slot] != e->tick_generation) return tick_place(e, slot, samples, nsamples, group);
+    // the slot already has its frame of the coming tick: later frames wait their turn (one per tick, submission order)
+    auto it = e->tick_overflow.find(slot);
+    if (it == e->tick_overflow.end()) {
+        it = e->tick_overflow.emplace(slot, std::deque<vad_engine::TickPending>()).first;
+        e->tick_overflow_order.push_back(slot);
+    }
+    auto &q = it->second;
+    if (q.size() >= 256) return e->fail(VAD_ERR_BUSY, "tick: slot %lld has 256 frames waiting - is vad_tick_run being called?", (long long)slot);
+    const size_t ss = vad_engine::tick_sample_bytes(group);
+    const int flen = vad_engine::tick_group_len(group, e->frame_samples);
+    const int32_t keep = e->tick_segments ? nsamples : std::min<int32_t>(nsamples, flen);
+    const uint8_t *src = static_cast<const uint8_t *>(samples);
+    q.push_back(vad_engine::TickPending{std::vector<uint8_t>(src, src + ss * (size_t)keep), nsamples, group});
     return VAD_OK;
 }
 }  // namespace
@@ -1356,38 +1584,30 @@ int vad_tick_push(vad_engine *e, int64_t slot, const void *samples, int32_t nsam
     std::lock_guard<std::mutex> lk(e->tick_mu);
     if (!samples || nsamples < 1 || frame_fmt < VAD_FMT_F32 || frame_fmt > VAD_FMT_I16_32768)
         return e->fail(VAD_ERR_INVALID_ARG, "tick: null frame, empty frame or unknown format");
-    if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
-        return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
-    const int group = frame_fmt * 2 + (gate_on ? 1 : 0);
-    if (e->tick_gen[(size_t)slot] != e->tick_generation) return tick_place(e, slot, samples, nsamples, group);
-    // the slot already has its frame of the coming tick: later frames wait their turn (one per tick, submission order)
-    auto &q = e->tick_overflow[slot];
-    if (q.size() >= 256) return e->fail(VAD_ERR_BUSY, "tick: slot %lld has 256 frames waiting - is vad_tick_run being called?", (long long)slot);
-    const size_t ss = frame_fmt == VAD_FMT_F32 ? 4 : 2;
-    const int32_t keep = e->tick_segments ? nsamples : std::min<int32_t>(nsamples, e->frame_samples);
-    const uint8_t *src = static_cast<const uint8_t *>(samples);
-    q.push_back(vad_engine::TickPending{std::vector<uint8_t>(src, src + ss * (size_t)keep), nsamples, group});
-    return VAD_OK;
+    return tick_push_locked(e, slot, samples, nsamples, frame_fmt, frame_fmt * 2 + (gate_on ? 1 : 0));
 }
 
 int vad_tick_push_rate(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int gate_on, int32_t sr_in) {
     if (!e) return VAD_ERR_INVALID_ARG;
     if (sr_in == e->sample_rate) return vad_tick_push(e, slot, samples, nsamples, frame_fmt, gate_on);
-    std::lock_guard<std::mutex> lk(e->tick_mu);
-    if (!samples || nsamples < 1 || frame_fmt < VAD_FMT_F32 || frame_fmt > VAD_FMT_I16_32768)
+    if (!samples || nsamples < 1 || frame_fmt < VAD_FMT_F32 || frame_fmt > VAD_FMT_I16_32768) {
+        std::lock_guard<std::mutex> lk(e->tick_mu);
         return e->fail(VAD_ERR_INVALID_ARG, "tick: null frame, empty frame or unknown format");
-    if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
-        return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
-    if (e->frame_samples != VAD_FRAME_SAMPLES || e->sample_rate != 16000)
+    }
+    if (e->frame_samples != VAD_FRAME_SAMPLES || e->sample_rate != 16000) {
+        std::lock_guard<std::mutex> lk(e->tick_mu);
         return e->fail(VAD_ERR_UNSUPPORTED, "Failed to resample audio: resampled streams need a 16 kHz engine");
+    }
     const int ri = sr_in == 8000 ? 0 : sr_in == 24000 ? 1 : sr_in == 48000 ? 2 : -1;
-    if (ri < 0)
-        return e->fail(VAD_ERR_UNSUPPORTED, "Failed to resample audio from %dHz to 16000Hz: supported input rates are 8000, 24000, 48000", sr_in);
-    const int group = 6 + 3 * (gate_on ? 1 : 0) + ri;
+    const int group = 6 + 3 * (gate_on ? 1 : 0) + (ri < 0 ? 0 : ri);
     const int want = vad_engine::tick_group_len(group, e->frame_samples);
-    if (nsamples != want)
+    if (ri < 0 || nsamples != want) {
+        std::lock_guard<std::mutex> lk(e->tick_mu);
+        if (ri < 0)
+            return e->fail(VAD_ERR_UNSUPPORTED, "Failed to resample audio from %dHz to 16000Hz: supported input rates are 8000, 24000, 48000", sr_in);
         return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio from %dHz to 16000Hz: a chunk must hold %d samples, got %d", sr_in, want, nsamples);
-    // staged as float32 (the resampler's input type): int16 wire frames are scaled here, with numpy's true division
+    }
+    // staged as float32 (the resampler's input type): int16 wire frames are scaled here - before the lock - with numpy's true division
     thread_local std::vector<float> cvt;
     const float *src = static_cast<const float *>(samples);
     if (frame_fmt != VAD_FMT_F32) {
@@ -1397,19 +1617,30 @@ int vad_tick_push_rate(vad_engine *e, int64_t slot, const void *samples, int32_t
         for (int32_t k = 0; k < nsamples; ++k) cvt[(size_t)k] = (float)q[k] / sc;
         src = cvt.data();
     }
-    if (e->tick_gen[(size_t)slot] != e->tick_generation) return tick_place(e, slot, src, nsamples, group);
-    auto &q = e->tick_overflow[slot];
-    if (q.size() >= 256) return e->fail(VAD_ERR_BUSY, "tick: slot %lld has 256 frames waiting - is vad_tick_run being called?", (long long)slot);
-    const uint8_t *b = reinterpret_cast<const uint8_t *>(src);
-    q.push_back(vad_engine::TickPending{std::vector<uint8_t>(b, b + 4 * (size_t)nsamples), nsamples, group});
-    return VAD_OK;
+    std::lock_guard<std::mutex> lk(e->tick_mu);
+    return tick_push_locked(e, slot, src, nsamples, VAD_FMT_F32, group);
 }
 
 int vad_tick_enable_segments(vad_engine *e, int on) {
     if (!e) return VAD_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->tick_mu);
     e->tick_segments = on != 0;
-    if (e->tick_segments && e->seg_state.size() < (size_t)e->max_streams) e->seg_state.resize((size_t)e->max_streams);
+    if (e->tick_segments) {
+        if (e->seg_state.size() < (size_t)e->max_streams) e->seg_state.resize((size_t)e->max_streams);
+        // one block per stream up to 64 MB, touched now; the arena grows by 8 MB chunks after that
+        try {
+            e->seg_arena.reserve_blocks(std::min<size_t>((size_t)e->max_streams, 2048));
+        } catch (const std::bad_alloc &) {
+            return e->fail(VAD_ERR_INVALID_ARG, "tick: out of host memory for the segment arena");
+        }
+        if (e->copy_crew.th.empty()) {
+            int want = 3;
+            if (const char *v = std::getenv("VAD_TICK_COPY_THREADS")) want = std::max(0, std::min(16, std::atoi(v)));
+            const unsigned hw = std::thread::hardware_concurrency();
+            if (hw && (int)hw / 2 < want + 1) want = std::max(0, (int)hw / 2 - 1);
+            e->copy_crew.start(want);
+        }
+    }
     return VAD_OK;
 }
 
@@ -1422,113 +1653,149 @@ int vad_tick_take_segment(vad_engine *e, int64_t slot, float *out, int64_t cap, 
     if (!out) return VAD_OK;                       // size query
     if (cap < d.samples) return e->fail(VAD_ERR_INVALID_ARG, "segment buffer too small (%lld < %lld samples)", (long long)cap, (long long)d.samples);
     d.to_float(out);
-    vad_engine::SegAudio().swap(d);
+    d.clear(e->seg_arena);
     return VAD_OK;
 }
 
 int vad_tick_push_many(vad_engine *e, const int64_t *slots, int64_t n, const void *frames, int32_t nsamples, int frame_fmt, int gate_on) {
     if (!e || n < 0 || (n > 0 && (!slots || !frames))) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->tick_mu);             // one lock for the batch
+    if (n > 0 && (nsamples < 1 || frame_fmt < VAD_FMT_F32 || frame_fmt > VAD_FMT_I16_32768))
+        return e->fail(VAD_ERR_INVALID_ARG, "tick: empty frame or unknown format");
     const size_t stride = (frame_fmt == VAD_FMT_F32 ? 4 : 2) * (size_t)(nsamples > 0 ? nsamples : 0);
+    const int group = frame_fmt * 2 + (gate_on ? 1 : 0);
     for (int64_t i = 0; i < n; ++i)
-        if (int rc = vad_tick_push(e, slots[i], static_cast<const uint8_t *>(frames) + (size_t)i * stride, nsamples, frame_fmt, gate_on)) return rc;
+        if (int rc = tick_push_locked(e, slots[i], static_cast<const uint8_t *>(frames) + (size_t)i * stride, nsamples, frame_fmt, group)) return rc;
     return VAD_OK;
+}
+
+int vad_tick_push_status(vad_engine *e, const int64_t *slots, int64_t n, const void *frames, int32_t nsamples, int frame_fmt, int gate_on,
+                         int32_t *status) {
+    if (!e || n < 0 || (n > 0 && (!slots || !frames || !status))) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->tick_mu);
+    if (n > 0 && (nsamples < 1 || frame_fmt < VAD_FMT_F32 || frame_fmt > VAD_FMT_I16_32768))
+        return e->fail(VAD_ERR_INVALID_ARG, "tick: empty frame or unknown format");
+    const size_t stride = (frame_fmt == VAD_FMT_F32 ? 4 : 2) * (size_t)(nsamples > 0 ? nsamples : 0);
+    const int group = frame_fmt * 2 + (gate_on ? 1 : 0);
+    int first = VAD_OK;
+    for (int64_t i = 0; i < n; ++i) {           // every frame is tried: one full queue or one closed stream does not hold the others back
+        status[i] = tick_push_locked(e, slots[i], static_cast<const uint8_t *>(frames) + (size_t)i * stride, nsamples, frame_fmt, group);
+        if (status[i] != VAD_OK && first == VAD_OK) first = status[i];
+    }
+    return first;
 }
 
 int vad_tick_cancel(vad_engine *e, int64_t slot) {
     if (!e) return VAD_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->tick_mu);
     if (slot < 0 || slot >= e->max_streams) return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is out of range", (long long)slot);
-    e->tick_overflow.erase(slot);
-    e->tick_tails.erase(slot);
-    if ((size_t)slot < e->seg_state.size()) e->seg_state[(size_t)slot] = vad_engine::SegState();
-    if (e->tick_gen[(size_t)slot] == e->tick_generation) {
-        for (auto &tb : e->tick_buf[e->tick_cur])
-            for (int64_t r = 0; r < tb.count; ++r)
-                if (tb.slots()[r] == (int32_t)slot) {          // the last row fills the hole
-                    const int64_t last = tb.count - 1;
-                    if (r != last) {
-                        std::memcpy(tb.row(r), tb.row(last), tb.row_bytes);
-                        tb.slots()[r] = tb.slots()[last];
-                        tb.lens()[r] = tb.lens()[last];
-                    }
-                    tb.count = last;
-                    break;
-                }
-        e->tick_gen[(size_t)slot] = 0;
+    tick_forget(e, slot);
+    return VAD_OK;
+}
+
+int vad_tick_pending(vad_engine *e, int64_t slot, int64_t *frames) {
+    if (!e || !frames) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->tick_mu);
+    if (slot < 0 || slot >= e->max_streams) return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is out of range", (long long)slot);
+    auto it = e->tick_overflow.find(slot);
+    *frames = (e->tick_gen[(size_t)slot] == e->tick_generation ? 1 : 0) + (it == e->tick_overflow.end() ? 0 : (int64_t)it->second.size());
+    return VAD_OK;
+}
+
+// ---- a stream's segment audio as bytes: what moves with vad_stream_save when a session changes engines ------------------------
+namespace {
+struct SegBlobHeader { uint32_t magic, active; uint32_t nruns[3]; uint32_t pad; uint64_t bytes[3]; };
+constexpr uint32_t SEG_BLOB_MAGIC = 0x31474553u;       // "SEG1"
+}  // namespace
+
+int vad_tick_segment_save(vad_engine *e, int64_t slot, void *buf, int64_t cap, int64_t *nbytes) {
+    if (!e || !nbytes) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->tick_mu);
+    if (slot < 0 || slot >= e->max_streams) return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is out of range", (long long)slot);
+    static const vad_engine::SegState none;
+    const vad_engine::SegState &st = (size_t)slot < e->seg_state.size() ? e->seg_state[(size_t)slot] : none;
+    const vad_engine::SegAudio *parts[3] = {&st.pre, &st.seg, &st.done};
+    SegBlobHeader h{};
+    h.magic = SEG_BLOB_MAGIC;
+    h.active = st.active ? 1u : 0u;
+    size_t total = sizeof h;
+    for (int k = 0; k < 3; ++k) {
+        h.nruns[k] = (uint32_t)parts[k]->runs.size();
+        h.bytes[k] = parts[k]->stored_bytes();
+        total += parts[k]->runs.size() * sizeof(vad_engine::SegAudio::Run) + (size_t)h.bytes[k];
+    }
+    *nbytes = (int64_t)total;
+    if (!buf) return VAD_OK;                       // size query
+    if (cap < (int64_t)total) return e->fail(VAD_ERR_INVALID_ARG, "segment save buffer too small (%lld < %lld bytes)", (long long)cap, (long long)total);
+    uint8_t *o = static_cast<uint8_t *>(buf);
+    std::memcpy(o, &h, sizeof h);
+    o += sizeof h;
+    for (int k = 0; k < 3; ++k) {
+        if (!parts[k]->runs.empty()) std::memcpy(o, parts[k]->runs.data(), parts[k]->runs.size() * sizeof(vad_engine::SegAudio::Run));
+        o += parts[k]->runs.size() * sizeof(vad_engine::SegAudio::Run);
+        parts[k]->for_each_piece([&](const vad_engine::SegAudio::Run &r, const uint8_t *src, size_t cnt) {
+            const size_t b = cnt * (vad_engine::SegAudio::is_i16(r.group) ? 2 : 4);
+            std::memcpy(o, src, b);
+            o += b;
+        });
     }
     return VAD_OK;
 }
 
-int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
-    if (!e || !out || out->struct_size < sizeof(vad_tick_result)) return VAD_ERR_INVALID_ARG;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
-        return (float)std::chrono::duration<double, std::micro>(b2 - a).count();
-    };
-    const auto t0 = now();
-    out->host_us[0] = out->host_us[1] = out->host_us[2] = 0.f;
-    int b;
-    {   // swap the staging buffers; every slot that has more frames waiting gets its next one into the new buffer
-        std::lock_guard<std::mutex> lk(e->tick_mu);
-        b = e->tick_cur;
-        e->tick_cur ^= 1;
-        for (auto &tb : e->tick_buf[e->tick_cur]) tb.count = 0;
-        if (++e->tick_generation == 0) {
-            std::fill(e->tick_gen.begin(), e->tick_gen.end(), 0u);
-            e->tick_generation = 1;
+int vad_tick_segment_restore(vad_engine *e, int64_t slot, const void *buf, int64_t nbytes) {
+    if (!e || !buf) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->tick_mu);
+    if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
+        return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
+    SegBlobHeader h;
+    if (nbytes < (int64_t)sizeof h) return e->fail(VAD_ERR_INVALID_ARG, "not a segment save blob (%lld bytes)", (long long)nbytes);
+    std::memcpy(&h, buf, sizeof h);
+    size_t total = sizeof h;
+    for (int k = 0; k < 3; ++k) total += (size_t)h.nruns[k] * sizeof(vad_engine::SegAudio::Run) + (size_t)h.bytes[k];
+    if (h.magic != SEG_BLOB_MAGIC || h.active > 1 || (int64_t)total != nbytes) return e->fail(VAD_ERR_INVALID_ARG, "corrupt segment save blob");
+    // check the runs against the byte counts before touching the slot
+    const uint8_t *p = static_cast<const uint8_t *>(buf) + sizeof h;
+    for (int k = 0; k < 3; ++k) {
+        size_t want = 0;
+        for (uint32_t r = 0; r < h.nruns[k]; ++r) {
+            vad_engine::SegAudio::Run run;
+            std::memcpy(&run, p + (size_t)r * sizeof run, sizeof run);
+            if (run.group < 0 || run.group >= vad_engine::TICK_GROUPS || run.samples < 1) return e->fail(VAD_ERR_INVALID_ARG, "corrupt segment save blob");
+            want += (size_t)run.samples * (vad_engine::SegAudio::is_i16(run.group) ? 2 : 4);
         }
-        for (auto it = e->tick_overflow.begin(); it != e->tick_overflow.end();) {
-            vad_engine::TickPending &p = it->second.front();
-            if (int rc = tick_place(e, it->first, p.data.data(), (int32_t)(p.data.size() / vad_engine::tick_sample_bytes(p.group)), p.group)) return rc;
-            e->tick_buf[e->tick_cur][p.group].lens()[e->tick_buf[e->tick_cur][p.group].count - 1] = p.nsamples;
-            it->second.pop_front();
-            it = it->second.empty() ? e->tick_overflow.erase(it) : std::next(it);
+        if (want != (size_t)h.bytes[k]) return e->fail(VAD_ERR_INVALID_ARG, "corrupt segment save blob");
+        p += (size_t)h.nruns[k] * sizeof(vad_engine::SegAudio::Run) + (size_t)h.bytes[k];
+    }
+    if (e->seg_state.size() < (size_t)e->max_streams) e->seg_state.resize((size_t)e->max_streams);
+    vad_engine::SegState &st = e->seg_state[(size_t)slot];
+    st.clear(e->seg_arena);
+    st.active = h.active != 0;
+    vad_engine::SegAudio *parts[3] = {&st.pre, &st.seg, &st.done};
+    p = static_cast<const uint8_t *>(buf) + sizeof h;
+    try {
+        for (int k = 0; k < 3; ++k) {
+            const uint8_t *runs = p, *data = p + (size_t)h.nruns[k] * sizeof(vad_engine::SegAudio::Run);
+            for (uint32_t r = 0; r < h.nruns[k]; ++r) {
+                vad_engine::SegAudio::Run run;
+                std::memcpy(&run, runs + (size_t)r * sizeof run, sizeof run);
+                parts[k]->append(e->seg_arena, run.group, run.thr, data, (size_t)run.samples, nullptr);
+                data += (size_t)run.samples * (vad_engine::SegAudio::is_i16(run.group) ? 2 : 4);
+            }
+            p = data;
         }
+    } catch (const std::bad_alloc &) {
+        st.clear(e->seg_arena);
+        return e->fail(VAD_ERR_INVALID_ARG, "tick: out of host memory for the segment arena");
     }
-    std::lock_guard<std::mutex> lk(e->mu);
-    const auto t1 = now();
-    out->host_us[0] = us(t0, t1);
-    vad_engine::TickBuf *tbs = e->tick_buf[b];
-    int64_t total = 0;
-    size_t frame_total = 0;
-    for (int g = 0; g < vad_engine::TICK_GROUPS; ++g) {
-        out->group_start[g] = total;
-        out->group_frames[g] = tbs[g].count ? tbs[g].h : nullptr;
-        total += tbs[g].count;
-        frame_total += ((size_t)tbs[g].count * tbs[g].row_bytes + 255) & ~(size_t)255;
-    }
-    out->group_start[vad_engine::TICK_GROUPS] = total;
-    out->n = total;
-    out->slots = nullptr; out->probs = nullptr; out->events = nullptr; out->seg_frames = nullptr; out->nsamples = nullptr;
-    if (total == 0) return VAD_OK;
-    HIP_TRY(e, hipSetDevice(e->device));
-    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    const size_t o_probs = up16(sizeof(int64_t) * (size_t)total), o_seg = o_probs + up16(sizeof(float) * (size_t)total);
-    const size_t o_ev = o_seg + up16(sizeof(int32_t) * (size_t)total), o_s32 = o_ev + up16((size_t)total);
-    const size_t o_len = o_s32 + up16(sizeof(int32_t) * (size_t)total);
-    const size_t out_bytes = o_len + up16(sizeof(int32_t) * (size_t)total);
-    if (out_bytes > e->tick_out_cap) {
-        const size_t cap = std::max(out_bytes, (size_t)e->max_streams * 28 + 128);
-        if (e->h_tick_out) (void)hipHostFree(e->h_tick_out);
-        if (e->d_tick_out) (void)hipFree(e->d_tick_out);
-        e->h_tick_out = e->d_tick_out = nullptr;
-        e->tick_out_cap = 0;
-        HIP_TRY(e, hipHostMalloc((void **)&e->h_tick_out, cap, hipHostMallocDefault));
-        HIP_TRY(e, hipMalloc((void **)&e->d_tick_out, cap));
-        e->tick_out_cap = cap;
-    }
+    return VAD_OK;
+}
+
+namespace {
+// the HIP half of a tick: copies in, launches, results back (mu held).  Fills the result pointers on success.
+int tick_execute(vad_engine *e, vad_engine::TickBuf *tbs, float denoise_thresh, vad_tick_result *out, int64_t total, size_t frame_total,
+                 size_t o_probs, size_t o_seg, size_t o_ev, size_t o_s32) {
     if (int rc = ensure(e, e->d_tick_frames, e->d_tick_frames_cap, frame_total)) return rc;
-    int64_t *h_slots = reinterpret_cast<int64_t *>(e->h_tick_out);
-    int32_t *h_s32 = reinterpret_cast<int32_t *>(e->h_tick_out + o_s32);
-    for (int g = 0; g < vad_engine::TICK_GROUPS; ++g)
-        for (int64_t r = 0; r < tbs[g].count; ++r) {
-            const int32_t sl = tbs[g].slots()[r];
-            if (sl < 0 || sl >= e->max_streams || !e->open[(size_t)sl])
-                return e->fail(VAD_ERR_BAD_SLOT, "tick: slot %d was closed with a frame pending (vad_tick_cancel it first)", sl);
-            h_slots[out->group_start[g] + r] = sl;
-            h_s32[out->group_start[g] + r] = sl;
-            reinterpret_cast<int32_t *>(e->h_tick_out + o_len)[out->group_start[g] + r] = tbs[g].lens()[r];
-        }
+    const int32_t *h_s32 = reinterpret_cast<const int32_t *>(e->h_tick_out + o_s32);
     HIP_TRY(e, hipMemcpyAsync(e->d_tick_out + o_s32, h_s32, sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, e->stream));
     size_t foff = 0;
     const float *d_rate_in[vad_engine::TICK_GROUPS] = {};
@@ -1576,53 +1843,182 @@ int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
     }
     HIP_TRY(e, hipMemcpyAsync(e->h_tick_out + o_probs, e->d_tick_out + o_probs, o_s32 - o_probs, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return VAD_OK;
+}
+}  // namespace
+
+int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
+    if (!e || !out || out->struct_size < sizeof(vad_tick_result)) return VAD_ERR_INVALID_ARG;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
+        return (float)std::chrono::duration<double, std::micro>(b2 - a).count();
+    };
+    const auto t0 = now();
+    out->host_us[0] = out->host_us[1] = out->host_us[2] = 0.f;
+    out->n = 0;
+    out->dropped = 0;
+    out->slots = nullptr; out->probs = nullptr; out->events = nullptr; out->seg_frames = nullptr; out->nsamples = nullptr;
+    for (int g = 0; g < vad_engine::TICK_GROUPS; ++g) { out->group_start[g] = 0; out->group_frames[g] = nullptr; }
+    out->group_start[vad_engine::TICK_GROUPS] = 0;
+    // `mu` first (lock order), for the whole tick: slots cannot be opened or closed under it
+    std::lock_guard<std::mutex> lk(e->mu);
+    int b;
+    vad_engine::TickBuf *tbs;
+    {   // swap the staging buffers; every slot that has more frames waiting gets its next one into the new buffer, in the order
+        // the slots started waiting; rows whose stream was closed (or closed and reopened) since the push are dropped
+        std::lock_guard<std::mutex> tl(e->tick_mu);
+        b = e->tick_cur;
+        tbs = e->tick_buf[b];
+        for (int g = 0; g < vad_engine::TICK_GROUPS; ++g)
+            for (int64_t r = 0; r < tbs[g].count;) {
+                const int32_t sl = tbs[g].slots()[r];
+                if (sl >= 0 && sl < e->max_streams && e->open[(size_t)sl] && tbs[g].epochs()[r] == e->slot_epoch[(size_t)sl]) { ++r; continue; }
+                tbs[g].drop_row(r);                            // (close and open forget the slot's tick state, so this is belt and braces)
+                out->dropped += 1;
+            }
+        e->tick_cur ^= 1;
+        for (auto &tb : e->tick_buf[e->tick_cur]) tb.count = 0;
+        if (++e->tick_generation == 0) {
+            std::fill(e->tick_gen.begin(), e->tick_gen.end(), 0u);
+            e->tick_generation = 1;
+        }
+        size_t keep = 0;
+        for (size_t k = 0; k < e->tick_overflow_order.size(); ++k) {
+            const int64_t sl = e->tick_overflow_order[k];
+            auto it = e->tick_overflow.find(sl);
+            if (it == e->tick_overflow.end() || it->second.empty()) {
+                if (it != e->tick_overflow.end()) e->tick_overflow.erase(it);
+                continue;
+            }
+            vad_engine::TickPending &p = it->second.front();
+            if (tick_place(e, sl, p.data.data(), (int32_t)(p.data.size() / vad_engine::tick_sample_bytes(p.group)), p.group) == VAD_OK) {
+                vad_engine::TickBuf &nb = e->tick_buf[e->tick_cur][p.group];
+                nb.lens()[nb.count - 1] = p.nsamples;
+                it->second.pop_front();
+            }                                                   // (a failed placement - pinned memory exhausted - leaves the frame waiting)
+            if (it->second.empty()) e->tick_overflow.erase(it);
+            else e->tick_overflow_order[keep++] = sl;
+        }
+        e->tick_overflow_order.resize(keep);
+    }
+    const auto t1 = now();
+    out->host_us[0] = us(t0, t1);
+    int64_t total = 0;
+    size_t frame_total = 0;
+    for (int g = 0; g < vad_engine::TICK_GROUPS; ++g) {
+        out->group_start[g] = total;
+        out->group_frames[g] = tbs[g].count ? tbs[g].h : nullptr;
+        total += tbs[g].count;
+        frame_total += ((size_t)tbs[g].count * tbs[g].row_bytes + 255) & ~(size_t)255;
+    }
+    out->group_start[vad_engine::TICK_GROUPS] = total;
+    if (total == 0) return VAD_OK;
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_probs = up16(sizeof(int64_t) * (size_t)total), o_seg = o_probs + up16(sizeof(float) * (size_t)total);
+    const size_t o_ev = o_seg + up16(sizeof(int32_t) * (size_t)total), o_s32 = o_ev + up16((size_t)total);
+    const size_t o_len = o_s32 + up16(sizeof(int32_t) * (size_t)total);
+    const size_t out_bytes = o_len + up16(sizeof(int32_t) * (size_t)total);
+    // a tick that fails from here on has consumed its frames: the tails that belong to them go too, so that the slots' queues
+    // stay aligned, and the caller is told which streams lost a frame (slots / nsamples / n are valid on failure, probs is NULL)
+    auto lost = [&](int rc) {
+        std::lock_guard<std::mutex> tl(e->tick_mu);
+        for (int g = 0; g < vad_engine::TICK_GROUPS; ++g) {
+            const int flen = vad_engine::tick_group_len(g, e->frame_samples);
+            for (int64_t r = 0; r < tbs[g].count; ++r)
+                if (tbs[g].lens()[r] > flen) {
+                    auto it = e->tick_tails.find(tbs[g].slots()[r]);
+                    if (it != e->tick_tails.end() && !it->second.empty()) it->second.pop_front();
+                }
+        }
+        out->probs = nullptr; out->events = nullptr; out->seg_frames = nullptr;
+        return rc;
+    };
+    hipError_t hr = hipSetDevice(e->device);
+    if (hr == hipSuccess && out_bytes > e->tick_out_cap) {
+        const size_t cap = std::max(out_bytes, (size_t)e->max_streams * 28 + 128);
+        if (e->h_tick_out) (void)hipHostFree(e->h_tick_out);
+        if (e->d_tick_out) (void)hipFree(e->d_tick_out);
+        e->h_tick_out = e->d_tick_out = nullptr;
+        e->tick_out_cap = 0;
+        hr = hipHostMalloc((void **)&e->h_tick_out, cap, hipHostMallocDefault);
+        if (hr == hipSuccess) hr = hipMalloc((void **)&e->d_tick_out, cap);
+        if (hr == hipSuccess) e->tick_out_cap = cap;
+    }
+    if (hr != hipSuccess) return lost(e->hip_fail(hr, "tick: result buffers"));
+    int64_t *h_slots = reinterpret_cast<int64_t *>(e->h_tick_out);
+    int32_t *h_s32 = reinterpret_cast<int32_t *>(e->h_tick_out + o_s32);
+    int32_t *h_len = reinterpret_cast<int32_t *>(e->h_tick_out + o_len);
+    for (int g = 0; g < vad_engine::TICK_GROUPS; ++g)
+        for (int64_t r = 0; r < tbs[g].count; ++r) {
+            const int32_t sl = tbs[g].slots()[r];
+            h_slots[out->group_start[g] + r] = sl;
+            h_s32[out->group_start[g] + r] = sl;
+            h_len[out->group_start[g] + r] = tbs[g].lens()[r];
+        }
+    out->n = total;
     out->slots = h_slots;
+    out->nsamples = h_len;
+    if (int rc = tick_execute(e, tbs, denoise_thresh, out, total, frame_total, o_probs, o_seg, o_ev, o_s32)) return lost(rc);
     out->probs = reinterpret_cast<const float *>(e->h_tick_out + o_probs);
     out->seg_frames = reinterpret_cast<const int32_t *>(e->h_tick_out + o_seg);
     out->events = e->h_tick_out + o_ev;
-    out->nsamples = reinterpret_cast<const int32_t *>(e->h_tick_out + o_len);
     const auto t2 = now();
     out->host_us[1] = us(t1, t2);
     if (e->tick_segments) {
-        // the host half of _process_voice_state, per stepped stream, on the staged audio: float32, gated like the model's input
-        // (utils/audio.py:117-118) when the group's gate is on
+        // the host half of _process_voice_state, per stepped stream, on the staged audio (kept in its wire format; float32 and
+        // the gate of utils/audio.py:117-118 are applied when the finished segment is taken).  This pass decides and PLANS -
+        // which buffer a frame goes to, which block and offset - and the copies themselves then run on the copy crew.
         std::lock_guard<std::mutex> tl(e->tick_mu);
         if (e->seg_state.size() < (size_t)e->max_streams) e->seg_state.resize((size_t)e->max_streams);
-        for (int g = 0; g < vad_engine::TICK_GROUPS; ++g) {
-            for (int64_t r = 0; r < tbs[g].count; ++r) {
-                const int64_t i = out->group_start[g] + r;
-                const size_t sl = (size_t)h_slots[i];
-                vad_engine::SegState &st = e->seg_state[sl];
-                const int ev = out->events[i];
-                const bool above = (double)out->probs[i] >= e->h_start_prob[sl];
-                const int32_t L = tbs[g].lens()[r];
+        std::vector<vad_engine::SegCopy> &plan = e->seg_copies;
+        plan.clear();
+        std::vector<std::vector<uint8_t>> spent;               // tails whose bytes the plan still points into
+        try {
+            for (int g = 0; g < vad_engine::TICK_GROUPS; ++g) {
                 const int flen = vad_engine::tick_group_len(g, e->frame_samples);
-                const bool is_long = L > flen;
-                std::deque<std::vector<uint8_t>> *tails = is_long ? &e->tick_tails[(int64_t)sl] : nullptr;
-                if (!st.active && !above) {                                            // idle stream: nothing is kept (:873-874)
-                    st.pre.clear();
-                    if (tails && !tails->empty()) tails->pop_front();
-                    continue;
-                }
-                vad_engine::SegAudio &dst = st.active ? st.seg : st.pre;               // :891 / :838-839
-                dst.append(g, denoise_thresh, tbs[g].row(r), (size_t)std::min<int32_t>(L, flen));
-                if (tails && !tails->empty()) {
-                    dst.append(g, denoise_thresh, tails->front().data(), tails->front().size() / vad_engine::tick_sample_bytes(g));
-                    tails->pop_front();
-                }
-                if (!st.active) {
-                    if (ev & VAD_EV_START) {                                           // :860-869
-                        st.active = true;
-                        st.seg.swap(st.pre);
-                        st.pre.clear();
+                const size_t ss = vad_engine::tick_sample_bytes(g);
+                for (int64_t r = 0; r < tbs[g].count; ++r) {
+                    const int64_t i = out->group_start[g] + r;
+                    const size_t sl = (size_t)h_slots[i];
+                    vad_engine::SegState &st = e->seg_state[sl];
+                    const int ev = out->events[i];
+                    const bool above = (double)out->probs[i] >= e->h_start_prob[sl];
+                    const int32_t L = tbs[g].lens()[r];
+                    std::deque<std::vector<uint8_t>> *tails = nullptr;
+                    if (L > flen) {
+                        auto it = e->tick_tails.find((int64_t)sl);
+                        if (it != e->tick_tails.end() && !it->second.empty()) tails = &it->second;
                     }
-                } else if (ev & VAD_EV_END) {                                          // :932-949
-                    st.done.swap(st.seg);
-                    st.seg.clear();
-                    st.active = false;
+                    if (!st.active && !above) {                                            // idle stream: nothing is kept (:873-874)
+                        if (!st.pre.empty()) st.pre.clear(e->seg_arena);
+                        if (tails) tails->pop_front();
+                        continue;
+                    }
+                    vad_engine::SegAudio &dst = st.active ? st.seg : st.pre;               // :891 / :838-839
+                    dst.append(e->seg_arena, g, denoise_thresh, tbs[g].row(r), (size_t)std::min<int32_t>(L, flen), &plan);
+                    if (tails) {
+                        spent.push_back(std::move(tails->front()));
+                        tails->pop_front();
+                        dst.append(e->seg_arena, g, denoise_thresh, spent.back().data(), spent.back().size() / ss, &plan);
+                    }
+                    if (!st.active) {
+                        if (ev & VAD_EV_START) {                                           // :860-869
+                            st.active = true;
+                            st.seg.swap(st.pre);
+                            st.pre.clear(e->seg_arena);
+                        }
+                    } else if (ev & VAD_EV_END) {                                          // :932-949
+                        st.done.clear(e->seg_arena);
+                        st.done.swap(st.seg);
+                        st.active = false;
+                    }
                 }
             }
+        } catch (const std::bad_alloc &) {
+            e->copy_crew.run(plan.data(), plan.size());        // what was planned is consistent; the rest of this tick's audio is lost
+            return e->fail(VAD_ERR_INVALID_ARG, "tick: out of host memory for the segment arena");
         }
+        e->copy_crew.run(plan.data(), plan.size());
         out->host_us[2] = us(t2, now());
     }
     return VAD_OK;

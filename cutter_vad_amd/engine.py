@@ -39,6 +39,10 @@ class Engine:
                  sample_rate: int = 16000, shared_gpu: bool = False):
         self._lib = _ffi.lib()
         self._h = C.c_void_p()
+        self._tickets = {}                  # ticket -> the buffers a pipelined call still reads (submit / collect)
+        self.last_tick_us = (0.0, 0.0, 0.0)
+        self.last_tick_dropped = 0
+        self.last_tick_lost = None
         self._weights = weights  # keep alive during create
         desc = _ffi.EngineDesc(C.sizeof(_ffi.EngineDesc), model_version, C.cast(C.c_char_p(weights), C.c_void_p),
                                len(weights), device_id, max_streams, sample_rate, 1 if shared_gpu else 0)  # VAD_ENGINE_SHARED_GPU
@@ -278,8 +282,49 @@ class Engine:
         self._check(self._lib.vad_tick_take_segment(self._h, int(slot), _ptr(out, C.c_float), out.size, C.byref(n)), VADError)
         return out
 
+    def tick_push_status(self, slots, frames, nsamples: int, gate_on: bool = True, i16_scale: int = 32767) -> np.ndarray:
+        """``frames``: int16 / float32 array [n, nsamples] or the same as one bytes object of int16 PCM; every frame is tried,
+        -> int32 status per frame (``vad_tick_push_status``; 0 = queued)."""
+        s = np.ascontiguousarray(slots, dtype=np.int64).reshape(-1)
+        if isinstance(frames, (bytes, bytearray, memoryview)):
+            buf, fmt = frames, (_ffi.VAD_FMT_I16_32768 if i16_scale == 32768 else _ffi.VAD_FMT_I16_32767)
+            if len(frames) != 2 * int(nsamples) * s.size:
+                raise AudioProcessingError(f"Model prediction failed: {len(frames)} bytes for {s.size} int16 frames of {nsamples} samples")
+            ptr = C.cast(C.c_char_p(bytes(frames) if not isinstance(frames, bytes) else frames), C.c_void_p)
+        else:
+            f = np.ascontiguousarray(frames)
+            if f.dtype == np.int16:
+                fmt = _ffi.VAD_FMT_I16_32768 if i16_scale == 32768 else _ffi.VAD_FMT_I16_32767
+            else:
+                f, fmt = np.ascontiguousarray(f, np.float32), _ffi.VAD_FMT_F32
+            if f.size != int(nsamples) * s.size:
+                raise AudioProcessingError(f"Model prediction failed: frames {f.shape} for {s.size} slots of {nsamples} samples")
+            buf, ptr = f, f.ctypes.data_as(C.c_void_p)
+        status = np.zeros(s.size, np.int32)
+        self._lib.vad_tick_push_status(self._h, _ptr(s, C.c_int64), s.size, ptr, int(nsamples), fmt, int(gate_on), _ptr(status, C.c_int32))
+        del buf
+        return status
+
     def tick_cancel(self, slot: int) -> None:
         self._check(self._lib.vad_tick_cancel(self._h, int(slot)), VADError)
+
+    def tick_pending(self, slot: int) -> int:
+        """frames of ``slot`` that have been pushed and not stepped yet (``vad_tick_pending``)"""
+        k = C.c_int64()
+        self._check(self._lib.vad_tick_pending(self._h, int(slot), C.byref(k)), VADError)
+        return int(k.value)
+
+    def save_segment(self, slot: int) -> bytes:
+        """the slot's segment audio (pre-roll, open segment, finished one not yet taken) as an opaque blob
+        (``vad_tick_segment_save``): with ``save_stream`` everything a session needs to continue on another engine"""
+        k = C.c_int64()
+        self._check(self._lib.vad_tick_segment_save(self._h, int(slot), None, 0, C.byref(k)), VADError)
+        buf = C.create_string_buffer(int(k.value))
+        self._check(self._lib.vad_tick_segment_save(self._h, int(slot), buf, int(k.value), C.byref(k)), VADError)
+        return buf.raw[:int(k.value)]
+
+    def restore_segment(self, slot: int, blob: bytes) -> None:
+        self._check(self._lib.vad_tick_segment_restore(self._h, int(slot), blob, len(blob)), VADError)
 
     def tick_run(self, denoise: float = 0.01):
         """Advance every slot with a pending frame by one frame (``vad_tick_run``) ->
@@ -290,7 +335,14 @@ class Engine:
         1536]) - and ``nsamples`` = the length each frame had when it was pushed."""
         r = _ffi.TickResult()
         r.struct_size = C.sizeof(_ffi.TickResult)
-        self._check(self._lib.vad_tick_run(self._h, float(denoise), C.byref(r)))
+        rc = self._lib.vad_tick_run(self._h, float(denoise), C.byref(r))
+        self.last_tick_dropped = int(r.dropped)   # frames left out because their stream was closed after the push
+        # a failed tick has consumed its frames: which streams lost one, and how long those frames were (TickFailure below)
+        self.last_tick_lost = None
+        if rc != _ffi.VAD_OK:
+            if int(r.n) and r.slots and r.nsamples:
+                self.last_tick_lost = (np.ctypeslib.as_array(r.slots, (int(r.n),)).copy(), np.ctypeslib.as_array(r.nsamples, (int(r.n),)).copy())
+            self._check(rc)
         n = int(r.n)
         self.last_tick_us = tuple(r.host_us)       # (swap, copies + launches + wait, segment assembly) of this tick
         gs = np.array(list(r.group_start), np.int64)
@@ -326,13 +378,15 @@ class Engine:
         t = C.c_int64()
         self._check(self._lib.vad_step_submit(self._h, _ptr(s, C.c_int64), s.size, T, f.ctypes.data_as(C.c_void_p), fmt, thr,
                                               C.byref(t)))
-        self._tickets = getattr(self, "_tickets", {})
         self._tickets[int(t.value)] = (s, f, T, f0.ndim == 3)      # keeps the buffers alive until collected
         return int(t.value)
 
     def collect(self, ticket: int):
         """-> (probs, events, seg_frames) of a submitted ticket; blocks until its results are on the host."""
-        s, _f, T, multi = self._tickets[int(ticket)]
+        held = self._tickets.get(int(ticket))
+        if held is None:
+            raise AudioProcessingError(f"Model prediction failed: ticket {ticket} is not outstanding")
+        s, _f, T, multi = held
         probs = np.empty((s.size, T), np.float32)
         ev = np.zeros((s.size, T), np.uint8)
         seg = np.zeros(s.size, np.int32)

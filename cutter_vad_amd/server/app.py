@@ -23,7 +23,7 @@ import contextlib
 import json
 import time
 import uuid
-from typing import Any, Dict, Optional
+from typing import Any, Dict, Optional, Sequence
 from urllib.parse import parse_qs
 
 import numpy as np
@@ -31,6 +31,7 @@ from fastapi import FastAPI, WebSocket, WebSocketDisconnect
 
 from ..core.config import SampleRate, SileroModelVersion, VADConfig
 from .shared_pool import PooledSession, SharedStreamPool
+from .sharded_pool import ShardedStreamPool
 
 _INT_KEYS = ("sample_rate", "channels", "sample_width", "frame_duration_ms", "start_frame_count", "end_frame_count")
 _FLOAT_KEYS = ("start_probability", "end_probability", "timeout")
@@ -232,9 +233,12 @@ class ClientSession:
         self.outbox.put_nowait(None)
 
 
-def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0.010, convert_rates: bool = False) -> FastAPI:
+def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0.010, convert_rates: bool = False,
+               devices: Optional[Sequence[int]] = None) -> FastAPI:
     """``convert_rates``: clients that announce 8 / 24 / 48 kHz with 32 ms frames are resampled on the GPU inside the pool's
-    tick (SharedStreamPool); off, such a client gets the reference's per-frame error."""
+    tick (SharedStreamPool); off, such a client gets the reference's per-frame error.
+    ``devices``: HIP device ordinals - one stream pool (engine + ticker thread) per GPU behind this one app
+    (``ShardedStreamPool``: a new client lands on the least-loaded GPU); a ready-made sharded pool may be passed as ``pool``."""
     state: Dict[str, Any] = {"pool": pool, "clients": {}, "ticker": None}
 
     @contextlib.asynccontextmanager
@@ -242,6 +246,8 @@ def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0
         yield
         if state["ticker"] is not None:
             state["ticker"].cancel()
+        if state["pool"] is not None and hasattr(state["pool"], "shards"):
+            state["pool"].stop()
 
     app = FastAPI(title="VAD WebSocket Server", description="Real-time Voice Activity Detection WebSocket Server "
                   "(shared MI355X stream pool)", version="1.0.0", lifespan=lifespan)
@@ -249,7 +255,10 @@ def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0
 
     def get_pool() -> SharedStreamPool:
         if state["pool"] is None:
-            state["pool"] = SharedStreamPool(tick_interval=tick_interval, convert_rates=convert_rates)
+            if devices is not None:
+                state["pool"] = ShardedStreamPool(devices=devices, tick_interval=tick_interval, convert_rates=convert_rates)
+            else:
+                state["pool"] = SharedStreamPool(tick_interval=tick_interval, convert_rates=convert_rates)
         return state["pool"]
 
     async def ticker() -> None:
@@ -267,7 +276,11 @@ def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0
             await asyncio.sleep(max(0.0, tick_interval - (time.perf_counter() - t0)))
 
     def ensure_ticker() -> None:
-        if state["ticker"] is None or state["ticker"].done():
+        p = get_pool()
+        if hasattr(p, "shards"):                 # one free-running ticker thread per GPU: a slow device holds nobody else back
+            p.tick_interval = tick_interval
+            p.start()
+        elif state["ticker"] is None or state["ticker"].done():
             state["ticker"] = asyncio.ensure_future(ticker())
 
     @app.get("/")

@@ -1,0 +1,177 @@
+"""Sessions of one process over SEVERAL GPUs: one stream pool - one engine, one ticker thread - per device.
+
+SURVEY §8 e: independent audio streams are the data-parallel axis, "a host thread (or process) per GPU drives its pool", no
+collective.  The reference's anchor is one ``VADWrapper`` per websocket client
+(/root/reference/websocket_service/server/vad_websocket_server.py:277): a client's stream never reads another's, so where it
+lives is a placement decision only.  ``ShardedStreamPool`` places a new session on the least-loaded shard and hands back the
+same :class:`PooledSession` a single pool would; every shard ticks on its own thread, so the devices step concurrently and a
+slow device does not hold the others' events back.
+
+``migrate(session, shard)`` moves a live session to another shard - in the middle of an utterance if need be: the frames it
+still has queued are stepped where it is (order is kept), then its recurrent state + state machine (``vad_stream_save``) and
+its segment audio (``vad_tick_segment_save``: pre-roll, open segment, finished one not yet taken) are restored on a fresh slot
+of the target engine; the session object, its callbacks and its counters carry over.  Results are bit-identical to a session
+that never moved (tests/test_gpu_server.py).  ``rebalance()`` uses it to even the shards out after clients have left.
+"""
+
+from __future__ import annotations
+
+import threading
+from typing import List, Optional, Sequence
+
+from ..core.config import SileroModelVersion, VADConfig
+from ..core.exceptions import AudioProcessingError
+from ..pool import EnginePool
+from .shared_pool import PooledSession, SharedStreamPool
+
+
+class ShardedStreamPool:
+    """``devices``: HIP device ordinals, one shard each (the same ordinal twice = two engines on one GPU, which is how the
+    single-GPU test box exercises it).  ``shards``: ready-made pools instead (tests on the CPU doubles)."""
+
+    def __init__(self, devices: Optional[Sequence[int]] = None, model_version: SileroModelVersion = SileroModelVersion.V5,
+                 max_streams: Optional[int] = None, tick_interval: float = 0.010, sample_rate: int = 16000,
+                 convert_rates: bool = False, shards: Optional[Sequence[SharedStreamPool]] = None) -> None:
+        if shards is None:
+            if not devices:
+                raise AudioProcessingError("ShardedStreamPool needs at least one device")
+            # every shard gets its own engine registry: two shards never share an engine, even on one device
+            shards = [SharedStreamPool(model_version=model_version, device_id=int(d), max_streams=max_streams, pool=EnginePool(),
+                                       tick_interval=tick_interval, sample_rate=sample_rate, convert_rates=convert_rates)
+                      for d in devices]
+        self.shards: List[SharedStreamPool] = list(shards)
+        if not self.shards:
+            raise AudioProcessingError("ShardedStreamPool needs at least one shard")
+        self.devices = list(devices) if devices is not None else list(range(len(self.shards)))
+        self.frame = self.shards[0].frame
+        self.convert_rates = self.shards[0].convert_rates
+        self.tick_interval = tick_interval
+        self._place = threading.Lock()             # placement and migration: one at a time
+        self.migrations = 0
+
+    # ------------------------------------------------------------------ sessions (the SharedStreamPool surface)
+    def shard_of(self, s: PooledSession) -> int:
+        return self.shards.index(s.pool)
+
+    def open_session(self, config: Optional[VADConfig] = None, shard: Optional[int] = None) -> PooledSession:
+        with self._place:
+            k = min(range(len(self.shards)), key=lambda i: self.shards[i].session_count) if shard is None else int(shard)
+            return self.shards[k].open_session(config)
+
+    def close_session(self, s: PooledSession) -> None:
+        s.pool.close_session(s)
+
+    def reconfigure(self, s: PooledSession, config: VADConfig) -> None:
+        s.pool.reconfigure(s, config)
+
+    @property
+    def session_count(self) -> int:
+        return sum(p.session_count for p in self.shards)
+
+    # ------------------------------------------------------------------ moving a live session
+    def migrate(self, s: PooledSession, shard: int) -> None:
+        dst = self.shards[int(shard)]
+        with self._place:
+            src = s.pool
+            if s.closed:
+                raise AudioProcessingError("session is closed")
+            if dst is src:
+                return
+            # 1. nothing new arrives for the session while it moves: producers wait on the source pool's submit lock; what is
+            #    already queued is stepped where the session lives (its events are delivered as usual, in order)
+            first, second = sorted((src, dst), key=id)
+            with src._lock:
+                src._flush_inbox()
+                s.moving = True
+            try:
+                while src.engine.tick_pending(s.slot) > 0:
+                    src.tick()
+                with first._tick_lock, second._tick_lock:
+                    if src.engine.tick_pending(s.slot) > 0:      # a frame slipped in between the last tick and the lock
+                        raise AudioProcessingError("session kept receiving frames while it was being moved")
+                    state = src.engine.save_stream(s.slot)
+                    audio = src.engine.save_segment(s.slot)
+                    new_slot = int(dst.engine.open_stream())
+                    try:
+                        dst.engine.tick_cancel(new_slot)
+                        dst.engine.restore_stream(new_slot, state)            # (h, c), thresholds, counters, history
+                        dst.engine.restore_segment(new_slot, audio)
+                    except Exception:
+                        dst.engine.close_stream(new_slot)
+                        raise
+                    old_slot = s.slot
+                    with src._lock, dst._lock:
+                        dst._grow(new_slot + 1)
+                        for name in ("_thr", "_active", "_cont", "_gate", "_lastp", "_done"):
+                            getattr(dst, name)[new_slot] = getattr(src, name)[old_slot]
+                        src._sessions.pop(old_slot, None)
+                        src._by_slot[old_slot] = None
+                        s.pool, s.slot = dst, new_slot
+                        dst._sessions[new_slot] = s
+                        dst._by_slot[new_slot] = s
+                    src.engine.tick_cancel(old_slot)
+                    src.engine.close_stream(old_slot)
+                    self.migrations += 1
+            finally:
+                s.moving = False
+
+    def rebalance(self, tolerance: int = 1) -> int:
+        """Move sessions from the fullest to the emptiest shard until they differ by at most ``tolerance``; -> moves made."""
+        moved = 0
+        while True:
+            counts = [p.session_count for p in self.shards]
+            hi, lo = max(range(len(counts)), key=counts.__getitem__), min(range(len(counts)), key=counts.__getitem__)
+            if counts[hi] - counts[lo] <= max(1, tolerance):
+                return moved
+            victim = next((x for x in self.shards[hi]._sessions.values() if not x.closed), None)
+            if victim is None:
+                return moved
+            self.migrate(victim, lo)
+            moved += 1
+
+    # ------------------------------------------------------------------ ticking
+    def tick(self) -> int:
+        """One tick on every shard, the devices side by side (each shard's tick on its own thread); -> frames processed.
+        The serving path uses ``start()`` instead: one free-running ticker per shard."""
+        if len(self.shards) == 1:
+            return self.shards[0].tick()
+        out = [0] * len(self.shards)
+
+        def one(i: int) -> None:
+            out[i] = self.shards[i].tick()
+        ths = [threading.Thread(target=one, args=(i,)) for i in range(1, len(self.shards))]
+        for t in ths:
+            t.start()
+        one(0)
+        for t in ths:
+            t.join()
+        return sum(out)
+
+    def drain(self, max_ticks: int = 1 << 30) -> int:
+        total = 0
+        for _ in range(max_ticks):
+            n = self.tick()
+            if n == 0:
+                break
+            total += n
+        return total
+
+    def start(self) -> None:
+        for p in self.shards:
+            p.tick_interval = self.tick_interval
+            p.start()
+
+    def stop(self) -> None:
+        for p in self.shards:
+            p.stop()
+
+    def close(self) -> None:
+        for p in self.shards:
+            p.close()
+
+    def stats(self) -> dict:
+        per = [p.stats() for p in self.shards]
+        frames, launches = sum(x["frames"] for x in per), sum(x["launches"] for x in per)
+        return {"sessions": self.session_count, "ticks": sum(x["ticks"] for x in per), "frames": frames, "launches": launches,
+                "frames_per_launch": frames / launches if launches else 0.0, "migrations": self.migrations,
+                "shards": [dict(x, device=d) for x, d in zip(per, self.devices)]}

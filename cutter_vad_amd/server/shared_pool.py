@@ -49,6 +49,7 @@ from ..pool import EnginePool, default_pool, resolve_model_path
 from ..utils.audio import AudioUtils
 from ..utils.wav_writer import WAVWriter
 
+_RETRY = object()       # submit's answer while a session is between two pools
 FRAME = 512      # the model's frame at 16 kHz; a pool's own frame length is ``SharedStreamPool.frame`` (256 on V5's 8 kHz sub-model)
 
 
@@ -56,7 +57,7 @@ class PooledSession:
     """One client stream: a slot of the shared engine + the host half of its voice segments."""
 
     __slots__ = ("pool", "slot", "config", "long_frames", "on_start", "on_end", "on_continue", "on_error", "closed",
-                 "wav_writer", "user", "rate")
+                 "wav_writer", "user", "rate", "moving")
 
     def __init__(self, pool: "SharedStreamPool", slot: int, config: VADConfig) -> None:
         self.pool = pool
@@ -68,6 +69,7 @@ class PooledSession:
         self.on_continue: Optional[Callable[[bytes], None]] = None
         self.on_error: Optional[Callable[[Exception], None]] = None
         self.closed = False
+        self.moving = False                        # ShardedStreamPool.migrate: frames wait while the session changes engines
         self.wav_writer = WAVWriter(sample_rate=config.output_wav_sample_rate, bit_depth=config.output_wav_bit_depth,
                                     channels=1)
         self.user = None
@@ -93,10 +95,12 @@ class PooledSession:
         self.pool._cont[self.slot] = voice_continue_callback is not None
 
     def submit(self, frame) -> None:
-        self.pool.submit(self, frame)
+        while self.pool.submit(self, frame) is _RETRY:       # the session is changing engines (ShardedStreamPool.migrate)
+            time.sleep(0.0005)
 
     def submit_pcm16(self, data: bytes) -> None:
-        self.pool.submit_pcm16(self, data)
+        while self.pool.submit_pcm16(self, data) is _RETRY:
+            time.sleep(0.0005)
 
     def is_voice_active(self) -> bool:
         return self.active
@@ -127,6 +131,9 @@ class SharedStreamPool:
         self._thread: Optional[threading.Thread] = None
         self._stop = threading.Event()
         self._grow(1024)
+        # int16 wire frames of exactly one model frame - what every websocket client sends - are not pushed one by one: they
+        # collect here (per gate value) and go to the engine as ONE vad_tick_push_status call at the start of the next tick
+        self._inbox: List[List] = [[], []]
         self.ticks = 0
         self.frames = 0
         self.launches = 0
@@ -207,6 +214,7 @@ class SharedStreamPool:
             with self._lock:
                 if s.closed:
                     return
+                self._flush_inbox()                # then the cancel below takes the session's frames out again
                 s.closed = True
                 s.long_frames.clear()
                 self._sessions.pop(s.slot, None)
@@ -220,6 +228,7 @@ class SharedStreamPool:
         self._check_session_rate(config)
         with self._tick_lock:
             with self._lock:
+                self._flush_inbox()
                 s.long_frames.clear()
             self.engine.tick_cancel(s.slot)
             self.engine.reset([s.slot])
@@ -255,6 +264,9 @@ class SharedStreamPool:
         with self._lock:
             if s.closed:
                 raise AudioProcessingError("session is closed")
+            if s.moving or s.pool is not self:
+                return _RETRY
+            self._flush_inbox()                            # frames of one session keep their order across both ingest paths
             self.engine.tick_push(s.slot, x, bool(self._gate[s.slot]), sample_rate=s.rate)
             if x.size > self.frame and s.rate is None:   # only voice_continue payloads need the whole frame here (the engine keeps its own)
                 s.long_frames.append(x)
@@ -262,16 +274,39 @@ class SharedStreamPool:
     def submit_pcm16(self, s: PooledSession, data: bytes) -> None:
         """Queue one frame as it arrives on the wire: little-endian int16 PCM.  The bytes go to the GPU as they are
         (half the transfer of float32); the kernel scales by 1/32767 with a true division, which is bit-for-bit what
-        the reference server does on the host (vad_websocket_server.py:341)."""
+        the reference server does on the host (vad_websocket_server.py:341).  A frame of exactly the model's length only joins
+        the pool's inbox here (a list append): the frames that arrived within one tick window reach the engine in one call."""
         if len(data) < 2 or len(data) & 1:
             raise AudioProcessingError("Audio data cannot be empty" if len(data) < 2 else
                                        "PCM16 frame with an odd number of bytes")
         with self._lock:
             if s.closed:
                 raise AudioProcessingError("session is closed")
+            if s.moving or s.pool is not self:
+                return _RETRY
+            if s.rate is None and len(data) == 2 * self.frame:
+                self._inbox[1 if self._gate[s.slot] else 0].append((s.slot, data))
+                return None
+            self._flush_inbox()
             self.engine.tick_push(s.slot, data, bool(self._gate[s.slot]), sample_rate=s.rate)
             if len(data) > 2 * self.frame and s.rate is None:
                 s.long_frames.append(np.frombuffer(data, dtype="<i2").astype(np.float32) / np.float32(32767.0))
+
+    def _flush_inbox(self) -> None:
+        """The collected wire frames -> the engine's tick staging, one call per gate value (``_lock`` held).  A frame the engine
+        refuses (its stream has 256 frames waiting, or was closed meanwhile) is reported to its own session only."""
+        for gate in (0, 1):
+            box = self._inbox[gate]
+            if not box:
+                continue
+            self._inbox[gate] = []
+            slots = np.fromiter((b[0] for b in box), np.int64, len(box))
+            status = self.engine.tick_push_status(slots, b"".join(b[1] for b in box), self.frame, bool(gate))
+            for i in np.nonzero(status)[0]:
+                s = self._by_slot[int(slots[i])]
+                if s is not None and not s.closed:
+                    why = "256 frames are waiting for this stream" if int(status[i]) == _ffi.VAD_ERR_BUSY else f"engine status {int(status[i])}"
+                    self._report(s, AudioProcessingError(f"Model prediction failed: frame not queued: {why}"))
 
     # ------------------------------------------------------------------ the tick
     def tick(self) -> int:
@@ -283,11 +318,29 @@ class SharedStreamPool:
         The engine also keeps the segments' audio (``vad_tick_enable_segments``): Python touches a session only on START,
         on END (to wrap the finished segment as WAV) and - if it asked for ``voice_continue`` payloads - while it talks."""
         with self._tick_lock:
+            with self._lock:
+                self._flush_inbox()
             try:
                 slots, p, ev, _seg, gs, frames, nsamp = self.engine.tick_run(0.01)
-            except Exception as e:                  # engine failure: every session hears about it
-                for s in list(self._sessions.values()):
-                    self._report(s, AudioProcessingError(f"Model prediction failed: {e}"))
+            except Exception as e:
+                # engine failure: the tick's frames are gone (the engine has dropped what belonged to them, so every stream's
+                # queue is still aligned); the sessions that lost a frame hear about it, and so does everyone if the engine
+                # cannot say who it was
+                lost = getattr(self.engine, "last_tick_lost", None)
+                err = AudioProcessingError(f"Model prediction failed: {e}")
+                if lost is None:
+                    victims = list(self._sessions.values())
+                else:
+                    victims = []
+                    for slot, L in zip(lost[0].tolist(), lost[1].tolist()):
+                        s = self._by_slot[slot] if slot < len(self._by_slot) else None
+                        if s is None or s.closed:
+                            continue
+                        if L > self.frame and s.rate is None and s.long_frames:
+                            s.long_frames.popleft()          # the whole over-long frame kept for voice_continue went with it
+                        victims.append(s)
+                for s in victims:
+                    self._report(s, err)
                 return 0
             n = int(slots.size)
             if n == 0:

@@ -42,7 +42,7 @@ extern "C" {
 #define VAD_API
 #endif
 
-#define VAD_ABI_VERSION 2
+#define VAD_ABI_VERSION 3
 #define VAD_FRAME_SAMPLES 512   /* core/silero_model.py:464-468: frames are padded/truncated to 512 (Silero V5 8 kHz engines: 256, see vad_info) */
 #define VAD_STATE_FLOATS 256    /* V5: state[2][1][128]; V4: h[2][1][64] then c[2][1][64]  (silero_model.py:391-401) */
 
@@ -275,7 +275,12 @@ VAD_API int vad_resample_generic_device(vad_engine *e, const void *d_in, int in_
  *       g = frame_fmt * 2 + gate_on, in push order, and group_frames[g] is that group's staged audio [count][frame] in frame_fmt
  *       (what segment assembly keeps).  All pointers are engine-owned and stay valid until the next vad_tick_run.
  *       Pushes may continue while a tick runs (double-buffered staging).  `thr` is the gate threshold of the gate_on groups.
- *   vad_tick_cancel(e, slot)   drops the slot's pending frames (call before vad_stream_close of a slot that may have some).
+ *       Frames that waited are placed first, in the order their slots started waiting, then the frames pushed since, in push order.
+ *       A tick that FAILS (a HIP error) has consumed its frames: res.n / res.slots / res.nsamples then list the streams that lost
+ *       one (res.probs is NULL), everything queued behind them is intact and the next tick carries on.
+ *   vad_tick_cancel(e, slot)   drops the slot's pending frames and segment audio.  vad_stream_close and vad_stream_open do the same
+ *       for their slot, so a recycled slot never sees its predecessor's frames.
+ *   vad_tick_pending(e, slot, &frames)   frames of `slot` that have not been stepped yet (staged + waiting).
  *   vad_tick_push_rate(e, slot, samples, nsamples, fmt, gate_on, sr_in)   the same for a client whose audio arrives at 8 / 24 /
  *       48 kHz (VADConfig.auto_convert_sample_rate; nsamples must be the chunk that yields one 16 kHz frame: 256 / 768 / 1536):
  *       the chunk is staged as float32 in group 6 + 3 * gate_on + {0, 1, 2}; vad_tick_run resamples those groups on the GPU and
@@ -294,6 +299,7 @@ typedef struct vad_tick_result {
     const void *group_frames[VAD_TICK_GROUPS];
     const int32_t *nsamples;       /* samples the caller pushed for entry i (before padding / truncation to the frame length) */
     float host_us[3];              /* where this tick's wall time went: buffer swap + queued frames | copies + launches + wait | segment assembly */
+    int64_t dropped;               /* ABI 3: staged frames left out because their stream was closed (or closed and reopened) after the push */
 } vad_tick_result;
 VAD_API int vad_tick_push(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int gate_on);
 VAD_API int vad_tick_push_rate(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int gate_on,
@@ -301,7 +307,13 @@ VAD_API int vad_tick_push_rate(vad_engine *e, int64_t slot, const void *samples,
 /* the same frame length / format / gate for n slots: frames [n][nsamples] (a front end that batches its sockets' frames) */
 VAD_API int vad_tick_push_many(vad_engine *e, const int64_t *slots, int64_t n, const void *frames, int32_t nsamples,
                                int frame_fmt, int gate_on);
+/* the same, but every frame is tried and status[i] receives its own result (VAD_OK, VAD_ERR_BAD_SLOT, VAD_ERR_BUSY ...): a
+ * front end that coalesces the frames its sockets received during one tick window into ONE call learns which of them to
+ * report to which client; returns the first failure (the last-error text belongs to the LAST one) */
+VAD_API int vad_tick_push_status(vad_engine *e, const int64_t *slots, int64_t n, const void *frames, int32_t nsamples,
+                                 int frame_fmt, int gate_on, int32_t *status);
 VAD_API int vad_tick_cancel(vad_engine *e, int64_t slot);
+VAD_API int vad_tick_pending(vad_engine *e, int64_t slot, int64_t *frames);
 /*
  * Segment assembly inside the tick (off by default).  When on, vad_tick_run also does the host half of
  * VADProcessor._process_voice_state (core/silero_model.py:838-869, 891-895, 925-949) for every stepped stream, on the staged
@@ -313,6 +325,11 @@ VAD_API int vad_tick_cancel(vad_engine *e, int64_t slot);
  */
 VAD_API int vad_tick_enable_segments(vad_engine *e, int on);
 VAD_API int vad_tick_take_segment(vad_engine *e, int64_t slot, float *out, int64_t cap, int64_t *nsamples);
+/* A stream's segment audio (pre-roll, open segment, finished segment not yet taken) as an opaque blob: with vad_stream_save /
+ * vad_stream_restore this is everything a session needs to continue on ANOTHER engine (another GPU) in the middle of an
+ * utterance.  buf = NULL: size query.  Restore replaces what the slot holds; blobs are checked before anything is touched. */
+VAD_API int vad_tick_segment_save(vad_engine *e, int64_t slot, void *buf, int64_t cap, int64_t *nbytes);
+VAD_API int vad_tick_segment_restore(vad_engine *e, int64_t slot, const void *buf, int64_t nbytes);
 VAD_API int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out);
 
 /*

@@ -130,6 +130,36 @@ class FakeEngine:
             g = 6 + 3 * int(bool(gate_on)) + ri
         q[int(slot)].append((g, x))
 
+    def tick_push_status(self, slots, frames, nsamples, gate_on=True, i16_scale=32767):
+        """vad_tick_push_status: every frame is tried, one status each (0 = queued, -6 = not an open stream, -8 = busy)"""
+        if isinstance(frames, (bytes, bytearray, memoryview)):
+            rows = [bytes(frames)[2 * nsamples * i:2 * nsamples * (i + 1)] for i in range(len(slots))]
+        else:
+            rows = list(np.asarray(frames).reshape(len(slots), nsamples))
+        self.push_status_calls = getattr(self, "push_status_calls", 0) + 1
+        st = np.zeros(len(slots), np.int32)
+        for i, (s, r) in enumerate(zip(slots, rows)):
+            if int(s) not in self.sm:
+                st[i] = -6
+                continue
+            try:
+                self.tick_push(int(s), r, gate_on, i16_scale)
+            except RuntimeError:
+                st[i] = -8
+        return st
+
+    def tick_pending(self, slot):
+        return len(self.__dict__.setdefault("_tickq", {}).get(int(slot), []))
+
+    def save_segment(self, slot):
+        import copy
+        return copy.deepcopy(self.__dict__.setdefault("_seg", {}).get(int(slot)))
+
+    def restore_segment(self, slot, blob):
+        import copy
+        if blob is not None:
+            self.__dict__.setdefault("_seg", {})[int(slot)] = copy.deepcopy(blob)
+
     def tick_cancel(self, slot):
         self.__dict__.setdefault("_tickq", {}).pop(int(slot), None)
         self.__dict__.setdefault("_seg", {}).pop(int(slot), None)

@@ -158,3 +158,117 @@ def test_concurrent_callers_on_one_engine_match_a_serial_run(version):
         for i in range(len(sizes)):
             assert np.array_equal(got[i], serial[i]), sizes[i]
             assert np.array_equal(eng.get_state(int(groups[i][-1])), states[i])
+
+
+def test_producers_push_while_the_tick_runs_and_every_stream_sees_its_frames_in_order():
+    """The serving tick under load, on the real kernels (the CPU twin with ThreadSanitizer / AddressSanitizer is
+    tests/test_tick_sanitizers.py): four producer threads push frames (float32, int16 wire frames, 48 kHz chunks resampled inside
+    the tick, over-long frames) for their own streams WHILE another thread loops vad_tick_run and takes finished segments; a
+    fifth thread opens / closes streams with frames still queued.  Per stream the result must be what a serial run gives: the
+    same probabilities in the same order (bit for bit - a frame is stepped exactly once, in push order), and segments of exactly
+    the samples the serial run keeps."""
+    import threading
+    import time
+    from cutter_vad_amd.engine import Engine
+    with open(weights_io.packaged_blob_path(5), "rb") as f:
+        blob = f.read()
+    P, PER, K = 4, 48, 24
+    n = P * PER
+    base = make_streams(n, K, seed=777)                                     # [n, K, 512]
+    base[1::2] *= 3.0                                                       # loud enough to open segments
+    np.clip(base, -1, 1, out=base)
+    rng = np.random.default_rng(3)
+    chunks48 = (0.2 * rng.standard_normal((n, K, 1536))).astype(np.float32)
+    kind = np.arange(n) % 4                                                 # 0 f32 | 1 int16 | 2 48 kHz chunk | 3 over-long f32 (600)
+    tail = (0.05 * rng.standard_normal((n, K, 88))).astype(np.float32)
+    thr = (0.3, 0.2, 0.5, 0.5, 2, 3)
+
+    def frame(i, k):
+        if kind[i] == 1:
+            return np.clip(np.round(base[i, k] * 32767.0), -32768, 32767).astype(np.int16), None
+        if kind[i] == 2:
+            return chunks48[i, k], 48000
+        if kind[i] == 3:
+            return np.concatenate([base[i, k], tail[i, k]]), None
+        return base[i, k], None
+
+    def run(eng, concurrent):
+        eng.tick_enable_segments(True)
+        slots = eng.open_streams(n)
+        eng.set_thresholds_many(slots, thr)
+        probs = {int(s): [] for s in slots}
+        segs = {int(s): [] for s in slots}
+        mine = set(int(s) for s in slots)
+        left = [P + (1 if concurrent else 0)]
+        lock = threading.Lock()
+        errors = []
+
+        def producer(t):
+            try:
+                for k in range(K):
+                    for j in range(PER):
+                        i = t * PER + j
+                        x, sr = frame(i, k)
+                        eng.tick_push(int(slots[i]), x, True, sample_rate=sr)
+                    if concurrent:
+                        time.sleep(0.0005)
+            except Exception as e:  # pragma: no cover
+                errors.append(e)
+            finally:
+                with lock:
+                    left[0] -= 1
+
+        def churn():
+            try:
+                for r in range(60):
+                    s = eng.open_streams(4)
+                    for k in range(3):
+                        for q in s:
+                            eng.tick_push(int(q), base[0, k], True)
+                    if r % 2:
+                        for q in s:
+                            eng.tick_cancel(int(q))
+                    for q in s:
+                        eng.close_stream(int(q))
+            except Exception as e:  # pragma: no cover
+                errors.append(e)
+            finally:
+                with lock:
+                    left[0] -= 1
+
+        ths = [threading.Thread(target=producer, args=(t,)) for t in range(P)]
+        if concurrent:
+            ths.append(threading.Thread(target=churn))
+            for t in ths:
+                t.start()
+        else:
+            for t in ths:
+                t.run()
+        while True:
+            done = left[0] == 0
+            sl, p, ev, _seg, _gs, _fr, _ns = eng.tick_run(0.01)
+            for s, pv, e in zip(sl.tolist(), p.tolist(), ev.tolist()):
+                if s in mine:
+                    probs[s].append(pv)
+                    if e & 2:
+                        segs[s].append(eng.tick_take_segment(s))
+            if done and sl.size == 0:
+                break
+        for t in ths:
+            if concurrent:
+                t.join()
+        assert not errors, errors
+        return [np.array(probs[int(s)], np.float32) for s in slots], [segs[int(s)] for s in slots]
+
+    with Engine(blob, max_streams=1024) as eng:
+        serial_p, serial_s = run(eng, False)
+    with Engine(blob, max_streams=1024) as eng:
+        conc_p, conc_s = run(eng, True)
+    n_seg = 0
+    for i in range(n):
+        assert serial_p[i].size == K and np.array_equal(serial_p[i], conc_p[i]), i
+        assert len(serial_s[i]) == len(conc_s[i]), i
+        for a, b in zip(serial_s[i], conc_s[i]):
+            assert np.array_equal(a, b), i
+            n_seg += 1
+    assert n_seg >= n // 4                                                  # the loud half does talk

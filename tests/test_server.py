@@ -314,3 +314,139 @@ def test_reconfigure_moves_a_session_between_native_and_resampled_ingest():
     with pytest.raises(AudioProcessingError, match="buffer_size"):
         pool.reconfigure(s, VADConfig(sample_rate=24000, buffer_size=512, **thr))
     pool.close()
+
+
+# ------------------------------------------------------------------ several pools behind one front (SURVEY §8 e)
+def _sharded(n=2):
+    from cutter_vad_amd.server import ShardedStreamPool
+    engines = [FakeEngine(fn=lambda fr: 0.9 if np.abs(fr).max() > 0.3 else 0.05) for _ in range(n)]
+    return ShardedStreamPool(shards=[SharedStreamPool(pool=FakePool(e)) for e in engines]), engines
+
+
+def _script(k):
+    """session k: quiet, an utterance, quiet, a second utterance"""
+    return [QUIET] * (k % 3) + [LOUD] * 4 + [QUIET] * 4 + [LOUD] * 3 + [QUIET] * 4
+
+
+def _run_sessions(pool, cfg, n, move=None):
+    sessions, logs = [], []
+    for k in range(n):
+        s = pool.open_session(cfg)
+        log = []
+        s.set_callbacks(lambda log=log: log.append("S"), lambda wav, log=log: log.append(("E", bytes(wav))),
+                        lambda pcm, log=log: log.append(("C", bytes(pcm))))
+        sessions.append(s)
+        logs.append(log)
+    for t in range(max(len(_script(k)) for k in range(n))):
+        for k, s in enumerate(sessions):
+            sc = _script(k)
+            if t < len(sc):
+                if k % 2:
+                    s.submit_pcm16((sc[t] * 32767).astype("<i2").tobytes())
+                else:
+                    s.submit(sc[t])
+        pool.tick()
+        if move is not None:
+            move(t, sessions)
+    pool.drain()
+    return sessions, logs
+
+
+def test_sharded_pool_places_migrates_and_matches_one_pool():
+    cfg = VADConfig(vad_start_probability=0.4, vad_end_probability=0.3, voice_start_frame_count=2, voice_end_frame_count=3,
+                    buffer_size=480)
+    single, _eng, _calls = make_pool()
+    _, want = _run_sessions(single, cfg, 7)
+    assert all(sum(1 for e in log if e == "S") == 2 for log in want)
+
+    pool, engines = _sharded(2)
+    moved = []
+
+    def move(t, sessions):
+        if t == 3:                                   # inside everyone's first utterance: segment open, pre-roll consumed
+            for k in (0, 1, 4):
+                src = pool.shard_of(sessions[k])
+                pool.migrate(sessions[k], 1 - src)
+                moved.append((k, src, pool.shard_of(sessions[k])))
+        if t == 9:
+            pool.migrate(sessions[0], pool.shard_of(sessions[0]))      # to where it already is: nothing happens
+    sessions, got = _run_sessions(pool, cfg, 7, move)
+    assert got == want                                                  # events, payload bytes and WAV bytes, session by session
+    assert [p.session_count for p in pool.shards] in ([4, 3], [3, 4], [5, 2], [2, 5]) and pool.session_count == 7
+    assert len(moved) == 3 and all(a != b for _, a, b in moved) and pool.migrations == 3
+    assert sum(getattr(e, "restores", 0) for e in engines) == 3
+    st = pool.stats()
+    assert st["sessions"] == 7 and st["migrations"] == 3 and len(st["shards"]) == 2 and st["frames"] == sum(len(_script(k)) for k in range(7))
+    # least-loaded placement and rebalancing after clients left
+    for s in [x for x in sessions if pool.shard_of(x) == 0]:
+        s.close()
+    assert pool.shards[0].session_count == 0
+    n1 = pool.shards[1].session_count
+    assert pool.shard_of(pool.open_session(cfg)) == 0
+    assert pool.rebalance() == (n1 - 1) // 2 and abs(pool.shards[0].session_count - pool.shards[1].session_count) <= 1
+    # a session that is closed cannot move; frames submitted by another thread while it moves wait and then land on the new pool
+    s = pool.open_session(cfg)
+    s.close()
+    with pytest.raises(AudioProcessingError, match="closed"):
+        pool.migrate(s, 0)
+    pool.close()
+    assert pool.session_count == 0
+
+
+def test_frames_submitted_during_a_migration_are_not_lost():
+    import threading
+    cfg = VADConfig(voice_start_frame_count=1, buffer_size=512)
+    pool, engines = _sharded(2)
+    s = pool.open_session(cfg, shard=0)
+    got = []
+    s.set_callbacks(voice_start_callback=lambda: got.append("S"), voice_continue_callback=lambda pcm: got.append("C"))
+    loud16 = (np.full(512, 0.5) * 32767).astype("<i2").tobytes()
+    stop = threading.Event()
+    sent = [0]
+
+    def producer():
+        import time
+        while not stop.is_set() and sent[0] < 200:       # (at most 256 frames may wait for one stream)
+            s.submit_pcm16(loud16)
+            sent[0] += 1
+            time.sleep(0.0002)
+
+    th = threading.Thread(target=producer)
+    th.start()
+    for k in range(20):
+        pool.tick()
+        pool.migrate(s, (k + 1) % 2)
+    stop.set()
+    th.join()
+    pool.drain()
+    assert s.frames_done == sent[0] and got[0] == "S" and len(got) == sent[0]      # every frame stepped once: START, then CONTINUEs
+    assert pool.migrations == 20 and pool.shard_of(s) == 0
+    pool.close()
+
+
+def test_wire_frames_are_coalesced_into_one_push_per_tick():
+    pool, eng, calls = make_pool()
+    cfg = VADConfig(voice_start_frame_count=1, buffer_size=512)
+    sessions = [pool.open_session(cfg) for _ in range(50)]
+    errs = []
+    for s in sessions:
+        s.set_callbacks(error_callback=errs.append)
+    loud16 = (np.full(512, 0.5) * 32767).astype("<i2").tobytes()
+    for s in sessions:
+        s.submit_pcm16(loud16)
+    assert getattr(eng, "push_status_calls", 0) == 0               # nothing has reached the engine yet
+    assert pool.tick() == 50 and eng.push_status_calls == 1 and calls == [50]
+    # order across the two ingest paths: an odd-sized frame flushes what was collected before it
+    a = sessions[0]
+    a.submit_pcm16(loud16)
+    a.submit_pcm16(loud16[:600])
+    a.submit_pcm16(loud16)
+    assert pool.drain() == 3 and a.frames_done == 4
+    assert [f.shape for f in eng.frames_seen[-3:]] == [(1, 512)] * 3 and np.all(eng.frames_seen[-2][0, 300:] == 0)
+    # a frame the engine refuses is reported to its own session only
+    for _ in range(300):
+        a.submit_pcm16(loud16)
+    pool.tick()
+    assert len(errs) >= 1 and all("256 frames are waiting" in str(e) for e in errs)
+    sessions[1].close()
+    pool.close()
