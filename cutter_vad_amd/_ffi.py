@@ -137,6 +137,7 @@ SIGNATURES = {
     "vad_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vad_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vad_tick_pending": (C.c_int, [_vp, C.c_int64, _i64p]),
+    "vad_tick_push_gather": (C.c_int, [_vp, _i64p, C.c_int64, C.POINTER(C.c_char_p), C.c_int32, C.c_int, C.c_int, _i32p]),
     "vad_tick_push_status": (C.c_int, [_vp, _i64p, C.c_int64, _vp, C.c_int32, C.c_int, C.c_int, _i32p]),
     "vad_tick_segment_save": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _i64p]),
     "vad_tick_segment_restore": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64]),

@@ -23,7 +23,7 @@ from dataclasses import dataclass
 from typing import Any, Callable, Dict, Iterator, List, Optional, Tuple, Type, Union
 
 import numpy as np
-from pydantic import ValidationError
+from pydantic import BaseModel, ConfigDict, Field, ValidationError, create_model, model_validator
 
 from ..utils.audio import AudioUtils
 from .config import SampleRate, SileroModelVersion, VADConfig
@@ -34,16 +34,74 @@ VoiceStartCallback = Callable[[], None]
 VoiceEndCallback = Callable[[bytes], None]
 VoiceContinueCallback = Callable[[bytes], None]
 
-# set_thresholds: (VADConfig field, default of the call, lowest, highest, message when outside) - vad_wrapper.py:130-199, 367-419.
-# The end-count default is 57 here and 50 in VADConfig: the reference's quirk, kept.
-_THRESHOLD_RULES: Tuple[Tuple[str, float, float, float, str], ...] = (
-    ("vad_start_probability", 0.7, 0.1, 1.0, "Start probability should be at least 0.1 for reliable detection"),
-    ("vad_end_probability", 0.7, 0.1, 1.0, "End probability should be at least 0.1 for reliable detection"),
-    ("voice_start_ratio", 0.8, 0.0, 1.0, "voice_start_ratio must lie in [0, 1]"),
-    ("voice_end_ratio", 0.95, 0.0, 1.0, "voice_end_ratio must lie in [0, 1]"),
-    ("voice_start_frame_count", 10, 1, 100, "Voice start frame count should not exceed 100 for responsive detection"),
-    ("voice_end_frame_count", 57, 1, 200, "Voice end frame count should not exceed 200 for responsive detection"),
+# set_thresholds: (VADConfig field, default of the call, schema bounds, "reasonable" bound checked after the schema: which side,
+# value, message) - vad_wrapper.py:130-199, 367-419.  The end-count default is 57 here and 50 in VADConfig: the reference's quirk,
+# kept.
+_THRESHOLD_RULES: Tuple[Tuple[str, Any, Dict[str, Any], Optional[Tuple[str, float, str]]], ...] = (
+    ("vad_start_probability", 0.7, dict(ge=0.0, le=1.0), ("min", 0.1, "Start probability should be at least 0.1 for reliable detection")),
+    ("vad_end_probability", 0.7, dict(ge=0.0, le=1.0), ("min", 0.1, "End probability should be at least 0.1 for reliable detection")),
+    ("voice_start_ratio", 0.8, dict(ge=0.0, le=1.0), None),
+    ("voice_end_ratio", 0.95, dict(ge=0.0, le=1.0), None),
+    ("voice_start_frame_count", 10, dict(ge=1), ("max", 100, "Voice start frame count should not exceed 100 for responsive detection")),
+    ("voice_end_frame_count", 57, dict(ge=1), ("max", 200, "Voice end frame count should not exceed 200 for responsive detection")),
 )
+
+
+def _reasonable(model):
+    """the reference's after-validator (vad_wrapper.py:183-199): the two probabilities first, then the two counts"""
+    for name, _default, _bounds, rule in _THRESHOLD_RULES:
+        if rule is not None:
+            side, limit, message = rule
+            v = getattr(model, name)
+            if (side == "min" and v < limit) or (side == "max" and v > limit):
+                raise ValueError(message)
+    return model
+
+
+# The validation model set_thresholds goes through, like the reference's: pydantic in lax mode, so numpy scalars, numeric
+# strings, bools and integral floats for the counts are coerced exactly as the reference coerces them, and a value outside a
+# bound fails with pydantic's own message for THAT bound.  Built from the rules table above.
+ThresholdConfiguration = create_model(
+    "ThresholdConfiguration", __config__=ConfigDict(validate_assignment=True, extra="forbid"),
+    __validators__={"validate_threshold_logic": model_validator(mode="after")(_reasonable)},
+    **{name: (type(default), Field(default=default, **bounds)) for name, default, bounds, _rule in _THRESHOLD_RULES})
+
+
+class CallbackConfiguration(BaseModel):
+    """Import compatibility with the reference module (vad_wrapper.py:84-127); the wrapper itself keeps its callbacks in a
+    name -> callable table."""
+    model_config = ConfigDict(arbitrary_types_allowed=True, validate_assignment=True, extra="forbid")
+    voice_start_callback: Optional[Callable[[], None]] = None
+    voice_end_callback: Optional[Callable[[bytes], None]] = None
+    voice_continue_callback: Optional[Callable[[bytes], None]] = None
+
+    def has_any_callback(self) -> bool:
+        return any(getattr(self, k) is not None for k in type(self).model_fields)
+
+
+class VADWrapperState(BaseModel):
+    """Import compatibility with the reference module (vad_wrapper.py:27-82): a snapshot type with the reference's field names;
+    ``VADWrapper.state_snapshot()`` fills one from the wrapper's counters."""
+    model_config = ConfigDict(validate_assignment=True, extra="forbid")
+    is_initialized: bool = False
+    total_frames_processed: int = Field(default=0, ge=0)
+    total_processing_time: float = Field(default=0.0, ge=0.0)
+    last_error: Optional[str] = None
+
+    @property
+    def average_processing_time_per_frame(self) -> float:
+        return self.total_processing_time / self.total_frames_processed if self.total_frames_processed else 0.0
+
+    def reset_statistics(self) -> None:
+        self.total_frames_processed, self.total_processing_time = 0, 0.0
+
+    def record_error(self, error: Exception) -> None:
+        self.last_error = str(error)
+
+    def clear_error(self) -> None:
+        self.last_error = None
+
+
 # set_sample_rate / set_silero_model: config field -> (enum it must be an instance of, what the error calls it)
 _ENUM_SETTERS: Dict[str, Tuple[type, str]] = {
     "sample_rate": (SampleRate, "sample rate"),
@@ -145,15 +203,17 @@ class VADWrapper:
                        voice_start_frame_count: int = 10, voice_end_frame_count: int = 57) -> None:
         given = dict(zip((r[0] for r in _THRESHOLD_RULES), (vad_start_probability, vad_end_probability, voice_start_ratio,
                                                            voice_end_ratio, voice_start_frame_count, voice_end_frame_count)))
-        with self._lock, self._mapped(lambda e: ConfigurationError("thresholds", "multiple", str(e))):
-            for name, _default, lo, hi, message in _THRESHOLD_RULES:
-                v = given[name]
-                if isinstance(v, bool) or not isinstance(v, (int, float)) or not (lo <= v <= hi):
-                    raise ValueError(f"{name} = {v!r}: {message}")
-            for name, v in given.items():
-                setattr(self._config, name, v)    # VADConfig validates on assignment as well
+        wrap = lambda e: ConfigurationError("thresholds", "multiple", str(e))       # noqa: E731
+        with self._lock, self._mapped(wrap, wrap):
+            checked = ThresholdConfiguration(**given)           # coerces and validates like the reference (pydantic, lax mode)
+            for name in given:
+                setattr(self._config, name, getattr(checked, name))    # VADConfig validates on assignment as well
             if self._processor:
                 self._processor.reset()           # counters restart under the new thresholds (vad_wrapper.py:412-413)
+
+    def state_snapshot(self) -> VADWrapperState:
+        return VADWrapperState(is_initialized=self._n.initialized, total_frames_processed=self._n.frames,
+                               total_processing_time=self._n.seconds, last_error=self._n.last_error)
 
     # ------------------------------------------------------------------ callbacks
     def set_callbacks(self, voice_start_callback: Optional[VoiceStartCallback] = None,

@@ -1367,15 +1367,27 @@ int step_rates_enqueue(vad_engine *e, int32_t nseg, const float *const *d_in, co
     if (!d_probs) return e->fail(VAD_ERR_INVALID_ARG, "Model prediction failed: null buffer");
     // Silero V5, at most 4 096 streams: ONE launch - every 16-stream tile resamples its own chunks into LDS and steps the
     // model from there (silero_v5_t16.hip, RS instantiation); the 16 kHz frames never exist in HBM
-    int64_t tiles16 = 0;                       // segments are padded to whole 16-stream tiles
-    for (int k = 0; k < nseg; ++k) tiles16 += (n[k] + 15) / 16;
+    // The tiles walk the segments laid end to end, so a tile may hold the tail of one input rate and the head of the next
+    // (it resamples the two parts one after the other): no padding per segment, 4 096 streams in uneven thirds are 256 tiles.
+    // The walk order pairs the most expensive prologue (48 kHz, ~20 us) with the cheapest (8 kHz, ~2 us) in the tiles that
+    // straddle a boundary: 48 k | 8 k | 24 k | 16 k.
+    const int64_t tiles16 = (total + 15) / 16;
     if (e->version == 5 && e->d_wstream16 && !e->shared_gpu && e->tile_policy != 32 && nseg <= vadk::RATE_MAX_SEGS && e->rates_fused &&
         tiles16 <= e->prop.multiProcessorCount) {      // at most one tile per CU: a second round of tiles would cost a whole tile time
         vadk::RateParams rp{};
-        int32_t tiles = 0, stream0 = 0, ns = 0;
+        int32_t stream0[vadk::RATE_MAX_SEGS], order[vadk::RATE_MAX_SEGS];
+        int32_t at = 0, ns = 0;
         for (int k = 0; k < nseg; ++k) {
-            if (n[k] == 0) continue;
-            vadk::RateSeg &sg = rp.seg[ns];
+            stream0[k] = at;
+            at += (int32_t)n[k];
+            if (n[k] > 0) order[ns++] = k;
+        }
+        auto rank = [&](int k) { return sr_in[k] == 48000 ? 0 : sr_in[k] == 8000 ? 1 : sr_in[k] == 24000 ? 2 : 3; };
+        std::stable_sort(order, order + ns, [&](int a, int b) { return rank(a) < rank(b); });
+        int32_t vstart = 0;
+        for (int i = 0; i < ns; ++i) {
+            const int k = order[i];
+            vadk::RateSeg &sg = rp.seg[i];
             if (sr_in[k] == 16000) {
                 sg.wstream = nullptr;
                 sg.n_in = VAD_FRAME_SAMPLES;
@@ -1393,13 +1405,12 @@ int step_rates_enqueue(vad_engine *e, int32_t nseg, const float *const *d_in, co
             }
             sg.in = d_in[k];
             sg.n = (int32_t)n[k];
-            sg.stream0 = stream0;
-            rp.tile_start[ns++] = tiles;
-            tiles += (int32_t)((n[k] + 15) / 16);
-            stream0 += (int32_t)n[k];
+            sg.stream0 = stream0[k];
+            sg.vstart = vstart;
+            vstart += (int32_t)n[k];
         }
         rp.nseg = ns;
-        rp.tile_start[ns] = tiles;
+        rp.total = vstart;
         vadk::StepParams p = e->base;
         p.wstream = e->d_wstream16;
         p.wstream_bytes = (uint32_t)e->wbytes16;
@@ -1680,6 +1691,22 @@ int vad_tick_push_status(vad_engine *e, const int64_t *slots, int64_t n, const v
     int first = VAD_OK;
     for (int64_t i = 0; i < n; ++i) {           // every frame is tried: one full queue or one closed stream does not hold the others back
         status[i] = tick_push_locked(e, slots[i], static_cast<const uint8_t *>(frames) + (size_t)i * stride, nsamples, frame_fmt, group);
+        if (status[i] != VAD_OK && first == VAD_OK) first = status[i];
+    }
+    return first;
+}
+
+int vad_tick_push_gather(vad_engine *e, const int64_t *slots, int64_t n, const void *const *frames, int32_t nsamples, int frame_fmt,
+                         int gate_on, int32_t *status) {
+    if (!e || n < 0 || (n > 0 && (!slots || !frames || !status))) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->tick_mu);
+    if (n > 0 && (nsamples < 1 || frame_fmt < VAD_FMT_F32 || frame_fmt > VAD_FMT_I16_32768))
+        return e->fail(VAD_ERR_INVALID_ARG, "tick: empty frame or unknown format");
+    const int group = frame_fmt * 2 + (gate_on ? 1 : 0);
+    int first = VAD_OK;
+    for (int64_t i = 0; i < n; ++i) {
+        status[i] = frames[i] ? tick_push_locked(e, slots[i], frames[i], nsamples, frame_fmt, group)
+                              : e->fail(VAD_ERR_INVALID_ARG, "tick: null frame");
         if (status[i] != VAD_OK && first == VAD_OK) first = status[i];
     }
     return first;

@@ -46,15 +46,17 @@ constexpr int T_ROWS_H = 32;
 static_assert(T_ROWS_X * QSD >= 192 * QSL, "the loader view must end before h");
 constexpr int T_LDS_F4 = (T_ROWS_X + T_ROWS_H) * QSD + 16 + 12 + 36 + 16 + 96;   // + head partials [4][16], |X128| [3][16], fold corrections [3][3][16], sink [64], state machines [16] x 96 B
 static_assert(T_LDS_F4 * 16 <= 80 * 1024, "stays under half a CU's LDS");
-// RS instantiation (fused resample -> step): no LDS of its own.  The resampler's folded input chunks (2 buffers x {ue, ve, uo, vo}
-// x 16 quad rows, loader stride) are staged in the activation region, which is idle until the frame loop starts; the tile's 16 kHz
-// frames F [16 streams][129 quads] (128 + 1 of padding: the recombination stores scalars down a column of streams) then take the
-// same place - the frame loop reads all three columns of F into registers BEFORE its first barrier, and the folds that overwrite
-// the region come after it.
+// RS instantiation (fused resample -> step).  The resampler's folded input chunks (2 buffers x {ue, ve, uo, vo} x 16 quad rows,
+// loader stride) are staged in the activation region, which is idle until the frame loop starts; the tile's 16 kHz frames
+// F [16 streams][129 quads] (128 + 1 of padding: the recombination stores scalars down a column of streams) have 33 KB of their
+// own behind the common layout (111.6 KB in all; the launch is one workgroup per CU anyway) - so a tile whose 16 streams come
+// from TWO segments (the last streams of one input rate and the first of the next) can resample one part after the other, each
+// with its own operator, without the second part's staging running over the first part's frames.
 constexpr int FQ = 129;
 constexpr int RS_CH_ROWS = 16;
 constexpr int RS_BUF = 4 * RS_CH_ROWS * QSL;
-static_assert(2 * RS_BUF <= 192 * QSL && MT16 * FQ <= 192 * QSL, "resampler staging and F must fit the loader view");
+static_assert(2 * RS_BUF <= 192 * QSL, "resampler staging must fit the loader view");
+static_assert((T_LDS_F4 + MT16 * FQ) * 16 <= 160 * 1024, "RS: common layout + F must fit one CU");
 
 __device__ __forceinline__ f32x4 mfma16(f32x4 w, f32x4 a, f32x4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a.x, acc, 0, 0, 0);
@@ -76,7 +78,7 @@ template <bool F32IN, bool RS>
 __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams P, const RateParams R) {
     using namespace vadk::v5;
     static_assert(!RS || F32IN, "resampled frames are float32");
-    __shared__ f32x4 lds[T_LDS_F4];
+    __shared__ f32x4 lds[T_LDS_F4 + (RS ? MT16 * FQ : 0)];     // RS: + the tile's 16 kHz frames F (one workgroup per CU either way)
     f32x4 *const RX = lds;
     f32x4 *const RE = lds + T_ROW_E * QSD;
     f32x4 *const RH = lds + T_ROWS_X * QSD;
@@ -93,18 +95,20 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     const int kq = lane >> 4;                     // channel group (B operand) = row quad of the D tile
     const int nq = kq * QSD + n;                  // lane's offset inside a group of 4 quad rows (dense view)
     const int nqL = kq * QSL + n;                 // the same in the loader view
-    // RS: which segment (input rate) does this tile serve?  block-uniform: scalar compares on kernel arguments
-    int sidx = 0;
+    // RS: the tile carries the virtual streams 16 b .. 16 b + 15 of the segments laid end to end (vad_layout.h); which segment a
+    // column belongs to is a handful of compares on kernel arguments
+    const int vcol = (int)blockIdx.x * MT16 + n;
+    int gf = vcol;
+    bool live = vcol < P.n;
     if constexpr (RS) {
+        int s0 = R.seg[0].stream0, vs = 0;
 #pragma unroll
         for (int k = 1; k < RATE_MAX_SEGS; ++k)
-            if (k < R.nseg && (int)blockIdx.x >= R.tile_start[k]) sidx = k;
+            if (k < R.nseg && vcol >= R.seg[k].vstart) { s0 = R.seg[k].stream0; vs = R.seg[k].vstart; }
+        gf = s0 + vcol - vs;
+        live = vcol < R.total;
     }
-    const int tis = RS ? (int)blockIdx.x - R.tile_start[sidx] : 0;        // tile within its segment
-    const int seg_n = RS ? R.seg[sidx].n : 0;
-    const int tile0 = RS ? R.seg[sidx].stream0 + tis * MT16 : (int)blockIdx.x * MT16;
-    const int gf = tile0 + n;
-    const bool live = RS ? tis * MT16 + n < seg_n : gf < P.n;
+    const int tile0 = (int)blockIdx.x * MT16;                      // (not RS: the tile's first stream in the call's arrays)
     const int slot = live ? (P.slots ? P.slots[gf] : gf) : 0;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wstream), 0, (int)P.wstream_bytes, 0x00020000);
     const int lane16 = lane * 16;
@@ -124,7 +128,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
     u32x4 xa_[4], xb_[4], xc_[4];                  // raw quads of the three columns
-    f32x4 *const F4 = lds;                         // RS: the tile's resampled frames (alias of the loader view, see FQ)
+    f32x4 *const F4 = lds + T_LDS_F4;              // RS: the tile's resampled frames
 #define X_ISSUE(c, XR, tt)                                                                                      \
     if constexpr (RS) {                                                                                         \
         _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                           \
@@ -170,16 +174,24 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
         // ---- the tile's 16 chunks -> 512 samples at 16 kHz each, into F (resample.hip has the algebra; pack_resample_operator_t16
         //      the operator layout): four folded inputs ue / ve / uo / vo of length Q = n_in / 4 against four 128-row operators
         //      (se, ae, so, ao); wave w owns rows o = 32 w .. 32 w + 31 (two row tiles) of all four
-        const RateSeg S = R.seg[sidx];
         float *const Ff = reinterpret_cast<float *>(F4);
-        const int ls0 = tis * MT16;                                   // first stream of the tile within the segment
+        const int v0 = (int)blockIdx.x * MT16;
+        for (int sk = 0; sk < R.nseg; ++sk) {
+        const RateSeg S = R.seg[sk];
+        // the part of this tile that belongs to segment sk: columns c0 .. c1 - 1 = the segment's streams ls0 .. (block-uniform)
+        const int c0 = max(S.vstart, v0) - v0, c1 = min(S.vstart + S.n, v0 + MT16) - v0;
+        if (c0 >= c1) continue;
+        const int ls0 = v0 - S.vstart;                                // column c holds the segment's stream ls0 + c (c0 <= c < c1)
+        auto in_part = [&](int c) { return c >= c0 && c < c1; };
+        constexpr int DEAD = 1 << 26;                                 // an index (in quads / samples) past every buffer: loads return 0
         if (S.wstream == nullptr) {                                   // already 16 kHz (resample_audio returns its input): copy
             const __amdgpu_buffer_rsrc_t xrs =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S.in), 0, (int)((unsigned)S.n * 2048u), 0x00020000);
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int idx = it * NTHREADS + tid, ms = idx >> 7, qd = idx & 127;
-                F4[ms * FQ + qd] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((ls0 + ms) * 128 + qd) * 16, 0, 0));
+                if (in_part(ms))
+                    F4[ms * FQ + qd] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((ls0 + ms) * 128 + qd) * 16, 0, 0));
             }
         } else {
             const int Q = S.n_in >> 2, nchunks = Q >> 6;
@@ -191,8 +203,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
             const int wbase = w * (int)S.wave_blocks;
             f32x4 acc[8];                                             // part p (se, ae, so, ao), row tile rt -> acc[2 p + rt]
             {   // the sample each half-size product cannot pair, x[Q] +- x[Q + H], is a rank-1 term: accumulator init
-                const float xa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ((ls0 + n) * S.n_in + Q) * 4, 0, 0));
-                const float xb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ((ls0 + n) * S.n_in + 3 * Q) * 4, 0, 0));
+                const int sb = in_part(n) ? (ls0 + n) * S.n_in : (DEAD << 2);     // columns of other segments contract zeros
+                const float xa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (sb + Q) * 4, 0, 0));
+                const float xb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (sb + 3 * Q) * 4, 0, 0));
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     acc[0 + rt] = OL(wbase + rt) * (xa + xb);
@@ -206,7 +219,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
             u32x4 xlA[6], xlB[6];
             const int cms = tid >> 4, cql = tid & 15;
             auto load_chunk = [&](int c, u32x4 *xl) {
-                const int qq = cql + 16 * c, base = (ls0 + cms) * Q;
+                const int qq = cql + 16 * c, base = in_part(cms) ? (ls0 + cms) * Q : DEAD;
                 xl[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + qq) * 16, 0, 0);
                 xl[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + qq + (Q >> 1)) * 16, 0, 0);
                 xl[2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (Q >> 1) - qq) * 16, 0, 0);
@@ -284,18 +297,20 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
                 const int row = 32 * w + 16 * rt + 4 * kq;
                 const f32x4 se = acc[0 + rt], ae = acc[2 + rt], so = acc[4 + rt], ao = acc[6 + rt];
                 const f32x4 pe = se + ae, me = se - ae, pO = so + ao, mO = so - ao;
-                F4[n * FQ + (row >> 2)] = pe + pO;
-                F4[n * FQ + 64 + (row >> 2)] = pe - pO;
-                const f32x4 lo = me + mO, hi = me - mO;
-                float *o = Ff + n * (4 * FQ);
-                if (row != 0) { o[256 - row] = lo.x; o[512 - row] = hi.x; }     // o = 0: y[256] and y[0] are written above
-                o[255 - row] = lo.y; o[511 - row] = hi.y;
-                o[254 - row] = lo.z; o[510 - row] = hi.z;
-                o[253 - row] = lo.w; o[509 - row] = hi.w;
+                if (in_part(n)) {
+                    F4[n * FQ + (row >> 2)] = pe + pO;
+                    F4[n * FQ + 64 + (row >> 2)] = pe - pO;
+                    const f32x4 lo = me + mO, hi = me - mO;
+                    float *o = Ff + n * (4 * FQ);
+                    if (row != 0) { o[256 - row] = lo.x; o[512 - row] = hi.x; }     // o = 0: y[256] and y[0] are written above
+                    o[255 - row] = lo.y; o[511 - row] = hi.y;
+                    o[254 - row] = lo.z; o[510 - row] = hi.z;
+                    o[253 - row] = lo.w; o[509 - row] = hi.w;
+                }
             }
             headp[rpart * 16 + (tid & 15)] = r128;                   // [16 parts][16 streams]: headp .. fcor are idle before the frame loop
             __syncthreads();
-            if (tid < MT16) {
+            if (tid < MT16 && in_part(tid)) {
                 float e = 0.f, od = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { e += headp[k * 16 + tid]; od += headp[(8 + k) * 16 + tid]; }
@@ -309,7 +324,8 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
             }
 #undef OL
         }
-        __syncthreads();                                              // F complete; the staging area is free for the frame loop
+        __syncthreads();                                              // this part of F is complete; staging and headp are free again
+        }                                                             // next segment
     }
 
     for (int t = 0; t < T; ++t) {
@@ -674,20 +690,20 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
             const float z = hb + ((headp[tid] + headp[16 + tid]) + (headp[32 + tid] + headp[48 + tid]));
             const float p = fminf(sigmoidf_(z), 1.0f);
             if (sm_thread) {
-                P.probs[(size_t)(tile0 + tid) * T + t] = p;
+                P.probs[(size_t)gf * T + t] = p;                       // tid < 16: this thread's column is stream gf
                 SmSlot sm = smL[tid];
                 int seg = 0;
                 const int ev = sm_step(sm, p, &seg);
                 if (t == T - 1) P.sm[sm_slot] = sm;
                 else smL[tid] = sm;
                 if (ev & 2) seg_last = seg;
-                if (P.events) P.events[(size_t)(tile0 + tid) * T + t] = (uint8_t)ev;
+                if (P.events) P.events[(size_t)gf * T + t] = (uint8_t)ev;
             }
         }
     }
 #undef X_ISSUE
 #undef WL
-    if (sm_thread && P.seg_frames) P.seg_frames[tile0 + tid] = seg_last;
+    if (sm_thread && P.seg_frames) P.seg_frames[gf] = seg_last;
 }
 
 extern "C" hipError_t vadk_launch_silero_v5_t16(const vadk::StepParams *p, hipStream_t stream) {
@@ -705,7 +721,7 @@ extern "C" hipError_t vadk_launch_silero_v5_t16(const vadk::StepParams *p, hipSt
 // one tick for streams at several input rates: resample + step fused, one launch (p->T must be 1, p->n = all streams)
 extern "C" hipError_t vadk_launch_silero_v5_t16_rates(const vadk::StepParams *p, const vadk::RateParams *r, hipStream_t stream) {
     (void)hipGetLastError();
-    const int tiles = r->tile_start[r->nseg];
+    const int tiles = (r->total + MT16 - 1) / MT16;
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL((silero_v5_step16<true, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, *r);
     return hipGetLastError();

@@ -182,21 +182,24 @@ struct ResampleParams {
 };
 
 // fused resample -> Silero V5 step on 16-stream tiles (csrc/silero_v5_t16.hip, RS instantiation): one launch for a tick whose
-// streams arrive at different rates.  Segment k = n streams of one input rate, served by 16-stream tiles tile_start[k] ..
-// tile_start[k+1]-1; stream0 = index of its first stream in the call's slots / probs / events arrays.
+// streams arrive at different rates.  Segment k = n streams of one input rate; stream0 = index of its first stream in the
+// call's slots / probs / events arrays.  The tiles walk the segments back to back in the order given here: tile b carries the
+// "virtual" streams 16 b .. 16 b + 15 of that concatenation (vstart = where the segment begins in it), so a tile may hold the
+// last streams of one segment and the first of the next - it then resamples each part with its own operator - and 4 096
+// streams in three uneven thirds are exactly 256 tiles, one per CU.
 struct RateSeg {
     const float *wstream;     // pack_resample_operator_t16; nullptr: the segment is 16 kHz already (`in` holds 512-sample frames)
     uint32_t wstream_bytes;
     uint32_t wave_blocks;     // operator blocks per wave
     uint32_t row128_block;
-    int32_t n, n_in, stream0;
+    int32_t n, n_in, stream0, vstart;
     const float *in;          // [n][n_in]
 };
 constexpr int RATE_MAX_SEGS = 8;
 struct RateParams {
     RateSeg seg[RATE_MAX_SEGS];
     int32_t nseg;
-    int32_t tile_start[RATE_MAX_SEGS + 1];
+    int32_t total;            // streams of all segments
 };
 
 }  // namespace vadk

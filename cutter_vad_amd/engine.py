@@ -305,6 +305,19 @@ class Engine:
         del buf
         return status
 
+    def tick_push_gather(self, slots, frames, nsamples: int, gate_on: bool = True, i16_scale: int = 32767) -> np.ndarray:
+        """``frames``: a sequence of ``bytes`` objects (int16 PCM, ``nsamples`` samples each), one per listed slot; they are
+        copied from where they are into the tick's staging (``vad_tick_push_gather``) -> int32 status per frame."""
+        s = np.ascontiguousarray(slots, dtype=np.int64).reshape(-1)
+        n = s.size
+        if len(frames) != n:
+            raise AudioProcessingError(f"Model prediction failed: {len(frames)} frames for {n} slots")
+        ptrs = (C.c_char_p * n)(*frames)               # borrows the bytes objects' buffers: `frames` stays alive through the call
+        status = np.zeros(n, np.int32)
+        fmt = _ffi.VAD_FMT_I16_32768 if i16_scale == 32768 else _ffi.VAD_FMT_I16_32767
+        self._lib.vad_tick_push_gather(self._h, _ptr(s, C.c_int64), n, ptrs, int(nsamples), fmt, int(gate_on), _ptr(status, C.c_int32))
+        return status
+
     def tick_cancel(self, slot: int) -> None:
         self._check(self._lib.vad_tick_cancel(self._h, int(slot)), VADError)
 

@@ -57,7 +57,7 @@ class PooledSession:
     """One client stream: a slot of the shared engine + the host half of its voice segments."""
 
     __slots__ = ("pool", "slot", "config", "long_frames", "on_start", "on_end", "on_continue", "on_error", "closed",
-                 "wav_writer", "user", "rate", "moving")
+                 "wav_writer", "user", "rate", "moving", "gate")
 
     def __init__(self, pool: "SharedStreamPool", slot: int, config: VADConfig) -> None:
         self.pool = pool
@@ -74,6 +74,7 @@ class PooledSession:
                                     channels=1)
         self.user = None
         self.rate: Optional[int] = pool._input_rate(config)      # None: frames at the engine's rate; else resampled in the tick
+        self.gate = bool(config.enable_denoising)                # plain bool copy of pool._gate[slot] for the per-frame path
 
     # the per-session scalars live in the pool's arrays (indexed by slot) so that a tick can work on all of them at once
     @property
@@ -131,9 +132,10 @@ class SharedStreamPool:
         self._thread: Optional[threading.Thread] = None
         self._stop = threading.Event()
         self._grow(1024)
-        # int16 wire frames of exactly one model frame - what every websocket client sends - are not pushed one by one: they
-        # collect here (per gate value) and go to the engine as ONE vad_tick_push_status call at the start of the next tick
-        self._inbox: List[List] = [[], []]
+        # int16 wire frames no longer than the model's frame - what every websocket client sends - are not pushed one by one:
+        # they collect here, per (byte length, gate), and go to the engine as ONE vad_tick_push_status call per key at the
+        # start of the next tick
+        self._inbox: Dict[tuple, List] = {}
         self.ticks = 0
         self.frames = 0
         self.launches = 0
@@ -237,6 +239,7 @@ class SharedStreamPool:
                                        config.voice_end_frame_count)
             s.config = config
             s.rate = self._input_rate(config)
+            s.gate = bool(config.enable_denoising)
             with self._lock:
                 self._init_slot(s.slot, config)
                 # the session keeps its callbacks across a reconfigure (the app binds them once, at open): so does the flag
@@ -274,8 +277,9 @@ class SharedStreamPool:
     def submit_pcm16(self, s: PooledSession, data: bytes) -> None:
         """Queue one frame as it arrives on the wire: little-endian int16 PCM.  The bytes go to the GPU as they are
         (half the transfer of float32); the kernel scales by 1/32767 with a true division, which is bit-for-bit what
-        the reference server does on the host (vad_websocket_server.py:341).  A frame of exactly the model's length only joins
-        the pool's inbox here (a list append): the frames that arrived within one tick window reach the engine in one call."""
+        the reference server does on the host (vad_websocket_server.py:341).  A frame no longer than the model's only joins
+        the pool's inbox here (a list append): the frames that arrived within one tick window reach the engine in one call per
+        frame length."""
         if len(data) < 2 or len(data) & 1:
             raise AudioProcessingError("Audio data cannot be empty" if len(data) < 2 else
                                        "PCM16 frame with an odd number of bytes")
@@ -284,8 +288,12 @@ class SharedStreamPool:
                 raise AudioProcessingError("session is closed")
             if s.moving or s.pool is not self:
                 return _RETRY
-            if s.rate is None and len(data) == 2 * self.frame:
-                self._inbox[1 if self._gate[s.slot] else 0].append((s.slot, data))
+            if s.rate is None and len(data) <= 2 * self.frame:
+                key = (len(data), s.gate)
+                box = self._inbox.get(key)
+                if box is None:
+                    box = self._inbox[key] = []
+                box.append((s.slot, data))
                 return None
             self._flush_inbox()
             self.engine.tick_push(s.slot, data, bool(self._gate[s.slot]), sample_rate=s.rate)
@@ -295,18 +303,21 @@ class SharedStreamPool:
     def _flush_inbox(self) -> None:
         """The collected wire frames -> the engine's tick staging, one call per gate value (``_lock`` held).  A frame the engine
         refuses (its stream has 256 frames waiting, or was closed meanwhile) is reported to its own session only."""
-        for gate in (0, 1):
-            box = self._inbox[gate]
-            if not box:
-                continue
-            self._inbox[gate] = []
-            slots = np.fromiter((b[0] for b in box), np.int64, len(box))
-            status = self.engine.tick_push_status(slots, b"".join(b[1] for b in box), self.frame, bool(gate))
-            for i in np.nonzero(status)[0]:
-                s = self._by_slot[int(slots[i])]
-                if s is not None and not s.closed:
-                    why = "256 frames are waiting for this stream" if int(status[i]) == _ffi.VAD_ERR_BUSY else f"engine status {int(status[i])}"
-                    self._report(s, AudioProcessingError(f"Model prediction failed: frame not queued: {why}"))
+        if not self._inbox:
+            return
+        inbox, self._inbox = self._inbox, {}
+        for (nbytes, gate), box in inbox.items():
+            slot_list, datas = zip(*box)
+            slots = np.array(slot_list, np.int64)
+            # one join + one call (measured at 8 192 sessions: 1.9 ms; an array of 8 192 ctypes pointers for vad_tick_push_gather
+            # costs more to build in Python than the join's extra copy)
+            status = self.engine.tick_push_status(slots, b"".join(datas), nbytes // 2, gate)
+            if status.any():
+                for i in np.nonzero(status)[0]:
+                    s = self._by_slot[int(slots[i])]
+                    if s is not None and not s.closed:
+                        why = "256 frames are waiting for this stream" if int(status[i]) == _ffi.VAD_ERR_BUSY else f"engine status {int(status[i])}"
+                        self._report(s, AudioProcessingError(f"Model prediction failed: frame not queued: {why}"))
 
     # ------------------------------------------------------------------ the tick
     def tick(self) -> int:

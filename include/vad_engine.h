@@ -312,6 +312,10 @@ VAD_API int vad_tick_push_many(vad_engine *e, const int64_t *slots, int64_t n, c
  * report to which client; returns the first failure (the last-error text belongs to the LAST one) */
 VAD_API int vad_tick_push_status(vad_engine *e, const int64_t *slots, int64_t n, const void *frames, int32_t nsamples,
                                  int frame_fmt, int gate_on, int32_t *status);
+/* the same with one pointer per frame (frames[i] -> nsamples samples): the sockets' receive buffers are copied straight into the
+ * tick's staging rows, without being gathered into one array first */
+VAD_API int vad_tick_push_gather(vad_engine *e, const int64_t *slots, int64_t n, const void *const *frames, int32_t nsamples,
+                                 int frame_fmt, int gate_on, int32_t *status);
 VAD_API int vad_tick_cancel(vad_engine *e, int64_t slot);
 VAD_API int vad_tick_pending(vad_engine *e, int64_t slot, int64_t *frames);
 /*

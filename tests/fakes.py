@@ -148,6 +148,10 @@ class FakeEngine:
                 st[i] = -8
         return st
 
+    def tick_push_gather(self, slots, frames, nsamples, gate_on=True, i16_scale=32767):
+        assert all(len(f) == 2 * nsamples for f in frames)
+        return self.tick_push_status(slots, b"".join(frames), nsamples, gate_on, i16_scale)
+
     def tick_pending(self, slot):
         return len(self.__dict__.setdefault("_tickq", {}).get(int(slot), []))
 

@@ -171,3 +171,38 @@ def test_config3_mixed_input_rates_one_product_call():
             eng.step_rates([(np.zeros((2, 700), np.float32), 24000)], slots[:2])
         with pytest.raises(Exception, match="supported input rates"):
             eng.step_rates([(np.zeros((2, 441), np.float32), 44100)], slots[:2])
+
+
+def test_config3_at_its_stated_size_is_one_fused_launch_with_tiles_that_straddle_the_rate_boundaries():
+    """configs[3] as BASELINE.json states it: 4 096 streams, a third each at 8 / 24 / 48 kHz = 1 365 + 1 365 + 1 366.  Per-segment
+    padding would need 258 sixteen-stream tiles (two more than CUs, so two launches); the tiles walk the segments end to end
+    instead, two of them hold the tail of one rate and the head of the next, and the tick is ONE launch of 256 tiles.  Checked:
+    the oracle chain (Fourier resample -> gate -> model) on a sample that includes every stream of the straddling tiles, and bit
+    equality with the same streams stepped one segment per call (pure tiles): a stream's result does not depend on its
+    neighbours' rates."""
+    from cutter_vad_amd.engine import Engine
+    from oracle import oracle
+    rates = ((8000, 256, 1365), (24000, 768, 1365), (48000, 1536, 1366))
+    B, T = 4096, 4
+    rng = np.random.default_rng(34)
+    base = make_streams(B, T * 3, seed=4321).reshape(B, -1)
+    om = oracle.OracleModel(_blob(5), "f64")
+    starts = np.cumsum([0] + [r[2] for r in rates])
+    # walk order inside the launch: 48 k | 8 k | 24 k -> the straddling tiles hold (48 k tail, 8 k head) and (8 k tail, 24 k head)
+    edge = np.concatenate([np.arange(starts[2] + 1366 - 8, starts[2] + 1366), np.arange(0, 12), np.arange(1365 - 12, 1365),
+                           np.arange(starts[1], starts[1] + 8)])
+    pick = np.unique(np.concatenate([edge, rng.choice(B, 40, replace=False)]))
+    seg_of = np.searchsorted(starts, pick, side="right") - 1
+    with Engine(_blob(5), model_version=5, max_streams=B) as eng, Engine(_blob(5), model_version=5, max_streams=B) as solo:
+        slots, slots2 = eng.open_streams(B), solo.open_streams(B)
+        st = np.zeros((pick.size, 256), np.float32)
+        for t in range(T):
+            segs = [(np.ascontiguousarray(base[starts[k]:starts[k + 1], t * n_in:(t + 1) * n_in]), sr) for k, (sr, n_in, _) in enumerate(rates)]
+            before = eng.info()["steps"]
+            p, ev, _ = eng.step_rates(segs, slots)
+            assert eng.info()["steps"] == before + 1                      # one launch: 256 tiles, one per CU
+            x16 = np.stack([oracle.resample(segs[k][0][i - starts[k]], 512) for i, k in zip(pick, seg_of)]).astype(np.float32)
+            ref = om.step_batch(oracle.denoise(x16).reshape(pick.size, 512), st, nthreads=8)
+            assert np.abs(p[pick] - ref).max() <= 5e-5, t
+            alone = np.concatenate([solo.step_rates([segs[k]], slots2[starts[k]:starts[k + 1]])[0] for k in range(3)])
+            assert np.array_equal(p, alone), t

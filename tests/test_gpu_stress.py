@@ -172,16 +172,18 @@ def test_producers_push_while_the_tick_runs_and_every_stream_sees_its_frames_in_
     from cutter_vad_amd.engine import Engine
     with open(weights_io.packaged_blob_path(5), "rb") as f:
         blob = f.read()
-    P, PER, K = 4, 48, 24
+    import os
+    P, PER, K = 4, 48, 48
     n = P * PER
-    base = make_streams(n, K, seed=777)                                     # [n, K, 512]
-    base[1::2] *= 3.0                                                       # loud enough to open segments
-    np.clip(base, -1, 1, out=base)
+    pcm = np.load(os.path.join(os.path.dirname(__file__), "golden", "speech16k_i16.npz"))["pcm"].astype(np.float32) / np.float32(32767.0)
+    span = K * 512
+    # every stream hears the reference's speech clip from its own offset: talk and pauses, so segments open AND finish
+    base = np.stack([pcm[(i * 3001) % (pcm.size - span):][:span].reshape(K, 512) for i in range(n)]).astype(np.float32)
     rng = np.random.default_rng(3)
-    chunks48 = (0.2 * rng.standard_normal((n, K, 1536))).astype(np.float32)
+    chunks48 = np.repeat(base, 3, axis=2) * np.float32(0.9)                 # 1536-sample chunks (a crude 48 kHz rendition: any signal will do)
     kind = np.arange(n) % 4                                                 # 0 f32 | 1 int16 | 2 48 kHz chunk | 3 over-long f32 (600)
     tail = (0.05 * rng.standard_normal((n, K, 88))).astype(np.float32)
-    thr = (0.3, 0.2, 0.5, 0.5, 2, 3)
+    thr = (0.4, 0.3, 0.5, 0.5, 2, 4)
 
     def frame(i, k):
         if kind[i] == 1:
@@ -271,4 +273,4 @@ def test_producers_push_while_the_tick_runs_and_every_stream_sees_its_frames_in_
         for a, b in zip(serial_s[i], conc_s[i]):
             assert np.array_equal(a, b), i
             n_seg += 1
-    assert n_seg >= n // 4                                                  # the loud half does talk
+    assert n_seg >= 20                                                      # segments do finish in this scenario

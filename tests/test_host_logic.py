@@ -249,6 +249,28 @@ def test_wrapper_errors_and_thresholds(wrapper):
         wrapper.set_thresholds(voice_end_frame_count=201)
     wrapper.set_thresholds()
     assert wrapper.config.voice_end_frame_count == 57            # the 57-vs-50 quirk
+    # the reference validates through pydantic in lax mode (vad_wrapper.py:130-199): numpy scalars, numeric strings, bools and
+    # integral floats for a count are coerced; each violated bound has its own message (checked against the reference's class
+    # side by side when this was written: identical strings for all of these)
+    wrapper.set_thresholds(vad_start_probability=np.float32(0.5), vad_end_probability="0.25", voice_start_ratio=True,
+                           voice_start_frame_count=np.int64(5), voice_end_frame_count=7.0)
+    c = wrapper.config
+    assert (c.vad_start_probability, c.vad_end_probability, c.voice_start_ratio, c.voice_start_frame_count, c.voice_end_frame_count) == \
+        (0.5, 0.25, 1.0, 5, 7) and type(c.voice_end_frame_count) is int
+    for kw, text in ((dict(voice_end_frame_count=0), "Input should be greater than or equal to 1"),
+                     (dict(voice_end_frame_count=201), "Voice end frame count should not exceed 200"),
+                     (dict(vad_start_probability=1.5), "Input should be less than or equal to 1"),
+                     (dict(vad_start_probability=0.05), "Start probability should be at least 0.1"),
+                     (dict(voice_start_frame_count=5.5), "got a number with a fractional part"),
+                     (dict(vad_end_probability="x"), "unable to parse string as a number")):
+        with pytest.raises(ConfigurationError) as ei:
+            wrapper.set_thresholds(**kw)
+        assert text in str(ei.value) and "ThresholdConfiguration" in str(ei.value), kw
+    from cutter_vad_amd.core.vad_wrapper import CallbackConfiguration, ThresholdConfiguration, VADWrapperState
+    assert ThresholdConfiguration().voice_end_frame_count == 57 and not CallbackConfiguration().has_any_callback()
+    snap = wrapper.state_snapshot()
+    assert isinstance(snap, VADWrapperState) and snap.is_initialized and snap.average_processing_time_per_frame >= 0.0
+    wrapper.set_thresholds()
     with pytest.raises(VADError):
         wrapper.set_callbacks(voice_start_callback="nope")
     with pytest.raises(ConfigurationError):

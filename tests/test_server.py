@@ -438,11 +438,13 @@ def test_wire_frames_are_coalesced_into_one_push_per_tick():
     assert pool.tick() == 50 and eng.push_status_calls == 1 and calls == [50]
     # order across the two ingest paths: an odd-sized frame flushes what was collected before it
     a = sessions[0]
+    long16 = (np.full(700, 0.5) * 32767).astype("<i2").tobytes()
     a.submit_pcm16(loud16)
+    a.submit_pcm16(long16)                                          # longer than the model's frame: pushed directly
     a.submit_pcm16(loud16[:600])
-    a.submit_pcm16(loud16)
     assert pool.drain() == 3 and a.frames_done == 4
-    assert [f.shape for f in eng.frames_seen[-3:]] == [(1, 512)] * 3 and np.all(eng.frames_seen[-2][0, 300:] == 0)
+    assert [f.shape for f in eng.frames_seen[-3:]] == [(1, 512)] * 3 and np.all(eng.frames_seen[-1][0, 300:] == 0)
+    assert np.all(eng.frames_seen[-2][0] != 0)
     # a frame the engine refuses is reported to its own session only
     for _ in range(300):
         a.submit_pcm16(loud16)

@@ -72,35 +72,37 @@ def tile_shapes():
 
 
 def config3(per=None):
+    """configs[3]: 4 096 streams, a third each at 8 / 24 / 48 kHz (1 365 + 1 365 + 1 366) unless `per` names another split"""
     B = 4096
-    per = per or B // 3
+    per = list(per) if per is not None else [1365, 1365, 1366]
     eng = Engine(blob(5), max_streams=B)
     eng.open_streams(B)
     rates = ((8000, 256), (24000, 768), (48000, 1536))
-    rings = [(0.1 * torch.randn(8, per, n_in, device="cuda")).contiguous() for _, n_in in rates]
-    probs = torch.empty(3 * per, device="cuda")
+    rings = [(0.1 * torch.randn(8, per[k], n_in, device="cuda")).contiguous() for k, (_, n_in) in enumerate(rates)]
+    total = sum(per)
+    probs = torch.empty(total, device="cuda")
     ts = torch.cuda.Stream()
 
     def step(i):
-        # ONE product call (vad_step_rates_device): the three input rates of the tick in one resample launch into engine-owned
-        # HBM, the model step right behind it on the same HIP stream
-        eng.step_rates_device([(rings[k][i % 8].data_ptr(), per, sr) for k, (sr, _n) in enumerate(rates)], probs.data_ptr(),
+        # ONE product call (vad_step_rates_device)
+        eng.step_rates_device([(rings[k][i % 8].data_ptr(), per[k], sr) for k, (sr, _n) in enumerate(rates)], probs.data_ptr(),
                               stream=ts.cuda_stream)
 
     dt = timed(step, [ts])
     eng.set_tile(-1)                  # the two-launch form of the same call: resample kernel, then the model kernel
     dt2 = timed(step, [ts])
     eng.close()
-    tiles = 3 * ((per + 15) // 16)
-    return {"config": f"configs[3]: batch={3 * per} (3 x {per}) mixed 8/24/48 kHz -> vad_step_rates_device; {tiles} 16-stream tiles: "
+    tiles = (total + 15) // 16
+    return {"config": f"configs[3]: batch={total} ({' + '.join(map(str, per))}) mixed 8/24/48 kHz -> vad_step_rates_device; {tiles} 16-stream tiles "
+                      "(the tiles walk the segments end to end; a tile at a rate boundary resamples its two parts in turn): "
                       + ("ONE fused launch (every tile resamples its chunks into LDS and steps from there)" if tiles <= 256 else
                          "more tiles than CUs -> resample launch + model launch"),
-            "us_per_step": dt * 1e6, "frames_per_s": 3 * per / dt, "us_per_step_two_launches_forced": dt2 * 1e6}
+            "us_per_step": dt * 1e6, "frames_per_s": total / dt, "us_per_step_two_launches_forced": dt2 * 1e6}
 
 
 def config3_255_tiles():
     """configs[3] with the three thirds rounded to whole tiles (3 x 1 360 = 4 080 streams = 255 tiles): the fused launch"""
-    return config3(1360)
+    return config3([1360, 1360, 1360])
 
 
 def config3_pipelined():

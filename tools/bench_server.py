@@ -11,12 +11,26 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cutter_vad_amd import VADConfig  # noqa: E402
-from cutter_vad_amd.server import SharedStreamPool  # noqa: E402
+from cutter_vad_amd.server import ShardedStreamPool, SharedStreamPool  # noqa: E402
 from tests.signals import make_streams  # noqa: E402
 
 
+DEVICES = None          # --devices 0,1,...: one pool per listed GPU behind a ShardedStreamPool (the same ordinal twice = two engines on one GPU)
+
+
+def make_pool(**kw):
+    if DEVICES is None:
+        return SharedStreamPool(max_streams=8192, **kw)
+    return ShardedStreamPool(devices=DEVICES, max_streams=8192, **kw)
+
+
+def tick_us(pool):
+    engines = [p.engine for p in pool.shards] if hasattr(pool, "shards") else [pool.engine]
+    return [max(e.last_tick_us[k] for e in engines) for k in range(3)]
+
+
 def run(n, ticks=40):
-    pool = SharedStreamPool(max_streams=8192)
+    pool = make_pool()
     cfg = VADConfig(vad_start_probability=0.4, vad_end_probability=0.3, voice_start_frame_count=6,
                     voice_end_frame_count=12, buffer_size=480)
     sessions = [pool.open_session(cfg) for _ in range(n)]
@@ -28,6 +42,7 @@ def run(n, ticks=40):
     pcm = np.clip(x * 32767.0, -32768, 32767).astype("<i2")
     wire = [[pcm[k % pcm.shape[0], t].tobytes() for k in range(n)] for t in range(ticks + 5)]
     t_sub = t_tick = 0.0
+    c_us = [0.0, 0.0, 0.0]
     for t in range(ticks + 5):
         a = time.perf_counter()
         for k, s in enumerate(sessions):
@@ -38,8 +53,12 @@ def run(n, ticks=40):
         if t >= 5:
             t_sub += b - a
             t_tick += c - b
+            for k, v in enumerate(tick_us(pool)):
+                c_us[k] += v
     pool.close()
-    return {"sessions": n, "ticks": ticks, "decode_submit_ms_per_tick": t_sub / ticks * 1e3,
+    return {"sessions": n, "ticks": ticks, "ingest": "submit_pcm16 per session (the ASGI app's path): frames collect in the pool's inbox, one vad_tick_push_status per tick",
+            "devices": DEVICES, "decode_submit_ms_per_tick": t_sub / ticks * 1e3,
+            "tick_in_C_us": {"swap": c_us[0] / ticks, "gpu": c_us[1] / ticks, "segments": c_us[2] / ticks},
             "tick_ms": t_tick / ticks * 1e3, "frames_per_s_host_inclusive": n * ticks / (t_sub + t_tick),
             "real_time_factor": (n * ticks / (t_sub + t_tick)) / (n * 1000 / 30), "events": counts}
 
@@ -47,7 +66,7 @@ def run(n, ticks=40):
 def run_batched(n, ticks=40):
     """The same load through the batch ingest a native front end would use (vad_tick_push_many): one call hands over the tick's
     frames of all sockets; everything else - tick, events, WAV payloads on END - is the same code path."""
-    pool = SharedStreamPool(max_streams=8192)
+    pool = SharedStreamPool(max_streams=8192)           # (one device: the batch call addresses one engine's slots)
     cfg = VADConfig(vad_start_probability=0.4, vad_end_probability=0.3, voice_start_frame_count=6,
                     voice_end_frame_count=12, buffer_size=480)
     sessions = [pool.open_session(cfg) for _ in range(n)]
@@ -124,6 +143,13 @@ def run_rates(n, ticks=40):
 
 
 if __name__ == "__main__":
+    if "--devices" in sys.argv:
+        i = sys.argv.index("--devices")
+        DEVICES = [int(d) for d in sys.argv[i + 1].split(",")]
+        del sys.argv[i:i + 2]
+        for n in (2048, 8192):
+            print(json.dumps(run(n)), flush=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "rates":
         for n in (2048, 8192):
             print(json.dumps(run_rates(n)), flush=True)
