@@ -362,11 +362,13 @@ def main() -> int:
             flop = sum(FLOP_PER_FRAME[v] for v in versions) * (B // len(versions))
             achieved = flop / ks
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if not mixed and os.path.exists(pmc):
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic_mix.json" if mixed else "pmc_traffic.json")
+            if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                    traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured in this run)"
+                    rec = json.load(open(pmc))
+                    traffic = rec.get("hbm_bytes_per_step") if mixed else rec.get("hbm_bytes_per_launch")
+                    traffic_src = (f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                   f"build {rec.get('build', 'see profiles/README.md')}; not re-measured in this run)")
                 except Exception:
                     traffic = None
             out["roofline"] = {

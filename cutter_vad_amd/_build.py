@@ -43,7 +43,13 @@ def up_to_date() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and up_to_date():
+    # kernel experiments on a GPU box (tools/variants.sh): VAD_KERNEL_DEFINES="-DX -DY" recompiles the .hip files named in
+    # VAD_KERNEL_DEFINES_FILES (comma separated; default: all) with those flags and relinks.  Never set by the product.
+    import shlex
+    defines = shlex.split(os.environ.get("VAD_KERNEL_DEFINES", ""))
+    only = [f for f in os.environ.get("VAD_KERNEL_DEFINES_FILES", "").split(",") if f]
+    experiment = "VAD_KERNEL_DEFINES" in os.environ
+    if not force and not experiment and up_to_date():
         return LIB
     cc = _hipcc()
     objs = []
@@ -55,13 +61,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     kernel_flags = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
     for s in HIP_SOURCES:
         o = os.path.join(bdir, s + ".o")
-        cmd = [cc, f"--offload-arch={ARCH}", *common, *kernel_flags, "-c", os.path.join(CSRC, s), "-o", o]
+        mine = experiment and (not only or s in only)
+        if experiment and not mine and os.path.exists(o) and not force:
+            objs.append(o)                      # an experiment rebuilds only the files it names
+            continue
+        cmd = [cc, f"--offload-arch={ARCH}", *common, *kernel_flags, *(defines if mine else []), "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
         subprocess.check_call(cmd)
         objs.append(o)
     for s in CPP_SOURCES:
         o = os.path.join(bdir, s + ".o")
+        if experiment and os.path.exists(o) and not force:
+            objs.append(o)
+            continue
         subprocess.check_call([cc, *common, "-fvisibility=hidden", "-c", os.path.join(CSRC, s), "-o", o])
         objs.append(o)
     tmp = LIB + ".tmp"

@@ -139,6 +139,51 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
             XR[k] = __builtin_amdgcn_raw_buffer_load_b128(frs, (fq + 16 * k) << qsh, 0, 0);                     \
     }
 
+    // ---- RS: the tile's parts.  A part = the columns c0 .. c1 - 1 of this tile that belong to one segment (one input rate); a tile
+    //      at a rate boundary has two.
+    struct Part {
+        RateSeg S;
+        int sk, c0, c1, ls0, Q;
+        bool valid;
+    };
+    constexpr int DEAD = 1 << 26;                  // an index (in quads / samples) past every buffer: loads return 0
+    const int v0 = (int)blockIdx.x * MT16;
+    auto mk_part = [&](int from) {
+        Part pt{};
+        pt.valid = false;
+        if constexpr (RS) {
+            for (int k = from; k < R.nseg; ++k) {                    // block-uniform: kernel arguments only
+                const int a0 = max(R.seg[k].vstart, v0) - v0, a1 = min(R.seg[k].vstart + R.seg[k].n, v0 + MT16) - v0;
+                if (a0 < a1) {
+                    pt.S = R.seg[k];
+                    pt.sk = k; pt.c0 = a0; pt.c1 = a1;
+                    pt.ls0 = v0 - pt.S.vstart;                       // column c holds the segment's stream ls0 + c (c0 <= c < c1)
+                    pt.Q = pt.S.n_in >> 2;
+                    pt.valid = true;
+                    break;
+                }
+            }
+        }
+        return pt;
+    };
+    // chunk loader: 16 streams x 16 folded quads = one per thread (stream ms = tid >> 4, quad ql = tid & 15)
+    u32x4 xlA[6], xlB[6];
+    const int cms = tid >> 4, cql = tid & 15;
+    auto load_chunk = [&](const Part &pt, int c, u32x4 *xl) {
+        const __amdgpu_buffer_rsrc_t xrs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pt.S.in), 0, (int)((unsigned)pt.S.n * (unsigned)pt.S.n_in * 4u), 0x00020000);
+        const int Q = pt.Q, qq = cql + 16 * c, base = (cms >= pt.c0 && cms < pt.c1) ? (pt.ls0 + cms) * Q : DEAD;
+        xl[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + qq) * 16, 0, 0);
+        xl[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + qq + (Q >> 1)) * 16, 0, 0);
+        xl[2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (Q >> 1) - qq) * 16, 0, 0);
+        xl[3] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (Q >> 1) - qq - 1) * 16, 0, 0);
+        xl[4] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (qq == 0 ? 0 : Q - qq)) * 16, 0, 0);
+        xl[5] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + Q - qq - 1) * 16, 0, 0);
+    };
+    Part cur = mk_part(0);
+    // (requesting the first part's first chunk right here, before the recurrent state is waited for, was measured: 48.6 - 49.7 us
+    //  against 47.9 - 48.2 for 4 096 streams at 48 kHz on one box - the request only delays the state loads queued behind it)
+
     // ---- prologue: h_{t-1} -> LDS quads (32 rows x 16 streams), c_{t-1} -> registers, state machines -> LDS ----
     f32x4 hv[2];
     const int fm = tid & 15, part = tid >> 4;      // fm == n: ONE slot lookup serves h, c and the state machine
@@ -175,15 +220,10 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
         //      the operator layout): four folded inputs ue / ve / uo / vo of length Q = n_in / 4 against four 128-row operators
         //      (se, ae, so, ao); wave w owns rows o = 32 w .. 32 w + 31 (two row tiles) of all four
         float *const Ff = reinterpret_cast<float *>(F4);
-        const int v0 = (int)blockIdx.x * MT16;
-        for (int sk = 0; sk < R.nseg; ++sk) {
-        const RateSeg S = R.seg[sk];
-        // the part of this tile that belongs to segment sk: columns c0 .. c1 - 1 = the segment's streams ls0 .. (block-uniform)
-        const int c0 = max(S.vstart, v0) - v0, c1 = min(S.vstart + S.n, v0 + MT16) - v0;
-        if (c0 >= c1) continue;
-        const int ls0 = v0 - S.vstart;                                // column c holds the segment's stream ls0 + c (c0 <= c < c1)
+        while (cur.valid) {
+        const RateSeg S = cur.S;
+        const int c0 = cur.c0, c1 = cur.c1, ls0 = cur.ls0;
         auto in_part = [&](int c) { return c >= c0 && c < c1; };
-        constexpr int DEAD = 1 << 26;                                 // an index (in quads / samples) past every buffer: loads return 0
         if (S.wstream == nullptr) {                                   // already 16 kHz (resample_audio returns its input): copy
             const __amdgpu_buffer_rsrc_t xrs =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S.in), 0, (int)((unsigned)S.n * 2048u), 0x00020000);
@@ -201,32 +241,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S.in), 0, (int)((unsigned)S.n * (unsigned)S.n_in * 4u), 0x00020000);
 #define OL(blk) ldw(ors, lane16, (blk))
             const int wbase = w * (int)S.wave_blocks;
-            f32x4 acc[8];                                             // part p (se, ae, so, ao), row tile rt -> acc[2 p + rt]
-            {   // the sample each half-size product cannot pair, x[Q] +- x[Q + H], is a rank-1 term: accumulator init
-                const int sb = in_part(n) ? (ls0 + n) * S.n_in : (DEAD << 2);     // columns of other segments contract zeros
-                const float xa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (sb + Q) * 4, 0, 0));
-                const float xb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (sb + 3 * Q) * 4, 0, 0));
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    acc[0 + rt] = OL(wbase + rt) * (xa + xb);
-                    acc[4 + rt] = OL(wbase + 2 + rt) * (xa - xb);
-                    acc[2 + rt] = acc[6 + rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            // chunk loader: 16 streams x 16 folded quads = one per thread (stream ms = tid >> 4, quad ql = tid & 15)
+            load_chunk(cur, 0, xlA);
             // (input chunks are requested TWO chunks ahead - two register sets - so that a chunk's HBM round trip has a whole
-            // chunk of MFMAs, ~1.7 us, more to hide under than it needs)
-            u32x4 xlA[6], xlB[6];
-            const int cms = tid >> 4, cql = tid & 15;
-            auto load_chunk = [&](int c, u32x4 *xl) {
-                const int qq = cql + 16 * c, base = in_part(cms) ? (ls0 + cms) * Q : DEAD;
-                xl[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + qq) * 16, 0, 0);
-                xl[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + qq + (Q >> 1)) * 16, 0, 0);
-                xl[2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (Q >> 1) - qq) * 16, 0, 0);
-                xl[3] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (Q >> 1) - qq - 1) * 16, 0, 0);
-                xl[4] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (qq == 0 ? 0 : Q - qq)) * 16, 0, 0);
-                xl[5] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + Q - qq - 1) * 16, 0, 0);
-            };
+            // chunk of MFMAs, ~1.7 us, more to hide under than it needs; chunk 0 has been on its way since before this part began)
             auto store_chunk = [&](int c, int buf, const u32x4 *xl) {
                 const f32x4 a = __builtin_bit_cast(f32x4, xl[0]), cc = __builtin_bit_cast(f32x4, xl[1]);
                 const f32x4 b0 = __builtin_bit_cast(f32x4, xl[2]), b1 = __builtin_bit_cast(f32x4, xl[3]);
@@ -241,56 +258,110 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
                 dst[2 * RS_CH_ROWS * QSL] = uo;
                 dst[3 * RS_CH_ROWS * QSL] = vo;
             };
+            // the sample each half-size product cannot pair, x[Q] +- x[Q + H], is a rank-1 term (accumulator init, rows 128 / 384)
+            const int sb = in_part(n) ? (ls0 + n) * S.n_in : (DEAD << 2);         // columns of other segments contract zeros
+            const float xa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (sb + Q) * 4, 0, 0));
+            const float xb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (sb + 3 * Q) * 4, 0, 0));
+            const f32x4 mid = ldw(ors, (Q >> 1) * 16, (int)S.row128_block);       // floats 2Q, 2Q + 1: RE[128][Q] / 2, RO[128][Q] / 2
+            f32x4 ini[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ini[k] = OL(wbase + k);
             // output rows 128 / 384 on the VALU: thread = (stream tid & 15, part tid >> 4); parts 0..7 dot ue with GSE[128],
             // 8..15 uo with GSO[128], two quads of every chunk each
             float r128 = 0.f;
             const int rpart = tid >> 4, pr = rpart & 7, psel = rpart >> 3;
-            constexpr int D = 4;                                      // operator blocks run D k-iterations ahead, across chunks
-            f32x4 wq[D][8], xq[4];
+#ifndef RS_D
+#define RS_D 4
+#endif
+            constexpr int D = RS_D;                                   // operator blocks run D - 1 k-iterations ahead, across chunks (4 or 8: the slot of
+                                                                      // a k-iteration must be static inside the two-chunk loop body)
+            f32x4 wq[D][8], xqA[4], xqB[4];
             int ws = wbase + 4;
-#define R_LDW(slot, j) _Pragma("unroll") for (int k = 0; k < 8; ++k) wq[slot][k] = OL(ws + 8 * (j) + k);
+#define R_LDW0(slot, j) _Pragma("unroll") for (int k = 0; k < 8; ++k) wq[slot][k] = OL(ws + 8 * (j) + k);
+            // (tools/variants.sh experiments, never defined in the product build: RS_EXP_NOLDW = the operator is not streamed,
+            //  RS_EXP_NOMFMA = 4 VALU FMAs stand in for each group of 4 MFMAs, RS_EXP_NOX = the input chunks are loaded once)
+#ifdef RS_EXP_NOLDW
+#define R_LDW(slot, j)
+#else
+#define R_LDW(slot, j) R_LDW0(slot, j)
+#endif
+#ifdef RS_EXP_NOMFMA
+#define RS_MMA(W, X, A) ((A) + (W) * (X))
+#else
+#define RS_MMA(W, X, A) mfma16((W), (X), (A))
+#endif
+#ifdef RS_EXP_NOLDW
 #pragma unroll
-            for (int d = 0; d < D - 1; ++d) { R_LDW(d, d) }
-            load_chunk(0, xlA);
+            for (int d = 0; d < D; ++d) { R_LDW0(d, d % (D - 1)) }
+#endif
+#pragma unroll
+            for (int d = 0; d < D - 1; ++d) { R_LDW0(d, d) }
+            if (nchunks > 1) load_chunk(cur, 1, xlB);
+            f32x4 acc[8];                                             // part p (se, ae, so, ao), row tile rt -> acc[2 p + rt]
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                acc[0 + rt] = ini[rt] * (xa + xb);
+                acc[4 + rt] = ini[2 + rt] * (xa - xb);
+                acc[2 + rt] = acc[6 + rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             store_chunk(0, 0, xlA);
-            if (nchunks > 1) load_chunk(1, xlB);
             __syncthreads();
-            // chunk c: the MFMAs read staging buffer c & 1; chunk c + 1 (already requested, in `XS`) is folded into the other buffer
-            // at the end; chunk c + 2 is requested into `XL` at the start
-#define RS_CHUNK(c, XS, XL)                                                                                     \
+            // Chunk c: the MFMAs read staging buffer c & 1.  Software pipeline inside a chunk: the activation quads of k-iteration
+            // j + 1 are read from LDS BEFORE the MFMAs of j are issued (two register sets), chunk c + 1 (requested two chunks ago,
+            // in `XS`) is folded into the other staging buffer while the MFMAs of j = 1 run, the VALU rows under j = 2, chunk c + 2
+            // is requested into `XL` at the start - so that the chunk's only exposed LDS round trip is the first read behind
+            // the barrier at its end.  (Before: four exposed reads + fold + barrier per chunk = 1.3 us on top of 1.7 us of MFMAs.)
+#ifdef RS_EXP_NOX
+#define RS_LOADX(c, XL)
+#else
+#define RS_LOADX(c, XL) load_chunk(cur, (c), XL)
+#endif
+#define RS_XQ(XQ, X, j) _Pragma("unroll") for (int p4 = 0; p4 < 4; ++p4) XQ[p4] = (X)[(p4 * RS_CH_ROWS + 4 * (j)) * QSL + nqL];
+#define RS_STEP(j, XC, XN, EXTRA)                                                                               \
+                {                                                                                               \
+                    R_LDW((4 * PAR_ + (j) + D - 1) % D, (j) + D - 1)   /* past j = 3: the next chunks' blocks (the stream is contiguous) */ \
+                    if ((j) < 3) { RS_XQ(XN, X, (j) + 1) }                                                      \
+                    EXTRA                                                                                       \
+                    SB();                                                                                       \
+                    _Pragma("unroll") for (int k = 0; k < 8; ++k) acc[k] = RS_MMA(wq[(4 * PAR_ + (j)) % D][k], XC[k >> 1], acc[k]); \
+                    SB();                                                                                       \
+                }
+#define RS_CHUNK(c, XS, XL, PAR)                                                                                \
             {                                                                                                   \
+                constexpr int PAR_ = PAR;                                                                       \
                 const f32x4 *X = lds + ((c) & 1) * RS_BUF;                                                      \
                 asm volatile("" : "+s"(ws));                                                                    \
                 f32x4 g128[2];                                                                                  \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
-                    R_LDW((j + D - 1) % D, j + D - 1)   /* past j = 3: the next chunk's blocks (the stream is contiguous) */ \
-                    if (j == 0) {                                                                               \
-                        if ((c) + 2 < nchunks) load_chunk((c) + 2, XL);                                         \
+                RS_STEP(0, xqA, xqB,                                                                            \
+                        if ((c) + 2 < nchunks) RS_LOADX((c) + 2, XL);                                           \
                         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                           \
-                            g128[i] = ldw(ors, (psel * (Q >> 2) + 16 * (c) + 2 * pr + i) * 16, (int)S.row128_block); \
-                    }                                                                                           \
-                    _Pragma("unroll") for (int p4 = 0; p4 < 4; ++p4) xq[p4] = X[(p4 * RS_CH_ROWS + 4 * j) * QSL + nqL]; \
-                    SB();                                                                                       \
-                    _Pragma("unroll") for (int k = 0; k < 8; ++k) acc[k] = mfma16(wq[j % D][k], xq[k >> 1], acc[k]); \
-                    SB();                                                                                       \
-                }                                                                                               \
-                ws += 32;                                                                                       \
-                {                                                                                               \
+                            g128[i] = ldw(ors, (psel * (Q >> 2) + 16 * (c) + 2 * pr + i) * 16, (int)S.row128_block);) \
+                RS_STEP(1, xqB, xqA, if ((c) + 1 < nchunks) store_chunk((c) + 1, ((c) + 1) & 1, XS);)           \
+                RS_STEP(2, xqA, xqB, {                                                                          \
                     const int ms = tid & 15;                                                                    \
                     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
                         const f32x4 uu = X[(psel * 2 * RS_CH_ROWS + 2 * pr + i) * QSL + ms];                    \
                         r128 += g128[i].x * uu.x + g128[i].y * uu.y + g128[i].z * uu.z + g128[i].w * uu.w;      \
                     }                                                                                           \
-                }                                                                                               \
-                if ((c) + 1 < nchunks) store_chunk((c) + 1, ((c) + 1) & 1, XS);                                 \
+                })                                                                                              \
+                RS_STEP(3, xqB, xqA, )                                                                          \
+                ws += 32;                                                                                       \
                 __syncthreads();                                                                                \
+                if ((c) + 1 < nchunks) { RS_XQ(xqA, lds + (((c) + 1) & 1) * RS_BUF, 0) }                        \
             }
+            RS_XQ(xqA, lds, 0)
             for (int c = 0; c < nchunks; c += 2) {
-                RS_CHUNK(c, xlB, xlA)
-                if (c + 1 < nchunks) RS_CHUNK(c + 1, xlA, xlB)
+                RS_CHUNK(c, xlB, xlA, 0)
+                if (c + 1 < nchunks) RS_CHUNK(c + 1, xlA, xlB, 1)
             }
 #undef RS_CHUNK
+#undef RS_STEP
+#undef RS_XQ
+#undef RS_LOADX
+#undef RS_MMA
 #undef R_LDW
+#undef R_LDW0
+            // every chunk of this part has been consumed: the next part's first chunk goes on its way under the tail below
             // recombine: y[o] = se+ae+so+ao, y[o+256] = se+ae-so-ao, y[256-o] = se-ae+so-ao, y[512-o] = se-ae-so+ao
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
@@ -310,22 +381,20 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
             }
             headp[rpart * 16 + (tid & 15)] = r128;                   // [16 parts][16 streams]: headp .. fcor are idle before the frame loop
             __syncthreads();
-            if (tid < MT16 && in_part(tid)) {
+            if (tid < MT16 && in_part(tid)) {                         // tid < 16: this thread's MFMA column n is stream tid - xa / xb are its x[Q], x[3Q]
                 float e = 0.f, od = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { e += headp[k * 16 + tid]; od += headp[(8 + k) * 16 + tid]; }
-                const float xq1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ((ls0 + tid) * S.n_in + Q) * 4, 0, 0));
-                const float xq3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ((ls0 + tid) * S.n_in + 3 * Q) * 4, 0, 0));
-                const f32x4 mid = ldw(ors, (Q >> 1) * 16, (int)S.row128_block);       // floats 2Q, 2Q + 1: RE[128][Q] / 2, RO[128][Q] / 2
-                e += mid.x * (xq1 + xq3);
-                od += mid.y * (xq1 - xq3);
+                e += mid.x * (xa + xb);
+                od += mid.y * (xa - xb);
                 Ff[tid * (4 * FQ) + 128] = e + od;
                 Ff[tid * (4 * FQ) + 384] = e - od;
             }
 #undef OL
         }
         __syncthreads();                                              // this part of F is complete; staging and headp are free again
-        }                                                             // next segment
+        cur = mk_part(cur.sk + 1);
+        }                                                             // next part
     }
 
     for (int t = 0; t < T; ++t) {

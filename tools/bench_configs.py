@@ -100,6 +100,27 @@ def config3(per=None):
             "us_per_step": dt * 1e6, "frames_per_s": total / dt, "us_per_step_two_launches_forced": dt2 * 1e6}
 
 
+def rates_one(which):
+    """every tile at ONE input rate (4 096 streams): the fused launch's time = model tile + that rate's resample prologue"""
+    per = [0, 0, 0]
+    per[which] = 4096
+    r = config3(per)
+    r["config"] = f"4 096 streams, all at {(8000, 24000, 48000)[which]} Hz, fused resample -> step"
+    return r
+
+
+def rates8():
+    return rates_one(0)
+
+
+def rates24():
+    return rates_one(1)
+
+
+def rates48():
+    return rates_one(2)
+
+
 def config3_255_tiles():
     """configs[3] with the three thirds rounded to whole tiles (3 x 1 360 = 4 080 streams = 255 tiles): the fused launch"""
     return config3([1360, 1360, 1360])
