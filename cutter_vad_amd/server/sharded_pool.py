@@ -84,8 +84,12 @@ class ShardedStreamPool:
                 src._flush_inbox()
                 s.moving = True
             try:
-                while src.engine.tick_pending(s.slot) > 0:
+                for _ in range(300):                        # at most 256 frames wait for one stream, one is stepped per tick
+                    if src.engine.tick_pending(s.slot) == 0:
+                        break
                     src.tick()
+                else:
+                    raise AudioProcessingError("session's queued frames could not be stepped on its current engine; not moved")
                 with first._tick_lock, second._tick_lock:
                     if src.engine.tick_pending(s.slot) > 0:      # a frame slipped in between the last tick and the lock
                         raise AudioProcessingError("session kept receiving frames while it was being moved")
