@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvad_engine.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["silero_v5.hip", "silero_v5_t16.hip", "silero_v4.hip", "silero_v4_t16.hip", "resample.hip", "resample_generic.hip", "vad_util.hip"]
+HIP_SOURCES = ["silero_v5.hip", "silero_v5_t16.hip", "silero_v4.hip", "silero_v4_t16.hip", "resample.hip", "resample_generic.hip", "resample_fft.hip", "vad_util.hip"]
 CPP_SOURCES = ["engine.cpp", "pack_weights.cpp", "resample_tables.cpp"]
 
 

@@ -144,6 +144,7 @@ SIGNATURES = {
     "vad_resample_generic": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, _f32p]),
     "vad_resample_generic_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, _vp]),
     "vad_debug_resample_operator": (C.c_int, [C.c_int32, _f32p, C.c_size_t]),
+    "vad_debug_resample_path": (C.c_int, [_vp, C.c_int]),
     "vad_debug_resample_generic_entries": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_size_t]),
     "vad_debug_pack_resample": (C.c_int, [C.c_int32, _f32p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
                                           C.POINTER(C.c_uint32)]),

@@ -357,6 +357,13 @@ struct vad_engine {
     static constexpr size_t RSG_CACHE_BYTES = 512u << 20;
     std::vector<RsgEntry> rsg_cache;
     uint64_t rsg_clock = 0;
+    // long arrays: chirp-z / FFT path (csrc/resample_fft.hip): tables of the last (n_in, n_out), work buffers
+    struct RsfPlan {
+        int64_t n_in = 0, n_out = 0, P1 = 0, P2 = 0;
+        void *W1 = nullptr, *W2 = nullptr, *B1 = nullptr, *B2 = nullptr;
+    } rsf_plan;
+    void *d_rsf_a = nullptr, *d_rsf_b = nullptr; size_t d_rsf_cap = 0;
+    int rsg_path = 0;                                // 0 = by size, 1 = direct kernel, 2 = FFT path (vad_debug_resample_path)
     double *d_rsg_partial = nullptr; size_t d_rsg_partial_cap = 0;
     void *d_rsg_in = nullptr;  size_t d_rsg_in_cap = 0;
     float *d_rsg_out = nullptr; size_t d_rsg_out_cap = 0;
@@ -708,6 +715,8 @@ void vad_engine_destroy(vad_engine *e) {
         if (c.d_tn) (void)hipFree(c.d_tn);
         if (c.d_tm) (void)hipFree(c.d_tm);
     }
+    for (void *q : {e->rsf_plan.W1, e->rsf_plan.W2, e->rsf_plan.B1, e->rsf_plan.B2, e->d_rsf_a, e->d_rsf_b})
+        if (q) (void)hipFree(q);
     if (e->d_rsg_partial) (void)hipFree(e->d_rsg_partial);
     if (e->d_rsg_in) (void)hipFree(e->d_rsg_in);
     if (e->d_rsg_out) (void)hipFree(e->d_rsg_out);
@@ -1205,14 +1214,76 @@ int vad_resample_multi_device(vad_engine *e, int32_t nseg, const float *const *d
 // ---- AudioUtils.resample_audio for any (length, rates): whole-array Fourier resampling, operator evaluated on the fly -----
 namespace {
 
+// which kernel serves a call: the direct one (every operator entry evaluated, O(n_in n_out), lowest latency) below 2^27 entries,
+// the chirp-z / FFT one (O(n log n), ~100 launches: 0.2 ms at least) from there - when its lengths allow - which is where the two
+// were measured to cross (profiles/r03_resample_generic.jsonl); vad_debug_resample_path pins one
+bool rsf_fits(int64_t n_in, int64_t n_out) { return n_in <= vadk::RSF_MAX_LEN && n_out <= vadk::RSF_MAX_LEN; }
+bool rsg_use_fft(const vad_engine *e, int64_t rows, int64_t n_in, int64_t n_out) {
+    if (e->rsg_path == 1 || !rsf_fits(n_in, n_out)) return false;
+    if (e->rsg_path == 2) return true;
+    return (unsigned __int128)(rows ? rows : 1) * (unsigned __int128)n_in * (unsigned __int128)n_out >= ((unsigned __int128)1 << 27);
+}
+
 int rsg_check(vad_engine *e, int64_t rows, int64_t n_in, int64_t n_out) {
     if (rows < 0 || n_in < 1 || n_out < 1 || n_in > vadk::RSG_MAX_LEN || n_out > vadk::RSG_MAX_LEN)
         return e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio: rows >= 0 and 1 <= n_in, n_out < 2^31 (rows = %lld, n_in = %lld, n_out = %lld)",
                        (long long)rows, (long long)n_in, (long long)n_out);
+    if (rsg_use_fft(e, rows, n_in, n_out)) return VAD_OK;
     const unsigned __int128 entries = (unsigned __int128)(rows ? rows : 1) * (unsigned __int128)n_in * (unsigned __int128)n_out;
     if (entries > (unsigned __int128)vadk::RSG_MAX_ENTRIES)
-        return e->fail(VAD_ERR_UNSUPPORTED, "Failed to resample audio: %lld arrays of %lld -> %lld samples are more than the 2^42 operator entries "
-                       "one call evaluates; resample in pieces", (long long)rows, (long long)n_in, (long long)n_out);
+        return e->fail(VAD_ERR_UNSUPPORTED, "Failed to resample audio: %lld arrays of %lld -> %lld samples: longer than the FFT path takes (2^25 samples) and "
+                       "more than the 2^42 operator entries the direct kernel evaluates per call", (long long)rows, (long long)n_in, (long long)n_out);
+    return VAD_OK;
+}
+
+// chirp-z / FFT path: tables of the last shape stay on the device; rows are processed in groups that keep a work buffer <= 1 GB
+int rsf_run(vad_engine *e, const void *d_in, int in_f64, int64_t rows, int64_t n_in, int64_t n_out, float *d_out, hipStream_t s) {
+    auto pow2 = [](int64_t v) { int64_t q = 1; while (q < v) q <<= 1; return q; };
+    vad_engine::RsfPlan &pl = e->rsf_plan;
+    const int64_t P1 = pow2(2 * n_in), P2 = pow2(2 * n_out), Pmax = std::max(P1, P2);
+    const int64_t rows_per = std::max<int64_t>(1, std::min<int64_t>({rows, 65535, (1ll << 26) / Pmax}));
+    const size_t need = (size_t)rows_per * (size_t)Pmax * 16;
+    if (need > e->d_rsf_cap) {
+        HIP_TRY(e, hipStreamSynchronize(s));
+        if (e->d_rsf_a) (void)hipFree(e->d_rsf_a);
+        if (e->d_rsf_b) (void)hipFree(e->d_rsf_b);
+        e->d_rsf_a = e->d_rsf_b = nullptr;
+        e->d_rsf_cap = 0;
+        HIP_TRY(e, hipMalloc(&e->d_rsf_a, need));
+        HIP_TRY(e, hipMalloc(&e->d_rsf_b, need));
+        e->d_rsf_cap = need;
+    }
+    vadk::RsfParams p{};
+    p.n_in = n_in; p.n_out = n_out; p.K = std::min(n_in, n_out) / 2;
+    p.P1 = P1; p.P2 = P2; p.Pmax = Pmax;
+    p.a = e->d_rsf_a; p.b = e->d_rsf_b;
+    p.x_f64 = in_f64 ? 1 : 0;
+    if (pl.n_in != n_in || pl.n_out != n_out) {
+        HIP_TRY(e, hipStreamSynchronize(s));
+        for (void **q : {&pl.W1, &pl.W2, &pl.B1, &pl.B2}) {
+            if (*q) (void)hipFree(*q);
+            *q = nullptr;
+        }
+        pl.n_in = pl.n_out = 0;
+        HIP_TRY(e, hipMalloc(&pl.W1, (size_t)P1 / 2 * 16));
+        HIP_TRY(e, hipMalloc(&pl.W2, (size_t)P2 / 2 * 16));
+        HIP_TRY(e, hipMalloc(&pl.B1, (size_t)P1 * 16));
+        HIP_TRY(e, hipMalloc(&pl.B2, (size_t)P2 * 16));
+        p.W1 = pl.W1; p.W2 = pl.W2; p.B1 = pl.B1; p.B2 = pl.B2;
+        p.rows = 1;
+        hipError_t r = vadk_rsf_build_tables(&p, s);
+        if (r != hipSuccess) return e->hip_fail(r, "resample kernel launch (tables)");
+        pl.n_in = n_in; pl.n_out = n_out; pl.P1 = P1; pl.P2 = P2;
+    }
+    p.W1 = pl.W1; p.W2 = pl.W2; p.B1 = pl.B1; p.B2 = pl.B2;
+    const size_t esz = in_f64 ? 8 : 4;
+    for (int64_t r0 = 0; r0 < rows; r0 += rows_per) {
+        p.rows = (int32_t)std::min(rows_per, rows - r0);
+        p.x = static_cast<const uint8_t *>(d_in) + (size_t)r0 * (size_t)n_in * esz;
+        p.y = d_out + (size_t)r0 * (size_t)n_out;
+        hipError_t r = vadk_rsf_run(&p, s);
+        if (r != hipSuccess) return e->hip_fail(r, "resample kernel launch");
+    }
     return VAD_OK;
 }
 
@@ -1257,6 +1328,7 @@ int rsg_tables(vad_engine *e, int64_t n_in, int64_t n_out, vad_engine::RsgEntry 
 
 // device buffers in, device buffer out; launches cover (rows chunk) x (output range) pieces of at most 2^34 entries each
 int rsg_run(vad_engine *e, const void *d_in, int in_f64, int64_t rows, int64_t n_in, int64_t n_out, float *d_out, hipStream_t s) {
+    if (rsg_use_fft(e, rows, n_in, n_out)) return rsf_run(e, d_in, in_f64, rows, n_in, n_out, d_out, s);
     vad_engine::RsgEntry *c = nullptr;
     if (int rc = rsg_tables(e, n_in, n_out, &c)) return rc;
     constexpr int64_t BUDGET = 1ll << 34;
@@ -1330,6 +1402,14 @@ int vad_resample_generic_device(vad_engine *e, const void *d_in, int in_f64, int
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (int rc = rsg_run(e, d_in, in_f64, rows, n_in, n_out, d_out, e->stream)) return rc;
     HIP_TRY(e, hipStreamSynchronize(e->stream));          // synchronous: d_out is complete on return
+    return VAD_OK;
+}
+
+int vad_debug_resample_path(vad_engine *e, int mode) {
+    if (!e) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (mode < 0 || mode > 2) return e->fail(VAD_ERR_INVALID_ARG, "vad_debug_resample_path: 0 = by size, 1 = direct kernel, 2 = FFT path");
+    e->rsg_path = mode;
     return VAD_OK;
 }
 

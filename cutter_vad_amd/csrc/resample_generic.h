@@ -55,7 +55,23 @@ struct RsgParams {
     double inv_n_in;
 };
 
+// ---- long arrays: the same function as two chirp-z transforms on power-of-two float64 FFTs (csrc/resample_fft.hip) -------------
+struct RsfParams {
+    const void *x;            // [rows][n_in] float32 or float64
+    float *y;                 // [rows][n_out]
+    void *a, *b;              // work: [rows][Pmax] complex float64 each
+    void *W1, *W2;            // twiddles e^{-2 pi i j / P}, j < P / 2
+    void *B1, *B2;            // FFT_P of the wrapped chirp kernels of the forward / inverse transform
+    int64_t n_in, n_out, K;   // K = min(n_in, n_out) / 2: the last bin scipy keeps
+    int64_t P1, P2, Pmax;     // powers of two >= 2 n_in, >= 2 n_out; Pmax = the larger = row stride of a / b
+    int32_t rows, x_f64;
+};
+// lengths the FFT path takes: P <= 2^26 (n <= 2^25 samples: 11 minutes of 48 kHz audio; 1 GB per work buffer and row)
+constexpr int64_t RSF_MAX_LEN = 1ll << 25;
+
 }  // namespace vadk
 
+extern "C" hipError_t vadk_rsf_build_tables(const vadk::RsfParams *p, hipStream_t stream);
+extern "C" hipError_t vadk_rsf_run(const vadk::RsfParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_rsg_partial(const vadk::RsgParams *p, hipStream_t stream);
 extern "C" hipError_t vadk_launch_rsg_finish(const vadk::RsgParams *p, hipStream_t stream);

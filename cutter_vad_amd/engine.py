@@ -470,6 +470,10 @@ class Engine:
                                            _ptr(out, C.c_float)))
         return out
 
+    def set_resample_path(self, mode: int) -> None:
+        """0 = by size, 1 = the direct kernel, 2 = the chirp-z / FFT path (``vad_debug_resample_path``)"""
+        self._check(self._lib.vad_debug_resample_path(self._h, int(mode)), VADError)
+
     def resample_generic(self, arrays, n_out: int) -> np.ndarray:
         """arrays [rows, n_in] (float32, or float64 for double-precision input) -> [rows, n_out] float32: each row through
         ``scipy.signal.resample(row, n_out)`` as a whole (``vad_resample_generic``; any lengths)."""

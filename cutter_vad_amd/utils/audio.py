@@ -100,10 +100,11 @@ class AudioUtils:
         complex resample, which is the resample of the real part).
 
         A 1-D float32 array that is exactly one streaming chunk (256 / 768 / 1536 samples at 8 / 24 / 48 kHz -> 512 at
-        16 kHz) takes the MFMA kernel the serving tick uses (``vad_resample``); everything else the generic kernel
-        (``vad_resample_generic``: the Fourier operator evaluated in float64, never stored).  Both are the same function of
-        the input up to float32 rounding (tests: <= 1e-5 against scipy).  Arrays beyond the generic kernel's size limit
-        (len * out_len * columns > 2^42) are refused with AudioProcessingError - never cut into pieces, which would give a
+        16 kHz) takes the MFMA kernel the serving tick uses (``vad_resample``); everything else ``vad_resample_generic``:
+        small calls evaluate the Fourier operator entry by entry in float64 (never stored), from 2^27 entries up the same
+        function runs as two chirp-z transforms on power-of-two float64 FFTs (O(n log n), up to 2^25 samples).  All three
+        are the same function of the input up to float32 rounding (tests: <= 1e-5 against scipy; measured <= 4e-7).  An
+        array beyond both kernels' limits is refused with AudioProcessingError - never cut into pieces, which would give a
         different answer from the reference's."""
         try:
             if original_rate == target_rate:

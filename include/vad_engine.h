@@ -249,11 +249,13 @@ VAD_API int vad_resample_multi_device(vad_engine *e, int32_t nseg, const float *
  * n_out exactly as the reference does (Python float arithmetic, utils/audio.py:43-46); only the two lengths enter the maths.
  * in [rows][n_in] float32 (in_f64 = 0) or float64 (in_f64 = 1: scipy transforms float64 / integer arrays in double precision)
  * -> out [rows][n_out] float32 (the reference's .astype(np.float32), :49); rows = independent arrays of one length (the
- * columns of an [N, C] array: scipy resamples along axis 0).  The operator is evaluated in float64 on the GPU, never stored
- * (csrc/resample_generic.hip).  Limits: n_in, n_out in 1 .. 2^31 - 1 and rows * n_in * n_out <= 2^42 (VAD_ERR_UNSUPPORTED
- * beyond; measured 0.5e12 entries / s on an MI355X: 1.5 ms for one second of 48 kHz audio to 16 kHz, 0.14 s for ten seconds, ~8 s at
- * the cap = 75 s of 48 kHz audio - the work is O(n_in * n_out), an FFT's is not; longer arrays must be cut by the caller - the
- * result of a cut array is NOT the reference's, which is why the engine refuses instead of cutting).
+ * columns of an [N, C] array: scipy resamples along axis 0).  Two kernels behind it, chosen by size: below 2^27 operator
+ * entries (rows * n_in * n_out) every entry is evaluated where it is used, in float64, never stored (csrc/resample_generic.hip:
+ * lowest latency, 70 us for 100 -> 50, 80 us for three 48 kHz chunks); from there the same function runs as two chirp-z
+ * transforms on power-of-two float64 FFTs (csrc/resample_fft.hip: O(n log n) for any pair of lengths, up to 2^25 samples = 11
+ * minutes of 48 kHz audio; host buffers in and out: 0.25 ms for one second of 48 kHz audio, 0.6 ms for ten, 37 ms for ten
+ * minutes of 44.1 kHz - 1 x, 5 x and 11 x scipy on the box's host).  Beyond both (n > 2^25 and rows * n_in * n_out > 2^42): VAD_ERR_UNSUPPORTED - never cut into pieces,
+ * the result of a cut array is NOT the reference's.
  * The _device form takes device pointers and is synchronous as well (the result is complete on return).
  */
 VAD_API int vad_resample_generic(vad_engine *e, const void *in, int in_f64, int64_t rows, int64_t n_in, int64_t n_out, float *out);
@@ -372,6 +374,8 @@ VAD_API int vad_debug_pack_weights(int32_t model_version, const void *weights, s
 VAD_API int vad_debug_resample_operator(int32_t n_in, float *R, size_t r_floats);
 /* rows m0 .. m1-1 of the operator vad_resample_generic applies, R[(m - m0) * n_in + n] in float64, evaluated on the HOST with the
  * arithmetic of the kernel (same tables, same small-angle rule): the CPU test-suite checks R @ x against scipy for awkward shapes */
+/* which kernel vad_resample_generic uses: 0 = chosen by size (default), 1 = the direct kernel, 2 = the chirp-z / FFT path (tests, benchmarks) */
+VAD_API int vad_debug_resample_path(vad_engine *e, int mode);
 VAD_API int vad_debug_resample_generic_entries(int64_t n_in, int64_t n_out, int64_t m0, int64_t m1, double *R, size_t r_doubles);
 
 /*

@@ -155,10 +155,56 @@ def test_generic_resampler_long_arrays_rows_and_launch_shapes(engine):
     st[5, 1] = np.inf
     ynan = AudioUtils.resample_audio(st, 48000, 16000)
     assert np.isnan(ynan[:, 1]).all() and np.abs(ynan[:, 0] - scipy.signal.resample(st[:, 0], 100)).max() <= TOL
-    # beyond the size limit: refused, never cut into pieces
+    # beyond both kernels' limits (longer than the FFT path takes AND too many entries for the direct kernel): refused, never cut
     with pytest.raises(AudioProcessingError, match="2\\^42 operator entries"):
-        engine.resample_generic(np.zeros((1, 3_000_000), np.float32), 2_000_000)
+        engine.resample_generic(np.zeros((1, (1 << 25) + 1), np.float32), 1 << 24)
     assert np.array_equal(engine.resample_generic(np.zeros((0, 10), np.float32), 5), np.zeros((0, 5), np.float32))
+
+
+def test_long_arrays_take_the_fft_path_and_both_paths_are_the_same_function(engine):
+    """vad_resample_generic has two kernels behind it: every operator entry evaluated (O(n_in n_out)) for small calls, two chirp-z
+    transforms on power-of-two float64 FFTs (O(n log n)) from 2^27 entries up.  Pinned to either (vad_debug_resample_path), both
+    must be scipy's function - on the reference-generated fixture shapes, awkward lengths, rows, float64 input - and agree with
+    each other; a ten-second and a one-minute array go through the size rule."""
+    import warnings
+    import scipy.signal
+    from cutter_vad_amd import AudioUtils
+    from tests.signals import resample_generic_inputs
+    g = np.load(os.path.join(GOLD, "resample_generic.npz"))
+    try:
+        for mode in (2, 1):                                   # 2 = FFT path, 1 = direct kernel
+            engine.set_resample_path(mode)
+            from cutter_vad_amd.pool import default_pool
+            default_pool().any_engine().set_resample_path(mode)            # the engine AudioUtils goes through
+            for name, x, r0, r1 in resample_generic_inputs():
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    got = AudioUtils.resample_audio(x, r0, r1)
+                want = g[name]
+                assert got.shape == want.shape and np.abs(got - want).max() <= TOL * max(1.0, float(np.abs(want).max())), (mode, name)
+        rng = np.random.default_rng(5)
+        for n_in, n_out in ((1, 1), (2, 1), (1, 5), (3, 3), (8, 8), (255, 256), (256, 255), (4097, 333), (333, 4097), (30011, 10007)):
+            x = (0.3 * rng.standard_normal((3, n_in))).astype(np.float32)
+            ref = scipy.signal.resample(x, n_out, axis=1).astype(np.float32)
+            engine.set_resample_path(2)
+            a = engine.resample_generic(x, n_out)
+            engine.set_resample_path(1)
+            b = engine.resample_generic(x, n_out)
+            assert np.abs(a - ref).max() <= 2e-6 and np.abs(b - ref).max() <= 2e-6 and np.abs(a - b).max() <= 5e-7, (n_in, n_out)
+        xd = rng.standard_normal((2, 5000)) * 1e4
+        engine.set_resample_path(2)
+        assert np.abs(engine.resample_generic(xd, 7777) - scipy.signal.resample(xd, 7777, axis=1).astype(np.float32)).max() <= 1e-6 * 1e4
+    finally:
+        engine.set_resample_path(0)
+        default_pool().any_engine().set_resample_path(0)
+    # the size rule: ten seconds (7.7e10 entries) and a minute of 48 kHz audio, and an array longer than the direct kernel's cap
+    for seconds in (10, 60):
+        x = (0.3 * rng.standard_normal(48000 * seconds)).astype(np.float32)
+        y = AudioUtils.resample_audio(x, 48000, 16000)
+        assert y.shape == (16000 * seconds,) and np.abs(y - scipy.signal.resample(x, 16000 * seconds).astype(np.float32)).max() <= TOL
+    x = (0.3 * rng.standard_normal(44100 * 120)).astype(np.float32)          # two minutes at 44.1 kHz: 1e13 entries
+    y = AudioUtils.resample_audio(x, 44100, 16000)
+    assert y.shape == (16000 * 120,) and np.abs(y - scipy.signal.resample(x, 16000 * 120).astype(np.float32)).max() <= TOL
 
 
 def test_config4_mixed_rates_resample_then_v5(engine):

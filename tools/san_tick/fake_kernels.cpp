@@ -80,6 +80,8 @@ extern "C" hipError_t vadk_launch_resample(const ResampleParams *p, hipStream_t)
 
 extern "C" hipError_t vadk_launch_rsg_partial(const RsgParams *, hipStream_t) { return hipErrorInvalidValue; }
 extern "C" hipError_t vadk_launch_rsg_finish(const RsgParams *, hipStream_t) { return hipErrorInvalidValue; }
+extern "C" hipError_t vadk_rsf_build_tables(const RsfParams *, hipStream_t) { return hipErrorInvalidValue; }
+extern "C" hipError_t vadk_rsf_run(const RsfParams *, hipStream_t) { return hipErrorInvalidValue; }
 
 extern "C" hipError_t vadk_launch_slot_control(SmSlot *sm, float *state, const int32_t *slots, int n, int op, const SmSlot *def,
                                                const vad_thresholds *thr, int nthr, hipStream_t) {
