@@ -452,3 +452,33 @@ def test_wire_frames_are_coalesced_into_one_push_per_tick():
     assert len(errs) >= 1 and all("256 frames are waiting" in str(e) for e in errs)
     sessions[1].close()
     pool.close()
+
+
+def test_asgi_app_over_a_sharded_pool_serves_clients_from_per_shard_tickers():
+    """create_app on a ShardedStreamPool: clients land on different shards, every shard's own ticker thread delivers its clients'
+    events, /stats reports per shard, and shutting the app down stops the tickers."""
+    from fastapi.testclient import TestClient
+    from cutter_vad_amd.server.app import create_app
+    pool, engines = _sharded(2)
+    app = create_app(pool, tick_interval=0.002)
+    loud = (np.full(480, 0.5) * 32767).astype("<i2").tobytes()
+    with TestClient(app) as client:
+        with client.websocket_connect("/vad?start_frame_count=2&end_frame_count=3") as a, \
+                client.websocket_connect("/vad?start_frame_count=2&end_frame_count=3") as b:
+            for ws in (a, b):
+                assert json.loads(ws.receive_text())["event"] == "INFO"
+            assert [p.session_count for p in pool.shards] == [1, 1]              # least-loaded placement
+            for ws in (a, b):
+                for _ in range(3):
+                    ws.send_bytes(loud)
+            for ws in (a, b):
+                seen = []
+                for _ in range(50):
+                    seen.append(json.loads(ws.receive_text())["event"])
+                    if "VOICE_CONTINUE" in seen:
+                        break
+                assert seen[:2] == ["VOICE_START", "VOICE_CONTINUE"]
+            st = client.get("/stats").json()
+            assert st["sessions"] == 2 and len(st["shards"]) == 2 and all(x["frames"] == 3 for x in st["shards"])
+        assert all(p._thread is not None for p in pool.shards)                  # one free-running ticker per shard
+    assert all(p._thread is None for p in pool.shards) and pool.session_count == 0
