@@ -147,8 +147,14 @@ int main(int argc, char **argv) {
                     const Plan p = plan_of(id);
                     make_frame(id, k, p, buf);
                     for (;;) {
-                        const int rc = p.rate == 16000 ? vad_tick_push(eng, slots[(size_t)id], buf.data(), p.len, p.fmt, p.gate)
-                                                       : vad_tick_push_rate(eng, slots[(size_t)id], buf.data(), p.len, p.fmt, p.gate, p.rate);
+                        // the three ways a frame at the engine's rate gets in: one by one, as a batch with per-frame status, gathered
+                        int rc;
+                        int32_t st = 0;
+                        const void *one = buf.data();
+                        if (p.rate != 16000) rc = vad_tick_push_rate(eng, slots[(size_t)id], buf.data(), p.len, p.fmt, p.gate, p.rate);
+                        else if ((k + j) % 3 == 0) rc = vad_tick_push(eng, slots[(size_t)id], buf.data(), p.len, p.fmt, p.gate);
+                        else if ((k + j) % 3 == 1) { rc = vad_tick_push_status(eng, &slots[(size_t)id], 1, buf.data(), p.len, p.fmt, p.gate, &st); CHECK(rc == st); }
+                        else { rc = vad_tick_push_gather(eng, &slots[(size_t)id], 1, &one, p.len, p.fmt, p.gate, &st); CHECK(rc == st); }
                         if (rc == VAD_OK) break;
                         CHECK(rc == VAD_ERR_BUSY);                 // 256 frames waiting: the ticker is behind, try again
                         std::this_thread::yield();
