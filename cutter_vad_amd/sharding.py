@@ -79,6 +79,14 @@ class ControlPlane:
         import datetime
         import torch
         import torch.distributed as dist
+        # gloo advertises the address its hostname resolves to; a container whose hostname does not resolve would fail right here,
+        # so a single-node job (rendezvous on the loopback address) is then pinned to the loopback interface
+        if "GLOO_SOCKET_IFNAME" not in os.environ and os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
+            import socket
+            try:
+                socket.gethostbyname(socket.gethostname())
+            except OSError:
+                os.environ["GLOO_SOCKET_IFNAME"] = "lo"
         dist.init_process_group("gloo", rank=info.rank, world_size=info.world)
         self._dist = dist
         self.backend = "gloo"
