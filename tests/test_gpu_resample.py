@@ -207,6 +207,34 @@ def test_long_arrays_take_the_fft_path_and_both_paths_are_the_same_function(engi
     assert y.shape == (16000 * 120,) and np.abs(y - scipy.signal.resample(x, 16000 * 120).astype(np.float32)).max() <= TOL
 
 
+def test_generic_resampler_on_random_shapes_both_kernels(engine):
+    """200 random (rows, n_in, n_out, dtype) - lengths 1 .. 20 000, up- and down-sampling, equal lengths, powers of two, primes -
+    through each of the two kernels: scipy's answer to float32 rounding every time."""
+    import scipy.signal
+    rng = np.random.default_rng(20260)
+    special = [1, 2, 3, 4, 5, 7, 8, 16, 17, 64, 127, 128, 129, 255, 256, 257, 511, 512, 513, 997, 1000, 1024, 4096, 4099, 8191, 8192, 16384]
+    worst = 0.0
+    try:
+        for k in range(200):
+            n_in = int(rng.choice(special)) if rng.random() < 0.35 else int(rng.integers(1, 20001))
+            n_out = n_in if rng.random() < 0.05 else (int(rng.choice(special)) if rng.random() < 0.35 else int(rng.integers(1, 20001)))
+            rows = int(rng.integers(1, 5))
+            wide = rng.random() < 0.3
+            x = rng.standard_normal((rows, n_in)) * (10.0 if wide else 0.3)
+            x = x if wide else x.astype(np.float32)
+            ref = scipy.signal.resample(x, n_out, axis=1).astype(np.float32)
+            scale = max(1.0, float(np.abs(ref).max()))
+            for mode in (1, 2):
+                engine.set_resample_path(mode)
+                got = engine.resample_generic(x, n_out)
+                err = float(np.abs(got - ref).max()) / scale
+                worst = max(worst, err)
+                assert got.shape == ref.shape and err <= 3e-6, (k, mode, rows, n_in, n_out, wide, err)
+    finally:
+        engine.set_resample_path(0)
+    assert worst > 0.0
+
+
 def test_config4_mixed_rates_resample_then_v5(engine):
     """4096-stream config scaled down: thirds at 8/24/48 kHz, on-GPU resample, V5; oracle on the same chain."""
     from cutter_vad_amd import weights_io
