@@ -114,6 +114,7 @@ class ClientSession:
         self.loop = loop
         self.start_time = time.time()
         self.segment_index = 0
+        self.sent = 0                 # frames handed to the pool since the stream (re)started; backlog = sent - frames stepped
         self.voice_start_time: Optional[float] = None
         self.last_voice_time: Optional[float] = None
         self.timeout_task: Optional[asyncio.Task] = None
@@ -133,6 +134,7 @@ class ClientSession:
                 self._bind()
             else:
                 self.pool.reconfigure(self.session, vc)
+            self.sent = 0                                  # a (re)configured stream starts from a clean state, queue included
             self.session_error = None
         except Exception as e:
             self.session_error = f"Audio processing failed: Frame processing failed: {e}"
@@ -211,11 +213,16 @@ class ClientSession:
                 self.session.submit_pcm16(data)
             else:
                 self.session.submit(x)
+            self.sent += 1
             self.last_voice_time = time.time()
             if self.cfg["timeout"] > 0 and not self.timeout_task:
                 self.timeout_task = asyncio.ensure_future(self._timeout_monitor())
         except Exception as e:
             self.send_error(f"Audio processing error: {e}")
+
+    def backlog(self) -> int:
+        """frames this client has sent that the pool has not stepped yet"""
+        return self.sent - self.session.frames_done if self.session is not None and not self.session.closed else 0
 
     def update_config(self, cfg: Dict[str, Any]) -> None:
         old, self.cfg = self.cfg, cfg
@@ -231,6 +238,9 @@ class ClientSession:
         if self.session is not None:
             self.session.close()
         self.outbox.put_nowait(None)
+
+
+BACKLOG_HIGH, BACKLOG_LOW = 96, 32          # frames a client may be ahead of the pool before / after its socket is paused
 
 
 def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0.010, convert_rates: bool = False,
@@ -353,6 +363,14 @@ def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0
                         break
                     if message.get("bytes") is not None:
                         client.process_audio_frame(message["bytes"])
+                        # Back-pressure.  The reference runs the model inside this loop (vad_websocket_server.py:369), so a client
+                        # that sends faster than real time - a file, not a microphone - is simply read as fast as its frames are
+                        # processed.  Here frames are queued and stepped one per tick: when a client is more than BACKLOG_HIGH
+                        # frames ahead, its socket is not read until the pool has caught up (TCP then slows the sender), instead
+                        # of running into the engine's 256-frames-waiting refusal.
+                        if (client.sent & 15) == 0 and client.backlog() > BACKLOG_HIGH:
+                            while client.backlog() > BACKLOG_LOW:
+                                await asyncio.sleep(tick_interval)
                     elif message.get("text") is not None:
                         try:
                             data = json.loads(message["text"])

@@ -482,3 +482,36 @@ def test_asgi_app_over_a_sharded_pool_serves_clients_from_per_shard_tickers():
             assert st["sessions"] == 2 and len(st["shards"]) == 2 and all(x["frames"] == 3 for x in st["shards"])
         assert all(p._thread is not None for p in pool.shards)                  # one free-running ticker per shard
     assert all(p._thread is None for p in pool.shards) and pool.session_count == 0
+
+
+def test_a_client_that_sends_faster_than_real_time_is_paused_not_refused():
+    """The reference processes a frame inside the socket's receive loop, so a client streaming a file at full speed is just read as
+    fast as it is processed.  Here a client 96 frames ahead of the pool is not read until the pool has caught up: 900 frames sent
+    back to back produce no error (the engine refuses a 257th waiting frame) and are all stepped, in order."""
+    from fastapi.testclient import TestClient
+    from cutter_vad_amd.server.app import create_app
+    pool, eng, calls = make_pool()
+    app = create_app(pool, tick_interval=0.001)
+    loud = (np.full(480, 0.5) * 32767).astype("<i2").tobytes()
+    quiet = np.zeros(480, "<i2").tobytes()
+    with TestClient(app) as client:
+        with client.websocket_connect("/vad?start_frame_count=2&end_frame_count=3") as ws:
+            assert json.loads(ws.receive_text())["event"] == "INFO"
+            for i in range(900):
+                ws.send_bytes(loud if (i // 10) % 2 == 0 else quiet)             # ten frames of talk, ten of silence
+            ws.send_text(json.dumps({"type": "HEARTBEAT"}))
+            events = []
+            while True:
+                m = json.loads(ws.receive_text())
+                if m["event"] == "INFO" and m.get("message") == "Heartbeat received":
+                    break
+                events.append(m["event"])
+            assert "ERROR" not in events
+            (state,) = app.state.vad["clients"].values()
+            deadline = __import__("time").time() + 20
+            while state.backlog() > 0 and __import__("time").time() < deadline:
+                __import__("time").sleep(0.01)
+            assert state.session.frames_done == 900 and state.sent == 900
+            # the heartbeat is answered when it is read - after the 900 frames - so by then at most BACKLOG_HIGH + 16 were waiting
+            assert events.count("VOICE_START") >= 40
+    pool.close()
