@@ -89,6 +89,7 @@ class TickResult(C.Structure):
         ("nsamples", C.POINTER(C.c_int32)),
         ("host_us", C.c_float * 3),
         ("dropped", C.c_int64),
+        ("staged_next", C.c_int64),
     ]
 
 

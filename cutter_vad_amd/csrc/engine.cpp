@@ -1964,6 +1964,7 @@ int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
     out->host_us[0] = out->host_us[1] = out->host_us[2] = 0.f;
     out->n = 0;
     out->dropped = 0;
+    out->staged_next = 0;
     out->slots = nullptr; out->probs = nullptr; out->events = nullptr; out->seg_frames = nullptr; out->nsamples = nullptr;
     for (int g = 0; g < vad_engine::TICK_GROUPS; ++g) { out->group_start[g] = 0; out->group_frames[g] = nullptr; }
     out->group_start[vad_engine::TICK_GROUPS] = 0;
@@ -2002,6 +2003,7 @@ int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
                 vad_engine::TickBuf &nb = e->tick_buf[e->tick_cur][p.group];
                 nb.lens()[nb.count - 1] = p.nsamples;
                 it->second.pop_front();
+                out->staged_next += 1;
             }                                                   // (a failed placement - pinned memory exhausted - leaves the frame waiting)
             if (it->second.empty()) e->tick_overflow.erase(it);
             else e->tick_overflow_order[keep++] = sl;

@@ -42,6 +42,7 @@ class Engine:
         self._tickets = {}                  # ticket -> the buffers a pipelined call still reads (submit / collect)
         self.last_tick_us = (0.0, 0.0, 0.0)
         self.last_tick_dropped = 0
+        self.last_tick_staged_next = 0
         self.last_tick_lost = None
         self._weights = weights  # keep alive during create
         desc = _ffi.EngineDesc(C.sizeof(_ffi.EngineDesc), model_version, C.cast(C.c_char_p(weights), C.c_void_p),
@@ -350,6 +351,7 @@ class Engine:
         r.struct_size = C.sizeof(_ffi.TickResult)
         rc = self._lib.vad_tick_run(self._h, float(denoise), C.byref(r))
         self.last_tick_dropped = int(r.dropped)   # frames left out because their stream was closed after the push
+        self.last_tick_staged_next = int(r.staged_next)   # frames that were waiting and are already staged for the next tick
         # a failed tick has consumed its frames: which streams lost one, and how long those frames were (TickFailure below)
         self.last_tick_lost = None
         if rc != _ffi.VAD_OK:

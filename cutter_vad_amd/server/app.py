@@ -283,6 +283,9 @@ def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0
                     raise
                 except Exception:                               # one bad tick must not stop every client's VAD events
                     logging.getLogger(__name__).exception("tick failed")
+            if getattr(p, "backlog", 0):                        # frames already staged for the next tick: catch up first
+                await asyncio.sleep(0)
+                continue
             await asyncio.sleep(max(0.0, tick_interval - (time.perf_counter() - t0)))
 
     def ensure_ticker() -> None:

@@ -68,6 +68,10 @@ class ShardedStreamPool:
     def session_count(self) -> int:
         return sum(p.session_count for p in self.shards)
 
+    @property
+    def backlog(self) -> int:
+        return sum(p.backlog for p in self.shards)
+
     # ------------------------------------------------------------------ moving a live session
     def migrate(self, s: PooledSession, shard: int) -> None:
         dst = self.shards[int(shard)]

@@ -136,6 +136,7 @@ class SharedStreamPool:
         # they collect here, per (byte length, gate), and go to the engine as ONE vad_tick_push_status call per key at the
         # start of the next tick
         self._inbox: Dict[tuple, List] = {}
+        self.backlog = 0                           # frames already staged for the next tick when the last one returned
         self.ticks = 0
         self.frames = 0
         self.launches = 0
@@ -354,6 +355,7 @@ class SharedStreamPool:
                     self._report(s, err)
                 return 0
             n = int(slots.size)
+            self.backlog = int(getattr(self.engine, "last_tick_staged_next", 0))    # > 0: someone is ahead of the ticker
             if n == 0:
                 return 0
             # launches: one per (format, gate) group; the resampled groups of a gate value share one
@@ -444,6 +446,8 @@ class SharedStreamPool:
                     self.tick()
                 except Exception:                   # the ticker outlives any single bad tick
                     pass
+                if self.backlog:                    # a client is ahead of real time (a file, a stall that ended): catch up, do not sleep
+                    continue
                 self._stop.wait(max(0.0, self.tick_interval - (time.perf_counter() - t0)))
 
         self._thread = threading.Thread(target=loop, name="vad-pool-ticker", daemon=True)

@@ -302,6 +302,8 @@ typedef struct vad_tick_result {
     const int32_t *nsamples;       /* samples the caller pushed for entry i (before padding / truncation to the frame length) */
     float host_us[3];              /* where this tick's wall time went: buffer swap + queued frames | copies + launches + wait | segment assembly */
     int64_t dropped;               /* ABI 3: staged frames left out because their stream was closed (or closed and reopened) after the push */
+    int64_t staged_next;           /* ABI 3: frames that had been waiting and are already staged for the NEXT tick - a ticker that sees
+                                      > 0 runs again at once instead of sleeping (a client that sends faster than real time) */
 } vad_tick_result;
 VAD_API int vad_tick_push(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int gate_on);
 VAD_API int vad_tick_push_rate(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int gate_on,

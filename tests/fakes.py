@@ -227,6 +227,7 @@ class FakeEngine:
                     for (slot, x), pi, ei in zip(rows, p, ev):
                         self._assemble(slot, g, x, np.float32(pi), int(ei), denoise)
             gs.append(len(slots))
+        self.last_tick_staged_next = len(q)                 # slots that still have a frame waiting
         return (np.array(slots, np.int64), np.array(probs, np.float32), np.array(events, np.uint8), np.array(segs, np.int32),
                 np.array(gs, np.int64), frames, np.array(ns, np.int32))
 

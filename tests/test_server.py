@@ -515,3 +515,21 @@ def test_a_client_that_sends_faster_than_real_time_is_paused_not_refused():
             # the heartbeat is answered when it is read - after the 900 frames - so by then at most BACKLOG_HIGH + 16 were waiting
             assert events.count("VOICE_START") >= 40
     pool.close()
+
+
+def test_the_ticker_catches_up_when_a_session_is_ahead_of_real_time():
+    """One frame per session and tick; a session that has 100 frames queued (a file, a stall that ended) is not made to wait
+    tick_interval between them: a tick that leaves frames staged for the next one is followed by the next one at once."""
+    import time
+    pool, eng, calls = make_pool()
+    pool.tick_interval = 0.05                                   # 100 frames would take 5 s at one per interval
+    s = pool.open_session(VADConfig(voice_start_frame_count=1, buffer_size=480))
+    for _ in range(100):
+        s.submit(LOUD)
+    t0 = time.time()
+    pool.start()
+    while s.frames_done < 100 and time.time() - t0 < 4:
+        time.sleep(0.005)
+    dt = time.time() - t0
+    pool.close()
+    assert s.frames_done == 100 and dt < 2.0, dt

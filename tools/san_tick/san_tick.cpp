@@ -200,6 +200,7 @@ int main(int argc, char **argv) {
         mineonly.n = (int64_t)sl.size(); mineonly.slots = sl.data(); mineonly.probs = pr.data(); mineonly.events = ev.data();
         take_all(mineonly, seen);
         frames += (long)sl.size();
+        CHECK(res.staged_next >= 0 && res.staged_next <= 1024);
         if (done && res.n == 0) break;
     }
     for (auto &t : th) t.join();
