@@ -17,7 +17,7 @@ import torch  # noqa: E402
 from cutter_vad_amd import weights_io  # noqa: E402
 from cutter_vad_amd.engine import Engine  # noqa: E402
 
-K, WU = 400, 50
+K, WU = int(os.environ.get("VAD_BENCH_K", "400")), int(os.environ.get("VAD_BENCH_WU", "50"))     # (tools/pmc_rs.sh shortens the runs under --pmc)
 
 
 def blob(v):
