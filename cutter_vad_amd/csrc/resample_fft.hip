@@ -11,8 +11,10 @@
 // a power of two P >= the convolution's span.  Chirp phases are reduced in integers (n^2 mod 2N in 64 bits) before sincospi, and
 // everything is float64 until the final cast, so the result is scipy's to float32 rounding (tests: <= 3e-7, as the direct kernel).
 //
-// FFT: Stockham autosort, radix 2, one pass over HBM per stage (reads contiguous, writes in runs of the stage's stride; the first
-// stage writes adjacent pairs).  HBM-bound: 2 x 16 P bytes per stage; a 60 s / 48 kHz array (P = 2^23) moves ~6 GB per transform.
+// FFT: Stockham autosort, radix 4 (one radix-2 stage when log2 P is odd), one pass over HBM per stage (reads contiguous, writes in
+// runs of the stage's stride; the first stage writes four adjacent elements per thread).  HBM-bound: 2 x 16 P bytes per stage,
+// ceil(log2(P) / 2) stages; a 60 s / 48 kHz array (P = 2^23) moves ~3 GB per transform.  Measured with radix-2 stages only: 5.0 TB/s
+// on the ten-minute array, i.e. the passes run near copy speed and the lever is the number of passes - hence radix 4.
 // The arrays this path exists for are off the serving path, so the simple pass structure was preferred to an LDS-blocked one.
 #include <hip/hip_runtime.h>
 
@@ -83,6 +85,26 @@ __global__ __launch_bounds__(256) void vadk_rsf_stage(const cplx *__restrict__ s
     dst[row + q + 2 * s * pp + s] = cmul(d, w);
 }
 
+// one Stockham radix-4 stage (n = P / s, n1 = n / 4): a quarter of the threads of a radix-2 stage move twice the elements each, and
+// the array crosses HBM half as often.  a, b, c, d = the four quarter-strided inputs; w1 = e^{-2 pi i p / n}, w2 = w1^2, w3 = w1 w2
+__global__ __launch_bounds__(256) void vadk_rsf_stage4(const cplx *__restrict__ src, cplx *__restrict__ dst, const cplx *__restrict__ W,
+                                                       int64_t P, int64_t s, int64_t Pmax) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t Q = P / 4;
+    if (t >= Q) return;
+    const size_t row = (size_t)blockIdx.y * (size_t)Pmax;
+    const int64_t pp = t / s, q = t - pp * s;
+    const cplx a = src[row + t], b = src[row + t + Q], c = src[row + t + 2 * Q], d = src[row + t + 3 * Q];
+    const cplx w1 = W[pp * s], w2 = W[2 * pp * s], w3 = cmul(w1, w2);
+    const cplx apc = {a.re + c.re, a.im + c.im}, amc = {a.re - c.re, a.im - c.im};
+    const cplx bpd = {b.re + d.re, b.im + d.im}, jbmd = {-(b.im - d.im), b.re - d.re};       // i (b - d)
+    cplx *o = dst + row + q + 4 * s * pp;
+    o[0] = {apc.re + bpd.re, apc.im + bpd.im};
+    o[s] = cmul(w1, cplx{amc.re - jbmd.re, amc.im - jbmd.im});
+    o[2 * s] = cmul(w2, cplx{apc.re - bpd.re, apc.im - bpd.im});
+    o[3 * s] = cmul(w3, cplx{amc.re + jbmd.re, amc.im + jbmd.im});
+}
+
 // A[i] = conj(A[i] * B[i]): the product, conjugated so that the FORWARD stages that follow compute the inverse transform
 // (ifft(v) = conj(fft(conj(v))) / P; the consumer takes the conjugate and the 1 / P)
 __global__ __launch_bounds__(256) void vadk_rsf_mulconj(cplx *A, const cplx *__restrict__ B, int64_t P, int64_t Pmax) {
@@ -124,11 +146,26 @@ __global__ __launch_bounds__(256) void vadk_rsf_store(const RsfParams p, const c
 
 inline dim3 grid_for(int64_t n, int rows) { return dim3((unsigned)((n + 255) / 256), (unsigned)rows); }
 
-// log2(P) stages, ping-pong between u and v; returns the buffer that holds the result
+// the stages of one FFT_P, ping-pong between u and v; returns the buffer that holds the result.  Radix 4 (one radix-2 stage first
+// when log2 P is odd): ceil(log2(P) / 2) passes over HBM.  -DRSF_RADIX2 keeps every stage radix 2 (tools/variants.sh A/B).
 cplx *fft_stages(cplx *u, cplx *v, const cplx *W, int64_t P, int64_t Pmax, int rows, hipStream_t stream) {
     cplx *src = u, *dst = v;
-    for (int64_t s = 1; s < P; s *= 2) {
-        hipLaunchKernelGGL(vadk_rsf_stage, grid_for(P / 2, rows), dim3(256), 0, stream, src, dst, W, P, s, Pmax);
+    int64_t s = 1;
+    int lg = 0;
+    while ((1ll << lg) < P) ++lg;
+#ifdef RSF_RADIX2
+    const bool all2 = true;
+#else
+    const bool all2 = false;
+#endif
+    while (s < P) {
+        if (all2 || ((lg & 1) && s == 1) || P / s < 4) {
+            hipLaunchKernelGGL(vadk_rsf_stage, grid_for(P / 2, rows), dim3(256), 0, stream, src, dst, W, P, s, Pmax);
+            s *= 2;
+        } else {
+            hipLaunchKernelGGL(vadk_rsf_stage4, grid_for(P / 4, rows), dim3(256), 0, stream, src, dst, W, P, s, Pmax);
+            s *= 4;
+        }
         cplx *t = src; src = dst; dst = t;
     }
     return src;
