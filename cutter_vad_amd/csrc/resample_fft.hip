@@ -11,11 +11,12 @@
 // a power of two P >= the convolution's span.  Chirp phases are reduced in integers (n^2 mod 2N in 64 bits) before sincospi, and
 // everything is float64 until the final cast, so the result is scipy's to float32 rounding (tests: <= 3e-7, as the direct kernel).
 //
-// FFT: Stockham autosort, radix 4 (one radix-2 stage when log2 P is odd), one pass over HBM per stage (reads contiguous, writes in
-// runs of the stage's stride; the first stage writes four adjacent elements per thread).  HBM-bound: 2 x 16 P bytes per stage,
-// ceil(log2(P) / 2) stages; a 60 s / 48 kHz array (P = 2^23) moves ~3 GB per transform.  Measured with radix-2 stages only: 5.0 TB/s
-// on the ten-minute array, i.e. the passes run near copy speed and the lever is the number of passes - hence radix 4.
-// The arrays this path exists for are off the serving path, so the simple pass structure was preferred to an LDS-blocked one.
+// FFT: Stockham autosort, radix 8 in registers (a radix-4 / radix-2 stage first for the remainder of log2 P), one pass over HBM per
+// stage (reads contiguous, writes in runs of the stage's stride; the first stage writes adjacent elements per thread).  HBM-bound:
+// 2 x 16 P bytes per stage, ceil(log2(P) / 3) stages; a 60 s / 48 kHz array (P = 2^23) moves ~2.1 GB per transform.  Measured with
+// radix-2 stages only: 5.0 TB/s on a ten-minute array, i.e. the passes run near copy speed and the lever is the NUMBER of passes:
+// 36.7 ms (radix 2) -> 23 ms (radix 4) -> 18.5 ms (radix 8) for that array.  The arrays this path exists for are off the serving
+// path, so plain passes were preferred to LDS-blocked ones.
 #include <hip/hip_runtime.h>
 
 #include "resample_generic.h"
@@ -105,6 +106,38 @@ __global__ __launch_bounds__(256) void vadk_rsf_stage4(const cplx *__restrict__ 
     o[3 * s] = cmul(w3, cplx{amc.re + jbmd.re, amc.im + jbmd.im});
 }
 
+// one Stockham radix-8 stage (n = P / s, n1 = n / 8): eight eighth-strided inputs per thread, an 8-point DFT in registers (three
+// radix-2 levels, decimation in frequency), output k scaled by w^k, w = e^{-2 pi i p / n}: a third of the passes of radix 2
+__global__ __launch_bounds__(256) void vadk_rsf_stage8(const cplx *__restrict__ src, cplx *__restrict__ dst, const cplx *__restrict__ W,
+                                                       int64_t P, int64_t s, int64_t Pmax) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t E = P / 8;
+    if (t >= E) return;
+    const size_t row = (size_t)blockIdx.y * (size_t)Pmax;
+    const int64_t pp = t / s, q = t - pp * s;
+    cplx a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = src[row + t + j * E];
+    auto add = [](cplx x, cplx y) { return cplx{x.re + y.re, x.im + y.im}; };
+    auto sub = [](cplx x, cplx y) { return cplx{x.re - y.re, x.im - y.im}; };
+    auto mulmi = [](cplx x) { return cplx{x.im, -x.re}; };                 // x * (-i)
+    const double h = 0.70710678118654752440;
+    const cplx b0 = add(a[0], a[4]), b4 = sub(a[0], a[4]), b1 = add(a[1], a[5]), b5 = sub(a[1], a[5]);
+    const cplx b2 = add(a[2], a[6]), b6 = sub(a[2], a[6]), b3 = add(a[3], a[7]), b7 = sub(a[3], a[7]);
+    // even outputs: the 4-point DFT of b0 .. b3
+    const cplx c0 = add(b0, b2), c2 = sub(b0, b2), c1 = add(b1, b3), c3 = mulmi(sub(b1, b3));
+    // odd outputs: the 4-point DFT of b4, b5 w8, b6 w8^2, b7 w8^3   (w8 = (1 - i) / sqrt 2)
+    const cplx d1 = {h * (b5.re + b5.im), h * (b5.im - b5.re)}, d2 = mulmi(b6), d3 = {h * (b7.im - b7.re), -h * (b7.re + b7.im)};
+    const cplx e0 = add(b4, d2), e2 = sub(b4, d2), e1 = add(d1, d3), e3 = mulmi(sub(d1, d3));
+    const cplx X[8] = {add(c0, c1), add(e0, e1), add(c2, c3), add(e2, e3), sub(c0, c1), sub(e0, e1), sub(c2, c3), sub(e2, e3)};
+    const cplx w1 = W[pp * s], w2 = W[2 * pp * s], w3 = W[3 * pp * s], w4 = W[4 * pp * s];
+    const cplx w[8] = {cplx{1.0, 0.0}, w1, w2, w3, w4, cmul(w4, w1), cmul(w4, w2), cmul(w4, w3)};
+    cplx *o = dst + row + q + 8 * s * pp;
+    o[0] = X[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) o[k * s] = cmul(w[k], X[k]);
+}
+
 // A[i] = conj(A[i] * B[i]): the product, conjugated so that the FORWARD stages that follow compute the inverse transform
 // (ifft(v) = conj(fft(conj(v))) / P; the consumer takes the conjugate and the 1 / P)
 __global__ __launch_bounds__(256) void vadk_rsf_mulconj(cplx *A, const cplx *__restrict__ B, int64_t P, int64_t Pmax) {
@@ -146,26 +179,27 @@ __global__ __launch_bounds__(256) void vadk_rsf_store(const RsfParams p, const c
 
 inline dim3 grid_for(int64_t n, int rows) { return dim3((unsigned)((n + 255) / 256), (unsigned)rows); }
 
-// the stages of one FFT_P, ping-pong between u and v; returns the buffer that holds the result.  Radix 4 (one radix-2 stage first
-// when log2 P is odd): ceil(log2(P) / 2) passes over HBM.  -DRSF_RADIX2 keeps every stage radix 2 (tools/variants.sh A/B).
+// the stages of one FFT_P, ping-pong between u and v; returns the buffer that holds the result.  Radix 8 wherever three stages are
+// left, then one radix-4 or radix-2 stage for the remainder: ceil(log2(P) / 3) passes over HBM.  -DRSF_RADIX=2 / 4 caps the radix
+// (tools/variants.sh A/B).
+#ifndef RSF_RADIX
+#define RSF_RADIX 8
+#endif
 cplx *fft_stages(cplx *u, cplx *v, const cplx *W, int64_t P, int64_t Pmax, int rows, hipStream_t stream) {
     cplx *src = u, *dst = v;
     int64_t s = 1;
-    int lg = 0;
-    while ((1ll << lg) < P) ++lg;
-#ifdef RSF_RADIX2
-    const bool all2 = true;
-#else
-    const bool all2 = false;
-#endif
-    while (s < P) {
-        if (all2 || ((lg & 1) && s == 1) || P / s < 4) {
-            hipLaunchKernelGGL(vadk_rsf_stage, grid_for(P / 2, rows), dim3(256), 0, stream, src, dst, W, P, s, Pmax);
-            s *= 2;
-        } else {
-            hipLaunchKernelGGL(vadk_rsf_stage4, grid_for(P / 4, rows), dim3(256), 0, stream, src, dst, W, P, s, Pmax);
-            s *= 4;
-        }
+    int left = 0;                                   // stages (of radix 2) still to do
+    while ((1ll << left) < P) ++left;
+    while (left > 0) {
+        // remainders first (left mod 3 at radix 8; left mod 2 at radix 4), so that the late stages - long contiguous runs - are the wide ones
+        int r = 1;
+        if (RSF_RADIX >= 8) r = left % 3 == 0 ? 3 : (left % 3 == 2 ? 2 : (left >= 4 ? 2 : 1));
+        else if (RSF_RADIX >= 4) r = left % 2 == 0 ? 2 : 1;
+        if (r == 3) hipLaunchKernelGGL(vadk_rsf_stage8, grid_for(P / 8, rows), dim3(256), 0, stream, src, dst, W, P, s, Pmax);
+        else if (r == 2) hipLaunchKernelGGL(vadk_rsf_stage4, grid_for(P / 4, rows), dim3(256), 0, stream, src, dst, W, P, s, Pmax);
+        else hipLaunchKernelGGL(vadk_rsf_stage, grid_for(P / 2, rows), dim3(256), 0, stream, src, dst, W, P, s, Pmax);
+        s <<= r;
+        left -= r;
         cplx *t = src; src = dst; dst = t;
     }
     return src;

@@ -253,8 +253,8 @@ VAD_API int vad_resample_multi_device(vad_engine *e, int32_t nseg, const float *
  * entries (rows * n_in * n_out) every entry is evaluated where it is used, in float64, never stored (csrc/resample_generic.hip:
  * lowest latency, 70 us for 100 -> 50, 80 us for three 48 kHz chunks); from there the same function runs as two chirp-z
  * transforms on power-of-two float64 FFTs (csrc/resample_fft.hip: O(n log n) for any pair of lengths, up to 2^25 samples = 11
- * minutes of 48 kHz audio; host buffers in and out: 0.2 ms for one second of 48 kHz audio, 0.4 ms for ten, 23 ms for ten
- * minutes of 44.1 kHz - 1.4 x, 7 x and 18 x scipy on the box's host).  Beyond both (n > 2^25 and rows * n_in * n_out > 2^42): VAD_ERR_UNSUPPORTED - never cut into pieces,
+ * minutes of 48 kHz audio; host buffers in and out: 0.14 ms for one second of 48 kHz audio, 0.33 ms for ten, 18.5 ms for ten
+ * minutes of 44.1 kHz - 2 x, 9 x and 22 x scipy on the box's host).  Beyond both (n > 2^25 and rows * n_in * n_out > 2^42): VAD_ERR_UNSUPPORTED - never cut into pieces,
  * the result of a cut array is NOT the reference's.
  * The _device form takes device pointers and is synchronous as well (the result is complete on return).
  */
