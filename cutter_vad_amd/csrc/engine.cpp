@@ -1214,14 +1214,14 @@ int vad_resample_multi_device(vad_engine *e, int32_t nseg, const float *const *d
 // ---- AudioUtils.resample_audio for any (length, rates): whole-array Fourier resampling, operator evaluated on the fly -----
 namespace {
 
-// which kernel serves a call: the direct one (every operator entry evaluated, O(n_in n_out), lowest latency) below 2^27 entries,
+// which kernel serves a call: the direct one (every operator entry evaluated, O(n_in n_out), lowest latency) below 2^25 entries,
 // the chirp-z / FFT one (O(n log n), ~100 launches: 0.2 ms at least) from there - when its lengths allow - which is where the two
 // were measured to cross (profiles/r03_resample_generic.jsonl); vad_debug_resample_path pins one
 bool rsf_fits(int64_t n_in, int64_t n_out) { return n_in <= vadk::RSF_MAX_LEN && n_out <= vadk::RSF_MAX_LEN; }
 bool rsg_use_fft(const vad_engine *e, int64_t rows, int64_t n_in, int64_t n_out) {
     if (e->rsg_path == 1 || !rsf_fits(n_in, n_out)) return false;
     if (e->rsg_path == 2) return true;
-    return (unsigned __int128)(rows ? rows : 1) * (unsigned __int128)n_in * (unsigned __int128)n_out >= ((unsigned __int128)1 << 27);
+    return (unsigned __int128)(rows ? rows : 1) * (unsigned __int128)n_in * (unsigned __int128)n_out >= ((unsigned __int128)1 << 25);
 }
 
 int rsg_check(vad_engine *e, int64_t rows, int64_t n_in, int64_t n_out) {

@@ -101,7 +101,7 @@ class AudioUtils:
 
         A 1-D float32 array that is exactly one streaming chunk (256 / 768 / 1536 samples at 8 / 24 / 48 kHz -> 512 at
         16 kHz) takes the MFMA kernel the serving tick uses (``vad_resample``); everything else ``vad_resample_generic``:
-        small calls evaluate the Fourier operator entry by entry in float64 (never stored), from 2^27 entries up the same
+        small calls evaluate the Fourier operator entry by entry in float64 (never stored), from 2^25 entries up the same
         function runs as two chirp-z transforms on power-of-two float64 FFTs (O(n log n), up to 2^25 samples).  All three
         are the same function of the input up to float32 rounding (tests: <= 1e-5 against scipy; measured <= 4e-7).  An
         array beyond both kernels' limits is refused with AudioProcessingError - never cut into pieces, which would give a

@@ -249,7 +249,7 @@ VAD_API int vad_resample_multi_device(vad_engine *e, int32_t nseg, const float *
  * n_out exactly as the reference does (Python float arithmetic, utils/audio.py:43-46); only the two lengths enter the maths.
  * in [rows][n_in] float32 (in_f64 = 0) or float64 (in_f64 = 1: scipy transforms float64 / integer arrays in double precision)
  * -> out [rows][n_out] float32 (the reference's .astype(np.float32), :49); rows = independent arrays of one length (the
- * columns of an [N, C] array: scipy resamples along axis 0).  Two kernels behind it, chosen by size: below 2^27 operator
+ * columns of an [N, C] array: scipy resamples along axis 0).  Two kernels behind it, chosen by size: below 2^25 operator
  * entries (rows * n_in * n_out) every entry is evaluated where it is used, in float64, never stored (csrc/resample_generic.hip:
  * lowest latency, 70 us for 100 -> 50, 80 us for three 48 kHz chunks); from there the same function runs as two chirp-z
  * transforms on power-of-two float64 FFTs (csrc/resample_fft.hip: O(n log n) for any pair of lengths, up to 2^25 samples = 11

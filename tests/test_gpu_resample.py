@@ -163,7 +163,7 @@ def test_generic_resampler_long_arrays_rows_and_launch_shapes(engine):
 
 def test_long_arrays_take_the_fft_path_and_both_paths_are_the_same_function(engine):
     """vad_resample_generic has two kernels behind it: every operator entry evaluated (O(n_in n_out)) for small calls, two chirp-z
-    transforms on power-of-two float64 FFTs (O(n log n)) from 2^27 entries up.  Pinned to either (vad_debug_resample_path), both
+    transforms on power-of-two float64 FFTs (O(n log n)) from 2^25 entries up.  Pinned to either (vad_debug_resample_path), both
     must be scipy's function - on the reference-generated fixture shapes, awkward lengths, rows, float64 input - and agree with
     each other; a ten-second and a one-minute array go through the size rule."""
     import warnings
