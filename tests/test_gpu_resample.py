@@ -138,10 +138,13 @@ def test_generic_resampler_long_arrays_rows_and_launch_shapes(engine):
     assert np.abs(y - scipy.signal.resample(x, 10007).astype(np.float32)).max() <= TOL
     # rows: many arrays of one shape in one call == one call each, bit for bit (fixed summation order), float64 input too
     xs = (0.3 * rng.standard_normal((37, 1411))).astype(np.float32)
-    ys = engine.resample_generic(xs, 512)
-    assert ys.shape == (37, 512)
-    for i in (0, 17, 36):
-        assert np.array_equal(ys[i], engine.resample_generic(xs[i:i + 1], 512)[0])
+    for mode in (1, 2):                                   # within a kernel (pinned: the size rule looks at rows x n_in x n_out)
+        engine.set_resample_path(mode)
+        ys = engine.resample_generic(xs, 512)
+        assert ys.shape == (37, 512)
+        for i in (0, 17, 36):
+            assert np.array_equal(ys[i], engine.resample_generic(xs[i:i + 1], 512)[0]), (mode, i)
+    engine.set_resample_path(0)
     assert np.abs(ys - scipy.signal.resample(xs, 512, axis=1).astype(np.float32)).max() <= TOL
     xd = rng.standard_normal((3, 2000)) * 1e4
     yd = engine.resample_generic(xd, 3000)
