@@ -17,12 +17,11 @@ so two workers are plenty for one stream; many streams belong in ``StreamBatch``
 from __future__ import annotations
 
 import asyncio
+import functools
 from concurrent.futures import ThreadPoolExecutor
-from typing import Any, Awaitable, Callable, Dict, List, Optional, Union
+from typing import Any, Awaitable, Callable, Optional
 
-import numpy as np
-
-from .config import SampleRate, SileroModelVersion, VADConfig
+from .config import VADConfig
 from .exceptions import CallbackError
 from .vad_wrapper import VADWrapper
 
@@ -80,72 +79,15 @@ class AsyncVADWrapper:
         self._async_voice_continue_callback = voice_continue_callback
 
     # ------------------------------------------------------------------ awaitable operations
-    async def _offload(self, fn: Callable[..., Any], *args) -> Any:
+    async def _offload(self, fn: Callable[..., Any], *args, **kwargs) -> Any:
         loop = asyncio.get_running_loop()
         if self._callback_loop is None or self._callback_loop.is_closed():
             self._callback_loop = loop          # callbacks come back to the loop that submitted the audio
-        return await loop.run_in_executor(self.executor, fn, *args)
+        return await loop.run_in_executor(self.executor, functools.partial(fn, *args, **kwargs))
 
-    async def set_sample_rate_async(self, sample_rate: SampleRate) -> None:
-        await self._offload(self.vad_wrapper.set_sample_rate, sample_rate)
-
-    async def set_silero_model_async(self, model_version: SileroModelVersion) -> None:
-        await self._offload(self.vad_wrapper.set_silero_model, model_version)
-
-    async def set_thresholds_async(self, vad_start_probability: float = 0.7, vad_end_probability: float = 0.7,
-                                   voice_start_ratio: float = 0.8, voice_end_ratio: float = 0.95,
-                                   voice_start_frame_count: int = 10, voice_end_frame_count: int = 57) -> None:
-        await self._offload(self.vad_wrapper.set_thresholds, vad_start_probability, vad_end_probability,
-                            voice_start_ratio, voice_end_ratio, voice_start_frame_count, voice_end_frame_count)
-
-    async def process_audio_data_async(self, audio_data: Union[np.ndarray, List[float]]) -> None:
-        await self._offload(self.vad_wrapper.process_audio_data, audio_data)
-
-    async def process_audio_data_with_buffer_async(self, audio_buffer: np.ndarray, count: int) -> None:
-        await self._offload(self.vad_wrapper.process_audio_data_with_buffer, audio_buffer, count)
-
-    async def reset_async(self) -> None:
-        await self._offload(self.vad_wrapper.reset)
-
-    async def get_statistics_async(self) -> Dict[str, Any]:
-        return await self._offload(self.vad_wrapper.get_statistics)
-
-    async def is_voice_active_async(self) -> bool:
-        return await self._offload(self.vad_wrapper.is_voice_active)
-
-    async def update_config_async(self, config: VADConfig) -> None:
-        await self._offload(self.vad_wrapper.update_config, config)
-
-    # ------------------------------------------------------------------ synchronous pass-throughs
-    def set_sample_rate(self, sample_rate: SampleRate) -> None:
-        self.vad_wrapper.set_sample_rate(sample_rate)
-
-    def set_silero_model(self, model_version: SileroModelVersion) -> None:
-        self.vad_wrapper.set_silero_model(model_version)
-
-    def set_thresholds(self, vad_start_probability: float = 0.7, vad_end_probability: float = 0.7,
-                       voice_start_ratio: float = 0.8, voice_end_ratio: float = 0.95,
-                       voice_start_frame_count: int = 10, voice_end_frame_count: int = 57) -> None:
-        self.vad_wrapper.set_thresholds(vad_start_probability, vad_end_probability, voice_start_ratio, voice_end_ratio,
-                                        voice_start_frame_count, voice_end_frame_count)
-
-    def process_audio_data(self, audio_data: Union[np.ndarray, List[float]]) -> None:
-        self.vad_wrapper.process_audio_data(audio_data)
-
-    def reset(self) -> None:
-        self.vad_wrapper.reset()
-
-    def get_statistics(self) -> Dict[str, Any]:
-        return self.vad_wrapper.get_statistics()
-
-    def is_voice_active(self) -> bool:
-        return self.vad_wrapper.is_voice_active()
-
-    def get_config(self) -> VADConfig:
-        return self.vad_wrapper.get_config()
-
-    def update_config(self, config: VADConfig) -> None:
-        self.vad_wrapper.update_config(config)
+    # The awaitable operations and the synchronous pass-throughs are generated below from two name tables: every one of them
+    # is "the wrapper's method of the same name" - on the executor for ``<name>_async``, inline otherwise - with the wrapper
+    # method's own signature, defaults and docstring (``functools.wraps``), so the two surfaces cannot drift apart.
 
     # ------------------------------------------------------------------ lifetime
     def cleanup(self) -> None:
@@ -175,3 +117,32 @@ class AsyncVADWrapper:
             self.cleanup()
         except Exception:
             pass
+
+
+# wrapper method -> which forms the facade has (the reference's surface: async_vad_wrapper.py:137-340)
+_BOTH = ("set_sample_rate", "set_silero_model", "set_thresholds", "process_audio_data", "reset", "get_statistics", "is_voice_active",
+         "update_config")
+_SYNC_ONLY = ("get_config",)
+_ASYNC_ONLY = ("process_audio_data_with_buffer",)
+
+
+def _inline(name: str):
+    @functools.wraps(getattr(VADWrapper, name))
+    def call(self, *args, **kwargs):
+        return getattr(self.vad_wrapper, name)(*args, **kwargs)
+    return call
+
+
+def _awaitable(name: str):
+    @functools.wraps(getattr(VADWrapper, name))
+    async def call(self, *args, **kwargs):
+        return await self._offload(getattr(self.vad_wrapper, name), *args, **kwargs)
+    call.__name__ = call.__qualname__ = f"{name}_async"
+    return call
+
+
+for _name in _BOTH + _SYNC_ONLY:
+    setattr(AsyncVADWrapper, _name, _inline(_name))
+for _name in _BOTH + _ASYNC_ONLY:
+    setattr(AsyncVADWrapper, f"{_name}_async", _awaitable(_name))
+del _name
