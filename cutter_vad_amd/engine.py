@@ -472,6 +472,12 @@ class Engine:
                                            _ptr(out, C.c_float)))
         return out
 
+    def resample_generic_device(self, d_in: int, rows: int, n_in: int, n_out: int, d_out: int, f64: bool = False) -> None:
+        """Device-pointer form (``vad_resample_generic_device``): ``d_in`` -> [rows, n_in] float32 (float64 with ``f64``),
+        ``d_out`` -> [rows, n_out] float32; synchronous - the result is complete on return."""
+        self._check(self._lib.vad_resample_generic_device(self._h, C.c_void_p(int(d_in)), int(bool(f64)), int(rows), int(n_in), int(n_out),
+                                                          C.c_void_p(int(d_out))))
+
     def set_resample_path(self, mode: int) -> None:
         """0 = by size, 1 = the direct kernel, 2 = the chirp-z / FFT path (``vad_debug_resample_path``)"""
         self._check(self._lib.vad_debug_resample_path(self._h, int(mode)), VADError)

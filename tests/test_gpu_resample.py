@@ -238,6 +238,27 @@ def test_generic_resampler_on_random_shapes_both_kernels(engine):
     assert worst > 0.0
 
 
+def test_generic_resampler_on_device_pointers(engine):
+    """vad_resample_generic_device: device buffers in and out (a GPU decode pipeline's audio never visits the host), both kernels,
+    float32 and float64 input; equal to the host-pointer form bit for bit."""
+    import torch
+    rng = np.random.default_rng(8)
+    try:
+        for mode, (rows, n_in, n_out) in ((1, (3, 1411, 512)), (2, (3, 1411, 512)), (2, (1, 96000, 32000))):
+            engine.set_resample_path(mode)
+            for dt in (np.float32, np.float64):
+                x = (0.3 * rng.standard_normal((rows, n_in))).astype(dt)
+                d_x = torch.from_numpy(x).cuda()
+                d_y = torch.zeros(rows, n_out, device="cuda")
+                torch.cuda.synchronize()
+                engine.resample_generic_device(d_x.data_ptr(), rows, n_in, n_out, d_y.data_ptr(), f64=dt is np.float64)
+                assert np.array_equal(d_y.cpu().numpy(), engine.resample_generic(x, n_out)), (mode, dt)
+        with pytest.raises(Exception, match="null buffer"):
+            engine.resample_generic_device(0, 1, 10, 5, 0)
+    finally:
+        engine.set_resample_path(0)
+
+
 def test_config4_mixed_rates_resample_then_v5(engine):
     """4096-stream config scaled down: thirds at 8/24/48 kHz, on-GPU resample, V5; oracle on the same chain."""
     from cutter_vad_amd import weights_io
