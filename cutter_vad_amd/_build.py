@@ -83,5 +83,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def wirebox_path() -> str:
+    import sysconfig
+    return os.path.join(HERE, "_wirebox" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_wirebox(force: bool = False) -> str:
+    """The serving pool's frame inbox (csrc/wirebox.c), a plain-C CPython extension: host plumbing, optional - the pool queues
+    frames in Python when it is absent (same results, ~3x the per-frame cost)."""
+    import sysconfig
+    src, out = os.path.join(CSRC, "wirebox.c"), wirebox_path()
+    if not force and os.path.exists(out) and os.path.getmtime(src) <= os.path.getmtime(out):
+        return out
+    cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
+    inc = sysconfig.get_paths()["include"]
+    if not cc or not os.path.exists(os.path.join(inc, "Python.h")):
+        raise RuntimeError("a C compiler and Python.h are needed to build _wirebox")
+    tmp = out + ".tmp"
+    subprocess.check_call([cc, "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-missing-field-initializers", "-Wno-cast-function-type",
+                           f"-I{inc}", src, "-o", tmp])
+    os.replace(tmp, out)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build_wirebox(force="--force" in sys.argv))

@@ -38,6 +38,7 @@ class Engine:
     def __init__(self, weights: bytes, model_version: int = 5, device_id: int = 0, max_streams: int = 8192,
                  sample_rate: int = 16000, shared_gpu: bool = False):
         self._lib = _ffi.lib()
+        self._gather_fn = int(C.cast(self._lib.vad_tick_push_gather, C.c_void_p).value)
         self._h = C.c_void_p()
         self._tickets = {}                  # ticket -> the buffers a pipelined call still reads (submit / collect)
         self.last_tick_us = (0.0, 0.0, 0.0)
@@ -318,6 +319,12 @@ class Engine:
         fmt = _ffi.VAD_FMT_I16_32768 if i16_scale == 32768 else _ffi.VAD_FMT_I16_32767
         self._lib.vad_tick_push_gather(self._h, _ptr(s, C.c_int64), n, ptrs, int(nsamples), fmt, int(gate_on), _ptr(status, C.c_int32))
         return status
+
+    def tick_gather_entry(self):
+        """(address of ``vad_tick_push_gather``, address of this engine) for callers that push from C (server/_wirebox)."""
+        if not self._h:
+            raise VADError("engine is closed")
+        return self._gather_fn, int(self._h.value)
 
     def tick_cancel(self, slot: int) -> None:
         self._check(self._lib.vad_tick_cancel(self._h, int(slot)), VADError)

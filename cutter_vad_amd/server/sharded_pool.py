@@ -85,6 +85,7 @@ class ShardedStreamPool:
             #    already queued is stepped where the session lives (its events are delivered as usual, in order)
             first, second = sorted((src, dst), key=id)
             with src._lock:
+                src._unbind_push(s)
                 src._flush_inbox()
                 s.moving = True
             try:
@@ -121,7 +122,9 @@ class ShardedStreamPool:
                     src.engine.close_stream(old_slot)
                     self.migrations += 1
             finally:
-                s.moving = False
+                with s.pool._lock:
+                    s.pool._bind_push(s)               # on the pool it ended up on
+                    s.moving = False
 
     def rebalance(self, tolerance: int = 1) -> int:
         """Move sessions from the fullest to the emptiest shard until they differ by at most ``tolerance``; -> moves made."""

@@ -33,6 +33,7 @@ and ``voice_continue`` payloads carry the audio at the rate it arrived in.
 
 from __future__ import annotations
 
+import os
 import threading
 import time
 from collections import deque
@@ -49,6 +50,25 @@ from ..pool import EnginePool, default_pool, resolve_model_path
 from ..utils.audio import AudioUtils
 from ..utils.wav_writer import WAVWriter
 
+def _load_wirebox():
+    """The C inbox for wire frames (csrc/wirebox.c).  Optional: without it frames queue in a Python dict, same results."""
+    if os.environ.get("VAD_POOL_WIREBOX", "1") == "0":
+        return None
+    try:
+        from .. import _wirebox
+        return _wirebox
+    except ImportError:
+        pass
+    try:
+        from .. import _build
+        _build.build_wirebox()
+        from .. import _wirebox
+        return _wirebox
+    except Exception:
+        return None
+
+
+_wirebox = _load_wirebox()
 _RETRY = object()       # submit's answer while a session is between two pools
 FRAME = 512      # the model's frame at 16 kHz; a pool's own frame length is ``SharedStreamPool.frame`` (256 on V5's 8 kHz sub-model)
 
@@ -57,7 +77,7 @@ class PooledSession:
     """One client stream: a slot of the shared engine + the host half of its voice segments."""
 
     __slots__ = ("pool", "slot", "config", "long_frames", "on_start", "on_end", "on_continue", "on_error", "closed",
-                 "wav_writer", "user", "rate", "moving", "gate")
+                 "wav_writer", "user", "rate", "moving", "gate", "_push", "_queued")
 
     def __init__(self, pool: "SharedStreamPool", slot: int, config: VADConfig) -> None:
         self.pool = pool
@@ -75,6 +95,8 @@ class PooledSession:
         self.user = None
         self.rate: Optional[int] = pool._input_rate(config)      # None: frames at the engine's rate; else resampled in the tick
         self.gate = bool(config.enable_denoising)                # plain bool copy of pool._gate[slot] for the per-frame path
+        self._push = None                                        # the pool's C inbox bound to this slot (SharedStreamPool._bind_push)
+        self._queued = (-1, 0)                                   # (inbox epoch, byte length) of the last frame queued in Python
 
     # the per-session scalars live in the pool's arrays (indexed by slot) so that a tick can work on all of them at once
     @property
@@ -100,6 +122,9 @@ class PooledSession:
             time.sleep(0.0005)
 
     def submit_pcm16(self, data: bytes) -> None:
+        push = self._push
+        if push is not None and push(data):       # a wire frame no longer than the model's, session live and in place: queued in C
+            return
         while self.pool.submit_pcm16(self, data) is _RETRY:
             time.sleep(0.0005)
 
@@ -136,6 +161,11 @@ class SharedStreamPool:
         # they collect here, per (byte length, gate), and go to the engine as ONE vad_tick_push_status call per key at the
         # start of the next tick
         self._inbox: Dict[tuple, List] = {}
+        self._epoch = 0                            # counts the flushes
+        # ... and with the _wirebox extension built they do not even take this pool's lock: each session holds a C callable bound
+        # to its slot that appends (slot, bytes) to an array, and the tick hands the arrays to vad_tick_push_gather as they are
+        self._wire = _wirebox.Inbox(2 * self.frame) if _wirebox is not None else None
+        self._wire_entry = getattr(self.engine, "tick_gather_entry", None)    # -> (function address, engine address); None: test doubles
         self.backlog = 0                           # frames already staged for the next tick when the last one returned
         self.ticks = 0
         self.frames = 0
@@ -188,7 +218,20 @@ class SharedStreamPool:
             self._init_slot(slot, cfg)
             self._sessions[slot] = s
             self._by_slot[slot] = s
+            self._bind_push(s)
         return s
+
+    def _bind_push(self, s: PooledSession) -> None:
+        """Give the session its fast ingest: a callable of the C inbox bound to (slot, gate).  ``_lock`` held."""
+        s._push = self._wire.pusher(s.slot, s.gate) if (self._wire is not None and s.rate is None and not s.closed) else None
+
+    @staticmethod
+    def _unbind_push(s: PooledSession) -> None:
+        """From here on the session's frames take the general path (which looks at closed / moving).  Always BEFORE the flush
+        that precedes a cancel: nothing can join the C inbox for this slot after it."""
+        if s._push is not None:
+            s._push.invalidate()
+            s._push = None
 
     def _input_rate(self, cfg: VADConfig) -> Optional[int]:
         """The rate a session's chunks are resampled from inside the tick, None if it sends the engine's own frames."""
@@ -217,6 +260,7 @@ class SharedStreamPool:
             with self._lock:
                 if s.closed:
                     return
+                self._unbind_push(s)
                 self._flush_inbox()                # then the cancel below takes the session's frames out again
                 s.closed = True
                 s.long_frames.clear()
@@ -231,6 +275,7 @@ class SharedStreamPool:
         self._check_session_rate(config)
         with self._tick_lock:
             with self._lock:
+                self._unbind_push(s)
                 self._flush_inbox()
                 s.long_frames.clear()
             self.engine.tick_cancel(s.slot)
@@ -246,6 +291,7 @@ class SharedStreamPool:
                 # the session keeps its callbacks across a reconfigure (the app binds them once, at open): so does the flag
                 # that makes the tick deliver voice_continue payloads to it
                 self._cont[s.slot] = s.on_continue is not None
+                self._bind_push(s)
             s.wav_writer = WAVWriter(sample_rate=config.output_wav_sample_rate, bit_depth=config.output_wav_bit_depth,
                                      channels=1)
 
@@ -290,6 +336,11 @@ class SharedStreamPool:
             if s.moving or s.pool is not self:
                 return _RETRY
             if s.rate is None and len(data) <= 2 * self.frame:
+                # the inbox is flushed group by group: a session's frame must not wait there behind a group that holds an
+                # EARLIER frame of it (another length: the last chunk of a file), nor behind the C inbox, which is flushed second
+                if (self._wire is not None and len(self._wire)) or (s._queued[0] == self._epoch and s._queued[1] != len(data)):
+                    self._flush_inbox()
+                s._queued = (self._epoch, len(data))
                 key = (len(data), s.gate)
                 box = self._inbox.get(key)
                 if box is None:
@@ -304,21 +355,35 @@ class SharedStreamPool:
     def _flush_inbox(self) -> None:
         """The collected wire frames -> the engine's tick staging, one call per gate value (``_lock`` held).  A frame the engine
         refuses (its stream has 256 frames waiting, or was closed meanwhile) is reported to its own session only."""
-        if not self._inbox:
-            return
-        inbox, self._inbox = self._inbox, {}
-        for (nbytes, gate), box in inbox.items():
-            slot_list, datas = zip(*box)
-            slots = np.array(slot_list, np.int64)
-            # one join + one call (measured at 8 192 sessions: 1.9 ms; an array of 8 192 ctypes pointers for vad_tick_push_gather
-            # costs more to build in Python than the join's extra copy)
-            status = self.engine.tick_push_status(slots, b"".join(datas), nbytes // 2, gate)
-            if status.any():
-                for i in np.nonzero(status)[0]:
-                    s = self._by_slot[int(slots[i])]
-                    if s is not None and not s.closed:
-                        why = "256 frames are waiting for this stream" if int(status[i]) == _ffi.VAD_ERR_BUSY else f"engine status {int(status[i])}"
-                        self._report(s, AudioProcessingError(f"Model prediction failed: frame not queued: {why}"))
+        self._epoch += 1
+        if self._inbox:
+            inbox, self._inbox = self._inbox, {}
+            for (nbytes, gate), box in inbox.items():
+                self._push_joined(nbytes, gate, box)
+        w = self._wire
+        if w is not None and len(w):
+            if self._wire_entry is not None:
+                for slot, status in w.flush(*self._wire_entry()):    # vad_tick_push_gather on the arrays, GIL released
+                    self._refused(slot, status)
+            else:
+                for nbytes, gate, box in w.drain():
+                    self._push_joined(nbytes, gate, box)
+
+    def _push_joined(self, nbytes: int, gate: bool, box: List) -> None:
+        slot_list, datas = zip(*box)
+        slots = np.array(slot_list, np.int64)
+        # one join + one call (measured at 8 192 sessions: 1.9 ms; an array of 8 192 ctypes pointers for vad_tick_push_gather
+        # costs more to build in Python than the join's extra copy - the C inbox builds it in C)
+        status = self.engine.tick_push_status(slots, b"".join(datas), nbytes // 2, gate)
+        if status.any():
+            for i in np.nonzero(status)[0]:
+                self._refused(int(slots[i]), int(status[i]))
+
+    def _refused(self, slot: int, status: int) -> None:
+        s = self._by_slot[slot] if 0 <= slot < len(self._by_slot) else None
+        if s is not None and not s.closed:
+            why = "256 frames are waiting for this stream" if status == _ffi.VAD_ERR_BUSY else f"engine status {status}"
+            self._report(s, AudioProcessingError(f"Model prediction failed: frame not queued: {why}"))
 
     # ------------------------------------------------------------------ the tick
     def tick(self) -> int:

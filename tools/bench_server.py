@@ -55,8 +55,10 @@ def run(n, ticks=40):
             t_tick += c - b
             for k, v in enumerate(tick_us(pool)):
                 c_us[k] += v
+    c_inbox = all(p._wire is not None for p in (pool.shards if hasattr(pool, "shards") else [pool]))
     pool.close()
-    return {"sessions": n, "ticks": ticks, "ingest": "submit_pcm16 per session (the ASGI app's path): frames collect in the pool's inbox, one vad_tick_push_status per tick",
+    return {"sessions": n, "ticks": ticks, "ingest": "submit_pcm16 per session (the ASGI app's path): frames collect in the pool's inbox, " +
+            ("the C one (_wirebox): one vad_tick_push_gather per tick" if c_inbox else "the Python one (VAD_POOL_WIREBOX=0): one join + vad_tick_push_status per tick"),
             "devices": DEVICES, "decode_submit_ms_per_tick": t_sub / ticks * 1e3,
             "tick_in_C_us": {"swap": c_us[0] / ticks, "gpu": c_us[1] / ticks, "segments": c_us[2] / ticks},
             "tick_ms": t_tick / ticks * 1e3, "frames_per_s_host_inclusive": n * ticks / (t_sub + t_tick),
