@@ -299,6 +299,68 @@ int main(int argc, char **argv) {
         std::printf("san_tick: migration mid-segment ok (%zu segments identical)\n", r.seg_samples.size());
     }
     vad_engine_destroy(eng);
+    // ---- batched pushes big enough for the copy crew (> 256 KB per call), on a fresh engine so that the staging grows in the
+    //      middle of a batch (256 rows -> 512) with copies already planned; a second thread pushes single frames meanwhile
+    {
+        OK(vad_engine_create(&d, &eng));
+        OK(vad_tick_enable_segments(eng, 1));
+        const int B = 300, KB = 24;
+        std::vector<int64_t> bs((size_t)B + 20);
+        OK(vad_stream_open_many(eng, B + 20, bs.data()));
+        OK(vad_stream_set_thresholds_many(eng, bs.data(), B + 20, &THR, 1));
+        const Plan p = {VAD_FMT_I16_32767, true, 16000, 480};
+        std::atomic<bool> side_done{false};
+        std::thread side([&] {
+            std::vector<uint8_t> buf;
+            for (int k = 0; k < KB; ++k)
+                for (int j = 0; j < 20; ++j) {
+                    make_frame(B + j, k, p, buf);
+                    while (vad_tick_push(eng, bs[(size_t)(B + j)], buf.data(), p.len, p.fmt, p.gate) != VAD_OK) std::this_thread::yield();
+                }
+            side_done.store(true);
+        });
+        std::vector<Seen> by(1024);
+        std::vector<std::vector<uint8_t>> fr((size_t)B);
+        std::vector<const void *> ptrs((size_t)B);
+        std::vector<uint8_t> flat;
+        std::vector<int32_t> st((size_t)B);
+        long got = 0;
+        for (int k = 0; k < KB; ++k) {
+            for (int j = 0; j < B; ++j) { make_frame(j, k, p, fr[(size_t)j]); ptrs[(size_t)j] = fr[(size_t)j].data(); }
+            if (k % 3 == 0) {
+                OK(vad_tick_push_gather(eng, bs.data(), B, ptrs.data(), p.len, p.fmt, p.gate, st.data()));
+            } else {
+                flat.clear();
+                for (int j = 0; j < B; ++j) flat.insert(flat.end(), fr[(size_t)j].begin(), fr[(size_t)j].end());
+                if (k % 3 == 1) OK(vad_tick_push_status(eng, bs.data(), B, flat.data(), p.len, p.fmt, p.gate, st.data()));
+                else OK(vad_tick_push_many(eng, bs.data(), B, flat.data(), p.len, p.fmt, p.gate));
+            }
+            for (auto &f2 : fr) std::fill(f2.begin(), f2.end(), 0x5a);       // the sources may go once the call has returned
+            std::fill(flat.begin(), flat.end(), 0x5a);
+            if (k % 4 != 3) {                                               // some batches queue up behind the previous one
+                OK(vad_tick_run(eng, 0.01f, &res));
+                take_all(res, by);
+                got += (long)res.n;
+            }
+        }
+        for (;;) {
+            const bool done = side_done.load();
+            OK(vad_tick_run(eng, 0.01f, &res));
+            take_all(res, by);
+            got += (long)res.n;
+            if (done && res.n == 0) break;
+        }
+        side.join();
+        CHECK(got == (long)(B + 20) * KB);
+        for (int j = 0; j < B + 20; ++j) {
+            Seen want;
+            expect(j, p, KB, want);
+            const Seen &g = by[(size_t)bs[(size_t)j]];
+            CHECK(g.probs == want.probs && g.events == want.events && g.seg_samples == want.seg_samples);
+        }
+        vad_engine_destroy(eng);
+        std::printf("san_tick: batched pushes on the copy crew ok (%d streams x %d frames)\n", B + 20, KB);
+    }
     std::printf("san_tick: all ok\n");
     return 0;
 }
