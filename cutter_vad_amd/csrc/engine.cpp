@@ -263,7 +263,6 @@ struct vad_engine {
     };
     SegArena seg_arena;
     std::vector<SegCopy> seg_copies;                 // the copies one tick planned
-    std::vector<SegCopy> push_copies;                // ... and the ones a batched push planned (both under tick_mu)
     // the threads that carry out a tick's planned copies next to the calling one
     struct CopyCrew {
         std::vector<std::thread> th;
@@ -1608,9 +1607,8 @@ int vad_step_rates(vad_engine *e, int32_t nseg, const float *const *in, const in
 
 // ---- tick assembler: the multi-stream caller's side of vad_step_events, in C ---------------------------------------------
 namespace {
-// one frame of `slot` into the staging of the coming tick (tick_mu held).  With `plan` the frame's bytes are not copied here: the
-// copy is appended to the plan, which the caller hands to the copy crew when its batch is placed (the source must live until then).
-int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int group, std::vector<vad_engine::SegCopy> *plan = nullptr) {
+// one frame of `slot` into the staging of the coming tick (tick_mu held)
+int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int group) {
     vad_engine::TickBuf &tb = e->tick_buf[e->tick_cur][group];
     const size_t ss = vad_engine::tick_sample_bytes(group);
     const int flen = vad_engine::tick_group_len(group, e->frame_samples);
@@ -1618,10 +1616,6 @@ int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsample
     if (tb.count == tb.cap) {
         const int64_t cap = std::min<int64_t>(e->max_streams, std::max<int64_t>(256, 2 * tb.cap));
         if (cap <= tb.cap) return e->fail(VAD_ERR_INVALID_ARG, "tick: more pending frames than slots");
-        if (plan && !plan->empty()) {               // planned copies point into the buffer that is about to move
-            e->copy_crew.run(plan->data(), plan->size());
-            plan->clear();
-        }
         uint8_t *nh = nullptr;
         hipError_t r = hipSetDevice(e->device);
         if (r == hipSuccess) r = hipHostMalloc((void **)&nh, (size_t)cap * (rb + 3 * sizeof(int32_t)), hipHostMallocDefault);
@@ -1640,8 +1634,7 @@ int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsample
     // SileroVADModel._prepare_audio_input (core/silero_model.py:464-468): right-zero-pad short frames, truncate long ones
     const size_t take = std::min<size_t>((size_t)nsamples, (size_t)flen) * ss;
     uint8_t *dst = tb.row(tb.count);
-    if (plan) plan->push_back(vad_engine::SegCopy{dst, static_cast<const uint8_t *>(samples), (uint32_t)take});
-    else std::memcpy(dst, samples, take);
+    std::memcpy(dst, samples, take);
     if (take < rb) std::memset(dst + take, 0, rb - take);
     if (e->tick_segments && nsamples > flen) {                  // the model sees the head; a segment keeps the whole frame
         const uint8_t *src = static_cast<const uint8_t *>(samples);
@@ -1656,11 +1649,10 @@ int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsample
 }
 
 // a frame at the engine's own rate (tick_mu held, arguments checked)
-int tick_push_locked(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int group,
-                     std::vector<vad_engine::SegCopy> *plan = nullptr) {
+int tick_push_locked(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int frame_fmt, int group) {
     if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot])
         return e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
-    if (e->tick_gen[(size_t)slot] != e->tick_generation) return tick_place(e, slot, samples, nsamples, group, plan);
+    if (e->tick_gen[(size_t)slot] != e->tick_generation) return tick_place(e, slot, samples, nsamples, group);
     // the slot already has its frame of the coming tick: later frames wait their turn (one per tick, submission order)
     auto it = e->tick_overflow.find(slot);
     if (it == e->tick_overflow.end()) {
@@ -1763,14 +1755,9 @@ int vad_tick_push_many(vad_engine *e, const int64_t *slots, int64_t n, const voi
         return e->fail(VAD_ERR_INVALID_ARG, "tick: empty frame or unknown format");
     const size_t stride = (frame_fmt == VAD_FMT_F32 ? 4 : 2) * (size_t)(nsamples > 0 ? nsamples : 0);
     const int group = frame_fmt * 2 + (gate_on ? 1 : 0);
-    std::vector<vad_engine::SegCopy> &plan = e->push_copies;          // rows are assigned here, the bytes move on the copy crew
-    plan.clear();
-    int rc = VAD_OK;
-    for (int64_t i = 0; i < n && rc == VAD_OK; ++i)
-        rc = tick_push_locked(e, slots[i], static_cast<const uint8_t *>(frames) + (size_t)i * stride, nsamples, frame_fmt, group, &plan);
-    e->copy_crew.run(plan.data(), plan.size());
-    plan.clear();
-    return rc;
+    for (int64_t i = 0; i < n; ++i)
+        if (int rc = tick_push_locked(e, slots[i], static_cast<const uint8_t *>(frames) + (size_t)i * stride, nsamples, frame_fmt, group)) return rc;
+    return VAD_OK;
 }
 
 int vad_tick_push_status(vad_engine *e, const int64_t *slots, int64_t n, const void *frames, int32_t nsamples, int frame_fmt, int gate_on,
@@ -1782,14 +1769,10 @@ int vad_tick_push_status(vad_engine *e, const int64_t *slots, int64_t n, const v
     const size_t stride = (frame_fmt == VAD_FMT_F32 ? 4 : 2) * (size_t)(nsamples > 0 ? nsamples : 0);
     const int group = frame_fmt * 2 + (gate_on ? 1 : 0);
     int first = VAD_OK;
-    std::vector<vad_engine::SegCopy> &plan = e->push_copies;
-    plan.clear();
     for (int64_t i = 0; i < n; ++i) {           // every frame is tried: one full queue or one closed stream does not hold the others back
-        status[i] = tick_push_locked(e, slots[i], static_cast<const uint8_t *>(frames) + (size_t)i * stride, nsamples, frame_fmt, group, &plan);
+        status[i] = tick_push_locked(e, slots[i], static_cast<const uint8_t *>(frames) + (size_t)i * stride, nsamples, frame_fmt, group);
         if (status[i] != VAD_OK && first == VAD_OK) first = status[i];
     }
-    e->copy_crew.run(plan.data(), plan.size());
-    plan.clear();
     return first;
 }
 
@@ -1801,15 +1784,11 @@ int vad_tick_push_gather(vad_engine *e, const int64_t *slots, int64_t n, const v
         return e->fail(VAD_ERR_INVALID_ARG, "tick: empty frame or unknown format");
     const int group = frame_fmt * 2 + (gate_on ? 1 : 0);
     int first = VAD_OK;
-    std::vector<vad_engine::SegCopy> &plan = e->push_copies;
-    plan.clear();
     for (int64_t i = 0; i < n; ++i) {
-        status[i] = frames[i] ? tick_push_locked(e, slots[i], frames[i], nsamples, frame_fmt, group, &plan)
+        status[i] = frames[i] ? tick_push_locked(e, slots[i], frames[i], nsamples, frame_fmt, group)
                               : e->fail(VAD_ERR_INVALID_ARG, "tick: null frame");
         if (status[i] != VAD_OK && first == VAD_OK) first = status[i];
     }
-    e->copy_crew.run(plan.data(), plan.size());
-    plan.clear();
     return first;
 }
 

@@ -299,8 +299,8 @@ int main(int argc, char **argv) {
         std::printf("san_tick: migration mid-segment ok (%zu segments identical)\n", r.seg_samples.size());
     }
     vad_engine_destroy(eng);
-    // ---- batched pushes big enough for the copy crew (> 256 KB per call), on a fresh engine so that the staging grows in the
-    //      middle of a batch (256 rows -> 512) with copies already planned; a second thread pushes single frames meanwhile
+    // ---- whole batches (many / status / gather), on a fresh engine so that the staging grows in the middle of a batch
+    //      (256 rows -> 512); a second thread pushes single frames meanwhile; the sources are overwritten right after each call
     {
         OK(vad_engine_create(&d, &eng));
         OK(vad_tick_enable_segments(eng, 1));
@@ -359,7 +359,7 @@ int main(int argc, char **argv) {
             CHECK(g.probs == want.probs && g.events == want.events && g.seg_samples == want.seg_samples);
         }
         vad_engine_destroy(eng);
-        std::printf("san_tick: batched pushes on the copy crew ok (%d streams x %d frames)\n", B + 20, KB);
+        std::printf("san_tick: batched pushes ok (%d streams x %d frames)\n", B + 20, KB);
     }
     std::printf("san_tick: all ok\n");
     return 0;
