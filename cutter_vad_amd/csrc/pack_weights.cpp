@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace vadk {
@@ -553,6 +554,25 @@ uint32_t pack_resample_operator_t16(int n_in, std::vector<float> &out, uint32_t 
         err = "resample operator lacks the symmetries the folded kernel relies on";
         return 0;
     }
+    // 24 / 48 kHz (n = 768 / 1536 = 3 n'): every third input sample sits ON an instant of the 512-sample output grid, m = 1536 / n
+    // output steps apart, and there the Dirichlet kernel is a delta plus the Nyquist bin's alternation:
+    //   R[o][3 i'] = (512 / n) [o == m i'] + (-1)^(o - m i') / n
+    // - a third of the operator's columns are a copy, a scale and ONE alternating sum per chunk.  The kernel does exactly that
+    // (silero_v5_t16.hip, "P3") and contracts only the folded samples j = 1, 2, 4, 5, 7, 8, ... : K = n / 6 per part instead of
+    // n / 4.  Checked here against the operator itself; any other length keeps the full contraction.
+    bool poly3 = (n == 768 || n == 1536) && !std::getenv("VAD_RS_DENSE");   // (the variable: diagnostic - A/B and tests of the two layouts)
+    if (poly3) {
+        const int m = 1536 / n;
+        double dev = 0;
+        for (int o = 0; o < 512; ++o)
+            for (int ip = 0; ip < n / 3; ++ip) {
+                const double want = ((o == m * ip) ? 512.0 / n : 0.0) + (((o - m * ip) & 1) ? -1.0 : 1.0) / n;
+                dev = std::max(dev, std::fabs(Rv(o, 3 * ip) - want));
+            }
+        if (dev > 1e-12) poly3 = false;
+    }
+    const int Kc = poly3 ? 2 * Q / 3 : Q;                                   // contraction length per folded part
+    auto jm = [&](int i) { return poly3 ? 3 * (i >> 1) + 1 + (i & 1) : i; };   // contraction index -> folded sample j
     auto RE = [&](int o, int i) { return Rv(o, i) + Rv(o, i + H); };
     auto RO = [&](int o, int i) { return Rv(o, i) - Rv(o, i + H); };
     auto G = [&](int part, int o, int j) -> float {
@@ -567,20 +587,20 @@ uint32_t pack_resample_operator_t16(int n_in, std::vector<float> &out, uint32_t 
     for (int w = 0; w < 4; ++w) {
         for (int rt = 0; rt < 2; ++rt) sb.vector_block16([&](int c) { return (float)(0.5 * RE(32 * w + 16 * rt + c, Q)); });
         for (int rt = 0; rt < 2; ++rt) sb.vector_block16([&](int c) { return (float)(0.5 * RO(32 * w + 16 * rt + c, Q)); });
-        for (int j = 0; j < Q / 16; ++j)
+        for (int j = 0; j < Kc / 16; ++j)
             for (int part = 0; part < 4; ++part)
                 for (int rt = 0; rt < 2; ++rt)
-                    sb.weight_block16([&](int r, int k) { return G(part, 32 * w + 16 * rt + r, k); }, j);
+                    sb.weight_block16([&](int r, int k) { return G(part, 32 * w + 16 * rt + r, jm(k)); }, j);
     }
     const uint32_t per_wave = sb.blocks() / 4;
     *row128_block = sb.blocks();
-    std::vector<float> row(2 * (size_t)Q + 2);
-    for (int j = 0; j < Q; ++j) {
-        row[j] = G(0, 128, j);
-        row[Q + j] = G(2, 128, j);
+    std::vector<float> row(2 * (size_t)Kc + 2);
+    for (int j = 0; j < Kc; ++j) {
+        row[j] = G(0, 128, jm(j));
+        row[Kc + j] = G(2, 128, jm(j));
     }
-    row[2 * Q] = (float)(0.5 * RE(128, Q));
-    row[2 * Q + 1] = (float)(0.5 * RO(128, Q));
+    row[2 * Kc] = (float)(0.5 * RE(128, Q));          // (with every third sample skipped the kernel does not use these two, nor
+    row[2 * Kc + 1] = (float)(0.5 * RO(128, Q));      //  the vector blocks above: x[Q] and x[3Q] are such samples)
     for (size_t j0 = 0; j0 < row.size(); j0 += BLK_FLOATS) {
         float *b = sb.new_block();
         for (size_t j = j0; j < j0 + BLK_FLOATS && j < row.size(); ++j) b[j - j0] = row[j];

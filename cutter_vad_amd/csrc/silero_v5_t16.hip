@@ -24,6 +24,7 @@
 // kernel for calls of at most 4 096 streams (256 tiles = one per CU) and the 32-stream tiles above that.
 // Weight stream: pack_silero_v5_t16.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "vad_layout.h"
 #include "sm_device.h"
 #include "vadk_device.h"
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     //      at a rate boundary has two.
     struct Part {
         RateSeg S;
-        int sk, c0, c1, ls0, Q;
+        int sk, c0, c1, ls0, Q, Kc;
         bool valid;
     };
     constexpr int DEAD = 1 << 26;                  // an index (in quads / samples) past every buffer: loads return 0
@@ -159,6 +160,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
                     pt.sk = k; pt.c0 = a0; pt.c1 = a1;
                     pt.ls0 = v0 - pt.S.vstart;                       // column c holds the segment's stream ls0 + c (c0 <= c < c1)
                     pt.Q = pt.S.n_in >> 2;
+                    pt.Kc = ((int)pt.S.wave_blocks - 4) * 2;         // contraction length per folded part: Q, or 2 Q / 3 ("P3", below)
                     pt.valid = true;
                     break;
                 }
@@ -169,16 +171,33 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     // chunk loader: 16 streams x 16 folded quads = one per thread (stream ms = tid >> 4, quad ql = tid & 15)
     u32x4 xlA[6], xlB[6];
     const int cms = tid >> 4, cql = tid & 15;
-    auto load_chunk = [&](const Part &pt, int c, u32x4 *xl) {
+    auto load_chunk = [&](auto p3tag, const Part &pt, int c, u32x4 *xl) {
         const __amdgpu_buffer_rsrc_t xrs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pt.S.in), 0, (int)((unsigned)pt.S.n * (unsigned)pt.S.n_in * 4u), 0x00020000);
         const int Q = pt.Q, qq = cql + 16 * c, base = (cms >= pt.c0 && cms < pt.c1) ? (pt.ls0 + cms) * Q : DEAD;
-        xl[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + qq) * 16, 0, 0);
-        xl[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + qq + (Q >> 1)) * 16, 0, 0);
-        xl[2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (Q >> 1) - qq) * 16, 0, 0);
-        xl[3] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (Q >> 1) - qq - 1) * 16, 0, 0);
-        xl[4] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (qq == 0 ? 0 : Q - qq)) * 16, 0, 0);
-        xl[5] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + Q - qq - 1) * 16, 0, 0);
+        if constexpr (decltype(p3tag)::value != 0) {
+            // P3 (24 / 48 kHz, see the part loop): compact quad g = the folded samples j = 6g+1, 6g+2, 6g+4, 6g+5; the thread reads
+            // six consecutive samples of each of the four regions - x[6g ..], x[H + 6g ..], x[H - 6g - 6 ..], x[n - 6g - 6 ..] -
+            // which hold those four j and the two samples 3 i' in between (8-byte aligned; wide loads need dword alignment only)
+            const int s6 = 6 * qq, sb = base * 4, H = 2 * Q, nn = 4 * Q;
+            xl[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (sb + s6) * 4, 0, 0);
+            xl[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (sb + H + s6) * 4, 0, 0);
+            xl[2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (sb + H - s6 - 4) * 4, 0, 0);
+            xl[3] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (sb + nn - s6 - 4) * 4, 0, 0);
+            const u32x2 a2 = __builtin_amdgcn_raw_buffer_load_b64(xrs, (sb + s6 + 4) * 4, 0, 0);
+            const u32x2 c2 = __builtin_amdgcn_raw_buffer_load_b64(xrs, (sb + H + s6 + 4) * 4, 0, 0);
+            const u32x2 b2 = __builtin_amdgcn_raw_buffer_load_b64(xrs, (sb + H - s6 - 6) * 4, 0, 0);
+            const u32x2 d2 = __builtin_amdgcn_raw_buffer_load_b64(xrs, (sb + nn - s6 - 6) * 4, 0, 0);
+            xl[4] = u32x4{a2.x, a2.y, c2.x, c2.y};
+            xl[5] = u32x4{b2.x, b2.y, d2.x, d2.y};
+        } else {
+            xl[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + qq) * 16, 0, 0);
+            xl[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + qq + (Q >> 1)) * 16, 0, 0);
+            xl[2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (Q >> 1) - qq) * 16, 0, 0);
+            xl[3] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (Q >> 1) - qq - 1) * 16, 0, 0);
+            xl[4] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + (qq == 0 ? 0 : Q - qq)) * 16, 0, 0);
+            xl[5] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (base + Q - qq - 1) * 16, 0, 0);
+        }
     };
     Part cur = mk_part(0);
     // (requesting the first part's first chunk right here, before the recurrent state is waited for, was measured: 48.6 - 49.7 us
@@ -234,38 +253,91 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
                     F4[ms * FQ + qd] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((ls0 + ms) * 128 + qd) * 16, 0, 0));
             }
         } else {
-            const int Q = S.n_in >> 2, nchunks = Q >> 6;
+          auto run_part = [&](auto p3tag) {
+            // P3 (24 / 48 kHz: n_in = 3 n'): the samples x[3 i'] sit ON output instants - R[o][3 i'] = (512 / n_in) [o == m i'] +
+            // (-1)^(o - m i') / n_in with m = 1536 / n_in (pack_resample_operator_t16 checks it and leaves those columns out of the
+            // stream) - so the loader threads copy them, scaled, straight to their place in F and add them into one alternating sum
+            // per stream, and the MFMAs contract only the other two thirds of the folded samples: 4 chunks instead of 6 (48 kHz),
+            // 2 instead of 3 (24 kHz).  x[0], x[H], x[Q], x[3Q] - the samples the fold cannot pair - are all of that kind.
+            // Compile-time per part shape (tag 0: every sample contracted, 1: 48 kHz, 2: 24 kHz - three instantiations of this
+            // body): branches inside the chunk loop cost ~0.4 us per chunk.
+            constexpr bool P3 = decltype(p3tag)::value != 0;
+            constexpr int om = decltype(p3tag)::value;                // output steps between two copied samples = 1536 / n_in
+            const int Q = S.n_in >> 2, Kc = cur.Kc, nchunks = Kc >> 6;
+            const float sc0 = 512.0f / (float)S.n_in;
+            constexpr float sg3 = om == 1 ? -1.f : 1.f;
+            float pA = 0.f;                                           // this thread's share of sum_i' (-1)^(m i') x[3 i']
             const __amdgpu_buffer_rsrc_t ors =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S.wstream), 0, (int)S.wstream_bytes, 0x00020000);
             const __amdgpu_buffer_rsrc_t xrs =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S.in), 0, (int)((unsigned)S.n * (unsigned)S.n_in * 4u), 0x00020000);
 #define OL(blk) ldw(ors, lane16, (blk))
             const int wbase = w * (int)S.wave_blocks;
-            load_chunk(cur, 0, xlA);
+            load_chunk(p3tag, cur, 0, xlA);
             // (input chunks are requested TWO chunks ahead - two register sets - so that a chunk's HBM round trip has a whole
             // chunk of MFMAs, ~1.7 us, more to hide under than it needs; chunk 0 has been on its way since before this part began)
             auto store_chunk = [&](int c, int buf, const u32x4 *xl) {
-                const f32x4 a = __builtin_bit_cast(f32x4, xl[0]), cc = __builtin_bit_cast(f32x4, xl[1]);
-                const f32x4 b0 = __builtin_bit_cast(f32x4, xl[2]), b1 = __builtin_bit_cast(f32x4, xl[3]);
-                const f32x4 d0 = __builtin_bit_cast(f32x4, xl[4]), d1 = __builtin_bit_cast(f32x4, xl[5]);
-                const f32x4 b = f32x4{b0.x, b1.w, b1.z, b1.y}, d = f32x4{d0.x, d1.w, d1.z, d1.y};
-                const f32x4 pe = a + cc, me = a - cc, qe = b + d, qo = b - d;
-                f32x4 ue = pe + qe, ve = pe - qe, uo = me + qo, vo = me - qo;
-                if (cql + 16 * c == 0) { ue.x = pe.x; ve.x = 0.f; uo.x = 0.f; vo.x = me.x; }     // j = 0 has no partner
-                f32x4 *dst = lds + buf * RS_BUF + cql * QSL + cms;
-                dst[0] = ue;
-                dst[RS_CH_ROWS * QSL] = ve;
-                dst[2 * RS_CH_ROWS * QSL] = uo;
-                dst[3 * RS_CH_ROWS * QSL] = vo;
+                if constexpr (P3) {
+                    const f32x4 A4 = __builtin_bit_cast(f32x4, xl[0]), C4 = __builtin_bit_cast(f32x4, xl[1]);
+                    const f32x4 B4 = __builtin_bit_cast(f32x4, xl[2]), D4 = __builtin_bit_cast(f32x4, xl[3]);
+                    const f32x4 AC = __builtin_bit_cast(f32x4, xl[4]), BD = __builtin_bit_cast(f32x4, xl[5]);
+                    // j = 6g+1, 6g+2, 6g+4, 6g+5: x[j], x[j+H] ascending; x[H-j], x[n-j] descending through their windows
+                    const f32x4 a = f32x4{A4.y, A4.z, AC.x, AC.y}, cc = f32x4{C4.y, C4.z, AC.z, AC.w};
+                    const f32x4 b = f32x4{B4.w, B4.z, B4.x, BD.y}, d = f32x4{D4.w, D4.z, D4.x, BD.w};
+                    const f32x4 pe = a + cc, me = a - cc, qe = b + d, qo = b - d;
+                    f32x4 *dst = lds + buf * RS_BUF + cql * QSL + cms;
+                    dst[0] = pe + qe;
+                    dst[RS_CH_ROWS * QSL] = pe - qe;
+                    dst[2 * RS_CH_ROWS * QSL] = me + qo;
+                    dst[3 * RS_CH_ROWS * QSL] = me - qo;
+                    // the copied samples: x[6g], x[6g+3] (and the same past H) -> outputs ob, ob + m; x[H-6g-3], x[H-6g-6] -> 256 - ob - m,
+                    // 256 - ob - 2m (likewise below 512): every output instant m i' exactly once over the part's chunks
+                    const float e0 = A4.x + C4.x + BD.x + BD.z, e3 = A4.w + C4.w + B4.y + D4.y;
+                    pA += e0 + sg3 * e3;
+                    if (cms >= c0 && cms < c1) {
+                        float *o = Ff + cms * (4 * FQ);
+                        const int ob = om * 2 * (cql + 16 * c);
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        if constexpr (om == 1) {          // 48 kHz: neighbours - four aligned pairs
+                            *reinterpret_cast<f32x2 *>(o + ob) = f32x2{sc0 * A4.x, sc0 * A4.w};
+                            *reinterpret_cast<f32x2 *>(o + 256 + ob) = f32x2{sc0 * C4.x, sc0 * C4.w};
+                            *reinterpret_cast<f32x2 *>(o + 254 - ob) = f32x2{sc0 * BD.x, sc0 * B4.y};
+                            *reinterpret_cast<f32x2 *>(o + 510 - ob) = f32x2{sc0 * BD.z, sc0 * D4.y};
+                        } else {                          // 24 kHz: every other output; the odd ones get nothing but the alternation
+                            *reinterpret_cast<f32x4 *>(o + ob) = f32x4{sc0 * A4.x, 0.f, sc0 * A4.w, 0.f};
+                            *reinterpret_cast<f32x4 *>(o + 256 + ob) = f32x4{sc0 * C4.x, 0.f, sc0 * C4.w, 0.f};
+                            *reinterpret_cast<f32x4 *>(o + 252 - ob) = f32x4{sc0 * BD.x, 0.f, sc0 * B4.y, 0.f};
+                            *reinterpret_cast<f32x4 *>(o + 508 - ob) = f32x4{sc0 * BD.z, 0.f, sc0 * D4.y, 0.f};
+                        }
+                    }
+                } else {
+                    const f32x4 a = __builtin_bit_cast(f32x4, xl[0]), cc = __builtin_bit_cast(f32x4, xl[1]);
+                    const f32x4 b0 = __builtin_bit_cast(f32x4, xl[2]), b1 = __builtin_bit_cast(f32x4, xl[3]);
+                    const f32x4 d0 = __builtin_bit_cast(f32x4, xl[4]), d1 = __builtin_bit_cast(f32x4, xl[5]);
+                    const f32x4 b = f32x4{b0.x, b1.w, b1.z, b1.y}, d = f32x4{d0.x, d1.w, d1.z, d1.y};
+                    const f32x4 pe = a + cc, me = a - cc, qe = b + d, qo = b - d;
+                    f32x4 ue = pe + qe, ve = pe - qe, uo = me + qo, vo = me - qo;
+                    if (cql + 16 * c == 0) { ue.x = pe.x; ve.x = 0.f; uo.x = 0.f; vo.x = me.x; }     // j = 0 has no partner
+                    f32x4 *dst = lds + buf * RS_BUF + cql * QSL + cms;
+                    dst[0] = ue;
+                    dst[RS_CH_ROWS * QSL] = ve;
+                    dst[2 * RS_CH_ROWS * QSL] = uo;
+                    dst[3 * RS_CH_ROWS * QSL] = vo;
+                }
             };
             // the sample each half-size product cannot pair, x[Q] +- x[Q + H], is a rank-1 term (accumulator init, rows 128 / 384)
             const int sb = in_part(n) ? (ls0 + n) * S.n_in : (DEAD << 2);         // columns of other segments contract zeros
-            const float xa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (sb + Q) * 4, 0, 0));
-            const float xb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (sb + 3 * Q) * 4, 0, 0));
-            const f32x4 mid = ldw(ors, (Q >> 1) * 16, (int)S.row128_block);       // floats 2Q, 2Q + 1: RE[128][Q] / 2, RO[128][Q] / 2
-            f32x4 ini[4];
+            float xa = 0.f, xb = 0.f;
+            f32x4 mid = f32x4{0.f, 0.f, 0.f, 0.f}, ini[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ini[k] = OL(wbase + k);
+            for (int k = 0; k < 4; ++k) ini[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!P3) {                                                  // (P3: x[Q] and x[3Q] are copied samples)
+                xa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (sb + Q) * 4, 0, 0));
+                xb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (sb + 3 * Q) * 4, 0, 0));
+                mid = ldw(ors, (Q >> 1) * 16, (int)S.row128_block);               // floats 2Q, 2Q + 1: RE[128][Q] / 2, RO[128][Q] / 2
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ini[k] = OL(wbase + k);
+            }
             // output rows 128 / 384 on the VALU: thread = (stream tid & 15, part tid >> 4); parts 0..7 dot ue with GSE[128],
             // 8..15 uo with GSO[128], two quads of every chunk each
             float r128 = 0.f;
@@ -296,7 +368,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
 #endif
 #pragma unroll
             for (int d = 0; d < D - 1; ++d) { R_LDW0(d, d) }
-            if (nchunks > 1) load_chunk(cur, 1, xlB);
+            if (nchunks > 1) load_chunk(p3tag, cur, 1, xlB);
             f32x4 acc[8];                                             // part p (se, ae, so, ao), row tile rt -> acc[2 p + rt]
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
@@ -314,7 +386,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
 #ifdef RS_EXP_NOX
 #define RS_LOADX(c, XL)
 #else
-#define RS_LOADX(c, XL) load_chunk(cur, (c), XL)
+#define RS_LOADX(c, XL) load_chunk(p3tag, cur, (c), XL)
 #endif
 #define RS_XQ(XQ, X, j) _Pragma("unroll") for (int p4 = 0; p4 < 4; ++p4) XQ[p4] = (X)[(p4 * RS_CH_ROWS + 4 * (j)) * QSL + nqL];
 #define RS_STEP(j, XC, XN, EXTRA)                                                                               \
@@ -335,7 +407,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
                 RS_STEP(0, xqA, xqB,                                                                            \
                         if ((c) + 2 < nchunks) RS_LOADX((c) + 2, XL);                                           \
                         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                           \
-                            g128[i] = ldw(ors, (psel * (Q >> 2) + 16 * (c) + 2 * pr + i) * 16, (int)S.row128_block);) \
+                            g128[i] = ldw(ors, (psel * (Kc >> 2) + 16 * (c) + 2 * pr + i) * 16, (int)S.row128_block);) \
                 RS_STEP(1, xqB, xqA, if ((c) + 1 < nchunks) store_chunk((c) + 1, ((c) + 1) & 1, XS);)           \
                 RS_STEP(2, xqA, xqB, {                                                                          \
                     const int ms = tid & 15;                                                                    \
@@ -361,35 +433,77 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
 #undef RS_MMA
 #undef R_LDW
 #undef R_LDW0
-            // every chunk of this part has been consumed: the next part's first chunk goes on its way under the tail below
-            // recombine: y[o] = se+ae+so+ao, y[o+256] = se+ae-so-ao, y[256-o] = se-ae+so-ao, y[512-o] = se-ae-so+ao
+            if constexpr (!P3) {
+                // recombine: y[o] = se+ae+so+ao, y[o+256] = se+ae-so-ao, y[256-o] = se-ae+so-ao, y[512-o] = se-ae-so+ao
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const int row = 32 * w + 16 * rt + 4 * kq;
-                const f32x4 se = acc[0 + rt], ae = acc[2 + rt], so = acc[4 + rt], ao = acc[6 + rt];
-                const f32x4 pe = se + ae, me = se - ae, pO = so + ao, mO = so - ao;
-                if (in_part(n)) {
-                    F4[n * FQ + (row >> 2)] = pe + pO;
-                    F4[n * FQ + 64 + (row >> 2)] = pe - pO;
-                    const f32x4 lo = me + mO, hi = me - mO;
-                    float *o = Ff + n * (4 * FQ);
-                    if (row != 0) { o[256 - row] = lo.x; o[512 - row] = hi.x; }     // o = 0: y[256] and y[0] are written above
-                    o[255 - row] = lo.y; o[511 - row] = hi.y;
-                    o[254 - row] = lo.z; o[510 - row] = hi.z;
-                    o[253 - row] = lo.w; o[509 - row] = hi.w;
+                for (int rt = 0; rt < 2; ++rt) {
+                    const int row = 32 * w + 16 * rt + 4 * kq;
+                    const f32x4 se = acc[0 + rt], ae = acc[2 + rt], so = acc[4 + rt], ao = acc[6 + rt];
+                    const f32x4 pe = se + ae, me = se - ae, pO = so + ao, mO = so - ao;
+                    if (in_part(n)) {
+                        F4[n * FQ + (row >> 2)] = pe + pO;
+                        F4[n * FQ + 64 + (row >> 2)] = pe - pO;
+                        const f32x4 lo = me + mO, hi = me - mO;
+                        float *o = Ff + n * (4 * FQ);
+                        if (row != 0) { o[256 - row] = lo.x; o[512 - row] = hi.x; }     // o = 0: y[256] and y[0] are written above
+                        o[255 - row] = lo.y; o[511 - row] = hi.y;
+                        o[254 - row] = lo.z; o[510 - row] = hi.z;
+                        o[253 - row] = lo.w; o[509 - row] = hi.w;
+                    }
+                }
+                headp[rpart * 16 + (tid & 15)] = r128;               // [16 parts][16 streams]: headp .. fcor are idle before the frame loop
+                __syncthreads();
+                if (tid < MT16 && in_part(tid)) {                     // tid < 16: this thread's MFMA column n is stream tid - xa / xb are its x[Q], x[3Q]
+                    float e = 0.f, od = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { e += headp[k * 16 + tid]; od += headp[(8 + k) * 16 + tid]; }
+                    e += mid.x * (xa + xb);
+                    od += mid.y * (xa - xb);
+                    Ff[tid * (4 * FQ) + 128] = e + od;
+                    Ff[tid * (4 * FQ) + 384] = e - od;
+                }
+            } else {
+                // rows 128 / 384 and the alternating sum meet in LDS first: the recombination needs the sum
+                headp[rpart * 16 + (tid & 15)] = r128;
+                float *const altL = fcor + FCOR_SINK;                 // [16 streams]
+                float a = pA;
+                a += __shfl_xor(a, 1, 16);
+                a += __shfl_xor(a, 2, 16);
+                a += __shfl_xor(a, 4, 16);
+                a += __shfl_xor(a, 8, 16);
+                if (cql == 0) altL[cms] = a * (1.0f / (float)S.n_in);
+                __syncthreads();
+                // the same recombination, on top of the copied samples already in F, plus (-1)^o times the stream's sum / n_in
+                const float altv = altL[n];
+                const f32x4 altq = f32x4{altv, -altv, altv, -altv};
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const int row = 32 * w + 16 * rt + 4 * kq;
+                    const f32x4 se = acc[0 + rt], ae = acc[2 + rt], so = acc[4 + rt], ao = acc[6 + rt];
+                    const f32x4 pe = se + ae, me = se - ae, pO = so + ao, mO = so - ao;
+                    if (in_part(n)) {
+                        float *o = Ff + n * (4 * FQ);
+                        F4[n * FQ + (row >> 2)] += pe + pO + altq;
+                        F4[n * FQ + 64 + (row >> 2)] += pe - pO + altq;
+                        const f32x4 lo = me + mO + altq, hi = me - mO + altq;       // 256 - row - k and 512 - row - k have the parity of k
+                        if (row != 0) { o[256 - row] += lo.x; o[512 - row] += hi.x; }
+                        o[255 - row] += lo.y; o[511 - row] += hi.y;
+                        o[254 - row] += lo.z; o[510 - row] += hi.z;
+                        o[253 - row] += lo.w; o[509 - row] += hi.w;
+                    }
+                }
+                if (tid < MT16 && in_part(tid)) {                     // rows 128 / 384 (even): on top of the copied x[Q], x[3Q]
+                    float e = altv, od = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { e += headp[k * 16 + tid]; od += headp[(8 + k) * 16 + tid]; }
+                    Ff[tid * (4 * FQ) + 128] += e + od;
+                    Ff[tid * (4 * FQ) + 384] += e - od;
                 }
             }
-            headp[rpart * 16 + (tid & 15)] = r128;                   // [16 parts][16 streams]: headp .. fcor are idle before the frame loop
-            __syncthreads();
-            if (tid < MT16 && in_part(tid)) {                         // tid < 16: this thread's MFMA column n is stream tid - xa / xb are its x[Q], x[3Q]
-                float e = 0.f, od = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { e += headp[k * 16 + tid]; od += headp[(8 + k) * 16 + tid]; }
-                e += mid.x * (xa + xb);
-                od += mid.y * (xa - xb);
-                Ff[tid * (4 * FQ) + 128] = e + od;
-                Ff[tid * (4 * FQ) + 384] = e - od;
-            }
+          };
+          if (cur.Kc == (S.n_in >> 2)) run_part(std::integral_constant<int, 0>{});
+          else if (S.n_in == 1536) run_part(std::integral_constant<int, 1>{});
+          else run_part(std::integral_constant<int, 2>{});
 #undef OL
         }
         __syncthreads();                                              // this part of F is complete; staging and headp are free again

@@ -710,24 +710,34 @@ def packed_resample_t16(n_in: int):
 
 
 def resample_t16(W, wave_blocks, row128_block, x):
-    """x [16, n_in] -> y [16, 512]: the RS prologue of silero_v5_t16.hip over pack_resample_operator_t16's stream (float64)."""
+    """x [16, n_in] -> y [16, 512]: the RS prologue of silero_v5_t16.hip over pack_resample_operator_t16's stream (float64).
+    24 / 48 kHz chunks ("P3": the stream's contraction length is n_in / 6, not n_in / 4): every third input sample is copied
+    (scaled) to its output instant and enters one alternating sum; the MFMAs contract the folded samples j = 1, 2, 4, 5, 7, ..."""
     x = x.astype(np.float64)
     n_in = x.shape[1]
     H, Q = n_in // 2, n_in // 4
+    Kc = (wave_blocks - 4) * 2
+    p3 = Kc != Q
+    assert Kc == (2 * Q // 3 if p3 else Q)
     xe, xo = x[:, :H] + x[:, H:], x[:, :H] - x[:, H:]
     j = np.arange(Q)
     rev = (H - j) % H
     ue, ve, uo, vo = xe[:, j] + xe[:, rev], xe[:, j] - xe[:, rev], xo[:, j] + xo[:, rev], xo[:, j] - xo[:, rev]
     ue[:, 0], ve[:, 0], uo[:, 0], vo[:, 0] = xe[:, 0], 0.0, 0.0, xo[:, 0]
-    parts = [a.reshape(16, Q // 4, 4).transpose(1, 0, 2) for a in (ue, ve, uo, vo)]      # quad rows [Q/4, 16 streams, 4]
+    if p3:
+        i = np.arange(Kc)
+        jm = 3 * (i >> 1) + 1 + (i & 1)
+        ue, ve, uo, vo = ue[:, jm], ve[:, jm], uo[:, jm], vo[:, jm]
+    parts = [a.reshape(16, Kc // 4, 4).transpose(1, 0, 2) for a in (ue, ve, uo, vo)]      # quad rows [Kc/4, 16 streams, 4]
     y = np.zeros((16, 512))
     for w in range(4):
         wb = w * wave_blocks
         for rt in range(2):
             acc = [np.zeros((16, 16)) for _ in range(4)]
-            acc[0] += _vec16(W[wb + rt])[:, None] * xe[:, Q][None, :]
-            acc[2] += _vec16(W[wb + 2 + rt])[:, None] * xo[:, Q][None, :]
-            for g in range(Q // 16):
+            if not p3:
+                acc[0] += _vec16(W[wb + rt])[:, None] * xe[:, Q][None, :]
+                acc[2] += _vec16(W[wb + 2 + rt])[:, None] * xo[:, Q][None, :]
+            for g in range(Kc // 16):
                 for p in range(4):
                     acc[p] += _mfma16(W[wb + 4 + 8 * g + 2 * p + rt], _rows16(parts[p], 4 * g))
             se, ae, so, ao = acc
@@ -739,9 +749,20 @@ def resample_t16(W, wave_blocks, row128_block, x):
                     y[:, 256 - o] = (se - ae + so - ao)[r]
                     y[:, 512 - o] = (se - ae - so + ao)[r]
     row = W[row128_block:].reshape(-1).astype(np.float64)
-    e = ue @ row[:Q] + row[2 * Q] * xe[:, Q]
-    od = uo @ row[Q:2 * Q] + row[2 * Q + 1] * xo[:, Q]
+    e = ue @ row[:Kc]
+    od = uo @ row[Kc:2 * Kc]
+    if not p3:
+        e = e + row[2 * Kc] * xe[:, Q]
+        od = od + row[2 * Kc + 1] * xo[:, Q]
     y[:, 128], y[:, 384] = e + od, e - od
+    if p3:
+        # the loader's side of the chunk: the samples 3 i' go straight to F (scaled), and into the alternating sum
+        m = 1536 // n_in
+        x0 = x[:, 0::3]
+        ip = np.arange(n_in // 3)
+        y[:, m * ip] += (512.0 / n_in) * x0
+        A = (x0 * np.where((m * ip) % 2 == 0, 1.0, -1.0)[None, :]).sum(1) if m == 1 else x0.sum(1)
+        y += (A / n_in)[:, None] * np.where(np.arange(512) % 2 == 0, 1.0, -1.0)[None, :]
     return y
 
 

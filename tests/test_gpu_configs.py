@@ -206,3 +206,26 @@ def test_config3_at_its_stated_size_is_one_fused_launch_with_tiles_that_straddle
             assert np.abs(p[pick] - ref).max() <= 5e-5, t
             alone = np.concatenate([solo.step_rates([segs[k]], slots2[starts[k]:starts[k + 1]])[0] for k in range(3)])
             assert np.array_equal(p, alone), t
+
+
+def test_fused_resampler_with_every_third_sample_copied_equals_the_full_contraction(monkeypatch):
+    """24 / 48 kHz chunks: the fused prologue copies the samples x[3 i'] (they sit on output instants) and contracts two thirds of
+    the folded operator (pack_resample_operator_t16, "P3").  VAD_RS_DENSE=1 (diagnostic, read when an engine first packs an
+    operator) keeps the full contraction: the two must agree to float32 rounding on every stream, boundary tiles included."""
+    from cutter_vad_amd.engine import Engine
+    rates = ((8000, 256, 700), (24000, 768, 1000), (48000, 1536, 1001), (16000, 512, 300))
+    B, T = sum(r[2] for r in rates), 4
+    base = make_streams(B, T * 3, seed=777).reshape(B, -1)
+    starts = np.cumsum([0] + [r[2] for r in rates])
+    with Engine(_blob(5), model_version=5, max_streams=B) as eng, Engine(_blob(5), model_version=5, max_streams=B) as full:
+        slots, slots2 = eng.open_streams(B), full.open_streams(B)
+        worst = 0.0
+        for t in range(T):
+            segs = [(np.ascontiguousarray(base[starts[k]:starts[k + 1], t * n_in:(t + 1) * n_in]), sr) for k, (sr, n_in, _) in enumerate(rates)]
+            p, ev, _ = eng.step_rates(segs, slots)
+            monkeypatch.setenv("VAD_RS_DENSE", "1")
+            p2, ev2, _ = full.step_rates(segs, slots2)
+            monkeypatch.delenv("VAD_RS_DENSE")
+            worst = max(worst, float(np.abs(p - p2).max()))
+            assert (ev == ev2).mean() > 0.999
+        assert 0.0 < worst <= 5e-6, worst             # not the same code path (> 0), the same answer
