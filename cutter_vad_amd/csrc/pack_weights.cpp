@@ -477,6 +477,23 @@ void build_resample_operator_d(int n_in, std::vector<double> &R) {
 // Packed layout: row tile t (4 of them) = rows o = 32 t .. 32 t + 31:
 //   4 vector blocks RE[o][Q] / 2, 4 vector blocks RO[o][Q] / 2, then per k-iteration (8 values of j) the blocks SE, AE, SO, AO;
 // after the four tiles: GSE[128][0..Q), GSO[128][0..Q), RE[128][Q] / 2, RO[128][Q] / 2 as plain floats.
+
+namespace {
+// R[o][3 i'] == (512 / n) [o == m i'] + (-1)^(o - m i') / n  (m = 1536 / n) for n = 768, 1536?  (VAD_RS_DENSE: diagnostic - A/B and
+// tests of the two operator layouts)
+bool resample_poly3(int n, const std::vector<double> &R) {
+    if ((n != 768 && n != 1536) || std::getenv("VAD_RS_DENSE")) return false;
+    const int m = 1536 / n;
+    double dev = 0;
+    for (int o = 0; o < 512; ++o)
+        for (int ip = 0; ip < n / 3; ++ip) {
+            const double want = ((o == m * ip) ? 512.0 / n : 0.0) + (((o - m * ip) & 1) ? -1.0 : 1.0) / n;
+            dev = std::max(dev, std::fabs(R[(size_t)o * n + 3 * ip] - want));
+        }
+    return dev <= 1e-12;
+}
+}  // namespace
+
 uint32_t pack_resample_operator(int n_in, std::vector<float> &out, uint32_t *row128_block, std::string &err) {
     std::vector<double> R;
     build_resample_operator_d(n_in, R);
@@ -496,6 +513,12 @@ uint32_t pack_resample_operator(int n_in, std::vector<float> &out, uint32_t *row
         err = "resample operator lacks the symmetries the folded kernel relies on";
         return 0;
     }
+    // (the fused kernel's layout, pack_resample_operator_t16 below, leaves every third column of the 24 / 48 kHz operators out and
+    // copies those samples.  Not here: this kernel's outputs go to HBM, the copied samples arrive chunk by chunk on other threads
+    // than the ones that own the output rows, and the 66 KB of LDS that would carry them across would end the two-workgroups-
+    // per-CU residency its small launches rely on.)
+    const int Kc = Q;
+    auto jm = [&](int i) { return i; };
     auto RE = [&](int o, int i) { return Rv(o, i) + Rv(o, i + H); };
     auto RO = [&](int o, int i) { return Rv(o, i) - Rv(o, i + H); };
     auto GSE = [&](int o, int j) -> float { return (float)(j == 0 ? 0.5 * RE(o, 0) : 0.25 * (RE(o, j) + RE(o, H - j))); };
@@ -506,22 +529,22 @@ uint32_t pack_resample_operator(int n_in, std::vector<float> &out, uint32_t *row
     for (int t = 0; t < 4; ++t) {
         sb.vector_blocks([&](int c) { return (float)(0.5 * RE(32 * t + c, Q)); });
         sb.vector_blocks([&](int c) { return (float)(0.5 * RO(32 * t + c, Q)); });
-        for (int j = 0; j < Q / 8; ++j) {
-            sb.weight_block([&](int np, int k) { return GSE(32 * t + np, k); }, j);
-            sb.weight_block([&](int np, int k) { return GAE(32 * t + np, k); }, j);
-            sb.weight_block([&](int np, int k) { return GSO(32 * t + np, k); }, j);
-            sb.weight_block([&](int np, int k) { return GAO(32 * t + np, k); }, j);
+        for (int j = 0; j < Kc / 8; ++j) {
+            sb.weight_block([&](int np, int k) { return GSE(32 * t + np, jm(k)); }, j);
+            sb.weight_block([&](int np, int k) { return GAE(32 * t + np, jm(k)); }, j);
+            sb.weight_block([&](int np, int k) { return GSO(32 * t + np, jm(k)); }, j);
+            sb.weight_block([&](int np, int k) { return GAO(32 * t + np, jm(k)); }, j);
         }
     }
     const uint32_t per_tile = sb.blocks() / 4;
     *row128_block = sb.blocks();
-    std::vector<float> row(2 * (size_t)Q + 2);
-    for (int j = 0; j < Q; ++j) {
-        row[j] = GSE(128, j);
-        row[Q + j] = GSO(128, j);
+    std::vector<float> row(2 * (size_t)Kc + 2);
+    for (int j = 0; j < Kc; ++j) {
+        row[j] = GSE(128, jm(j));
+        row[Kc + j] = GSO(128, jm(j));
     }
-    row[2 * Q] = (float)(0.5 * RE(128, Q));
-    row[2 * Q + 1] = (float)(0.5 * RO(128, Q));
+    row[2 * Kc] = (float)(0.5 * RE(128, Q));
+    row[2 * Kc + 1] = (float)(0.5 * RO(128, Q));
     for (size_t j0 = 0; j0 < row.size(); j0 += BLK_FLOATS) {
         float *b = sb.new_block();
         for (size_t j = j0; j < j0 + BLK_FLOATS && j < row.size(); ++j) b[j - j0] = row[j];
@@ -560,17 +583,7 @@ uint32_t pack_resample_operator_t16(int n_in, std::vector<float> &out, uint32_t 
     // - a third of the operator's columns are a copy, a scale and ONE alternating sum per chunk.  The kernel does exactly that
     // (silero_v5_t16.hip, "P3") and contracts only the folded samples j = 1, 2, 4, 5, 7, 8, ... : K = n / 6 per part instead of
     // n / 4.  Checked here against the operator itself; any other length keeps the full contraction.
-    bool poly3 = (n == 768 || n == 1536) && !std::getenv("VAD_RS_DENSE");   // (the variable: diagnostic - A/B and tests of the two layouts)
-    if (poly3) {
-        const int m = 1536 / n;
-        double dev = 0;
-        for (int o = 0; o < 512; ++o)
-            for (int ip = 0; ip < n / 3; ++ip) {
-                const double want = ((o == m * ip) ? 512.0 / n : 0.0) + (((o - m * ip) & 1) ? -1.0 : 1.0) / n;
-                dev = std::max(dev, std::fabs(Rv(o, 3 * ip) - want));
-            }
-        if (dev > 1e-12) poly3 = false;
-    }
+    const bool poly3 = resample_poly3(n, R);
     const int Kc = poly3 ? 2 * Q / 3 : Q;                                   // contraction length per folded part
     auto jm = [&](int i) { return poly3 ? 3 * (i >> 1) + 1 + (i & 1) : i; };   // contraction index -> folded sample j
     auto RE = [&](int o, int i) { return Rv(o, i) + Rv(o, i + H); };
