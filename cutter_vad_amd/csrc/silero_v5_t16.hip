@@ -200,8 +200,8 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
         }
     };
     Part cur = mk_part(0);
-    // (requesting the first part's first chunk right here, before the recurrent state is waited for, was measured: 48.6 - 49.7 us
-    //  against 47.9 - 48.2 for 4 096 streams at 48 kHz on one box - the request only delays the state loads queued behind it)
+    // (requesting the first part's first chunk right here, IN FRONT of the state loads, was measured: 48.6 - 49.7 us against
+    //  47.9 - 48.2 for 4 096 streams at 48 kHz on one box - it delays the state loads queued behind it.  Behind them: below.)
 
     // ---- prologue: h_{t-1} -> LDS quads (32 rows x 16 streams), c_{t-1} -> registers, state machines -> LDS ----
     f32x4 hv[2];
@@ -224,6 +224,18 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     f32x4 smq[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) smq[k] = reinterpret_cast<const f32x4 *>(P.sm + slot)[k];
+    // RS, first part at 48 kHz (the tiles that set a mixed tick's time): its first chunk is requested right BEHIND the state loads -
+    // loads return in order, so the state is not delayed - and has its HBM round trip under the state's waits, the LDS writes and
+    // the operator prefetch.  Same box: 43.3 -> 42.9 us (4 096 streams at 48 kHz), configs[3] 46.0 -> 45.5; for 8 / 24 kHz first
+    // parts it changes nothing (+- 0.1), so they keep the request where the part begins.
+    bool chunk0_requested = false;
+    if constexpr (RS) {
+        if (cur.valid && cur.S.wstream != nullptr && cur.S.n_in == 1536) {
+            if (cur.Kc == cur.Q) load_chunk(std::integral_constant<int, 0>{}, cur, 0, xlA);
+            else load_chunk(std::integral_constant<int, 1>{}, cur, 0, xlA);
+            chunk0_requested = true;
+        }
+    }
     SB();
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) RH[(part * 2 + qq) * QSD + fm] = hv[qq];
@@ -273,7 +285,8 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S.in), 0, (int)((unsigned)S.n * (unsigned)S.n_in * 4u), 0x00020000);
 #define OL(blk) ldw(ors, lane16, (blk))
             const int wbase = w * (int)S.wave_blocks;
-            load_chunk(p3tag, cur, 0, xlA);
+            if (!chunk0_requested) load_chunk(p3tag, cur, 0, xlA);
+            chunk0_requested = false;
             // (input chunks are requested TWO chunks ahead - two register sets - so that a chunk's HBM round trip has a whole
             // chunk of MFMAs, ~1.7 us, more to hide under than it needs; chunk 0 has been on its way since before this part began)
             auto store_chunk = [&](int c, int buf, const u32x4 *xl) {
