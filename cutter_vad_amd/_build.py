@@ -59,13 +59,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # MFMA accumulators in VGPRs where they fit: the epilogues (|.|, interpolation, cell) read them with VALU instructions,
     # which cannot address AGPRs - every accumulator kept there costs a v_accvgpr_read/write (measured: V5 49.2 -> 48.9 us)
     kernel_flags = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+    # leading scalar kernel arguments arrive in SGPRs with the wave instead of through s_load (gfx950 kernarg preload; the V5
+    # kernels have such arguments: 0.15 - 0.25 us of 50 per headline step)
+    preload = ["-mllvm", "-amdgpu-kernarg-preload-count=8"]
+    per_file_flags = {"silero_v5.hip": preload, "silero_v5_t16.hip": preload}
     for s in HIP_SOURCES:
         o = os.path.join(bdir, s + ".o")
         mine = experiment and (not only or s in only)
         if experiment and not mine and os.path.exists(o) and not force:
             objs.append(o)                      # an experiment rebuilds only the files it names
             continue
-        cmd = [cc, f"--offload-arch={ARCH}", *common, *kernel_flags, *(defines if mine else []), "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [cc, f"--offload-arch={ARCH}", *common, *kernel_flags, *per_file_flags.get(s, []), *(defines if mine else []), "-c",
+               os.path.join(CSRC, s), "-o", o]
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
         subprocess.check_call(cmd)

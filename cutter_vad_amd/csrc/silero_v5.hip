@@ -39,8 +39,15 @@ using namespace vadk::dev;
 // K8: the graph's 8 kHz sub-model (If_0 else-branch) on 256-sample frames: the same dataflow at half the
 // front-end size (vad_layout.h): window 128, hop 64, K = 32 per folded contraction, 64 complex bins on waves 0 / 1 (waves 2 / 3
 // sit out the STFT MFMAs), bin 64 on the VALU, encoder.0 with 65 input channels; everything from enc1 on is identical.
+// The first eight arguments repeat the fields of P that the kernel needs before anything else (slot lookup, state, first weight
+// blocks, first frame column): scalar arguments at the head of the list are PRELOADED into SGPRs by the command processor on
+// gfx950 (`-mllvm -amdgpu-kernarg-preload-count=8` in _build.py: 13 dwords), struct fields are fetched with s_load after the wave
+// has started.  Same box: 49.98 - 50.13 -> 49.84 - 49.87 us per step of 8 192 streams (KP(f) = that field's preloaded copy).
 template <bool F32IN, bool K8>
-__global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P) {
+__global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wstream, float *k_state, SmSlot *k_sm, const int32_t *k_slots,
+                                                              const void *k_frames, const int k_n, const uint32_t k_wstream_bytes, const int k_T,
+                                                              const StepParams P) {
+#define KP(f) k_##f
     using namespace vadk::v5;
     constexpr int QL = K8 ? 8 : 16;               // lanes per stream in the loader = quads per quarter column
     constexpr int CS = 4 * QL;                    // folded-operand rows per column (pe | po | qe | qo)
@@ -66,19 +73,19 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
     const int tile0 = blockIdx.x * MT;
     STAMP(19);                                    // kernel entry
     const int gf = tile0 + m;                     // this lane's stream index within the call
-    const bool live = gf < P.n;
-    const int slot = live ? (P.slots ? P.slots[gf] : gf) : 0;
+    const bool live = gf < KP(n);
+    const int slot = live ? (KP(slots) ? KP(slots)[gf] : gf) : 0;
     // Weight streams are read through ONE buffer descriptor (SGPRs, built from kernel arguments only):
     // voffset = lane * 16 (a single VGPR for every load of the kernel), soffset = block * 1024 (SALU).
     // With flat 64-bit VGPR addresses hipcc hoisted ~150 loop-invariant pointers out of the frame loop
     // and spilled them (cdna_hip_programming.md T8/T20).
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wstream), 0, (int)P.wstream_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(KP(wstream)), 0, (int)KP(wstream_bytes), 0x00020000);
     const int lane16 = lane * 16;
 #define WL(blk) ldw(wrs, lane16, (blk))
     const int o_stft = (int)P.sect[w][S_STFT], o_nyq = (int)P.sect[w][S_NYQ], o_e0 = (int)P.sect[w][S_ENC0];
     const int o_e1 = (int)P.sect[w][S_ENC1], o_e2 = (int)P.sect[w][S_ENC2], o_e3 = (int)P.sect[w][S_ENC3];
     const int o_l = (int)P.sect[w][S_LSTM];
-    const int T = P.T;
+    const int T = KP(T);
     const int hq = h * QS + m;                    // lane's offset inside a quad-row pair
 
     // ---- frame ingest set-up (loop-invariant) ----
@@ -89,7 +96,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
     constexpr int qsh = f32in ? 4 : 3;             // log2(bytes per 4-sample quad)
     const float sc = P.fmt == 1 ? 32767.0f : 32768.0f, rsc = 1.0f / sc;
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * ((f32in ? 2048u : 1024u) >> (K8 ? 1 : 0))), 0x00020000);
+        const_cast<void *>(KP(frames)), 0, (int)((unsigned)KP(n) * (unsigned)T * ((f32in ? 2048u : 1024u) >> (K8 ? 1 : 0))), 0x00020000);
     u32x4 xa_[8], xb_[8];                          // raw quads of a column (both 16-stream halves), as bits
     // Column c of frame tt -> XR: lane q of a 16-lane row (one stream per row) loads quads q, 16+q, 32+q, 48+q of the
     // column: every sample once, 4 branch-free 16-byte loads per lane and stream half.
@@ -117,7 +124,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
         // fm == m (a wave is 64 lanes): the stream this thread loads h for is the stream of its MFMA column -> ONE slot lookup
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            const f32x4 v = reinterpret_cast<const f32x4 *>(P.state + (size_t)slot * 256)[part * 4 + qq];
+            const f32x4 v = reinterpret_cast<const f32x4 *>(KP(state) + (size_t)slot * 256)[part * 4 + qq];
             hv[qq] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -128,7 +135,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
         f32x4 c4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(P.state + (size_t)slot * 256 + 128 + 32 * w + 8 * g + 4 * h);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(KP(state) + (size_t)slot * 256 + 128 + 32 * w + 8 * g + 4 * h);
             c4[g] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         cst = acc_of(c4[0], c4[1], c4[2], c4[3]);
@@ -141,7 +148,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
     const int sm_slot = slot;
     f32x4 smq[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) smq[k] = reinterpret_cast<const f32x4 *>(P.sm + slot)[k];
+    for (int k = 0; k < 6; ++k) smq[k] = reinterpret_cast<const f32x4 *>(KP(sm) + slot)[k];
     SB();
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) RH[(part * 4 + qq) * QS + fm] = hv[qq];
@@ -150,12 +157,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
 #pragma unroll
         for (int k = 0; k < 6; ++k) reinterpret_cast<f32x4 *>(smL + tid)[k] = smq[k];
     }
-    const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];    // head bias
+    const float hb = KP(wstream)[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];    // head bias
 
     // every kernel argument the frame loop needs, fetched NOW (scalar loads from the kernarg segment cost a round
     // trip when they are left to the point of first use, after the barrier)
     {
-        const void *a0 = P.state, *a1 = P.sm, *a2 = P.probs, *a3 = P.events, *a4 = P.frames;
+        const void *a0 = KP(state), *a1 = KP(sm), *a2 = P.probs, *a3 = P.events, *a4 = KP(frames);
         const int a5 = __builtin_bit_cast(int, P.thresh), a6 = P.fmt;
         asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6));
     }
@@ -610,8 +617,8 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
 #undef CELL
                 RH[(8 * w + 2 * g) * QS + hq] = hn;
                 if (t == T - 1 && live) {   // last frame of the call: h' and c' go back to HBM under barrier (8), head and state machine
-                    *reinterpret_cast<f32x4 *>(P.state + (size_t)slot * 256 + 32 * w + 8 * g + 4 * h) = hn;
-                    *reinterpret_cast<f32x4 *>(P.state + (size_t)slot * 256 + 128 + 32 * w + 8 * g + 4 * h) = cn;
+                    *reinterpret_cast<f32x4 *>(KP(state) + (size_t)slot * 256 + 32 * w + 8 * g + 4 * h) = hn;
+                    *reinterpret_cast<f32x4 *>(KP(state) + (size_t)slot * 256 + 128 + 32 * w + 8 * g + 4 * h) = cn;
                 }
                 switch (g) {
                     case 0: cst.s0 = cn.x; cst.s1 = cn.y; cst.s2 = cn.z; cst.s3 = cn.w; break;
@@ -635,7 +642,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
                 SmSlot sm = smL[tid];
                 int seg = 0;
                 const int ev = sm_step(sm, p, &seg);
-                if (t == T - 1) P.sm[sm_slot] = sm;
+                if (t == T - 1) KP(sm)[sm_slot] = sm;
                 else smL[tid] = sm;
                 if (ev & 2) seg_last = seg;
                 if (P.events) P.events[(size_t)(tile0 + tid) * T + t] = (uint8_t)ev;
@@ -651,19 +658,22 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const StepParams P
     if (sm_thread && P.seg_frames) P.seg_frames[tile0 + tid] = seg_last;
 }
 
+#undef KP
 // host-callable launcher (engine.cpp is plain C++ and never sees <<<>>>)
 extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream_t stream) {
     (void)hipGetLastError();   // HIP's last-error slot is sticky and process-wide: a stale failure from anywhere else must not become ours
     const int tiles = (p->n + vadk::MT - 1) / vadk::MT;
     if (tiles <= 0) return hipSuccess;
+#define V5_ARGS p->wstream, p->state, p->sm, p->slots, p->frames, (int)p->n, p->wstream_bytes, (int)p->T, *p
     if (p->variant == 1) {       // the 8 kHz sub-model, 256-sample frames
         if (p->fmt == 0)
-            hipLaunchKernelGGL((silero_v5_step<true, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+            hipLaunchKernelGGL((silero_v5_step<true, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS);
         else
-            hipLaunchKernelGGL((silero_v5_step<false, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+            hipLaunchKernelGGL((silero_v5_step<false, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS);
     } else if (p->fmt == 0)
-        hipLaunchKernelGGL((silero_v5_step<true, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+        hipLaunchKernelGGL((silero_v5_step<true, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS);
     else
-        hipLaunchKernelGGL((silero_v5_step<false, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p);
+        hipLaunchKernelGGL((silero_v5_step<false, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS);
+#undef V5_ARGS
     return hipGetLastError();
 }

@@ -76,7 +76,11 @@ template <bool F32IN, bool RS>
 // One workgroup per CU also here.  Built for two (a tick's segments are padded to whole tiles, so it can have a few more tiles
 // than CUs), the dispatcher packs consecutive workgroups onto the same CU: 258 tiles ran on ~130 CUs, 69.9 us per tick against
 // 55.6 for the two-launch form - so the engine uses this launch only when the tick has at most one tile per CU.
-__global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams P, const RateParams R) {
+// (the eight leading arguments: the fields of P the kernel needs first, preloaded into SGPRs - see silero_v5.hip; KP(f) = that copy)
+__global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_wstream, float *k_state, SmSlot *k_sm, const int32_t *k_slots,
+                                                                const void *k_frames, const int k_n, const uint32_t k_wstream_bytes, const int k_T,
+                                                                const StepParams P, const RateParams R) {
+#define KP(f) k_##f
     using namespace vadk::v5;
     static_assert(!RS || F32IN, "resampled frames are float32");
     __shared__ f32x4 lds[T_LDS_F4 + (RS ? MT16 * FQ : 0)];     // RS: + the tile's 16 kHz frames F (one workgroup per CU either way)
@@ -100,7 +104,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     // column belongs to is a handful of compares on kernel arguments
     const int vcol = (int)blockIdx.x * MT16 + n;
     int gf = vcol;
-    bool live = vcol < P.n;
+    bool live = vcol < KP(n);
     if constexpr (RS) {
         int s0 = R.seg[0].stream0, vs = 0;
 #pragma unroll
@@ -110,14 +114,14 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
         live = vcol < R.total;
     }
     const int tile0 = (int)blockIdx.x * MT16;                      // (not RS: the tile's first stream in the call's arrays)
-    const int slot = live ? (P.slots ? P.slots[gf] : gf) : 0;
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wstream), 0, (int)P.wstream_bytes, 0x00020000);
+    const int slot = live ? (KP(slots) ? KP(slots)[gf] : gf) : 0;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(KP(wstream)), 0, (int)KP(wstream_bytes), 0x00020000);
     const int lane16 = lane * 16;
 #define WL(blk) ldw(wrs, lane16, (blk))
     const int o_stft = (int)P.sect[w][S_STFT], o_nyq = (int)P.sect[w][S_NYQ], o_e0 = (int)P.sect[w][S_ENC0];
     const int o_e1 = (int)P.sect[w][S_ENC1], o_e2 = (int)P.sect[w][S_ENC2], o_e3 = (int)P.sect[w][S_ENC3];
     const int o_l = (int)P.sect[w][S_LSTM];
-    const int T = P.T;
+    const int T = KP(T);
 
     // ---- frame ingest set-up: 16 lanes per stream, 16 streams per fold call (ms = tid >> 4) ----
     const float thr = P.thresh;
@@ -127,7 +131,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     constexpr int qsh = f32in ? 4 : 3;
     const float sc = P.fmt == 1 ? 32767.0f : 32768.0f, rsc = 1.0f / sc;
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void *>(P.frames), 0, (int)((unsigned)P.n * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
+        const_cast<void *>(KP(frames)), 0, (int)((unsigned)KP(n) * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
     u32x4 xa_[4], xb_[4], xc_[4];                  // raw quads of the three columns
     f32x4 *const F4 = lds + T_LDS_F4;              // RS: the tile's resampled frames
 #define X_ISSUE(c, XR, tt)                                                                                      \
@@ -208,7 +212,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     const int fm = tid & 15, part = tid >> 4;      // fm == n: ONE slot lookup serves h, c and the state machine
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) {
-        const f32x4 v = reinterpret_cast<const f32x4 *>(P.state + (size_t)slot * 256)[part * 2 + qq];
+        const f32x4 v = reinterpret_cast<const f32x4 *>(KP(state) + (size_t)slot * 256)[part * 2 + qq];
         hv[qq] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const f32x4 W1 = ldw(wrs, q * 16, o_nyq), W3 = ldw(wrs, (32 + q) * 16, o_nyq);
@@ -216,14 +220,14 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     f32x4 cst[2];                                  // c of units 32 w + 16 rt + 4 kq + i
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(P.state + (size_t)slot * 256 + 128 + 32 * w + 16 * rt + 4 * kq);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(KP(state) + (size_t)slot * 256 + 128 + 32 * w + 16 * rt + 4 * kq);
         cst[rt] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const bool sm_thread = (tid < MT16) && live;
     const int sm_slot = slot;
     f32x4 smq[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) smq[k] = reinterpret_cast<const f32x4 *>(P.sm + slot)[k];
+    for (int k = 0; k < 6; ++k) smq[k] = reinterpret_cast<const f32x4 *>(KP(sm) + slot)[k];
     // RS, first part at 48 kHz (the tiles that set a mixed tick's time): its first chunk is requested right BEHIND the state loads -
     // loads return in order, so the state is not delayed - and has its HBM round trip under the state's waits, the LDS writes and
     // the operator prefetch.  Same box: 43.3 -> 42.9 us (4 096 streams at 48 kHz), configs[3] 46.0 -> 45.5; for 8 / 24 kHz first
@@ -244,7 +248,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
 #pragma unroll
         for (int k = 0; k < 6; ++k) reinterpret_cast<f32x4 *>(smL + tid)[k] = smq[k];
     }
-    const float hb = P.wstream[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];
+    const float hb = KP(wstream)[(size_t)P.sect[0][S_HEADB] * BLK_FLOATS];
 
     if constexpr (RS) {
         // ---- the tile's 16 chunks -> 512 samples at 16 kHz each, into F (resample.hip has the algebra; pack_resample_operator_t16
@@ -871,8 +875,8 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
 #undef CELL
                 RH[(8 * w + 4 * rt) * QSD + nq] = hn;
                 if (t == T - 1 && live) {
-                    *reinterpret_cast<f32x4 *>(P.state + (size_t)slot * 256 + 32 * w + 16 * rt + 4 * kq) = hn;
-                    *reinterpret_cast<f32x4 *>(P.state + (size_t)slot * 256 + 128 + 32 * w + 16 * rt + 4 * kq) = cn;
+                    *reinterpret_cast<f32x4 *>(KP(state) + (size_t)slot * 256 + 32 * w + 16 * rt + 4 * kq) = hn;
+                    *reinterpret_cast<f32x4 *>(KP(state) + (size_t)slot * 256 + 128 + 32 * w + 16 * rt + 4 * kq) = cn;
                 }
                 cst[rt] = cn;
             }
@@ -890,7 +894,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
                 SmSlot sm = smL[tid];
                 int seg = 0;
                 const int ev = sm_step(sm, p, &seg);
-                if (t == T - 1) P.sm[sm_slot] = sm;
+                if (t == T - 1) KP(sm)[sm_slot] = sm;
                 else smL[tid] = sm;
                 if (ev & 2) seg_last = seg;
                 if (P.events) P.events[(size_t)gf * T + t] = (uint8_t)ev;
@@ -902,15 +906,18 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const StepParams
     if (sm_thread && P.seg_frames) P.seg_frames[gf] = seg_last;
 }
 
+#undef KP
+
+#define V5_ARGS p->wstream, p->state, p->sm, p->slots, p->frames, (int)p->n, p->wstream_bytes, (int)p->T, *p
 extern "C" hipError_t vadk_launch_silero_v5_t16(const vadk::StepParams *p, hipStream_t stream) {
     (void)hipGetLastError();
     const int tiles = (p->n + MT16 - 1) / MT16;
     if (tiles <= 0) return hipSuccess;
     const vadk::RateParams none{};
     if (p->fmt == 0)
-        hipLaunchKernelGGL((silero_v5_step16<true, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, none);
+        hipLaunchKernelGGL((silero_v5_step16<true, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS, none);
     else
-        hipLaunchKernelGGL((silero_v5_step16<false, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, none);
+        hipLaunchKernelGGL((silero_v5_step16<false, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS, none);
     return hipGetLastError();
 }
 
@@ -919,6 +926,6 @@ extern "C" hipError_t vadk_launch_silero_v5_t16_rates(const vadk::StepParams *p,
     (void)hipGetLastError();
     const int tiles = (r->total + MT16 - 1) / MT16;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL((silero_v5_step16<true, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, *p, *r);
+    hipLaunchKernelGGL((silero_v5_step16<true, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS, *r);
     return hipGetLastError();
 }
