@@ -7,7 +7,7 @@ TAG=$1
 B=${2:-4096}
 OUT=$PWD/gpurun_out
 REPO=$PWD
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DKB_TILE16 -o /tmp/kb16 tools/kbench.cpp cutter_vad_amd/csrc/silero_v5_t16.hip cutter_vad_amd/csrc/pack_weights.cpp 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-kernarg-preload-count=8 -DKB_TILE16 -o /tmp/kb16 tools/kbench.cpp cutter_vad_amd/csrc/silero_v5_t16.hip cutter_vad_amd/csrc/pack_weights.cpp 2>/dev/null
 /tmp/kb16 "$REPO/cutter_vad_amd/weights/silero_v5_16k.svw" $B 200 > "$OUT/${TAG}_kb16.log" 2>&1
 cd /tmp && export TMPDIR=/tmp
 i=0

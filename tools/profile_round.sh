@@ -9,7 +9,7 @@ OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 echo "bench done" >> "$OUT/${TAG}_progress.log"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -o /tmp/kb tools/kbench.cpp cutter_vad_amd/csrc/silero_v5.hip cutter_vad_amd/csrc/pack_weights.cpp 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-kernarg-preload-count=8 -o /tmp/kb tools/kbench.cpp cutter_vad_amd/csrc/silero_v5.hip cutter_vad_amd/csrc/pack_weights.cpp 2>/dev/null
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_prof" -o bench -- python3 "$REPO/bench.py" --no-cpu --steps 500 --warmup 100 > "$OUT/${TAG}_prof.log" 2>&1
