@@ -148,12 +148,15 @@ bool check_windowed_dft(const float *stft, std::string &err, int N = 256) {
 
 // cos / -sin blocks of the 4-way folded DFT: wave w owns the 32 bins bin_of_channel(32 w + r); k-iteration j
 // contracts n = 8j .. 8j+7 (n = 0 is an unused slot: weight 0)
-// the same for a window of 128 (Silero V5's 8 kHz sub-model): 4 k-iterations, parity `par` owns the bins 2 r + par, r = 0..31
-void pack_dft4_wave_128(StreamBuilder &sb, int par) {
+// the same for a window of 128 (Silero V5's 8 kHz sub-model), as 16-row tiles for v_mfma_f32_16x16x4_f32 so that all four waves
+// share the 64 complex bins: wave w owns the bins 2 (16 (w & 1) + r) + (w >> 1), r = 0..15 (channels 16 w + r: parity w >> 1, the
+// channel order of bin_of_channel_8k); two k-iterations of 16 folded samples, {cos, -sin} each
+void pack_dft4_wave_128_t16(StreamBuilder &sb, int w) {
     const double two_pi = 6.283185307179586476925286766559;
-    for (int j = 0; j < 4; ++j) {
-        sb.weight_block([&](int np, int n) { const int k = 2 * np + par; return n == 0 ? 0.f : (float)std::cos(two_pi * (double)((k * n) & 127) / 128.0); }, j);
-        sb.weight_block([&](int np, int n) { const int k = 2 * np + par; return n == 0 ? 0.f : (float)-std::sin(two_pi * (double)((k * n) & 127) / 128.0); }, j);
+    const int par = w >> 1, hf = w & 1;
+    for (int j = 0; j < 2; ++j) {
+        sb.weight_block16([&](int r, int n) { const int k = 2 * (16 * hf + r) + par; return n == 0 ? 0.f : (float)std::cos(two_pi * (double)((k * n) & 127) / 128.0); }, j);
+        sb.weight_block16([&](int r, int n) { const int k = 2 * (16 * hf + r) + par; return n == 0 ? 0.f : (float)-std::sin(two_pi * (double)((k * n) & 127) / 128.0); }, j);
     }
 }
 
@@ -211,7 +214,7 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
         // k-iteration j contracts n = 8j+1 .. 8j+8 (quad 2j on the lower half-wave, 2j+1 on the upper)
         out.sect[w][S_STFT] = sb.blocks();
         if (!k8) pack_dft4_wave(sb, w);
-        else if (w < 2) pack_dft4_wave_128(sb, w);        // 64 bins = two 32-row tiles: waves 0 (even bins) and 1 (odd bins)
+        else pack_dft4_wave_128_t16(sb, w);               // 64 bins = four 16-row tiles, one per wave
         // enc0 as a Toom-3 product (vad_layout.h): out channels 32w.., per k-iteration the five point-wise weight blocks
         // V(0) = w2, V(1)/2, V(-1)/2, V(2), V(inf) = w0 of V(z) = w2 + w1 z + w0 z^2 (evaluated in double); then the
         // Nyquist input channel: block A = points 0, 1, -1, 2 in the four components (lower half-wave), block B = inf

@@ -37,8 +37,8 @@ using namespace vadk::dev;
 // F32IN: frames are float32 (else int16).  A template parameter, not a branch: the frame fold must stay in one basic
 // block with the recurrent-half MFMAs for the instruction interleave below to be possible.
 // K8: the graph's 8 kHz sub-model (If_0 else-branch) on 256-sample frames: the same dataflow at half the
-// front-end size (vad_layout.h): window 128, hop 64, K = 32 per folded contraction, 64 complex bins on waves 0 / 1 (waves 2 / 3
-// sit out the STFT MFMAs), bin 64 on the VALU, encoder.0 with 65 input channels; everything from enc1 on is identical.
+// front-end size (vad_layout.h): window 128, hop 64, K = 32 per folded contraction, 64 complex bins as four 16-row tiles (one per
+// wave, v_mfma_f32_16x16x4_f32), bin 64 on the VALU, encoder.0 with 65 input channels; everything from enc1 on is identical.
 // The first eight arguments repeat the fields of P that the kernel needs before anything else (slot lookup, state, first weight
 // blocks, first frame column): scalar arguments at the head of the list are PRELOADED into SGPRs by the command processor on
 // gfx950 (`-mllvm -amdgpu-kernarg-preload-count=8` in _build.py: 13 dwords), struct fields are fetched with s_load after the wave
@@ -332,6 +332,87 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
         // ---- STFT: wave w owns the 32 bins bin_of_channel(32w + r): cos on pe|po, -sin on qe|qo, 3 columns ----
         // enc0's bias and first weights ride along (requested at the end of this phase)
         f32x4 e0b0, e0b1, e0b2, e0b3, E0w[5];
+        if constexpr (K8) {
+            // 8 kHz sub-model: 64 complex bins.  As two 32-row tiles they kept waves 0 / 1 busy for 96 MFMAs while waves 2 / 3 had
+            // none; as FOUR 16-row tiles on v_mfma_f32_16x16x4_f32 (lane = (stream n16 + 16 sh, channel group kq), the 16-stream
+            // kernel's fragment convention; pack_dft4_wave_128_t16) every wave has 96 MFMAs of half the cycles: wave w owns the
+            // bins 2 (16 (w & 1) + r) + (w >> 1), r = 0..15 - waves 0 / 1 the even bins (pe / qe), 2 / 3 the odd ones (po / qo).
+            // Same rank-1 start as below: tile row r = 4 kq + i, (-1)^r = (-1)^i.
+            const int n16 = lane & 15, kq = lane >> 4;
+            const bool even = w < 2;
+            f32x4 sre[3][2], sim[3][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int sh = 0; sh < 2; ++sh) {
+                    const int ms = n16 + 16 * sh;
+                    const float y128 = fcor[(c * 3 + 0) * 32 + ms], a64 = fcor[(c * 3 + 1) * 32 + ms], b64 = fcor[(c * 3 + 2) * 32 + ms];
+                    const float rp = even ? y128 + a64 : -y128, rm = even ? y128 - a64 : -y128;
+                    const float ip = even ? 0.f : -b64, im_ = even ? 0.f : b64;
+                    sre[c][sh] = f32x4{rp, rm, rp, rm};
+                    sim[c][sh] = f32x4{ip, im_, ip, im_};
+                }
+            const int rR = even ? 0 : QL, rI = even ? 2 * QL : 3 * QL;
+            const f32x4 wre0 = WL(ws_stft), wim0 = WL(ws_stft + 1), wre1 = WL(ws_stft + 2), wim1 = WL(ws_stft + 3);
+            auto mma16 = [](f32x4 wv, f32x4 a, f32x4 acc) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, a.w, acc, 0, 0, 0);
+                return acc;
+            };
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {                       // K = 32 folded samples = two k-iterations of 16
+                const f32x4 wr = j ? wre1 : wre0, wi = j ? wim1 : wim0;
+                f32x4 u[3][2], v[3][2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int sh = 0; sh < 2; ++sh) {
+                        u[c][sh] = RX[(CS * c + rR + 4 * j + kq) * QS + n16 + 16 * sh];
+                        v[c][sh] = RX[(CS * c + rI + 4 * j + kq) * QS + n16 + 16 * sh];
+                    }
+                SB();
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int sh = 0; sh < 2; ++sh) {
+                        sre[c][sh] = mma16(wr, u[c][sh], sre[c][sh]);
+                        sim[c][sh] = mma16(wi, v[c][sh], sim[c][sh]);
+                    }
+                SB();
+            }
+            e0b0 = WL(ws_e0); e0b1 = WL(ws_e0 + 1); e0b2 = WL(ws_e0 + 2); e0b3 = WL(ws_e0 + 3);
+#pragma unroll
+            for (int p = 0; p < 5; ++p) E0w[p] = WL(ws_e0 + 4 + p);
+            SB();
+            STAMP(16);
+            __syncthreads();   // (1b) every wave is done reading u/v: the magnitudes may overwrite them
+            // magnitudes -> Toom-3 evaluations, rows 16 p + (channel / 4) = 16 p + 4 w + kq
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                f32x4 mg[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x4 r = sre[c][sh], i = sim[c][sh];
+                    mg[c] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
+                }
+                const f32x4 s02 = mg[0] + mg[2];
+                f32x4 *o = RX + (4 * w + kq) * QS + n16 + 16 * sh;
+                st2(o, mg[0]);
+                st2(o + PS * QS, s02 + mg[1]);
+                st2(o + 2 * PS * QS, s02 - mg[1]);
+                st2(o + 3 * PS * QS, f32x4{fmaf(4.f, mg[2].x, fmaf(2.f, mg[1].x, mg[0].x)), fmaf(4.f, mg[2].y, fmaf(2.f, mg[1].y, mg[0].y)),
+                                           fmaf(4.f, mg[2].z, fmaf(2.f, mg[1].z, mg[0].z)), fmaf(4.f, mg[2].w, fmaf(2.f, mg[1].w, mg[0].w))});
+                st2(o + 4 * PS * QS, mg[2]);
+            }
+            if (tid < 64) {    // |X64|: as |X128| below
+                const float n0 = nyqv[m], n1 = nyqv[32 + m], n2 = nyqv[64 + m];
+                const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                RX[ROWN * QS + hq] = h == 0 ? f32x4{n0, (n0 + n2) + n1, (n0 + n2) - n1, fmaf(4.f, n2, fmaf(2.f, n1, n0))} : z4;
+                RX[(ROWN + 2) * QS + hq] = h == 0 ? f32x4{n2, 0.f, 0.f, 0.f} : z4;
+            }
+        } else
         {
             // The accumulators START from the rank-1 terms of n = 0, 64, 128 (the samples the fold cannot pair), so the
             // epilogue only takes magnitudes.  Register 4g+i holds tile row r = 8g+4h+i: (-1)^r = (-1)^i.

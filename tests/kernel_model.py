@@ -102,7 +102,37 @@ def v5_step(W, sect, x, hc, gate=0.01, k8=False):
     # STFT: wave w owns bins bin_of_channel(32w + r); even bins contract pe / qe, odd bins po / qo
     mags = {}
     sgn = np.where(np.arange(32) % 2 == 0, 1.0, -1.0)[:, None]                # (-1)^r per tile row
-    stft_waves = (0, 1) if k8 else (0, 1, 2, 3)
+    if k8:
+        # 64 complex bins = four 16-row tiles on v_mfma_f32_16x16x4_f32, one per wave (pack_dft4_wave_128_t16): wave w owns the
+        # channels 16 w + r (waves 0 / 1 even bins: pe / qe, 2 / 3 odd bins: po / qo); two k-iterations of 16 folded samples
+        sgn16 = np.where(np.arange(16) % 2 == 0, 1.0, -1.0)[:, None]
+        mg8 = {}
+        for w in range(4):
+            ws = sect[w][S_STFT]
+            even = w < 2
+            rR, rI = (0, 2 * QL) if even else (QL, 3 * QL)
+            mg = []
+            for c in range(3):
+                are, aim = np.zeros((16, 32)), np.zeros((16, 32))
+                for j in range(2):
+                    wre = W[ws + 2 * j].astype(np.float64).reshape(4, 16, 4)        # [kq][row][i]
+                    wim = W[ws + 2 * j + 1].astype(np.float64).reshape(4, 16, 4)
+                    u = RX[CS * c + rR + 4 * j:CS * c + rR + 4 * j + 4]              # [kq][stream][i]
+                    v = RX[CS * c + rI + 4 * j:CS * c + rI + 4 * j + 4]
+                    are += np.einsum("kri,kmi->rm", wre, u)
+                    aim += np.einsum("kri,kmi->rm", wim, v)
+                y128, a64, b64 = fcor[c, 0][None, :], fcor[c, 1][None, :], fcor[c, 2][None, :]
+                if even:
+                    re, im = are + y128 + sgn16 * a64, aim
+                else:
+                    re, im = are - y128, aim - sgn16 * b64
+                mg.append(np.sqrt(re ** 2 + im ** 2))                               # [16 channels, 32 streams]
+            mg8[w] = mg
+        for w in range(4):                                                          # (behind the kernel's barrier 1b)
+            m0, m1, m2 = mg8[w]
+            for p, val in enumerate((m0, (m0 + m2) + m1, (m0 + m2) - m1, m0 + 2 * m1 + 4 * m2, m2)):
+                RX[PS * p + 4 * w:PS * p + 4 * w + 4] = val.reshape(4, 4, 32).transpose(0, 2, 1)   # quad row = channel / 4
+    stft_waves = () if k8 else (0, 1, 2, 3)
     for w in stft_waves:
         ws = sect[w][S_STFT]
         even = (w == 0) if k8 else (w < 2)
