@@ -229,3 +229,30 @@ def test_fused_resampler_with_every_third_sample_copied_equals_the_full_contract
             worst = max(worst, float(np.abs(p - p2).max()))
             assert (ev == ev2).mean() > 0.999
         assert 0.0 < worst <= 5e-6, worst             # not the same code path (> 0), the same answer
+
+
+def test_one_tile_with_four_parts_equals_the_segments_stepped_alone():
+    """Ten streams at four rates are ONE 16-stream tile with four parts (48 k | 8 k | 24 k | 16 k in the launch's walk order): each part
+    resamples with its own operator (two of them with every third sample copied), columns of other parts contract zeros and keep
+    their frames.  Bit-equal to each segment stepped by a call of its own, and within 5e-5 of the oracle chain."""
+    from cutter_vad_amd.engine import Engine
+    from oracle import oracle
+    rates = ((48000, 1536, 3), (8000, 256, 2), (24000, 768, 4), (16000, 512, 1))
+    B, T = sum(r[2] for r in rates), 6
+    base = make_streams(B, T * 3, seed=99).reshape(B, -1)
+    starts = np.cumsum([0] + [r[2] for r in rates])
+    om = oracle.OracleModel(_blob(5), "f64")
+    st = np.zeros((B, 256), np.float32)
+    with Engine(_blob(5), model_version=5, max_streams=64) as eng, Engine(_blob(5), model_version=5, max_streams=64) as solo:
+        slots, slots2 = eng.open_streams(B), solo.open_streams(B)
+        for t in range(T):
+            segs = [(np.ascontiguousarray(base[starts[k]:starts[k + 1], t * n_in:(t + 1) * n_in]), sr) for k, (sr, n_in, _) in enumerate(rates)]
+            before = eng.info()["steps"]
+            p, ev, _ = eng.step_rates(segs, slots)
+            assert eng.info()["steps"] == before + 1
+            alone = np.concatenate([solo.step_rates([segs[k]], slots2[starts[k]:starts[k + 1]])[0] for k in range(len(rates))])
+            assert np.array_equal(p, alone), t
+            x16 = np.stack([oracle.resample(segs[k][0][i], 512) if rates[k][0] != 16000 else segs[k][0][i]
+                            for k in range(len(rates)) for i in range(rates[k][2])]).astype(np.float32)
+            ref = om.step_batch(oracle.denoise(x16).reshape(B, 512), st, nthreads=4)
+            assert np.abs(p - ref).max() <= 5e-5, t
