@@ -484,6 +484,14 @@ void build_resample_operator_d(int n_in, std::vector<double> &R) {
 namespace {
 // R[o][3 i'] == (512 / n) [o == m i'] + (-1)^(o - m i') / n  (m = 1536 / n) for n = 768, 1536?  (VAD_RS_DENSE: diagnostic - A/B and
 // tests of the two operator layouts)
+// n = 256 (8 kHz -> 16 kHz, up by exactly two): R[2 i][i'] == [i == i'] - every input sample IS an even output sample
+bool resample_up2(int n, const std::vector<double> &R) {
+    if (n != 256 || std::getenv("VAD_RS_DENSE")) return false;
+    double dev = 0;
+    for (int i = 0; i < 256; ++i)
+        for (int ip = 0; ip < 256; ++ip) dev = std::max(dev, std::fabs(R[(size_t)(2 * i) * n + ip] - (i == ip ? 1.0 : 0.0)));
+    return dev <= 1e-12;
+}
 bool resample_poly3(int n, const std::vector<double> &R) {
     if ((n != 768 && n != 1536) || std::getenv("VAD_RS_DENSE")) return false;
     const int m = 1536 / n;
@@ -599,8 +607,21 @@ uint32_t pack_resample_operator_t16(int n_in, std::vector<float> &out, uint32_t 
             default: return (float)(j == 0 ? 0.5 * RO(o, 0) : 0.25 * (RO(o, j) - RO(o, H - j)));  // GAO
         }
     };
+    // 8 kHz (n = 256, up by two): the even outputs are the input samples themselves (checked above all else by resample_up2),
+    // and an output's parity is the parity of its folded row o - so only the ODD rows are contracted: per wave ONE 16-row tile,
+    // rows 32 w + 2 r + 1, two vector blocks (RE, RO) and four weight blocks per k-iteration.  The kernel copies the samples
+    // (silero_v5_t16.hip, part shape 3) and reads the layout off the block count.
+    const bool up2 = resample_up2(n, R);
     StreamBuilder sb;
     for (int w = 0; w < 4; ++w) {
+        if (up2) {
+            sb.vector_block16([&](int c) { return (float)(0.5 * RE(32 * w + 2 * c + 1, Q)); });
+            sb.vector_block16([&](int c) { return (float)(0.5 * RO(32 * w + 2 * c + 1, Q)); });
+            for (int j = 0; j < Q / 16; ++j)
+                for (int part = 0; part < 4; ++part)
+                    sb.weight_block16([&](int r, int k) { return G(part, 32 * w + 2 * r + 1, k); }, j);
+            continue;
+        }
         for (int rt = 0; rt < 2; ++rt) sb.vector_block16([&](int c) { return (float)(0.5 * RE(32 * w + 16 * rt + c, Q)); });
         for (int rt = 0; rt < 2; ++rt) sb.vector_block16([&](int c) { return (float)(0.5 * RO(32 * w + 16 * rt + c, Q)); });
         for (int j = 0; j < Kc / 16; ++j)

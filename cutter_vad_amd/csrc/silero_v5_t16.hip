@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
     //      at a rate boundary has two.
     struct Part {
         RateSeg S;
-        int sk, c0, c1, ls0, Q, Kc;
+        int sk, c0, c1, ls0, Q, Kc, shape;
         bool valid;
     };
     constexpr int DEAD = 1 << 26;                  // an index (in quads / samples) past every buffer: loads return 0
@@ -164,7 +164,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
                     pt.sk = k; pt.c0 = a0; pt.c1 = a1;
                     pt.ls0 = v0 - pt.S.vstart;                       // column c holds the segment's stream ls0 + c (c0 <= c < c1)
                     pt.Q = pt.S.n_in >> 2;
-                    pt.Kc = ((int)pt.S.wave_blocks - 4) * 2;         // contraction length per folded part: Q, or 2 Q / 3 ("P3", below)
+                    // the operator stream says how the part is contracted (pack_resample_operator_t16): 0 = every folded sample, two row
+                    // tiles per wave; 1 / 2 = 48 / 24 kHz with every third sample copied ("P3"); 3 = 8 kHz with the even outputs copied
+                    // and only the odd row tile contracted ("U2")
+                    const int wbk = (int)pt.S.wave_blocks;
+                    pt.shape = wbk == 4 + (pt.Q >> 4) * 8 ? 0 : wbk == 2 + (pt.Q >> 4) * 4 ? 3 : pt.S.n_in == 1536 ? 1 : 2;
+                    pt.Kc = (pt.shape == 1 || pt.shape == 2) ? (2 * pt.Q) / 3 : pt.Q;      // contraction length per folded part
                     pt.valid = true;
                     break;
                 }
@@ -179,7 +184,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
         const __amdgpu_buffer_rsrc_t xrs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pt.S.in), 0, (int)((unsigned)pt.S.n * (unsigned)pt.S.n_in * 4u), 0x00020000);
         const int Q = pt.Q, qq = cql + 16 * c, base = (cms >= pt.c0 && cms < pt.c1) ? (pt.ls0 + cms) * Q : DEAD;
-        if constexpr (decltype(p3tag)::value != 0) {
+        if constexpr (decltype(p3tag)::value == 1 || decltype(p3tag)::value == 2) {
             // P3 (24 / 48 kHz, see the part loop): compact quad g = the folded samples j = 6g+1, 6g+2, 6g+4, 6g+5; the thread reads
             // six consecutive samples of each of the four regions - x[6g ..], x[H + 6g ..], x[H - 6g - 6 ..], x[n - 6g - 6 ..] -
             // which hold those four j and the two samples 3 i' in between (8-byte aligned; wide loads need dword alignment only)
@@ -235,7 +240,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
     bool chunk0_requested = false;
     if constexpr (RS) {
         if (cur.valid && cur.S.wstream != nullptr && cur.S.n_in == 1536) {
-            if (cur.Kc == cur.Q) load_chunk(std::integral_constant<int, 0>{}, cur, 0, xlA);
+            if (cur.shape == 0) load_chunk(std::integral_constant<int, 0>{}, cur, 0, xlA);
             else load_chunk(std::integral_constant<int, 1>{}, cur, 0, xlA);
             chunk0_requested = true;
         }
@@ -275,10 +280,15 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             // stream) - so the loader threads copy them, scaled, straight to their place in F and add them into one alternating sum
             // per stream, and the MFMAs contract only the other two thirds of the folded samples: 4 chunks instead of 6 (48 kHz),
             // 2 instead of 3 (24 kHz).  x[0], x[H], x[Q], x[3Q] - the samples the fold cannot pair - are all of that kind.
-            // Compile-time per part shape (tag 0: every sample contracted, 1: 48 kHz, 2: 24 kHz - three instantiations of this
-            // body): branches inside the chunk loop cost ~0.4 us per chunk.
-            constexpr bool P3 = decltype(p3tag)::value != 0;
-            constexpr int om = decltype(p3tag)::value;                // output steps between two copied samples = 1536 / n_in
+            // U2 (8 kHz: up by two): every input sample IS an even output sample (R[2 i][i'] = [i == i'], checked by the packer), and
+            // the parity of an output is the parity of its folded row - so the loader threads copy the chunk into the even places of
+            // F, the stream holds ONE 16-row tile per wave (the odd rows 32 w + 2 r + 1) and half the MFMAs and the VALU rows go.
+            // Compile-time per part shape (tag 0: every sample contracted, 1: 48 kHz, 2: 24 kHz, 3: 8 kHz - four instantiations of
+            // this body): branches inside the chunk loop cost ~0.4 us per chunk.
+            constexpr int SHAPE = decltype(p3tag)::value;
+            constexpr bool P3 = SHAPE == 1 || SHAPE == 2, U2 = SHAPE == 3;
+            constexpr int NB = U2 ? 4 : 8;                            // operator blocks per k-iteration
+            constexpr int om = SHAPE;                                 // P3: output steps between two copied samples = 1536 / n_in
             const int Q = S.n_in >> 2, Kc = cur.Kc, nchunks = Kc >> 6;
             const float sc0 = 512.0f / (float)S.n_in;
             constexpr float sg3 = om == 1 ? -1.f : 1.f;
@@ -340,6 +350,23 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
                     dst[RS_CH_ROWS * QSL] = ve;
                     dst[2 * RS_CH_ROWS * QSL] = uo;
                     dst[3 * RS_CH_ROWS * QSL] = vo;
+                    if constexpr (U2) {
+                        // y[2 i] = x[i]: the four aligned quads this thread holds - x[4 qq ..], x[H + 4 qq ..], x[H - 4 qq - 4 ..],
+                        // x[n - 4 qq - 4 ..] - cover every sample of the chunk exactly once over the 16 loader threads of a stream;
+                        // the odd places get zeros here and their values from the recombination, behind the barrier
+                        if (cms >= c0 && cms < c1) {
+                            float *o = Ff + cms * (4 * FQ);
+                            const int qq = cql + 16 * c;
+                            auto put = [&](int first, f32x4 v) {
+                                *reinterpret_cast<f32x4 *>(o + 2 * first) = f32x4{v.x, 0.f, v.y, 0.f};
+                                *reinterpret_cast<f32x4 *>(o + 2 * first + 4) = f32x4{v.z, 0.f, v.w, 0.f};
+                            };
+                            put(4 * qq, a);
+                            put(2 * Q + 4 * qq, cc);
+                            put(2 * Q - 4 * qq - 4, b1);
+                            put(4 * Q - 4 * qq - 4, d1);
+                        }
+                    }
                 }
             };
             // the sample each half-size product cannot pair, x[Q] +- x[Q + H], is a rank-1 term (accumulator init, rows 128 / 384)
@@ -351,9 +378,14 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             if constexpr (!P3) {                                                  // (P3: x[Q] and x[3Q] are copied samples)
                 xa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (sb + Q) * 4, 0, 0));
                 xb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (sb + 3 * Q) * 4, 0, 0));
-                mid = ldw(ors, (Q >> 1) * 16, (int)S.row128_block);               // floats 2Q, 2Q + 1: RE[128][Q] / 2, RO[128][Q] / 2
+                if constexpr (U2) {                                               // (rows 128 / 384 are even: copies)
+                    ini[0] = OL(wbase);
+                    ini[1] = OL(wbase + 1);
+                } else {
+                    mid = ldw(ors, (Q >> 1) * 16, (int)S.row128_block);           // floats 2Q, 2Q + 1: RE[128][Q] / 2, RO[128][Q] / 2
 #pragma unroll
-                for (int k = 0; k < 4; ++k) ini[k] = OL(wbase + k);
+                    for (int k = 0; k < 4; ++k) ini[k] = OL(wbase + k);
+                }
             }
             // output rows 128 / 384 on the VALU: thread = (stream tid & 15, part tid >> 4); parts 0..7 dot ue with GSE[128],
             // 8..15 uo with GSO[128], two quads of every chunk each
@@ -364,9 +396,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 #endif
             constexpr int D = RS_D;                                   // operator blocks run D - 1 k-iterations ahead, across chunks (4 or 8: the slot of
                                                                       // a k-iteration must be static inside the two-chunk loop body)
-            f32x4 wq[D][8], xqA[4], xqB[4];
-            int ws = wbase + 4;
-#define R_LDW0(slot, j) _Pragma("unroll") for (int k = 0; k < 8; ++k) wq[slot][k] = OL(ws + 8 * (j) + k);
+            f32x4 wq[D][NB], xqA[4], xqB[4];
+            int ws = wbase + (U2 ? 2 : 4);
+#define R_LDW0(slot, j) _Pragma("unroll") for (int k = 0; k < NB; ++k) wq[slot][k] = OL(ws + NB * (j) + k);
             // (tools/variants.sh experiments, never defined in the product build: RS_EXP_NOLDW = the operator is not streamed,
             //  RS_EXP_NOMFMA = 4 VALU FMAs stand in for each group of 4 MFMAs, RS_EXP_NOX = the input chunks are loaded once)
 #ifdef RS_EXP_NOLDW
@@ -386,12 +418,18 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 #pragma unroll
             for (int d = 0; d < D - 1; ++d) { R_LDW0(d, d) }
             if (nchunks > 1) load_chunk(p3tag, cur, 1, xlB);
-            f32x4 acc[8];                                             // part p (se, ae, so, ao), row tile rt -> acc[2 p + rt]
+            f32x4 acc[NB];                                            // part p (se, ae, so, ao), row tile rt -> acc[2 p + rt]; U2: acc[p]
+            if constexpr (U2) {
+                acc[0] = ini[0] * (xa + xb);
+                acc[2] = ini[1] * (xa - xb);
+                acc[1] = acc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                acc[0 + rt] = ini[rt] * (xa + xb);
-                acc[4 + rt] = ini[2 + rt] * (xa - xb);
-                acc[2 + rt] = acc[6 + rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int rt = 0; rt < 2; ++rt) {
+                    acc[0 + rt] = ini[rt] * (xa + xb);
+                    acc[4 + rt] = ini[2 + rt] * (xa - xb);
+                    acc[2 + rt] = acc[6 + rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
             store_chunk(0, 0, xlA);
             __syncthreads();
@@ -412,7 +450,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
                     if ((j) < 3) { RS_XQ(XN, X, (j) + 1) }                                                      \
                     EXTRA                                                                                       \
                     SB();                                                                                       \
-                    _Pragma("unroll") for (int k = 0; k < 8; ++k) acc[k] = RS_MMA(wq[(4 * PAR_ + (j)) % D][k], XC[k >> 1], acc[k]); \
+                    _Pragma("unroll") for (int k = 0; k < NB; ++k) acc[k] = RS_MMA(wq[(4 * PAR_ + (j)) % D][k], XC[U2 ? k : k >> 1], acc[k]); \
                     SB();                                                                                       \
                 }
 #define RS_CHUNK(c, XS, XL, PAR)                                                                                \
@@ -423,10 +461,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
                 f32x4 g128[2];                                                                                  \
                 RS_STEP(0, xqA, xqB,                                                                            \
                         if ((c) + 2 < nchunks) RS_LOADX((c) + 2, XL);                                           \
-                        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                           \
-                            g128[i] = ldw(ors, (psel * (Kc >> 2) + 16 * (c) + 2 * pr + i) * 16, (int)S.row128_block);) \
+                        if constexpr (!U2) {                                                                    \
+                            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                       \
+                                g128[i] = ldw(ors, (psel * (Kc >> 2) + 16 * (c) + 2 * pr + i) * 16, (int)S.row128_block); \
+                        })                                                                                      \
                 RS_STEP(1, xqB, xqA, if ((c) + 1 < nchunks) store_chunk((c) + 1, ((c) + 1) & 1, XS);)           \
-                RS_STEP(2, xqA, xqB, {                                                                          \
+                RS_STEP(2, xqA, xqB, if constexpr (!U2) {                                                       \
                     const int ms = tid & 15;                                                                    \
                     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
                         const f32x4 uu = X[(psel * 2 * RS_CH_ROWS + 2 * pr + i) * QSL + ms];                    \
@@ -434,7 +474,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
                     }                                                                                           \
                 })                                                                                              \
                 RS_STEP(3, xqB, xqA, )                                                                          \
-                ws += 32;                                                                                       \
+                ws += 4 * NB;                                                                                   \
                 __syncthreads();                                                                                \
                 if ((c) + 1 < nchunks) { RS_XQ(xqA, lds + (((c) + 1) & 1) * RS_BUF, 0) }                        \
             }
@@ -450,7 +490,21 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 #undef RS_MMA
 #undef R_LDW
 #undef R_LDW0
-            if constexpr (!P3) {
+            if constexpr (U2) {
+                // the odd outputs: lane (n, kq) holds rows o = 32 w + 8 kq + 2 i + 1 of se, ae, so, ao.  The barrier that ended the
+                // chunk is also the one that separates these scalars from the loader's zeros in the same places.
+                const f32x4 se = acc[0], ae = acc[1], so = acc[2], ao = acc[3];
+                const f32x4 pe = se + ae, me = se - ae, pO = so + ao, mO = so - ao;
+                const f32x4 y0 = pe + pO, y1 = pe - pO, lo = me + mO, hi = me - mO;
+                if (in_part(n)) {
+                    float *o = Ff + n * (4 * FQ);
+                    const int o0 = 32 * w + 8 * kq + 1;
+                    o[o0] = y0.x;     o[o0 + 256] = y1.x; o[256 - o0] = lo.x; o[512 - o0] = hi.x;
+                    o[o0 + 2] = y0.y; o[o0 + 258] = y1.y; o[254 - o0] = lo.y; o[510 - o0] = hi.y;
+                    o[o0 + 4] = y0.z; o[o0 + 260] = y1.z; o[252 - o0] = lo.z; o[508 - o0] = hi.z;
+                    o[o0 + 6] = y0.w; o[o0 + 262] = y1.w; o[250 - o0] = lo.w; o[506 - o0] = hi.w;
+                }
+            } else if constexpr (!P3) {
                 // recombine: y[o] = se+ae+so+ao, y[o+256] = se+ae-so-ao, y[256-o] = se-ae+so-ao, y[512-o] = se-ae-so+ao
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
@@ -518,9 +572,10 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
                 }
             }
           };
-          if (cur.Kc == (S.n_in >> 2)) run_part(std::integral_constant<int, 0>{});
-          else if (S.n_in == 1536) run_part(std::integral_constant<int, 1>{});
-          else run_part(std::integral_constant<int, 2>{});
+          if (cur.shape == 0) run_part(std::integral_constant<int, 0>{});
+          else if (cur.shape == 1) run_part(std::integral_constant<int, 1>{});
+          else if (cur.shape == 2) run_part(std::integral_constant<int, 2>{});
+          else run_part(std::integral_constant<int, 3>{});
 #undef OL
         }
         __syncthreads();                                              // this part of F is complete; staging and headp are free again

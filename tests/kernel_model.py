@@ -739,11 +739,45 @@ def packed_resample_t16(n_in: int):
     return out.reshape(-1, 64, 4), int(wb.value), int(r128.value)
 
 
+def _resample_t16_up2(W, wave_blocks, x):
+    """8 kHz chunks (part shape 3 of the RS prologue): the even outputs are the input samples, copied by the loader threads; per wave
+    ONE 16-row tile - the odd rows 32 w + 2 r + 1 - is contracted: two vector blocks (RE, RO at the unpaired sample), then four
+    weight blocks (se, ae, so, ao) per k-iteration of 16 folded samples."""
+    n_in = 256
+    H, Q = 128, 64
+    xe, xo = x[:, :H] + x[:, H:], x[:, :H] - x[:, H:]
+    j = np.arange(Q)
+    rev = (H - j) % H
+    ue, ve, uo, vo = xe[:, j] + xe[:, rev], xe[:, j] - xe[:, rev], xo[:, j] + xo[:, rev], xo[:, j] - xo[:, rev]
+    ue[:, 0], ve[:, 0], uo[:, 0], vo[:, 0] = xe[:, 0], 0.0, 0.0, xo[:, 0]
+    parts = [a.reshape(16, Q // 4, 4).transpose(1, 0, 2) for a in (ue, ve, uo, vo)]
+    y = np.zeros((16, 512))
+    y[:, 0::2] = x                                                       # the loader's copies
+    for w in range(4):
+        wb = w * wave_blocks
+        acc = [np.zeros((16, 16)) for _ in range(4)]
+        acc[0] += _vec16(W[wb])[:, None] * xe[:, Q][None, :]
+        acc[2] += _vec16(W[wb + 1])[:, None] * xo[:, Q][None, :]
+        for g in range(Q // 16):
+            for p in range(4):
+                acc[p] += _mfma16(W[wb + 2 + 4 * g + p], _rows16(parts[p], 4 * g))
+        se, ae, so, ao = acc
+        for r in range(16):
+            o = 32 * w + 2 * r + 1
+            y[:, o] = (se + ae + so + ao)[r]
+            y[:, o + 256] = (se + ae - so - ao)[r]
+            y[:, 256 - o] = (se - ae + so - ao)[r]
+            y[:, 512 - o] = (se - ae - so + ao)[r]
+    return y
+
+
 def resample_t16(W, wave_blocks, row128_block, x):
     """x [16, n_in] -> y [16, 512]: the RS prologue of silero_v5_t16.hip over pack_resample_operator_t16's stream (float64).
     24 / 48 kHz chunks ("P3": the stream's contraction length is n_in / 6, not n_in / 4): every third input sample is copied
     (scaled) to its output instant and enters one alternating sum; the MFMAs contract the folded samples j = 1, 2, 4, 5, 7, ..."""
     x = x.astype(np.float64)
+    if x.shape[1] == 256 and wave_blocks == 2 + 4 * 4:
+        return _resample_t16_up2(W, wave_blocks, x)
     n_in = x.shape[1]
     H, Q = n_in // 2, n_in // 4
     Kc = (wave_blocks - 4) * 2
