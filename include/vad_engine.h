@@ -389,7 +389,10 @@ VAD_API int vad_debug_pack_resample(int32_t n_in, float *out, size_t out_floats,
                                     uint32_t *tile_blocks, uint32_t *row128_block);
 
 /* the same operator as the fused resample -> step kernel streams it (16 x 16 x 4 tiles: pack_resample_operator_t16);
- * wave_blocks = 1 KiB blocks per wave (4 vector blocks + 8 per 16-sample k-iteration) */
+ * wave_blocks = 1 KiB blocks per wave, which also tells the kernel the stream's shape: 4 vector blocks + 8 per k-iteration of 16
+ * folded samples - over n_in / 4 samples per part (every sample contracted), or over n_in / 6 for n_in = 768 / 1536 (24 / 48 kHz:
+ * every third input sample sits on an output instant and is copied) - or, for n_in = 256 (8 kHz: the even outputs are the input
+ * samples), 2 vector blocks + 4 per k-iteration: only the odd output rows */
 VAD_API int vad_debug_pack_resample_t16(int32_t n_in, float *out, size_t out_floats, size_t *n_floats,
                                         uint32_t *wave_blocks, uint32_t *row128_block);
 
