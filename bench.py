@@ -195,6 +195,11 @@ def main() -> int:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args, sys.argv[1:])
+    # stdout carries the ONE JSON line and nothing else: gloo and RCCL announce themselves on fd 1 from C ("[Gloo] Rank 0 is
+    # connected ...", "RCCL version : ...") - from here on fd 1 is stderr, the line goes to the kept copy of the real stdout
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     from cutter_vad_amd import sharding
@@ -397,7 +402,8 @@ def main() -> int:
                 base_, parity = cpu_leg(ring_h, gpu_probs.cpu().numpy())
                 out["cpu_baseline"] = base_
                 out["parity"] = parity
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     cp.close()
     if not fake:
         for e in engines:

@@ -122,6 +122,8 @@ def test_bench_gpus_n_launches_n_ranks_itself_and_reports_n():
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
     assert len(lines) == 1                                    # rank 0 prints, once
+    # ... and stdout is that line alone: gloo / RCCL announce themselves on fd 1 from C, bench.py points fd 1 at stderr
+    assert r.stdout.strip().splitlines() == [x for x in r.stdout.splitlines() if x.startswith("{")] and "[Gloo]" not in r.stdout
     out = lines[0]
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["value"] == pytest.approx(2 * 8192 * 20 / (out["ms_per_step"] * 1e-3 * 20))
