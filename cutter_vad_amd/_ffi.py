@@ -120,6 +120,7 @@ SIGNATURES = {
     "vad_step_collect": (C.c_int, [_vp, C.c_int64, _f32p, _u8p, _i32p]),
     "vad_tick_push": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, C.c_int, C.c_int]),
     "vad_tick_push_rate": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, C.c_int, C.c_int, C.c_int32]),
+    "vad_tick_push_rate_gather": (C.c_int, [_vp, _i64p, C.c_int64, C.POINTER(C.c_char_p), C.c_int32, C.c_int, C.c_int, C.c_int32, _i32p]),
     "vad_tick_cancel": (C.c_int, [_vp, C.c_int64]),
     "vad_tick_push_many": (C.c_int, [_vp, _i64p, C.c_int64, _vp, C.c_int32, C.c_int, C.c_int]),
     "vad_tick_enable_segments": (C.c_int, [_vp, C.c_int]),

@@ -1792,6 +1792,47 @@ int vad_tick_push_gather(vad_engine *e, const int64_t *slots, int64_t n, const v
     return first;
 }
 
+int vad_tick_push_rate_gather(vad_engine *e, const int64_t *slots, int64_t n, const void *const *frames, int32_t nsamples, int frame_fmt,
+                              int gate_on, int32_t sr_in, int32_t *status) {
+    if (!e || n < 0 || (n > 0 && (!slots || !frames || !status))) return VAD_ERR_INVALID_ARG;
+    if (sr_in == e->sample_rate) return vad_tick_push_gather(e, slots, n, frames, nsamples, frame_fmt, gate_on, status);
+    std::lock_guard<std::mutex> lk(e->tick_mu);             // one lock for the batch
+    auto all = [&](int rc) {
+        for (int64_t i = 0; i < n; ++i) status[i] = rc;
+        return rc;
+    };
+    if (n == 0) return VAD_OK;
+    if (nsamples < 1 || frame_fmt < VAD_FMT_F32 || frame_fmt > VAD_FMT_I16_32768)
+        return all(e->fail(VAD_ERR_INVALID_ARG, "tick: empty frame or unknown format"));
+    if (e->frame_samples != VAD_FRAME_SAMPLES || e->sample_rate != 16000)
+        return all(e->fail(VAD_ERR_UNSUPPORTED, "Failed to resample audio: resampled streams need a 16 kHz engine"));
+    const int ri = sr_in == 8000 ? 0 : sr_in == 24000 ? 1 : sr_in == 48000 ? 2 : -1;
+    if (ri < 0)
+        return all(e->fail(VAD_ERR_UNSUPPORTED, "Failed to resample audio from %dHz to 16000Hz: supported input rates are 8000, 24000, 48000", sr_in));
+    const int group = 6 + 3 * (gate_on ? 1 : 0) + ri;
+    const int want = vad_engine::tick_group_len(group, e->frame_samples);
+    if (nsamples != want)
+        return all(e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio from %dHz to 16000Hz: a chunk must hold %d samples, got %d", sr_in, want, nsamples));
+    std::vector<float> cvt(frame_fmt == VAD_FMT_F32 ? 0 : (size_t)nsamples);
+    const float sc = frame_fmt == VAD_FMT_I16_32767 ? 32767.0f : 32768.0f;
+    int first = VAD_OK;
+    for (int64_t i = 0; i < n; ++i) {
+        if (!frames[i]) {
+            status[i] = e->fail(VAD_ERR_INVALID_ARG, "tick: null frame");
+        } else {
+            const float *src = static_cast<const float *>(frames[i]);
+            if (frame_fmt != VAD_FMT_F32) {                // numpy's true division, as vad_tick_push_rate does it
+                const int16_t *q = static_cast<const int16_t *>(frames[i]);
+                for (int32_t k = 0; k < nsamples; ++k) cvt[(size_t)k] = (float)q[k] / sc;
+                src = cvt.data();
+            }
+            status[i] = tick_push_locked(e, slots[i], src, nsamples, VAD_FMT_F32, group);
+        }
+        if (status[i] != VAD_OK && first == VAD_OK) first = status[i];
+    }
+    return first;
+}
+
 int vad_tick_cancel(vad_engine *e, int64_t slot) {
     if (!e) return VAD_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->tick_mu);

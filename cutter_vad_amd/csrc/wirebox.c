@@ -9,13 +9,16 @@
  * into the bytes objects, which vad_tick_push_gather (include/vad_engine.h) copies straight into the tick's staging rows.
  *
  *   box = Inbox(max_bytes)                 frames longer than max_bytes (or odd-sized, or empty) are not taken
- *   push = box.pusher(slot, gate_on)       a callable bound to one session: push(data) -> True (queued) / False (not taken: the
- *                                          caller goes the general way); push.invalidate() makes every later call return False
+ *   push = box.pusher(slot, gate_on[, rate, nbytes])   a callable bound to one session: push(data) -> True (queued) / False (not
+ *                                          taken: the caller goes the general way); push.invalidate() makes every later call return
+ *                                          False.  rate != 0: a session whose chunks arrive at another rate and are resampled in the
+ *                                          tick (vad_tick_push_rate): only chunks of exactly `nbytes` bytes are taken
  *   len(box)                               frames waiting
- *   box.flush(fn_address, engine_address)  fn = vad_tick_push_gather; called once per (frame length, gate) with the GIL released;
+ *   box.flush(fn_address, engine_address[, rate_fn_address])   fn = vad_tick_push_gather, rate_fn = vad_tick_push_rate_gather; one
+ *                                          call per (frame length, gate, rate) with the GIL released;
  *                                          -> [(slot, status), ...] for the frames the engine refused
- *   box.drain()                            -> [(nbytes, gate, [(slot, data), ...]), ...] and empties the inbox (engines without a
- *                                          C entry point: the test doubles)
+ *   box.drain()                            -> [(nbytes, gate, rate, [(slot, data), ...]), ...] and empties the inbox (engines
+ *                                          without a C entry point: the test doubles)
  * All methods run under the GIL; a frame's bytes object is kept alive until its flush.
  */
 #define PY_SSIZE_T_CLEAN
@@ -27,9 +30,13 @@
 typedef int (*push_gather_fn)(void *e, const int64_t *slots, int64_t n, const void *const *frames, int32_t nsamples, int frame_fmt,
                               int gate_on, int32_t *status);
 
+typedef int (*push_rate_gather_fn)(void *e, const int64_t *slots, int64_t n, const void *const *frames, int32_t nsamples, int frame_fmt,
+                                   int gate_on, int32_t sr_in, int32_t *status);
+
 typedef struct {
     int32_t nbytes;
     int gate;
+    int32_t rate;            /* 0: frames at the engine's rate */
     int64_t *slots;
     PyObject **data;
     Py_ssize_t n, cap;
@@ -49,6 +56,8 @@ typedef struct {
     Inbox *inbox;
     int64_t slot;
     int gate;
+    int32_t rate;            /* 0, or the session's input rate ... */
+    int32_t want_bytes;      /* ... and the one chunk length it may send */
     int valid;
     Py_ssize_t box;          /* index of the box this session last used (its frames have one length almost always) */
     uint64_t epoch;          /* the inbox epoch of this session's last frame ... */
@@ -63,10 +72,12 @@ static void box_release(Box *b) {
     b->n = 0;
 }
 
-static Box *inbox_box(Inbox *self, int32_t nbytes, int gate, Py_ssize_t *hint) {
-    if (*hint >= 0 && *hint < self->nboxes && self->boxes[*hint].nbytes == nbytes && self->boxes[*hint].gate == gate) return &self->boxes[*hint];
+static Box *inbox_box(Inbox *self, int32_t nbytes, int gate, int32_t rate, Py_ssize_t *hint) {
+    if (*hint >= 0 && *hint < self->nboxes && self->boxes[*hint].nbytes == nbytes && self->boxes[*hint].gate == gate &&
+        self->boxes[*hint].rate == rate)
+        return &self->boxes[*hint];
     for (Py_ssize_t k = 0; k < self->nboxes; ++k)
-        if (self->boxes[k].nbytes == nbytes && self->boxes[k].gate == gate) {
+        if (self->boxes[k].nbytes == nbytes && self->boxes[k].gate == gate && self->boxes[k].rate == rate) {
             *hint = k;
             return &self->boxes[k];
         }
@@ -77,6 +88,7 @@ static Box *inbox_box(Inbox *self, int32_t nbytes, int gate, Py_ssize_t *hint) {
     memset(b, 0, sizeof *b);
     b->nbytes = nbytes;
     b->gate = gate;
+    b->rate = rate;
     *hint = self->nboxes++;
     return b;
 }
@@ -109,12 +121,13 @@ static PyObject *pusher_vectorcall(PyObject *callable, PyObject *const *args, si
     PyObject *data = args[0];
     if (!self->valid || !PyBytes_CheckExact(data)) Py_RETURN_FALSE;
     const Py_ssize_t nb = PyBytes_GET_SIZE(data);
-    if (nb < 2 || (nb & 1) || nb > self->inbox->max_bytes) Py_RETURN_FALSE;
+    if (nb < 2 || (nb & 1)) Py_RETURN_FALSE;
+    if (self->rate ? nb != self->want_bytes : nb > self->inbox->max_bytes) Py_RETURN_FALSE;
     /* frames are grouped by length for the engine, and the groups go one after the other: two frames of ONE session with different
      * lengths (the last chunk of a file) must not wait in the same flush, or the later one could overtake.  The second one is not
      * taken; the general path flushes first. */
     if (self->epoch == self->inbox->epoch && self->nbytes != (int32_t)nb) Py_RETURN_FALSE;
-    Box *b = inbox_box(self->inbox, (int32_t)nb, self->gate, &self->box);
+    Box *b = inbox_box(self->inbox, (int32_t)nb, self->gate, self->rate, &self->box);
     if (!b || box_append(b, self->slot, data) < 0) return PyErr_NoMemory();
     self->inbox->total += 1;
     self->epoch = self->inbox->epoch;
@@ -164,14 +177,20 @@ static void inbox_dealloc(Inbox *self) {
 
 static PyObject *inbox_pusher(Inbox *self, PyObject *args) {
     long long slot;
-    int gate;
-    if (!PyArg_ParseTuple(args, "Lp", &slot, &gate)) return NULL;
+    int gate, rate = 0, want = 0;
+    if (!PyArg_ParseTuple(args, "Lp|ii", &slot, &gate, &rate, &want)) return NULL;
+    if (rate && (want < 2 || (want & 1))) {
+        PyErr_SetString(PyExc_ValueError, "pusher(slot, gate_on, rate, nbytes): a rate needs its chunk length in bytes (even, >= 2)");
+        return NULL;
+    }
     Pusher *p = PyObject_New(Pusher, &PusherType);
     if (!p) return NULL;
     Py_INCREF((PyObject *)self);
     p->inbox = self;
     p->slot = (int64_t)slot;
     p->gate = gate ? 1 : 0;
+    p->rate = rate;
+    p->want_bytes = want;
     p->valid = 1;
     p->box = -1;
     p->epoch = (uint64_t)-1;
@@ -199,7 +218,7 @@ static PyObject *inbox_drain(Inbox *self, PyObject *Py_UNUSED(ignored)) {
             }
             PyList_SET_ITEM(items, i, t);
         }
-        PyObject *row = Py_BuildValue("(iON)", (int)b->nbytes, b->gate ? Py_True : Py_False, items);
+        PyObject *row = Py_BuildValue("(iOiN)", (int)b->nbytes, b->gate ? Py_True : Py_False, (int)b->rate, items);
         if (!row || PyList_Append(out, row) < 0) {
             Py_XDECREF(row);
             goto fail;
@@ -215,13 +234,19 @@ fail:
 }
 
 static PyObject *inbox_flush(Inbox *self, PyObject *args) {
-    unsigned long long fn_addr, eng_addr;
-    if (!PyArg_ParseTuple(args, "KK", &fn_addr, &eng_addr)) return NULL;
+    unsigned long long fn_addr, eng_addr, rate_fn_addr = 0;
+    if (!PyArg_ParseTuple(args, "KK|K", &fn_addr, &eng_addr, &rate_fn_addr)) return NULL;
     if (!fn_addr || !eng_addr) {
         PyErr_SetString(PyExc_ValueError, "flush(fn_address, engine_address): both must be non-zero");
         return NULL;
     }
     push_gather_fn fn = (push_gather_fn)(uintptr_t)fn_addr;
+    push_rate_gather_fn rate_fn = (push_rate_gather_fn)(uintptr_t)rate_fn_addr;
+    for (Py_ssize_t k = 0; k < self->nboxes; ++k)
+        if (self->boxes[k].n && self->boxes[k].rate && !rate_fn) {
+            PyErr_SetString(PyExc_ValueError, "flush: chunks at another rate are waiting and no rate entry point was given");
+            return NULL;
+        }
     PyObject *fails = PyList_New(0);
     if (!fails) return NULL;
     self->epoch += 1;
@@ -234,6 +259,7 @@ static PyObject *inbox_flush(Inbox *self, PyObject *args) {
         PyObject **data = b->data;
         const int32_t nbytes = b->nbytes;
         const int gate = b->gate;
+        const int32_t rate = b->rate;
         const Py_ssize_t cap = b->cap;
         b->slots = NULL; b->data = NULL; b->n = 0; b->cap = 0;
         self->total -= n;
@@ -243,7 +269,8 @@ static PyObject *inbox_flush(Inbox *self, PyObject *args) {
         if (ok) {
             for (Py_ssize_t i = 0; i < n; ++i) ptrs[i] = PyBytes_AS_STRING(data[i]);
             Py_BEGIN_ALLOW_THREADS
-            (void)fn((void *)(uintptr_t)eng_addr, slots, (int64_t)n, ptrs, nbytes / 2, /* VAD_FMT_I16_32767 */ 1, gate, status);
+            if (rate) (void)rate_fn((void *)(uintptr_t)eng_addr, slots, (int64_t)n, ptrs, nbytes / 2, /* VAD_FMT_I16_32767 */ 1, gate, rate, status);
+            else (void)fn((void *)(uintptr_t)eng_addr, slots, (int64_t)n, ptrs, nbytes / 2, /* VAD_FMT_I16_32767 */ 1, gate, status);
             Py_END_ALLOW_THREADS
             for (Py_ssize_t i = 0; i < n && ok; ++i)
                 if (status[i] != 0) {
@@ -274,9 +301,9 @@ static PyObject *inbox_flush(Inbox *self, PyObject *args) {
 }
 
 static PyMethodDef inbox_methods[] = {
-    {"pusher", (PyCFunction)inbox_pusher, METH_VARARGS, "pusher(slot, gate_on) -> callable push(data) -> bool"},
-    {"flush", (PyCFunction)inbox_flush, METH_VARARGS, "flush(fn_address, engine_address) -> [(slot, status), ...] of refused frames"},
-    {"drain", (PyCFunction)inbox_drain, METH_NOARGS, "drain() -> [(nbytes, gate, [(slot, data), ...]), ...]; empties the inbox"},
+    {"pusher", (PyCFunction)inbox_pusher, METH_VARARGS, "pusher(slot, gate_on[, rate, nbytes]) -> callable push(data) -> bool"},
+    {"flush", (PyCFunction)inbox_flush, METH_VARARGS, "flush(fn_address, engine_address[, rate_fn_address]) -> [(slot, status), ...] of refused frames"},
+    {"drain", (PyCFunction)inbox_drain, METH_NOARGS, "drain() -> [(nbytes, gate, rate, [(slot, data), ...]), ...]; empties the inbox"},
     {NULL, NULL, 0, NULL}};
 static PySequenceMethods inbox_as_sequence = {.sq_length = (lenfunc)inbox_len};
 

@@ -39,6 +39,7 @@ class Engine:
                  sample_rate: int = 16000, shared_gpu: bool = False):
         self._lib = _ffi.lib()
         self._gather_fn = int(C.cast(self._lib.vad_tick_push_gather, C.c_void_p).value)
+        self._rate_gather_fn = int(C.cast(self._lib.vad_tick_push_rate_gather, C.c_void_p).value)
         self._h = C.c_void_p()
         self._tickets = {}                  # ticket -> the buffers a pipelined call still reads (submit / collect)
         self.last_tick_us = (0.0, 0.0, 0.0)
@@ -320,11 +321,29 @@ class Engine:
         self._lib.vad_tick_push_gather(self._h, _ptr(s, C.c_int64), n, ptrs, int(nsamples), fmt, int(gate_on), _ptr(status, C.c_int32))
         return status
 
+    def tick_push_rate_gather(self, slots, frames, sample_rate: int, gate_on: bool = True, i16_scale: int = 32767) -> np.ndarray:
+        """``frames``: a sequence of ``bytes`` objects, one int16 chunk of ``512 * sample_rate / 16000`` samples per listed slot, all
+        at ONE input rate (``vad_tick_push_rate_gather``) -> int32 status per chunk."""
+        s = np.ascontiguousarray(slots, dtype=np.int64).reshape(-1)
+        n = s.size
+        if len(frames) != n:
+            raise AudioProcessingError(f"Model prediction failed: {len(frames)} frames for {n} slots")
+        nsamples = len(frames[0]) // 2 if n else 0
+        if any(len(f) != 2 * nsamples for f in frames):
+            raise AudioProcessingError("Model prediction failed: chunks of one call must have one length")
+        ptrs = (C.c_char_p * n)(*frames)
+        status = np.zeros(n, np.int32)
+        fmt = _ffi.VAD_FMT_I16_32768 if i16_scale == 32768 else _ffi.VAD_FMT_I16_32767
+        self._lib.vad_tick_push_rate_gather(self._h, _ptr(s, C.c_int64), n, ptrs, int(nsamples), fmt, int(gate_on), int(sample_rate),
+                                            _ptr(status, C.c_int32))
+        return status
+
     def tick_gather_entry(self):
-        """(address of ``vad_tick_push_gather``, address of this engine) for callers that push from C (server/_wirebox)."""
+        """(address of ``vad_tick_push_gather``, address of this engine, address of ``vad_tick_push_rate_gather``) for callers
+        that push from C (server/_wirebox)."""
         if not self._h:
             raise VADError("engine is closed")
-        return self._gather_fn, int(self._h.value)
+        return self._gather_fn, int(self._h.value), self._rate_gather_fn
 
     def tick_cancel(self, slot: int) -> None:
         self._check(self._lib.vad_tick_cancel(self._h, int(slot)), VADError)

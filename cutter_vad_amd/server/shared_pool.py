@@ -217,7 +217,12 @@ class SharedStreamPool:
 
     def _bind_push(self, s: PooledSession) -> None:
         """Give the session its fast ingest: a callable of the C inbox bound to (slot, gate).  ``_lock`` held."""
-        s._push = self._wire.pusher(s.slot, s.gate) if (self._wire is not None and s.rate is None and not s.closed) else None
+        if self._wire is None or s.closed:
+            s._push = None
+        elif s.rate is None:
+            s._push = self._wire.pusher(s.slot, s.gate)
+        else:                                       # a client at 8 / 24 / 48 kHz: only its exact 32 ms chunk is taken (int16 bytes)
+            s._push = self._wire.pusher(s.slot, s.gate, int(s.rate), 2 * (FRAME * int(s.rate) // 16000))
 
     @staticmethod
     def _unbind_push(s: PooledSession) -> None:
@@ -360,8 +365,15 @@ class SharedStreamPool:
                 for slot, status in w.flush(*self._wire_entry()):    # vad_tick_push_gather on the arrays, GIL released
                     self._refused(slot, status)
             else:
-                for nbytes, gate, box in w.drain():
-                    self._push_joined(nbytes, gate, box)
+                for nbytes, gate, rate, box in w.drain():
+                    if rate:
+                        for slot, data in box:      # (test doubles: one by one)
+                            try:
+                                self.engine.tick_push(slot, data, gate, sample_rate=rate)
+                            except Exception:
+                                self._refused(slot, _ffi.VAD_ERR_BUSY)
+                    else:
+                        self._push_joined(nbytes, gate, box)
 
     def _push_joined(self, nbytes: int, gate: bool, box: List) -> None:
         slot_list, datas = zip(*box)

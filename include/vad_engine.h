@@ -320,6 +320,11 @@ VAD_API int vad_tick_push_status(vad_engine *e, const int64_t *slots, int64_t n,
  * tick's staging rows, without being gathered into one array first */
 VAD_API int vad_tick_push_gather(vad_engine *e, const int64_t *slots, int64_t n, const void *const *frames, int32_t nsamples,
                                  int frame_fmt, int gate_on, int32_t *status);
+/* vad_tick_push_rate for n clients at ONE input rate, one pointer per chunk, a result per chunk: what vad_tick_push_gather is for
+ * frames at the engine's rate (the reference declares this conversion and leaves it empty, vad_wrapper.py:621-624; its server
+ * would call it once per message, vad_websocket_server.py:326-382).  int16 chunks are scaled to float32 on the way in. */
+VAD_API int vad_tick_push_rate_gather(vad_engine *e, const int64_t *slots, int64_t n, const void *const *frames, int32_t nsamples,
+                                      int frame_fmt, int gate_on, int32_t sr_in, int32_t *status);
 VAD_API int vad_tick_cancel(vad_engine *e, int64_t slot);
 VAD_API int vad_tick_pending(vad_engine *e, int64_t slot, int64_t *frames);
 /*

@@ -383,6 +383,28 @@ def test_tick_rate_groups_equal_step_rates(eng):
             eng.tick_push(int(slots[1]), q.astype(np.float32) / np.float32(32767.0), gate_on=False, sample_rate=8000)
             _, p, *_ = eng.tick_run(0.01)
             assert p[0] == p[1]
+            # vad_tick_push_rate_gather: n clients at one rate in ONE call (int16 chunks, one pointer each) == the same chunks pushed
+            # one by one; a closed stream and a 257th chunk get their own status, a wrong length or rate fails the whole call
+            eng.reset(slots)
+            for k, (sr, n_in) in enumerate(rates):
+                chunks = [np.round(base[k * per + i, :n_in] * 32767).astype("<i2").tobytes() for i in range(per)]
+                st = eng.tick_push_rate_gather(slots[k * per:(k + 1) * per], chunks, sr, gate_on=True)
+                assert not st.any()
+            _, p_g, ev_g, *_ = eng.tick_run(0.01)
+            eng.reset(slots)
+            for k, (sr, n_in) in enumerate(rates):
+                for i in range(per):
+                    eng.tick_push(int(slots[k * per + i]), np.round(base[k * per + i, :n_in] * 32767).astype("<i2").tobytes(), gate_on=True, sample_rate=sr)
+            _, p_1, ev_1, *_ = eng.tick_run(0.01)
+            assert np.array_equal(p_g, p_1) and np.array_equal(ev_g, ev_1) and p_g.size == 3 * per
+            c8 = bytes(512)
+            st = eng.tick_push_rate_gather([int(slots[0]), 999999, int(slots[1])], [c8, c8, c8], 8000)
+            assert st.tolist() == [0, _ffi.VAD_ERR_BAD_SLOT, 0]
+            st = eng.tick_push_rate_gather([int(slots[0])] * 257, [c8] * 257, 8000)
+            assert st.tolist() == [0] * 256 + [_ffi.VAD_ERR_BUSY]
+            assert (eng.tick_push_rate_gather([int(slots[2])], [bytes(500)], 8000) == _ffi.VAD_ERR_INVALID_ARG).all()
+            assert (eng.tick_push_rate_gather([int(slots[2])], [bytes(882)], 44100) == _ffi.VAD_ERR_UNSUPPORTED).all()
+            assert eng.tick_pending(int(slots[2])) == 0
         finally:
             for s_ in slots:
                 eng.tick_cancel(int(s_))

@@ -36,7 +36,7 @@ def test_push_takes_only_short_even_bytes_and_drain_returns_them_in_order():
         a(f512, f512)
     assert len(box) == 4
     got = box.drain()
-    assert got == [(1024, True, [(3, f512), (3, f512)]), (1024, False, [(9, f512)]), (480, True, [(4, f240)])]
+    assert got == [(1024, True, 0, [(3, f512), (3, f512)]), (1024, False, 0, [(9, f512)]), (480, True, 0, [(4, f240)])]
     assert len(box) == 0 and box.drain() == []
     assert a(f240) and not a(f512) and len(box) == 1               # ... after a flush it is
     box.drain()
@@ -46,6 +46,20 @@ def test_push_takes_only_short_even_bytes_and_drain_returns_them_in_order():
         _wirebox.Inbox(1)
     with pytest.raises(ValueError):
         box.flush(0, 0)
+    # a session at another rate: exactly its chunk length (which may exceed max_bytes), its own group
+    r48 = box.pusher(11, True, 48000, 3072)
+    r8 = box.pusher(12, True, 8000, 512)
+    c48, c8 = bytes(3072), bytes(512)
+    assert r48(c48) and r8(c8) and not r48(c8) and not r8(c48) and not r48(bytes(3070))
+    box.drain()
+    assert r48(c48) and r8(c8) and b(c8)
+    assert sorted(box.drain()) == sorted([(512, False, 0, [(9, c8)]), (3072, True, 48000, [(11, c48)]), (512, True, 8000, [(12, c8)])])
+    with pytest.raises(ValueError):
+        box.pusher(1, True, 48000)                       # a rate needs its chunk length
+    assert r48(c48)
+    with pytest.raises(ValueError, match="rate entry point"):
+        box.flush(1, 1)                                  # chunks at another rate waiting, no entry point for them
+    box.drain()
 
 
 def test_flush_hands_slots_and_frame_pointers_to_the_engine_entry_and_reports_refusals():
@@ -79,6 +93,32 @@ def test_flush_hands_slots_and_frame_pointers_to_the_engine_entry_and_reports_re
         box.pusher(slot, True)(frames[slot])
     seen.clear()
     assert box.flush(C.cast(cb, C.c_void_p).value, 0xABCD) == [(7, -6), (21, -6)] and len(seen) == len(frames)
+
+
+RATE_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_void_p), C.c_int32, C.c_int, C.c_int,
+                          C.c_int32, C.POINTER(C.c_int32))
+
+
+def test_flush_sends_chunks_at_another_rate_through_the_rate_entry_point():
+    box = _wirebox.Inbox(1024)
+    seen = []
+
+    def entry(eng, slots, n, ptrs, nsamples, fmt, gate, status):
+        seen.append(("rate0", [int(slots[i]) for i in range(n)], nsamples, gate))
+        return 0
+
+    def rate_entry(eng, slots, n, ptrs, nsamples, fmt, gate, sr, status):
+        seen.append((sr, [int(slots[i]) for i in range(n)], nsamples, gate, C.string_at(ptrs[0], 4)))
+        if n > 1:
+            status[1] = -8
+        return 0
+
+    cb, rcb = GATHER(entry), RATE_GATHER(rate_entry)
+    a, r1, r2, r3 = box.pusher(1, True), box.pusher(2, True, 8000, 512), box.pusher(3, True, 8000, 512), box.pusher(4, False, 48000, 3072)
+    assert a(bytes(960)) and r1(b"\x01\x02\x03\x04" * 128) and r2(bytes(512)) and r3(b"\x09" * 3072)
+    refused = box.flush(C.cast(cb, C.c_void_p).value, 0x77, C.cast(rcb, C.c_void_p).value)
+    assert refused == [(3, -8)] and len(box) == 0
+    assert seen == [("rate0", [1], 480, 1), (8000, [2, 3], 256, 1, b"\x01\x02\x03\x04"), (48000, [4], 1536, 0, b"\x09" * 4)]
 
 
 def test_frames_pushed_while_a_flush_is_in_the_engine_are_kept_for_the_next_one():

@@ -151,7 +151,8 @@ int main(int argc, char **argv) {
                         int rc;
                         int32_t st = 0;
                         const void *one = buf.data();
-                        if (p.rate != 16000) rc = vad_tick_push_rate(eng, slots[(size_t)id], buf.data(), p.len, p.fmt, p.gate, p.rate);
+                        if (p.rate != 16000 && (k + j) % 2 == 0) rc = vad_tick_push_rate(eng, slots[(size_t)id], buf.data(), p.len, p.fmt, p.gate, p.rate);
+                        else if (p.rate != 16000) { rc = vad_tick_push_rate_gather(eng, &slots[(size_t)id], 1, &one, p.len, p.fmt, p.gate, p.rate, &st); CHECK(rc == st); }
                         else if ((k + j) % 3 == 0) rc = vad_tick_push(eng, slots[(size_t)id], buf.data(), p.len, p.fmt, p.gate);
                         else if ((k + j) % 3 == 1) { rc = vad_tick_push_status(eng, &slots[(size_t)id], 1, buf.data(), p.len, p.fmt, p.gate, &st); CHECK(rc == st); }
                         else { rc = vad_tick_push_gather(eng, &slots[(size_t)id], 1, &one, p.len, p.fmt, p.gate, &st); CHECK(rc == st); }
