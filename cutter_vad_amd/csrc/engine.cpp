@@ -179,7 +179,18 @@ struct vad_engine {
         }
         void put(uint8_t *b) { free_blocks.push_back(b); }
     };
-    struct SegCopy { uint8_t *dst; const uint8_t *src; uint32_t bytes; };
+    // one planned copy.  kind 0: `bytes` bytes as they are; 1 / 2: `bytes` bytes of int16 -> float32 / 32767 | / 32768 (dst holds
+    // 2 x bytes): the resampled groups' chunks, converted by whoever carries the plan out
+    struct SegCopy {
+        uint8_t *dst; const uint8_t *src; uint32_t bytes; uint32_t kind = 0;
+        void carry_out() const {
+            if (kind == 0) { std::memcpy(dst, src, bytes); return; }
+            const float sc = kind == 1 ? 32767.0f : 32768.0f;
+            const int16_t *q = reinterpret_cast<const int16_t *>(src);
+            float *o = reinterpret_cast<float *>(dst);
+            for (uint32_t k = 0; k < bytes / 2; ++k) o[k] = (float)q[k] / sc;       // numpy's true division
+        }
+    };
     struct SegAudio {
         struct Run { int32_t group; float thr; int64_t samples; };      // group as in the tick: tells sample type, int16 scale, gate
         std::vector<uint8_t *> blocks;
@@ -263,6 +274,7 @@ struct vad_engine {
     };
     SegArena seg_arena;
     std::vector<SegCopy> seg_copies;                 // the copies one tick planned
+    std::vector<SegCopy> push_copies;                // ... and the conversions a batched rate push planned (both under tick_mu)
     // the threads that carry out a tick's planned copies next to the calling one
     struct CopyCrew {
         std::vector<std::thread> th;
@@ -279,7 +291,7 @@ struct vad_engine {
                 const size_t a = next.fetch_add(128, std::memory_order_relaxed);
                 if (a >= n) return;
                 const size_t b = std::min(n, a + 128);
-                for (size_t k = a; k < b; ++k) std::memcpy(it[k].dst, it[k].src, it[k].bytes);
+                for (size_t k = a; k < b; ++k) it[k].carry_out();
             }
         }
         void start(int threads) {
@@ -304,7 +316,7 @@ struct vad_engine {
             size_t bytes = 0;
             for (size_t k = 0; k < cnt; ++k) bytes += it[k].bytes;
             if (th.empty() || bytes < (256u << 10)) {
-                for (size_t k = 0; k < cnt; ++k) std::memcpy(it[k].dst, it[k].src, it[k].bytes);
+                for (size_t k = 0; k < cnt; ++k) it[k].carry_out();
                 return;
             }
             {
@@ -1607,8 +1619,11 @@ int vad_step_rates(vad_engine *e, int32_t nseg, const float *const *in, const in
 
 // ---- tick assembler: the multi-stream caller's side of vad_step_events, in C ---------------------------------------------
 namespace {
-// one frame of `slot` into the staging of the coming tick (tick_mu held)
-int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int group) {
+// one frame of `slot` into the staging of the coming tick (tick_mu held).  With `defer` the row is assigned and its address handed
+// back in defer->dst, the samples are NOT copied: the caller carries that out later (a batch converting int16 chunks on the copy
+// crew); `pending` is then the caller's plan so far - it points into this buffer and is carried out before the buffer moves.
+int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsamples, int group, vad_engine::SegCopy *defer = nullptr,
+               std::vector<vad_engine::SegCopy> *pending = nullptr) {
     vad_engine::TickBuf &tb = e->tick_buf[e->tick_cur][group];
     const size_t ss = vad_engine::tick_sample_bytes(group);
     const int flen = vad_engine::tick_group_len(group, e->frame_samples);
@@ -1616,6 +1631,10 @@ int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsample
     if (tb.count == tb.cap) {
         const int64_t cap = std::min<int64_t>(e->max_streams, std::max<int64_t>(256, 2 * tb.cap));
         if (cap <= tb.cap) return e->fail(VAD_ERR_INVALID_ARG, "tick: more pending frames than slots");
+        if (pending && !pending->empty()) {
+            e->copy_crew.run(pending->data(), pending->size());
+            pending->clear();
+        }
         uint8_t *nh = nullptr;
         hipError_t r = hipSetDevice(e->device);
         if (r == hipSuccess) r = hipHostMalloc((void **)&nh, (size_t)cap * (rb + 3 * sizeof(int32_t)), hipHostMallocDefault);
@@ -1634,7 +1653,8 @@ int tick_place(vad_engine *e, int64_t slot, const void *samples, int32_t nsample
     // SileroVADModel._prepare_audio_input (core/silero_model.py:464-468): right-zero-pad short frames, truncate long ones
     const size_t take = std::min<size_t>((size_t)nsamples, (size_t)flen) * ss;
     uint8_t *dst = tb.row(tb.count);
-    std::memcpy(dst, samples, take);
+    if (defer) defer->dst = dst;
+    else std::memcpy(dst, samples, take);
     if (take < rb) std::memset(dst + take, 0, rb - take);
     if (e->tick_segments && nsamples > flen) {                  // the model sees the head; a segment keeps the whole frame
         const uint8_t *src = static_cast<const uint8_t *>(samples);
@@ -1813,23 +1833,38 @@ int vad_tick_push_rate_gather(vad_engine *e, const int64_t *slots, int64_t n, co
     const int want = vad_engine::tick_group_len(group, e->frame_samples);
     if (nsamples != want)
         return all(e->fail(VAD_ERR_INVALID_ARG, "Failed to resample audio from %dHz to 16000Hz: a chunk must hold %d samples, got %d", sr_in, want, nsamples));
-    std::vector<float> cvt(frame_fmt == VAD_FMT_F32 ? 0 : (size_t)nsamples);
-    const float sc = frame_fmt == VAD_FMT_I16_32767 ? 32767.0f : 32768.0f;
+    // rows are assigned here, under the lock; the chunks themselves - int16 -> float32 is most of this call's time - are converted
+    // into their rows by the copy crew once the batch is placed.  A chunk that has to WAIT (its stream already has one in this
+    // tick) is converted on the spot into the stream's queue.
+    std::vector<float> cvt;
+    std::vector<vad_engine::SegCopy> &plan = e->push_copies;
+    plan.clear();
+    const uint32_t kind = frame_fmt == VAD_FMT_F32 ? 0u : frame_fmt == VAD_FMT_I16_32767 ? 1u : 2u;
+    const uint32_t src_bytes = (uint32_t)nsamples * (kind ? 2u : 4u);
     int first = VAD_OK;
     for (int64_t i = 0; i < n; ++i) {
+        const int64_t slot = slots[i];
         if (!frames[i]) {
             status[i] = e->fail(VAD_ERR_INVALID_ARG, "tick: null frame");
+        } else if (slot < 0 || slot >= e->max_streams || !e->open[(size_t)slot]) {
+            status[i] = e->fail(VAD_ERR_BAD_SLOT, "slot %lld is not an open stream", (long long)slot);
+        } else if (e->tick_gen[(size_t)slot] != e->tick_generation) {
+            vad_engine::SegCopy cp{nullptr, static_cast<const uint8_t *>(frames[i]), src_bytes, kind};
+            status[i] = tick_place(e, slot, frames[i], nsamples, group, &cp, &plan);
+            if (status[i] == VAD_OK) plan.push_back(cp);
         } else {
             const float *src = static_cast<const float *>(frames[i]);
-            if (frame_fmt != VAD_FMT_F32) {                // numpy's true division, as vad_tick_push_rate does it
-                const int16_t *q = static_cast<const int16_t *>(frames[i]);
-                for (int32_t k = 0; k < nsamples; ++k) cvt[(size_t)k] = (float)q[k] / sc;
+            if (kind) {
+                cvt.resize((size_t)nsamples);
+                vad_engine::SegCopy{reinterpret_cast<uint8_t *>(cvt.data()), static_cast<const uint8_t *>(frames[i]), src_bytes, kind}.carry_out();
                 src = cvt.data();
             }
-            status[i] = tick_push_locked(e, slots[i], src, nsamples, VAD_FMT_F32, group);
+            status[i] = tick_push_locked(e, slot, src, nsamples, VAD_FMT_F32, group);
         }
         if (status[i] != VAD_OK && first == VAD_OK) first = status[i];
     }
+    e->copy_crew.run(plan.data(), plan.size());
+    plan.clear();
     return first;
 }
 

@@ -305,11 +305,15 @@ int main(int argc, char **argv) {
     {
         OK(vad_engine_create(&d, &eng));
         OK(vad_tick_enable_segments(eng, 1));
-        const int B = 300, KB = 24;
-        std::vector<int64_t> bs((size_t)B + 20);
-        OK(vad_stream_open_many(eng, B + 20, bs.data()));
-        OK(vad_stream_set_thresholds_many(eng, bs.data(), B + 20, &THR, 1));
+        const int B = 300, KB = 24, RB = 100;                        // RB streams at 48 kHz: their chunks go in as ONE rate batch per tick
+        std::vector<int64_t> bs((size_t)B + 20 + RB);
+        OK(vad_stream_open_many(eng, B + 20 + RB, bs.data()));
+        OK(vad_stream_set_thresholds_many(eng, bs.data(), B + 20 + RB, &THR, 1));
         const Plan p = {VAD_FMT_I16_32767, true, 16000, 480};
+        const Plan pr = {VAD_FMT_I16_32767, true, 48000, 1536};
+        std::vector<std::vector<uint8_t>> rfr((size_t)RB);
+        std::vector<const void *> rptrs((size_t)RB);
+        std::vector<int32_t> rst((size_t)RB);
         std::atomic<bool> side_done{false};
         std::thread side([&] {
             std::vector<uint8_t> buf;
@@ -336,6 +340,10 @@ int main(int argc, char **argv) {
                 if (k % 3 == 1) OK(vad_tick_push_status(eng, bs.data(), B, flat.data(), p.len, p.fmt, p.gate, st.data()));
                 else OK(vad_tick_push_many(eng, bs.data(), B, flat.data(), p.len, p.fmt, p.gate));
             }
+            // 100 x 3 072 bytes: above the copy crew's threshold, so the int16 -> float32 conversions run on its threads
+            for (int j = 0; j < RB; ++j) { make_frame(B + 20 + j, k, pr, rfr[(size_t)j]); rptrs[(size_t)j] = rfr[(size_t)j].data(); }
+            OK(vad_tick_push_rate_gather(eng, bs.data() + B + 20, RB, rptrs.data(), pr.len, pr.fmt, pr.gate, pr.rate, rst.data()));
+            for (auto &f2 : rfr) std::fill(f2.begin(), f2.end(), 0x5a);
             for (auto &f2 : fr) std::fill(f2.begin(), f2.end(), 0x5a);       // the sources may go once the call has returned
             std::fill(flat.begin(), flat.end(), 0x5a);
             if (k % 4 != 3) {                                               // some batches queue up behind the previous one
@@ -352,15 +360,15 @@ int main(int argc, char **argv) {
             if (done && res.n == 0) break;
         }
         side.join();
-        CHECK(got == (long)(B + 20) * KB);
-        for (int j = 0; j < B + 20; ++j) {
+        CHECK(got == (long)(B + 20 + RB) * KB);
+        for (int j = 0; j < B + 20 + RB; ++j) {
             Seen want;
-            expect(j, p, KB, want);
+            expect(j, j < B + 20 ? p : pr, KB, want);
             const Seen &g = by[(size_t)bs[(size_t)j]];
             CHECK(g.probs == want.probs && g.events == want.events && g.seg_samples == want.seg_samples);
         }
         vad_engine_destroy(eng);
-        std::printf("san_tick: batched pushes ok (%d streams x %d frames)\n", B + 20, KB);
+        std::printf("san_tick: batched pushes ok (%d streams x %d frames, %d of them rate batches)\n", B + 20 + RB, KB, RB);
     }
     std::printf("san_tick: all ok\n");
     return 0;
