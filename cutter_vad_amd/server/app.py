@@ -144,7 +144,8 @@ class ClientSession:
         post = self.loop.call_soon_threadsafe
         self.session.set_callbacks(lambda: post(self._on_voice_start), lambda wav: post(self._on_voice_end),
                                    lambda pcm: post(self._on_voice_continue),
-                                   lambda e: post(self.send_error, f"Audio processing error: {e}"))
+                                   lambda e: post(self.send_error, f"Audio processing error: {e}"),
+                                   continue_payload=False)        # VOICE_CONTINUE carries no audio (:420-430)
 
     # -- events (:83-124, :428-498)
     def _emit(self, event: str, **fields) -> None:

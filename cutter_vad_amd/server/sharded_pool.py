@@ -111,7 +111,7 @@ class ShardedStreamPool:
                     old_slot = s.slot
                     with src._lock, dst._lock:
                         dst._grow(new_slot + 1)
-                        for name in ("_thr", "_active", "_cont", "_gate", "_lastp", "_done"):
+                        for name in ("_thr", "_active", "_cont", "_contp", "_gate", "_lastp", "_done"):
                             getattr(dst, name)[new_slot] = getattr(src, name)[old_slot]
                         src._sessions.pop(old_slot, None)
                         src._by_slot[old_slot] = None

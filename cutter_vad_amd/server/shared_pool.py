@@ -106,10 +106,14 @@ class PooledSession:
         return int(self.pool._done[self.slot])
 
     def set_callbacks(self, voice_start_callback=None, voice_end_callback=None, voice_continue_callback=None,
-                      error_callback=None) -> None:
+                      error_callback=None, continue_payload: bool = True) -> None:
+        """``continue_payload=False``: the voice_continue callback is only a notification (the reference server's is:
+        ``_on_voice_continue`` ignores its ``pcm_data``, vad_websocket_server.py:420-430) - it is called with ``b""`` and the tick does
+        not build the frame's float32 bytes for it (≈ 10 µs per talking session and tick)."""
         self.on_start, self.on_end, self.on_continue = voice_start_callback, voice_end_callback, voice_continue_callback
         self.on_error = error_callback
         self.pool._cont[self.slot] = voice_continue_callback is not None
+        self.pool._contp[self.slot] = voice_continue_callback is not None and bool(continue_payload)
 
     def submit(self, frame) -> None:
         while self.pool.submit(self, frame) is _RETRY:       # the session is changing engines (ShardedStreamPool.migrate)
@@ -180,6 +184,7 @@ class SharedStreamPool:
         ext("_thr", np.float64)        # vad_start_probability
         ext("_active", bool)           # inside a segment
         ext("_cont", bool)             # registered a voice_continue callback
+        ext("_contp", bool)            # ... that wants the frame's bytes
         ext("_gate", bool)             # enable_denoising
         ext("_lastp", np.float32)
         ext("_done", np.int64)
@@ -189,7 +194,7 @@ class SharedStreamPool:
         self._grow(slot + 1)
         self._thr[slot] = float(cfg.vad_start_probability)
         self._gate[slot] = bool(cfg.enable_denoising)
-        self._active[slot] = self._cont[slot] = False
+        self._active[slot] = self._cont[slot] = self._contp[slot] = False
         self._lastp[slot] = 0.0
         self._done[slot] = 0
 
@@ -285,11 +290,12 @@ class SharedStreamPool:
             s.config = config
             s.rate = self._input_rate(config)
             s.gate = bool(config.enable_denoising)
+            contp = bool(self._contp[s.slot])
             with self._lock:
                 self._init_slot(s.slot, config)
                 # the session keeps its callbacks across a reconfigure (the app binds them once, at open): so does the flag
                 # that makes the tick deliver voice_continue payloads to it
-                self._cont[s.slot] = s.on_continue is not None
+                self._cont[s.slot], self._contp[s.slot] = s.on_continue is not None, contp
                 self._bind_push(s)
             s.wav_writer = WAVWriter(sample_rate=config.output_wav_sample_rate, bit_depth=config.output_wav_bit_depth,
                                      channels=1)
@@ -462,7 +468,9 @@ class SharedStreamPool:
                     # (core/vad_wrapper.py:505-519)
                     if wav is not None:
                         self._call(s.on_end, "voice_end", wav)
-                    if wants[i] and s.on_continue is not None:
+                    if wants[i] and s.on_continue is not None and not self._contp[int(slots[i])]:
+                        self._call(s.on_continue, "voice_continue", b"")          # a notification: no payload is built
+                    elif wants[i] and s.on_continue is not None:
                         if whole is None:
                             x = frames[g][i - int(gs[g])][:L]
                             whole = x.astype(np.float32) / np.float32(32767.0 if g < 4 else 32768.0) if 2 <= g < 6 else x.copy()

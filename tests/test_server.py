@@ -533,3 +533,26 @@ def test_the_ticker_catches_up_when_a_session_is_ahead_of_real_time():
     dt = time.time() - t0
     pool.close()
     assert s.frames_done == 100 and dt < 2.0, dt
+
+
+def test_voice_continue_as_a_notification_gets_no_payload_and_the_same_calls():
+    """The reference server's voice_continue handler ignores its pcm_data (vad_websocket_server.py:420-430): with
+    ``continue_payload=False`` the tick calls the callback with b"" at the same frames and builds nothing for it; a reconfigure
+    keeps the choice."""
+    pool, eng, _ = make_pool()
+    cfg = dict(vad_start_probability=0.4, vad_end_probability=0.3, voice_start_frame_count=2, voice_end_frame_count=3, buffer_size=480)
+    a, b = pool.open_session(VADConfig(**cfg)), pool.open_session(VADConfig(**cfg))
+    la, lb = [], []
+    a.set_callbacks(lambda: la.append("S"), lambda wav: la.append("E"), lambda pcm: la.append(len(pcm)))
+    b.set_callbacks(lambda: lb.append("S"), lambda wav: lb.append("E"), lambda pcm: lb.append(len(pcm)), continue_payload=False)
+    for f in [LOUD] * 4 + [QUIET] * 4:
+        a.submit(f)
+        b.submit(f)
+    pool.drain()
+    assert la == ["S", 1920, 1920, 1920, 1920, "E", 1920] and lb == ["S", 0, 0, 0, 0, "E", 0]
+    pool.reconfigure(b, VADConfig(**cfg))
+    for f in [LOUD] * 3:
+        b.submit(f)
+    pool.drain()
+    assert lb[-2:] == ["S", 0]
+    pool.close()

@@ -29,15 +29,24 @@ def tick_us(pool):
     return [max(e.last_tick_us[k] for e in engines) for k in range(3)]
 
 
+CONTINUE = None         # "payload" / "notify": also register a voice_continue callback (the reference server does, and ignores its bytes)
+
+
 def run(n, ticks=40):
     pool = make_pool()
     cfg = VADConfig(vad_start_probability=0.4, vad_end_probability=0.3, voice_start_frame_count=6,
                     voice_end_frame_count=12, buffer_size=480)
     sessions = [pool.open_session(cfg) for _ in range(n)]
     counts = {"start": 0, "end": 0}
+    counts["continue"] = 0
     for s in sessions:
-        s.set_callbacks(lambda: counts.__setitem__("start", counts["start"] + 1),
-                        lambda wav: counts.__setitem__("end", counts["end"] + 1), None)
+        if CONTINUE is None:
+            s.set_callbacks(lambda: counts.__setitem__("start", counts["start"] + 1),
+                            lambda wav: counts.__setitem__("end", counts["end"] + 1), None)
+        else:
+            s.set_callbacks(lambda: counts.__setitem__("start", counts["start"] + 1),
+                            lambda wav: counts.__setitem__("end", counts["end"] + 1),
+                            lambda pcm: counts.__setitem__("continue", counts["continue"] + 1), continue_payload=CONTINUE == "payload")
     x = make_streams(min(n, 512), ticks + 5, seed=9)[:, :, :480]
     pcm = np.clip(x * 32767.0, -32768, 32767).astype("<i2")
     wire = [[pcm[k % pcm.shape[0], t].tobytes() for k in range(n)] for t in range(ticks + 5)]
@@ -57,7 +66,7 @@ def run(n, ticks=40):
                 c_us[k] += v
     c_inbox = all(p._wire is not None for p in (pool.shards if hasattr(pool, "shards") else [pool]))
     pool.close()
-    return {"sessions": n, "ticks": ticks, "ingest": "submit_pcm16 per session (the ASGI app's path): frames collect in the pool's inbox, " +
+    return {"sessions": n, "ticks": ticks, "voice_continue": CONTINUE or "no callback", "ingest": "submit_pcm16 per session (the ASGI app's path): frames collect in the pool's inbox, " +
             ("the C one (_wirebox): one vad_tick_push_gather per tick" if c_inbox else "the Python one (VAD_POOL_WIREBOX=0): one join + vad_tick_push_status per tick"),
             "devices": DEVICES, "decode_submit_ms_per_tick": t_sub / ticks * 1e3,
             "tick_in_C_us": {"swap": c_us[0] / ticks, "gpu": c_us[1] / ticks, "segments": c_us[2] / ticks},
@@ -163,6 +172,11 @@ if __name__ == "__main__":
         del sys.argv[i:i + 2]
         for n in (2048, 8192):
             print(json.dumps(run(n)), flush=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "continue":          # every talking session gets a voice_continue call per tick
+        for mode in ("payload", "notify"):
+            CONTINUE = mode
+            print(json.dumps(run(8192)), flush=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "rates":
         for n in (2048, 8192):
