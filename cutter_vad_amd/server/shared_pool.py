@@ -448,7 +448,22 @@ class SharedStreamPool:
             wants = self._cont[slots] & was_active          # voice_continue payloads: only for sessions that registered one
             long = nsamp > self.frame
             long[int(gs[6]):] = False                       # chunks at another rate always have their exact length
-            busy = np.nonzero(started | ended | wants | long)[0]
+            # sessions whose only business this tick is a voice_continue NOTIFICATION (no payload wanted, no START / END, no
+            # over-long frame): one tight loop - the reference protocol sends such an event per frame and talking client
+            notify = wants & ~self._contp[slots]
+            special = started | ended | long
+            plain = np.nonzero(notify & ~special)[0]
+            if plain.size:
+                by_slot = self._by_slot
+                for slot in slots[plain].tolist():
+                    s = by_slot[slot]
+                    if s is None or s.closed or s.on_continue is None:
+                        continue
+                    try:
+                        s.on_continue(b"")
+                    except Exception as e:
+                        self._report(s, CallbackError("voice_continue", e))
+            busy = np.nonzero(special | (wants & ~notify) | (notify & special))[0]
             if busy.size == 0:                      # idle and silently talking sessions cost no Python at all
                 return n
             grp = np.searchsorted(gs[1:], busy, side="right")
