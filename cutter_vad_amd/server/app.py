@@ -21,8 +21,10 @@ import asyncio
 import logging
 import contextlib
 import json
+import threading
 import time
 import uuid
+import weakref
 from typing import Any, Dict, Optional, Sequence
 from urllib.parse import parse_qs
 
@@ -102,6 +104,44 @@ def vad_config_of(cfg: Dict[str, Any]) -> VADConfig:
                      buffer_size=int(a["sample_rate"] * (a["frame_duration_ms"] / 1000)))
 
 
+class LoopRelay:
+    """Pool callbacks run on a ticker's thread; the sockets live on an event loop.  ``call_soon_threadsafe`` per event wakes the
+    loop through its self-pipe every time - a tick of a busy pool produces thousands of events (one VOICE_CONTINUE per talking
+    client and frame).  The relay queues them and wakes the loop ONCE per batch: the first event of an empty queue schedules a
+    drain on the loop, which takes whatever has arrived by then, in order."""
+
+    def __init__(self, loop: asyncio.AbstractEventLoop) -> None:
+        self.loop = loop
+        self._items: list = []
+        self._lock = threading.Lock()
+
+    def post(self, fn, *args) -> None:
+        with self._lock:
+            self._items.append((fn, args))
+            first = len(self._items) == 1
+        if first:
+            self.loop.call_soon_threadsafe(self._drain)
+
+    def _drain(self) -> None:
+        with self._lock:
+            items, self._items = self._items, []
+        for fn, args in items:
+            try:
+                fn(*args)
+            except Exception:
+                logging.getLogger(__name__).exception("event delivery failed")
+
+
+_RELAYS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()      # one relay per event loop, gone with it
+
+
+def relay_of(loop: asyncio.AbstractEventLoop) -> LoopRelay:
+    r = _RELAYS.get(loop)
+    if r is None:
+        r = _RELAYS[loop] = LoopRelay(loop)
+    return r
+
+
 class ClientSession:
     """One websocket client: wire decoding, event encoding, timeout; the audio goes to the pool."""
 
@@ -140,8 +180,8 @@ class ClientSession:
             self.session_error = f"Audio processing failed: Frame processing failed: {e}"
 
     def _bind(self) -> None:
-        # pool callbacks run on the ticker's thread: hand the event to the socket's loop, in order
-        post = self.loop.call_soon_threadsafe
+        # pool callbacks run on the ticker's thread: hand the event to the socket's loop, in order, one wake-up per batch
+        post = relay_of(self.loop).post
         self.session.set_callbacks(lambda: post(self._on_voice_start), lambda wav: post(self._on_voice_end),
                                    lambda pcm: post(self._on_voice_continue),
                                    lambda e: post(self.send_error, f"Audio processing error: {e}"),

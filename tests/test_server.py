@@ -556,3 +556,34 @@ def test_voice_continue_as_a_notification_gets_no_payload_and_the_same_calls():
     pool.drain()
     assert lb[-2:] == ["S", 0]
     pool.close()
+
+
+def test_loop_relay_delivers_in_order_with_one_wakeup_per_batch():
+    """Events posted from a ticker thread reach the loop in order; a burst costs one call_soon_threadsafe, not one per event; an
+    event whose handler raises does not stop the ones behind it."""
+    import asyncio
+    from cutter_vad_amd.server.app import LoopRelay
+
+    async def main():
+        loop = asyncio.get_running_loop()
+        relay = LoopRelay(loop)
+        wakeups = []
+        orig = loop.call_soon_threadsafe
+        loop.call_soon_threadsafe = lambda cb, *a: (wakeups.append(1), orig(cb, *a))[1]
+        got = []
+
+        def boom():
+            raise RuntimeError("handler failed")
+
+        def burst():
+            for i in range(1000):
+                relay.post(got.append, i)
+                if i == 500:
+                    relay.post(boom)
+        await loop.run_in_executor(None, burst)
+        for _ in range(100):
+            if len(got) == 1000:
+                break
+            await asyncio.sleep(0.001)
+        assert got == list(range(1000)) and 1 <= len(wakeups) <= 50
+    asyncio.run(main())
