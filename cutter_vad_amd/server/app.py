@@ -204,7 +204,8 @@ class ClientSession:
         self._emit("VOICE_START", segment_index=self.segment_index)
 
     def _on_voice_continue(self) -> None:
-        self._emit("VOICE_CONTINUE", segment_index=self.segment_index)
+        # one per frame and talking client: the text json.dumps would produce, without the dict and the encoder
+        self.outbox.put_nowait('{"event": "VOICE_CONTINUE", "timestamp_ms": %d, "segment_index": %d}' % (now_ms(), self.segment_index))
 
     def _on_voice_end(self) -> None:
         t = time.time()
