@@ -12,6 +12,7 @@ from tests.signals import gate, make_streams, model_cases_8k
 
 pytestmark = pytest.mark.gpu
 TOL_P = 2e-5      # bar: 1e-4
+STATE_REL = 2e-4  # final (h, c), relative to max(1, |ref|): fixed (see test_interpreter_goldens_gate_int16_and_edges)
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -33,6 +34,15 @@ def engine(blob):
 def om(blob):
     from oracle import oracle
     return oracle.OracleModel(blob, "f64")
+
+
+def continuation_8k(T=200):
+    """200 further 256-sample frames that keep the state in play: 50-frame blocks of the harmonic "voice" and of quiet noise."""
+    x = gate(make_streams(2, T // 2, seed=4040).reshape(2, T, 256))
+    out = np.empty((T, 256), np.float32)
+    for b in range(0, T, 50):
+        out[b:b + 50] = x[(b // 50 + 1) % 2, b:b + 50]
+    return out
 
 
 def _frames(n, T, seed):
@@ -67,29 +77,33 @@ def test_step_matches_oracle(engine, om, n):
 
 def test_interpreter_goldens_gate_int16_and_edges(engine, om, blob):
     from oracle import oracle
-    om32 = oracle.OracleModel(blob, "f32")
     g = np.load(os.path.join(GOLD, "model_v5_8k.npz"))
     pcm = np.load(os.path.join(GOLD, "speech16k_i16.npz"))["pcm"]
     cases = model_cases_8k(pcm)
+    cont = continuation_8k()
     s = engine.open_stream()
     try:
         for name in ("speech_gate", "noise_0.3", "harmonic", "zeros", "square_fullscale", "short200_padded"):
             engine.reset([s])
             got = np.array([engine.step([s], f[None], denoise=None)[0] for f in cases[name]], np.float32)   # cases are pre-gated
             assert np.abs(got - g[f"{name}.probs"]).max() <= TOL_P, name
+            # Final (h, c).  c is an unbounded accumulator (|c| reaches 140 over the 530 speech frames), so the bar is relative
+            # to max(1, |ref|), and it is ONE fixed number: STATE_REL = 2e-4, the figure every other state check of the suite
+            # uses (absolute 2e-4 on states of magnitude <= 8).  It does not follow any measurement: the table of what the
+            # kernel, the oracle's float32 build and PyTorch's float32 operators show on these six cases is
+            # profiles/r04_v5_8k_state_table.json (largest: oracle-f32 1.04e-4 on `zeros`, kernel 5.6e-5 on the square wave).
             ref_s = g[f"{name}.state"]
-            # c is an unbounded accumulator (|c| reaches 140 over the 530 speech frames), so the state bar is relative - and it
-            # is tied to the float32 yardstick on the same input: what the oracle's own float32 build is off from its float64
-            # build.  Two float32 evaluations of this graph differ from each other by more than a factor of ten on these inputs
-            # (speech: oracle-f32 6.1e-5, torch-f32 4.8e-6, profiles/r03_f32_yardsticks.json); the kernel sits between 0.5 x and
-            # 3.3 x the oracle's float32 build over the six cases (profiles/r03c_v5_8k_state_yardsticks.json: speech 3.4e-5 vs
-            # 6.1e-5, noise 1.4e-5 vs 4.2e-6 - its STFT sums in chains of four on 16-row tiles since round 3, before in chains of
-            # two: another order, not another accuracy).  Bar: 4 x the yardstick, at least 2e-5.
-            st32 = np.zeros((1, 256), np.float32)
+            dev_s = engine.get_state(s)
+            rel = np.abs(dev_s - ref_s) / np.maximum(1.0, np.abs(ref_s))
+            assert rel.max() <= STATE_REL, (name, float(rel.max()))
+            # ... and the consequence that matters: 200 further frames from the kernel's state on the device and from the
+            # float64 oracle's own state on the host give the same probabilities to the ordinary bar.
+            st64 = np.zeros((1, 256), np.float32)
             for f in cases[name]:
-                om32.step_batch(np.ascontiguousarray(f[None]), st32, nthreads=1)
-            rel = lambda a: np.abs(a - ref_s) / np.maximum(1.0, np.abs(ref_s))
-            assert rel(engine.get_state(s)).max() <= max(2e-5, 4 * float(rel(st32[0]).max())), name
+                om.step_batch(np.ascontiguousarray(f[None]), st64, nthreads=1)
+            got_c = np.array([engine.step([s], f[None], denoise=None)[0] for f in cont], np.float32)
+            ref_c = np.array([om.step_batch(np.ascontiguousarray(f[None]), st64, nthreads=1)[0] for f in cont], np.float32)
+            assert np.abs(got_c - ref_c).max() <= TOL_P, (name, float(np.abs(got_c - ref_c).max()))
         # the gate in the kernel == the gate of the fixture generator; no gate on the ungated speech
         engine.reset([s])
         sp = (pcm[::2].astype(np.float32) / np.float32(32767.0))[: 120 * 256].reshape(120, 256)
