@@ -79,6 +79,14 @@ class ProcessingStatistics(BaseModel):
     voice_buffer_size: int = Field(ge=0)
     current_voice_length: int = Field(ge=0)
 
+    @field_validator("recent_probabilities")
+    @classmethod
+    def _in_range(cls, v: List[float]) -> List[float]:
+        for p in v:                                                     # silero_model.py:191-199
+            if not 0.0 <= p <= 1.0:
+                raise ValueError(f"Probability {p} must be between 0.0 and 1.0")
+        return v
+
 
 class ModelConfiguration(BaseModel):
     """silero_model.py:202-232.  Besides ``.onnx`` an ``.svw`` weight blob is accepted."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes the envelopes of the README known answer (tests/readme_known_answer.py, tests/test_readme_known_answer.py):
-`--cpu` the float64 oracle's -> profiles/r04_readme_known_answer_oracle.json (container or box),
+`--cpu` the float64 oracle's -> gpurun_out/r04_readme_known_answer_oracle.json (container or box),
 `--gpu` oracle + HIP path on the MI355X -> gpurun_out/r04_readme_known_answer.json (copy to profiles/).
 TEST INFRASTRUCTURE: imports oracle/."""
 import json
@@ -26,7 +26,7 @@ if __name__ == "__main__":
         path = os.path.join(ROOT, "gpurun_out", "r04_readme_known_answer.json")
     else:
         res = dict(HEAD, oracle_f64=t.oracle_envelopes())
-        path = os.path.join(ROOT, "profiles", "r04_readme_known_answer_oracle.json")
+        path = os.path.join(ROOT, "gpurun_out", "r04_readme_known_answer_oracle.json")
     with open(path, "w") as f:
         json.dump(res, f, indent=1)
     print({k: v["misses"] for k, v in res["oracle_f64"].items()}, {k: v["misses"] for k, v in res.get("hip", {}).items()})
