@@ -146,6 +146,32 @@ bool check_windowed_dft(const float *stft, std::string &err, int N = 256) {
     return true;
 }
 
+// silero_v4_t16.hip folds the even bins k = 2 m once more, about n = 32: the operand of bin 2 m pairs pe[n] with (-1)^m pe[64 - n]
+// and qe[n] with -(-1)^m qe[64 - n], n = 1..31.  That is exact if and only if the tables the packer generates have
+// cos(2 pi (2 m) (64 - n) / 256) = (-1)^m cos(2 pi (2 m) n / 256) and sin(2 pi (2 m) (64 - n) / 256) = -(-1)^m sin(2 pi (2 m) n / 256),
+// and the unpaired n = 32 has cos = 0 for m odd, sin = 0 for m even: checked on the very values the blocks are built from (the
+// stored basis is tied to these analytic tables by check_windowed_dft)
+bool check_even_bin_fold(std::string &err) {
+    const double two_pi = 6.283185307179586476925286766559;
+    double worst = 0;
+    for (int m = 0; m < 64; ++m) {
+        const int k = 2 * m;
+        const double sg = (m & 1) ? -1.0 : 1.0;
+        for (int n = 1; n < 32; ++n) {
+            const double a = two_pi * (double)((k * n) & 255) / 256.0, b = two_pi * (double)((k * (64 - n)) & 255) / 256.0;
+            worst = std::max(worst, std::fabs(std::cos(b) - sg * std::cos(a)));
+            worst = std::max(worst, std::fabs(std::sin(b) + sg * std::sin(a)));
+        }
+        const double c32 = std::cos(two_pi * (double)((k * 32) & 255) / 256.0), s32 = std::sin(two_pi * (double)((k * 32) & 255) / 256.0);
+        worst = std::max(worst, (m & 1) ? std::fabs(c32) : std::fabs(s32));
+    }
+    if (worst > 1e-12) {
+        err = "Failed to load model: the DFT tables lack the even-bin symmetry about n = 32 that the 16-stream V4 kernel folds on";
+        return false;
+    }
+    return true;
+}
+
 // cos / -sin blocks of the 4-way folded DFT: wave w owns the 32 bins bin_of_channel(32 w + r); k-iteration j
 // contracts n = 8j .. 8j+7 (n = 0 is an unused slot: weight 0)
 // the same for a window of 128 (Silero V5's 8 kHz sub-model), as 16-row tiles for v_mfma_f32_16x16x4_f32 so that all four waves
@@ -702,7 +728,7 @@ bool load_v4(const void *blob, size_t len, Blob &B, V4Tensors &t, std::string &e
 
 // the STFT kernels emit their 128 regular bins in the even/odd order of the 4-way folded DFT (v5::bin_of_channel);
 // the first layer's per-channel tables and weight columns follow that order.  Channel 128 (Nyquist) stays.
-inline int v4_bin(int c) { return c < 128 ? v5::bin_of_channel(c) : c; }
+inline int v4_bin32(int c) { return c < 128 ? v5::bin_of_channel(c) : c; }
 
 // depthwise taps (k = 0..4) + bias (k = 5) per channel quad as float4 rows: row = (q * 6 + k), value i = channel 4q + i
 uint32_t v4_dw_table(StreamBuilder &sb, const float *w5, const float *b, int C, int nquads) {
@@ -725,7 +751,7 @@ uint32_t v4_dw_table(StreamBuilder &sb, const float *w5, const float *b, int C, 
 // S_DW0: part 0 = magnitude channels 0..128 (34 quads), part 1 = normalised channels 129..257, then the 7-tap filter.
 // S_L0: 16 outputs.  Bias block, then the Nyquist channel's four weight columns (pw|mag, proj|mag, pw|norm, proj|norm; that
 // channel is contracted on the VALU), then per k-iteration of 16 channels the same four operands.
-void v4_first_layer(StreamBuilder &sb, const V4Tensors &t, uint32_t *sec) {
+void v4_first_layer(StreamBuilder &sb, const V4Tensors &t, uint32_t *sec, int (*v4_bin)(int)) {
     using namespace v4;
     sec[S_DW0] = sb.blocks();
     std::vector<float> tab((size_t)(2 * 34 * 6 + 2) * 4, 0.f);
@@ -770,7 +796,7 @@ bool pack_silero_v4(const void *blob, size_t len, PackedWeights &out, std::strin
     StreamBuilder sb;
     uint32_t sec[S_COUNT] = {};
     auto dw_table = [&](const float *w5, const float *b, int C, int, int nquads) { return v4_dw_table(sb, w5, b, C, nquads); };
-    v4_first_layer(sb, t, sec);
+    v4_first_layer(sb, t, sec, v4_bin32);
     // S_S0: 16 -> 16 (rows 0..15)
     sec[S_S0] = sb.blocks();
     sb.vector_blocks([&](int c) { return c < 16 ? sbias[0][c] : 0.f; });
@@ -863,7 +889,8 @@ bool pack_silero_v4_t16(const void *blob, size_t len, PackedWeights &out, std::s
     out.variant = t.variant;
     StreamBuilder sb;
     uint32_t sec[S_COUNT] = {};
-    v4_first_layer(sb, t, sec);
+    if (!check_even_bin_fold(err)) return false;
+    v4_first_layer(sb, t, sec, [](int c) { return c < 128 ? v4::bin_of_channel_t16(c) : c; });
     auto bias16 = [&](const float *a, const float *b2, int rt) {
         sb.vector_block16([&](int c) { return a[16 * rt + c] + (b2 ? b2[16 * rt + c] : 0.f); });
     };
@@ -927,16 +954,28 @@ bool pack_silero_v4_t16(const void *blob, size_t len, PackedWeights &out, std::s
         for (int k = 0; k < S_COUNT; ++k) out.sect[w][k] = sec[k];
         out.sect[w][S_LSTM0] = lstm_sec[0][w];
         out.sect[w][S_LSTM1] = lstm_sec[1][w];
-        // STFT: per k-iteration (n = 16 j .. 16 j + 15): cos rt0, cos rt1, -sin rt0, -sin rt1 (bins bin_of_channel(32 w + 16 rt + r))
+        // STFT (vad_layout.h, v4::bin_of_channel_t16).  Row tile 0 = 16 odd bins against the 4-way folded operands po | qo, K = 64:
+        // k-iterations j = 0..3 (n = 16 j .. 16 j + 15; n = 0 is an unused slot), {cos, -sin} each.  Row tile 1 = 16 even bins
+        // k = 2 m against the operands folded once more about n = 32 (cos(2 pi m (64 - n) / 128) = (-1)^m cos(2 pi m n / 128), the sine
+        // with the opposite sign), K = 32: k-iterations j = 0, 1 (n = 16 j .. 16 j + 15), {cos, -sin} each.  Slot n = 0 of those
+        // operands carries the sample the second fold cannot pair, n = 32: pe[32] for m even (weight cos(pi m / 2)), qe[32] for m
+        // odd (weight -sin(pi m / 2)); the other two are zero.
         out.sect[w][S_STFT] = sb.blocks();
         for (int j = 0; j < 4; ++j)
             for (int part = 0; part < 2; ++part)
-                for (int rt = 0; rt < 2; ++rt)
-                    sb.weight_block16([&](int r, int n) {
-                        const int k = v5::bin_of_channel(32 * w + 16 * rt + r);
-                        const double ph = two_pi * (double)((k * n) & 255) / 256.0;
-                        return n == 0 ? 0.f : (float)(part == 0 ? std::cos(ph) : -std::sin(ph));
-                    }, j);
+                sb.weight_block16([&](int r, int n) {
+                    const int k = bin_of_channel_t16(32 * w + r);
+                    const double ph = two_pi * (double)((k * n) & 255) / 256.0;
+                    return n == 0 ? 0.f : (float)(part == 0 ? std::cos(ph) : -std::sin(ph));
+                }, j);
+        for (int j = 0; j < 2; ++j)
+            for (int part = 0; part < 2; ++part)
+                sb.weight_block16([&](int r, int n) {
+                    const int k = bin_of_channel_t16(32 * w + 16 + r), m = k / 2;
+                    const double ph = two_pi * (double)((k * (n == 0 ? 32 : n)) & 255) / 256.0;
+                    if (n == 0 && (part == 0) != (m % 2 == 0)) return 0.f;       // pe[32] enters the even m, qe[32] the odd m
+                    return (float)(part == 0 ? std::cos(ph) : -std::sin(ph));
+                }, j);
     }
     out.data = std::move(sb.data);
     return true;

@@ -68,8 +68,29 @@ __device__ __forceinline__ f32x4 mfma16(f32x4 w, f32x4 a, f32x4 acc) {
     return acc;
 }
 
+// Quad arithmetic as PACKED fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes of a register pair per instruction, same
+// rounding as the scalar forms).  fp32 MFMAs and VALU work share the vector pipe, so every plain VALU instruction not issued is
+// time; left to itself the compiler packs about a fifth of these.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 cat2(f32x2 lo, f32x2 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3); }
 __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) {
-    return f32x4{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
+    return cat2(__builtin_elementwise_fma(a.lo, b.lo, c.lo), __builtin_elementwise_fma(a.hi, b.hi, c.hi));
+}
+__device__ __forceinline__ f32x4 mul4(f32x4 a, f32x4 b) { return cat2(a.lo * b.lo, a.hi * b.hi); }
+__device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 b) { return cat2(a.lo + b.lo, a.hi + b.hi); }
+// a - b: the backend scalarises a two-lane subtract (and folds fma(b, -1, a) back into one), so the packed add with its
+// negate modifier on the second source is written out
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) { return cat2(pk_sub(a.lo, b.lo), pk_sub(a.hi, b.hi)); }
+__device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+// |re + i im| of a quad: fma(re, re, im * im) as in mag_(), packed, then the four square roots
+__device__ __forceinline__ f32x4 mag4(f32x4 re, f32x4 im) {
+    const f32x4 q = fma4(re, re, mul4(im, im));
+    return f32x4{__builtin_amdgcn_sqrtf(q.x), __builtin_amdgcn_sqrtf(q.y), __builtin_amdgcn_sqrtf(q.z), __builtin_amdgcn_sqrtf(q.w)};
 }
 
 // a double moved across lanes by a DPP control (quad_perm / row_half_mirror) on its two halves
@@ -81,10 +102,26 @@ __device__ __forceinline__ double dpp_f64(double v) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// fold partner of a quad of folded samples: lane fq of a 16-lane row holds n = 4 fq + i, the result holds the values at 64 - n
+// (i = 0: lane 16 - fq, component 0 = row_mirror then row_shr:1; i = 1, 2, 3: lane 15 - fq, components 3, 2, 1 = row_mirror).
+// Lane 0's component 0 has no partner (n = 0 <-> 64): the DPP's bound control leaves 0 there and the caller overrides it.
+__device__ __forceinline__ f32x4 mirror64(f32x4 v) {
+    return f32x4{dpp_f32<0x111>(dpp_f32<0x140>(v.x)), dpp_f32<0x140>(v.w), dpp_f32<0x140>(v.z), dpp_f32<0x140>(v.y)};
+}
+
 __device__ __forceinline__ float log1p20(float mag) {   // log(1 + mag * 2^20): Mul, Add, Log of the graph
     return __builtin_amdgcn_logf(1.0f + mag * 1048576.0f) * 0.69314718055994531f;
 }
 __device__ __forceinline__ float lognorm(float mag, float mm) { return log1p20(mag) - mm; }     // minus the adaptive-normalisation mean
+__device__ __forceinline__ f32x4 log1p20_4(f32x4 mag) {     // the same three operations on a quad, the multiply-add and the scaling packed
+    const f32x4 a = fma4(mag, splat4(1048576.0f), splat4(1.0f));
+    const f32x4 l = f32x4{__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y), __builtin_amdgcn_logf(a.z), __builtin_amdgcn_logf(a.w)};
+    return mul4(l, splat4(0.69314718055994531f));
+}
 
 }  // namespace
 
@@ -133,9 +170,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
     const f32x4 W1 = ldw(wrs, fq * 16, o_win), W3 = ldw(wrs, (32 + fq) * 16, o_win);
     const float w64 = ldw(wrs, 16 * 16, o_win).x;                 // w[64] = w[192]
     const f32x4 wtq = ldw(wrs, (tid & 63) * 16, o_win);
-    f32x4 S0w[16];                                   // ... and so are the DFT blocks of the first column pair (4 k-iterations x 4)
+    f32x4 S0w[12];                                   // ... and so are the DFT blocks of the first column pair (6 k-iterations x {cos, -sin})
 #pragma unroll
-    for (int k = 0; k < 16; ++k) S0w[k] = WL(o_stft + k);
+    for (int k = 0; k < 12; ++k) S0w[k] = WL(o_stft + k);
     // ---- raw frame -> LDS (gate + int16 scaling fused): 16 streams x 128 quads, 8 per thread; piece `it` = quads 16 it .. 16 it + 15
     //      of every stream.  The first column pair needs only pieces 0..3 (+ the left mirror): they are requested first, stored and
     //      folded while 4..7 - requested when 0..3 have arrived, so that HBM serves every workgroup's first half first - are on
@@ -230,10 +267,22 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
                 fcor[(cp * 3 + 1) * 16 + fms] = y64 + y192;     // a64
                 fcor[(cp * 3 + 2) * 16 + fms] = y64 - y192;     // b64
             }
-            st2(&UV[(64 * cp + fq) * QSL + fms], pe);
-            st2(&UV[(64 * cp + 16 + fq) * QSL + fms], po);
-            st2(&UV[(64 * cp + 32 + fq) * QSL + fms], qe);
-            st2(&UV[(64 * cp + 48 + fq) * QSL + fms], qo);
+            // the even bins k = 2 m fold once more, about n = 32 (vad_layout.h, bin_of_channel_t16): m even pairs pe[n] + pe[64 - n]
+            // and qe[n] - qe[64 - n], m odd the opposite signs, n = 1..31; the unpaired n = 32 (lane 8, component 0) rides in the
+            // free slot n = 0: pe[32] for m even, qe[32] for m odd (the packer put cos / -sin of n = 32 there), zero in the other two
+            const f32x4 pm = mirror64(pe), qm = mirror64(qe);
+            f32x4 pee = add4(pe, pm), peo = sub4(pe, pm), qee = sub4(qe, qm), qeo = add4(qe, qm);
+            const float pe32 = dpp_f32<0x108>(pe.x), qe32 = dpp_f32<0x108>(qe.x);      // row_shl:8: lane 0 <- lane 8
+            if (fq == 0) { pee.x = pe32; peo.x = 0.f; qee.x = 0.f; qeo.x = qe32; }
+            // rows of a column: po 0..15 | qo 16..31 | pee 32..39 | peo 40..47 | qee 48..55 | qeo 56..63
+            st2(&UV[(64 * cp + fq) * QSL + fms], po);
+            st2(&UV[(64 * cp + 16 + fq) * QSL + fms], qo);
+            if (fq < 8) {
+                st2(&UV[(64 * cp + 32 + fq) * QSL + fms], pee);
+                st2(&UV[(64 * cp + 40 + fq) * QSL + fms], peo);
+                st2(&UV[(64 * cp + 48 + fq) * QSL + fms], qee);
+                st2(&UV[(64 * cp + 56 + fq) * QSL + fms], qeo);
+            }
         }
         // ---- the two REAL bins, k = 0 and k = 128, in float64 straight from the samples (DESIGN.md §3 "Numerics"): X0 = E + O,
         //      X128 = E - O with E / O = sum over even / odd n of w[n] xp[n].  32 (column, stream) pairs, 8 lanes each; lane (blk,
@@ -265,62 +314,73 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
                 nyqv[cp * 16 + ms] = fabsf((float)(e - o));
             }
         }
-        f32x4 Aw[4], Bw[4];
+        f32x4 Aw[2], Bw[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) Aw[k] = grp == 0 ? S0w[k] : WL(ws + k);
+        for (int k = 0; k < 2; ++k) Aw[k] = grp == 0 ? S0w[k] : WL(ws + k);
         SB();
         if (grp == 0) STAMP(2);
         __syncthreads();
         if (grp == 0) STAMP(3);
-        // ---- MFMA: wave w = bins bin_of_channel(32 w + 16 rt + r): cos on pe | po, -sin on qe | qo (even | odd bins), two columns,
-        //      K = 64; the accumulators start from the rank-1 terms of n = 0, 64, 128 (register i of a D quad is tile row 4 rq + i)
+        // ---- MFMA: wave w, row tile 0 = its 16 odd bins: cos on po, -sin on qo, K = 64 (k-iterations 0..3); row tile 1 = its 16
+        //      even bins: cos on pee | peo, -sin on qee | qeo (waves 2, 3 | waves 0, 1), K = 32 (k-iterations 4, 5); two columns;
+        //      the accumulators start from the rank-1 terms of n = 0, 64, 128 (register i of a D quad is tile row 4 rq + i):
+        //      odd k: re = -y128, im = -+ b64 (sin(pi k / 2) alternates along the rows); even k = 2 m: re = y128 + (-1)^m a64, im = 0
         f32x4 are[2][2], aim[2][2];
 #pragma unroll
         for (int cp = 0; cp < 2; ++cp) {
             const float y128 = fcor[(cp * 3 + 0) * 16 + n], a64 = fcor[(cp * 3 + 1) * 16 + n], b64 = fcor[(cp * 3 + 2) * 16 + n];
-            const float rp = w < 2 ? y128 + a64 : -y128, rm = w < 2 ? y128 - a64 : -y128;
-            const float ip = w < 2 ? 0.f : -b64, im_ = w < 2 ? 0.f : b64;
-            are[cp][0] = are[cp][1] = f32x4{rp, rm, rp, rm};
-            aim[cp][0] = aim[cp][1] = f32x4{ip, im_, ip, im_};
+            const float re1 = w < 2 ? y128 - a64 : y128 + a64;
+            are[cp][0] = f32x4{-y128, -y128, -y128, -y128};
+            aim[cp][0] = f32x4{-b64, b64, -b64, b64};
+            are[cp][1] = f32x4{re1, re1, re1, re1};
+            aim[cp][1] = zero4;
         }
         {
-            const int rR = w < 2 ? 0 : 16, rI = w < 2 ? 32 : 48;
-            const f32x4 *const XR = UV + rR * QSL + nqL, *const XI = UV + rI * QSL + nqL;
+            const int eR = w < 2 ? 40 : 32, eI = w < 2 ? 56 : 48;
+            const f32x4 *const XB = UV + nqL;
+            // operand rows of k-iteration t: odd tile t = 0..3: po rows 4 t + kq, qo rows 16 + 4 t + kq; even tile t = 4, 5
+#define S_ROW_R(t) ((t) < 4 ? 4 * (t) : eR + 4 * ((t) - 4))
+#define S_ROW_I(t) ((t) < 4 ? 16 + 4 * (t) : eI + 4 * ((t) - 4))
             f32x4 Au[2], Av[2], Bu[2], Bv[2];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) { Au[c] = XR[(64 * c) * QSL]; Av[c] = XI[(64 * c) * QSL]; }
-#define S_LD(S, jj)                                                                        \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) S##w[k] = grp == 0 ? S0w[4 * (jj) + k] : WL(ws + 4 * (jj) + k);   \
-    _Pragma("unroll") for (int c = 0; c < 2; ++c) { S##u[c] = XR[(64 * c + 4 * (jj)) * QSL]; S##v[c] = XI[(64 * c + 4 * (jj)) * QSL]; }
-#define S_MMA(S)                                                                           \
+            for (int c = 0; c < 2; ++c) { Au[c] = XB[(64 * c + S_ROW_R(0)) * QSL]; Av[c] = XB[(64 * c + S_ROW_I(0)) * QSL]; }
+#define S_LD(S, tt)                                                                        \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) S##w[k] = grp == 0 ? S0w[2 * (tt) + k] : WL(ws + 2 * (tt) + k);   \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) { S##u[c] = XB[(64 * c + S_ROW_R(tt)) * QSL]; S##v[c] = XB[(64 * c + S_ROW_I(tt)) * QSL]; }
+#define S_MMA(S, rt)                                                                       \
     _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                        \
-        are[c][0] = mfma16(S##w[0], S##u[c], are[c][0]); are[c][1] = mfma16(S##w[1], S##u[c], are[c][1]);   \
-        aim[c][0] = mfma16(S##w[2], S##v[c], aim[c][0]); aim[c][1] = mfma16(S##w[3], S##v[c], aim[c][1]);   \
+        are[c][rt] = mfma16(S##w[0], S##u[c], are[c][rt]);                                 \
+        aim[c][rt] = mfma16(S##w[1], S##v[c], aim[c][rt]);                                 \
     }
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                S_LD(B, j + 1) SB();
-                S_MMA(A) SB();
-                const int jn = j + 2 < 4 ? j + 2 : 2;
-                S_LD(A, jn) SB();
-                S_MMA(B) SB();
-            }
+            S_LD(B, 1) SB();
+            S_MMA(A, 0) SB();
+            S_LD(A, 2) SB();
+            S_MMA(B, 0) SB();
+            S_LD(B, 3) SB();
+            S_MMA(A, 0) SB();
+            S_LD(A, 4) SB();
+            S_MMA(B, 0) SB();
+            S_LD(B, 5) SB();
+            S_MMA(A, 1) SB();
+            S_MMA(B, 1) SB();
 #undef S_LD
 #undef S_MMA
+#undef S_ROW_R
+#undef S_ROW_I
         }
         if (grp == 0) STAMP(4);
-        {   // bin 0 (wave 0, row tile 0, tile row 0 = component 0 of the lanes kq = 0) takes the float64 sum; its im is identically 0
-            const bool own0 = (w == 0) & (kq == 0);
+        {   // bin 0 (wave 2, row tile 1, tile row 0 = component 0 of the lanes kq = 0) takes the float64 sum; its im is identically 0
+            const bool own0 = (w == 2) & (kq == 0);
             const float d0 = dcv[n], d1 = dcv[16 + n];
-            are[0][0].x = own0 ? d0 : are[0][0].x;
-            are[1][0].x = own0 ? d1 : are[1][0].x;
+            are[0][1].x = own0 ? d0 : are[0][1].x;
+            are[1][1].x = own0 ? d1 : are[1][1].x;
         }
 #pragma unroll
         for (int cp = 0; cp < 2; ++cp)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const f32x4 r = are[cp][rt], i = aim[cp][rt];
-                mg[2 * grp + cp][rt] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
+                mg[2 * grp + cp][rt] = mag4(r, i);
             }
         nyq[grp] = nyqv[((tid >> 4) & 1) * 16 + n];
         if (grp == 0) { X_PUT(4) X_PUT(5) }
@@ -365,7 +425,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const f32x4 v = mg[tc][rt];
-            const f32x4 l = f32x4{log1p20(v.x), log1p20(v.y), log1p20(v.z), log1p20(v.w)};
+            const f32x4 l = log1p20_4(v);
             lg[tc][rt] = l;
             s += (l.x + l.y) + (l.z + l.w);
         }
@@ -446,7 +506,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
             for (int tc = 0; tc < 8; ++tc) {
                 mgc[tc] = mg[tc][it];
                 const f32x4 l = lg[tc][it];
-                spc[tc] = f32x4{l.x - mm, l.y - mm, l.z - mm, l.w - mm};       // Sub of the graph: the adaptive normalisation
+                spc[tc] = sub4(l, splat4(mm));       // Sub of the graph: the adaptive normalisation
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {

@@ -97,6 +97,14 @@ enum Section {
     S_L0,                         // first layer: pw(relu(dw(x1))) + proj(x1), 16 outputs (rows 16..31 of the tile are zero)
     S_S0, S_L1, S_S1, S_L2, S_S2, S_L3, S_S3, S_LSTM0, S_LSTM1, S_HEADB, S_COUNT
 };
+// Channel order of the 16-STREAM kernel's STFT (silero_v4_t16.hip; the 32-stream kernel keeps v5::bin_of_channel): wave w owns the
+// channels 32 w .. 32 w + 31 as two 16-row tiles.  Row tile 0: the odd bins 2 (16 w + r) + 1 (4-way folded operands, K = 64).
+// Row tile 1: even bins, whose operands fold once more about n = 32 (K = 32) into two classes by k / 2's parity - waves 0, 1:
+// k = 4 (16 w + r) + 2 (k / 2 odd), waves 2, 3: k = 4 (16 (w - 2) + r) (k / 2 even; bin 0 = wave 2, tile 1, row 0).
+__host__ __device__ constexpr int bin_of_channel_t16(int ch) {
+    return (ch & 16) == 0 ? 2 * (16 * (ch >> 5) + (ch & 15)) + 1
+                          : ((ch >> 5) < 2 ? 4 * (16 * (ch >> 5) + (ch & 15)) + 2 : 4 * (16 * ((ch >> 5) - 2) + (ch & 15)));
+}
 constexpr int MAG_Q = 33;                      // quads per STFT column: 128 bins + Nyquist (+3 pad channels)
 constexpr int MAG_ROWS = 8 * MAG_Q;            // 264 rows per tile, row = 33 t + q
 // STFT part, LDS: reflect-padded frame [32][704] f32 + the 4-way fold of two columns (2 x 64 quad rows: pe, po, qe, qo as in

@@ -249,53 +249,68 @@ static PyObject *inbox_flush(Inbox *self, PyObject *args) {
         }
     PyObject *fails = PyList_New(0);
     if (!fails) return NULL;
+    /* EVERY box's arrays are taken out before the GIL is released for the first time: a frame that arrives while one group is in
+     * the engine starts a fresh array and waits for the NEXT flush, whatever its box.  (Walking the live boxes instead let such a
+     * frame - it passes the epoch guard of pusher_vectorcall, its session's last frame carries the previous epoch - leave in this
+     * flush from a box not yet visited, ahead of the session's earlier frame in a box visited later.) */
+    const Py_ssize_t nsnap = self->nboxes;
+    Box *snap = (Box *)PyMem_Calloc((size_t)(nsnap ? nsnap : 1), sizeof(Box));
+    if (!snap) {
+        Py_DECREF(fails);
+        return PyErr_NoMemory();
+    }
     self->epoch += 1;
-    for (Py_ssize_t k = 0; k < self->nboxes; ++k) {
+    for (Py_ssize_t k = 0; k < nsnap; ++k) {
         Box *b = &self->boxes[k];
-        const Py_ssize_t n = b->n;
-        if (!n) continue;
-        /* the box's arrays are taken out before the GIL is released: frames that arrive during the call start a fresh array */
-        int64_t *slots = b->slots;
-        PyObject **data = b->data;
-        const int32_t nbytes = b->nbytes;
-        const int gate = b->gate;
-        const int32_t rate = b->rate;
-        const Py_ssize_t cap = b->cap;
+        snap[k] = *b;
         b->slots = NULL; b->data = NULL; b->n = 0; b->cap = 0;
-        self->total -= n;
-        const void **ptrs = (const void **)PyMem_Malloc((size_t)n * sizeof(void *));
-        int32_t *status = (int32_t *)PyMem_Calloc((size_t)n, sizeof(int32_t));
-        int ok = ptrs && status;
-        if (ok) {
-            for (Py_ssize_t i = 0; i < n; ++i) ptrs[i] = PyBytes_AS_STRING(data[i]);
-            Py_BEGIN_ALLOW_THREADS
-            if (rate) (void)rate_fn((void *)(uintptr_t)eng_addr, slots, (int64_t)n, ptrs, nbytes / 2, /* VAD_FMT_I16_32767 */ 1, gate, rate, status);
-            else (void)fn((void *)(uintptr_t)eng_addr, slots, (int64_t)n, ptrs, nbytes / 2, /* VAD_FMT_I16_32767 */ 1, gate, status);
-            Py_END_ALLOW_THREADS
-            for (Py_ssize_t i = 0; i < n && ok; ++i)
-                if (status[i] != 0) {
-                    PyObject *t = Py_BuildValue("(Li)", (long long)slots[i], (int)status[i]);
-                    if (!t || PyList_Append(fails, t) < 0) ok = 0;
-                    Py_XDECREF(t);
-                }
+        self->total -= snap[k].n;
+    }
+    int ok = 1;
+    for (Py_ssize_t k = 0; k < nsnap; ++k) {
+        int64_t *slots = snap[k].slots;
+        PyObject **data = snap[k].data;
+        const Py_ssize_t n = snap[k].n;
+        if (n && ok) {
+            const int32_t nbytes = snap[k].nbytes;
+            const int gate = snap[k].gate;
+            const int32_t rate = snap[k].rate;
+            const void **ptrs = (const void **)PyMem_Malloc((size_t)n * sizeof(void *));
+            int32_t *status = (int32_t *)PyMem_Calloc((size_t)n, sizeof(int32_t));
+            ok = ptrs && status;
+            if (ok) {
+                for (Py_ssize_t i = 0; i < n; ++i) ptrs[i] = PyBytes_AS_STRING(data[i]);
+                Py_BEGIN_ALLOW_THREADS
+                if (rate) (void)rate_fn((void *)(uintptr_t)eng_addr, slots, (int64_t)n, ptrs, nbytes / 2, /* VAD_FMT_I16_32767 */ 1, gate, rate, status);
+                else (void)fn((void *)(uintptr_t)eng_addr, slots, (int64_t)n, ptrs, nbytes / 2, /* VAD_FMT_I16_32767 */ 1, gate, status);
+                Py_END_ALLOW_THREADS
+                for (Py_ssize_t i = 0; i < n && ok; ++i)
+                    if (status[i] != 0) {
+                        PyObject *t = Py_BuildValue("(Li)", (long long)slots[i], (int)status[i]);
+                        if (!t || PyList_Append(fails, t) < 0) ok = 0;
+                        Py_XDECREF(t);
+                    }
+            }
+            PyMem_Free(ptrs);
+            PyMem_Free(status);
         }
-        for (Py_ssize_t i = 0; i < n; ++i) Py_DECREF(data[i]);
-        PyMem_Free(ptrs);
-        PyMem_Free(status);
-        /* hand the (empty) arrays back if nothing arrived meanwhile, so that a steady stream of ticks does not reallocate */
-        b = &self->boxes[k];
+        for (Py_ssize_t i = 0; i < n; ++i) Py_DECREF(data[i]);      /* also the groups behind a failure: their frames are dropped */
+        /* hand the (empty) arrays back if nothing arrived meanwhile, so that a steady stream of ticks does not reallocate
+         * (self->boxes may have moved while the GIL was away: index, never a kept pointer) */
+        Box *b = &self->boxes[k];
         if (b->slots == NULL && b->data == NULL) {
             b->slots = slots;
             b->data = data;
-            b->cap = cap;
+            b->cap = snap[k].cap;
         } else {
             PyMem_Free(slots);
             PyMem_Free(data);
         }
-        if (!ok) {
-            Py_DECREF(fails);
-            return PyErr_NoMemory();
-        }
+    }
+    PyMem_Free(snap);
+    if (!ok) {
+        Py_DECREF(fails);
+        return PyErr_NoMemory();
     }
     return fails;
 }

@@ -111,16 +111,23 @@ class LoopRelay:
     drain on the loop, which takes whatever has arrived by then, in order."""
 
     def __init__(self, loop: asyncio.AbstractEventLoop) -> None:
-        self.loop = loop
-        self._items: list = []
+        self._loop = weakref.ref(loop)           # weak: the relay is the VALUE of a WeakKeyDictionary keyed by the loop - a strong
+        self._items: list = []                   # reference from here would keep every loop ever used (and its relay) alive
         self._lock = threading.Lock()
+
+    @property
+    def loop(self) -> Optional[asyncio.AbstractEventLoop]:
+        return self._loop()
 
     def post(self, fn, *args) -> None:
         with self._lock:
             self._items.append((fn, args))
             first = len(self._items) == 1
         if first:
-            self.loop.call_soon_threadsafe(self._drain)
+            loop = self._loop()
+            if loop is None:
+                raise RuntimeError("event loop is gone")
+            loop.call_soon_threadsafe(self._drain)
 
     def _drain(self) -> None:
         with self._lock:
@@ -263,8 +270,27 @@ class ClientSession:
             self.send_error(f"Audio processing error: {e}")
 
     def backlog(self) -> int:
-        """frames this client has sent that the pool has not stepped yet"""
-        return self.sent - self.session.frames_done if self.session is not None and not self.session.closed else 0
+        """frames this client has sent that the pool has neither stepped nor dropped (a failed tick, a refused push: `lost`)"""
+        s = self.session
+        return self.sent - s.frames_done - s.lost if s is not None and not s.closed else 0
+
+    async def wait_for_pool(self, interval: float) -> None:
+        """Back-pressure: do not read the socket until the pool is within BACKLOG_LOW frames of this client.  The wait ends with
+        the session (closed, failed) and cannot outlive the pool's progress: STALL_INTERVALS intervals in which not one of the
+        client's frames was stepped or dropped mean the count is off (frames the engine lost without saying whose), and the
+        count is resynchronised instead of leaving the socket unread for good."""
+        stalled, last = 0, -1
+        while self.backlog() > BACKLOG_LOW:
+            s = self.session
+            if s is None or s.closed or self.session_error is not None:
+                return
+            moved = s.frames_done + s.lost
+            stalled = stalled + 1 if moved == last else 0
+            last = moved
+            if stalled >= STALL_INTERVALS:
+                self.sent = moved
+                return
+            await asyncio.sleep(interval)
 
     def update_config(self, cfg: Dict[str, Any]) -> None:
         old, self.cfg = self.cfg, cfg
@@ -283,6 +309,7 @@ class ClientSession:
 
 
 BACKLOG_HIGH, BACKLOG_LOW = 96, 32          # frames a client may be ahead of the pool before / after its socket is paused
+STALL_INTERVALS = 100                       # tick intervals without progress after which a paused socket is read again
 
 
 def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0.010, convert_rates: bool = False,
@@ -414,8 +441,7 @@ def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0
                         # frames ahead, its socket is not read until the pool has caught up (TCP then slows the sender), instead
                         # of running into the engine's 256-frames-waiting refusal.
                         if (client.sent & 15) == 0 and client.backlog() > BACKLOG_HIGH:
-                            while client.backlog() > BACKLOG_LOW:
-                                await asyncio.sleep(tick_interval)
+                            await client.wait_for_pool(tick_interval)
                     elif message.get("text") is not None:
                         try:
                             data = json.loads(message["text"])

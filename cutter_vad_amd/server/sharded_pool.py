@@ -59,10 +59,12 @@ class ShardedStreamPool:
             return self.shards[k].open_session(config)
 
     def close_session(self, s: PooledSession) -> None:
-        s.pool.close_session(s)
+        with self._place:                          # not while the session is between two shards: `s.pool` is stable in here
+            s.pool.close_session(s)
 
     def reconfigure(self, s: PooledSession, config: VADConfig) -> None:
-        s.pool.reconfigure(s, config)
+        with self._place:
+            s.pool.reconfigure(s, config)
 
     @property
     def session_count(self) -> int:
@@ -81,8 +83,9 @@ class ShardedStreamPool:
                 raise AudioProcessingError("session is closed")
             if dst is src:
                 return
-            # 1. nothing new arrives for the session while it moves: producers wait on the source pool's submit lock; what is
-            #    already queued is stepped where the session lives (its events are delivered as usual, in order)
+            # 1. nothing new reaches an engine for the session while it moves: frames submitted meanwhile are held on the session
+            #    (producers do not wait - one of them may be an event loop) and replayed on the pool it lands on; what is already
+            #    queued is stepped where the session lives (its events are delivered as usual, in order)
             first, second = sorted((src, dst), key=id)
             with src._lock:
                 src._unbind_push(s)
@@ -115,6 +118,7 @@ class ShardedStreamPool:
                             getattr(dst, name)[new_slot] = getattr(src, name)[old_slot]
                         src._sessions.pop(old_slot, None)
                         src._by_slot[old_slot] = None
+                        s._home = (dst, new_slot)      # readers of the pair (frames_done, active) never see a mixed one
                         s.pool, s.slot = dst, new_slot
                         dst._sessions[new_slot] = s
                         dst._by_slot[new_slot] = s
@@ -122,8 +126,9 @@ class ShardedStreamPool:
                     src.engine.close_stream(old_slot)
                     self.migrations += 1
             finally:
-                with s.pool._lock:
-                    s.pool._bind_push(s)               # on the pool it ended up on
+                with s.pool._lock:                     # on the pool it ended up on
+                    s.pool._replay_held(s)             # what arrived meanwhile, in order, before anything newer can get in
+                    s.pool._bind_push(s)
                     s.moving = False
 
     def rebalance(self, tolerance: int = 1) -> int:

@@ -70,12 +70,15 @@ FRAME = 512      # the model's frame at 16 kHz; a pool's own frame length is ``S
 class PooledSession:
     """One client stream: a slot of the shared engine + the host half of its voice segments."""
 
-    __slots__ = ("pool", "slot", "config", "long_frames", "on_start", "on_end", "on_continue", "on_error", "closed",
-                 "wav_writer", "user", "rate", "moving", "gate", "_push", "_queued")
+    __slots__ = ("pool", "slot", "_home", "config", "long_frames", "on_start", "on_end", "on_continue", "on_error", "closed",
+                 "wav_writer", "user", "rate", "moving", "gate", "_push", "_queued", "lost", "_held")
 
     def __init__(self, pool: "SharedStreamPool", slot: int, config: VADConfig) -> None:
         self.pool = pool
         self.slot = slot
+        self._home = (pool, slot)                  # ONE attribute for readers that need the pair (migrate stores it in one go)
+        self.lost = 0                              # frames taken from this session and never stepped (failed tick, refused push)
+        self._held: Deque = deque()                # frames that arrived while the session was changing engines (migrate replays them)
         self.config = config
         self.long_frames: Deque = deque()          # frames longer than the model's frame, whole: segments keep all of a frame
         self.on_start: Optional[Callable[[], None]] = None
@@ -95,15 +98,18 @@ class PooledSession:
     # the per-session scalars live in the pool's arrays (indexed by slot) so that a tick can work on all of them at once
     @property
     def active(self) -> bool:
-        return bool(self.pool._active[self.slot])
+        pool, slot = self._home
+        return bool(pool._active[slot])
 
     @property
     def last_probability(self) -> float:
-        return float(self.pool._lastp[self.slot])
+        pool, slot = self._home
+        return float(pool._lastp[slot])
 
     @property
     def frames_done(self) -> int:
-        return int(self.pool._done[self.slot])
+        pool, slot = self._home
+        return int(pool._done[slot])
 
     def set_callbacks(self, voice_start_callback=None, voice_end_callback=None, voice_continue_callback=None,
                       error_callback=None, continue_payload: bool = True) -> None:
@@ -116,15 +122,17 @@ class PooledSession:
         self.pool._contp[self.slot] = voice_continue_callback is not None and bool(continue_payload)
 
     def submit(self, frame) -> None:
-        while self.pool.submit(self, frame) is _RETRY:       # the session is changing engines (ShardedStreamPool.migrate)
-            time.sleep(0.0005)
+        # _RETRY: this thread read `self.pool` just before a migration swapped it - the next read sees the new pool.  A session
+        # that is still moving does not make its producer wait (it may be an event loop): the frame is held and replayed.
+        while self.pool.submit(self, frame) is _RETRY:
+            pass
 
     def submit_pcm16(self, data: bytes) -> None:
         push = self._push
         if push is not None and push(data):       # a wire frame no longer than the model's, session live and in place: queued in C
             return
         while self.pool.submit_pcm16(self, data) is _RETRY:
-            time.sleep(0.0005)
+            pass
 
     def is_voice_active(self) -> bool:
         return self.active
@@ -260,45 +268,70 @@ class SharedStreamPool:
                                        f"sub-model, the session asks for sample rate {int(cfg.sample_rate)}")
 
     def close_session(self, s: PooledSession) -> None:
-        with self._tick_lock:                      # never under a running launch
-            with self._lock:
-                if s.closed:
+        """Closes the session WHERE IT LIVES: a caller that read ``s.pool`` before a migration finished arrives here with the
+        old pool; acting on it would cancel and close whatever stream has taken ``s.slot``'s number in this engine."""
+        while True:
+            home = s.pool
+            if home is not self:
+                return home.close_session(s)
+            with self._tick_lock:                  # never under a running launch
+                with self._lock:
+                    if s.closed:
+                        return
+                    mine = s.pool is self and not s.moving
+                    if mine:
+                        slot = s.slot
+                        self._unbind_push(s)
+                        self._flush_inbox()        # then the cancel below takes the session's frames out again
+                        s.closed = True
+                        s.long_frames.clear()
+                        s._held.clear()
+                        self._sessions.pop(slot, None)
+                        self._by_slot[slot] = None
+                if mine:
+                    self.engine.tick_cancel(slot)
+                    self.engine.close_stream(slot)
                     return
-                self._unbind_push(s)
-                self._flush_inbox()                # then the cancel below takes the session's frames out again
-                s.closed = True
-                s.long_frames.clear()
-                self._sessions.pop(s.slot, None)
-                self._by_slot[s.slot] = None
-            self.engine.tick_cancel(s.slot)
-            self.engine.close_stream(s.slot)
+            time.sleep(0.0005)                     # mid-migration: wait for it to land, then close it there
 
     def reconfigure(self, s: PooledSession, config: VADConfig) -> None:
         """New thresholds / frame length for a live session; like ``ClientState.update_config`` rebuilding its
         wrapper (vad_websocket_server.py:300-318) the stream starts from a clean state."""
-        self._check_session_rate(config)
-        with self._tick_lock:
-            with self._lock:
-                self._unbind_push(s)
-                self._flush_inbox()
-                s.long_frames.clear()
-            self.engine.tick_cancel(s.slot)
-            self.engine.reset([s.slot])
-            self.engine.set_thresholds(s.slot, config.vad_start_probability, config.vad_end_probability,
-                                       config.voice_start_ratio, config.voice_end_ratio, config.voice_start_frame_count,
-                                       config.voice_end_frame_count)
-            s.config = config
-            s.rate = self._input_rate(config)
-            s.gate = bool(config.enable_denoising)
-            contp = bool(self._contp[s.slot])
-            with self._lock:
-                self._init_slot(s.slot, config)
-                # the session keeps its callbacks across a reconfigure (the app binds them once, at open): so does the flag
-                # that makes the tick deliver voice_continue payloads to it
-                self._cont[s.slot], self._contp[s.slot] = s.on_continue is not None, contp
-                self._bind_push(s)
-            s.wav_writer = WAVWriter(sample_rate=config.output_wav_sample_rate, bit_depth=config.output_wav_bit_depth,
-                                     channels=1)
+        while True:
+            home = s.pool
+            if home is not self:
+                return home.reconfigure(s, config)
+            self._check_session_rate(config)
+            with self._tick_lock:
+                with self._lock:
+                    if s.closed:
+                        raise AudioProcessingError("session is closed")
+                    mine = s.pool is self and not s.moving
+                    if mine:
+                        self._unbind_push(s)
+                        self._flush_inbox()
+                        s.long_frames.clear()
+                if mine:
+                    self.engine.tick_cancel(s.slot)
+                    self.engine.reset([s.slot])
+                    self.engine.set_thresholds(s.slot, config.vad_start_probability, config.vad_end_probability,
+                                               config.voice_start_ratio, config.voice_end_ratio, config.voice_start_frame_count,
+                                               config.voice_end_frame_count)
+                    s.config = config
+                    s.rate = self._input_rate(config)
+                    s.gate = bool(config.enable_denoising)
+                    contp = bool(self._contp[s.slot])
+                    with self._lock:
+                        self._init_slot(s.slot, config)
+                        # the session keeps its callbacks across a reconfigure (the app binds them once, at open): so does the flag
+                        # that makes the tick deliver voice_continue payloads to it
+                        self._cont[s.slot], self._contp[s.slot] = s.on_continue is not None, contp
+                        s.lost = 0
+                        self._bind_push(s)
+                    s.wav_writer = WAVWriter(sample_rate=config.output_wav_sample_rate, bit_depth=config.output_wav_bit_depth,
+                                             channels=1)
+                    return
+            time.sleep(0.0005)
 
     @property
     def session_count(self) -> int:
@@ -319,12 +352,19 @@ class SharedStreamPool:
         with self._lock:
             if s.closed:
                 raise AudioProcessingError("session is closed")
-            if s.moving or s.pool is not self:
+            if s.pool is not self:
                 return _RETRY
-            self._flush_inbox()                            # frames of one session keep their order across both ingest paths
-            self.engine.tick_push(s.slot, x, bool(self._gate[s.slot]), sample_rate=s.rate)
-            if x.size > self.frame and s.rate is None:   # only voice_continue payloads need the whole frame here (the engine keeps its own)
-                s.long_frames.append(x)
+            if s.moving:
+                s._held.append(x)
+                return None
+            self._ingest_f32(s, x)
+
+    def _ingest_f32(self, s: PooledSession, x: np.ndarray) -> None:
+        """``_lock`` held, session in place."""
+        self._flush_inbox()                                # frames of one session keep their order across both ingest paths
+        self.engine.tick_push(s.slot, x, bool(self._gate[s.slot]), sample_rate=s.rate)
+        if x.size > self.frame and s.rate is None:       # only voice_continue payloads need the whole frame here (the engine keeps its own)
+            s.long_frames.append(x)
 
     def submit_pcm16(self, s: PooledSession, data: bytes) -> None:
         """Queue one frame as it arrives on the wire: little-endian int16 PCM.  The bytes go to the GPU as they are
@@ -338,24 +378,45 @@ class SharedStreamPool:
         with self._lock:
             if s.closed:
                 raise AudioProcessingError("session is closed")
-            if s.moving or s.pool is not self:
+            if s.pool is not self:
                 return _RETRY
-            if s.rate is None and len(data) <= 2 * self.frame:
-                # the inbox is flushed group by group: a session's frame must not wait there behind a group that holds an
-                # EARLIER frame of it (another length: the last chunk of a file), nor behind the C inbox, which is flushed second
-                if (self._wire is not None and len(self._wire)) or (s._queued[0] == self._epoch and s._queued[1] != len(data)):
-                    self._flush_inbox()
-                s._queued = (self._epoch, len(data))
-                key = (len(data), s.gate)
-                box = self._inbox.get(key)
-                if box is None:
-                    box = self._inbox[key] = []
-                box.append((s.slot, data))
+            if s.moving:
+                s._held.append(data)
                 return None
-            self._flush_inbox()
-            self.engine.tick_push(s.slot, data, bool(self._gate[s.slot]), sample_rate=s.rate)
-            if len(data) > 2 * self.frame and s.rate is None:
-                s.long_frames.append(np.frombuffer(data, dtype="<i2").astype(np.float32) / np.float32(32767.0))
+            self._ingest_pcm16(s, data)
+
+    def _ingest_pcm16(self, s: PooledSession, data: bytes) -> None:
+        """``_lock`` held, session in place."""
+        if s.rate is None and len(data) <= 2 * self.frame:
+            # the inbox is flushed group by group: a session's frame must not wait there behind a group that holds an
+            # EARLIER frame of it (another length: the last chunk of a file), nor behind the C inbox, which is flushed second
+            if (self._wire is not None and len(self._wire)) or (s._queued[0] == self._epoch and s._queued[1] != len(data)):
+                self._flush_inbox()
+            s._queued = (self._epoch, len(data))
+            key = (len(data), s.gate)
+            box = self._inbox.get(key)
+            if box is None:
+                box = self._inbox[key] = []
+            box.append((s.slot, data))
+            return None
+        self._flush_inbox()
+        self.engine.tick_push(s.slot, data, bool(self._gate[s.slot]), sample_rate=s.rate)
+        if len(data) > 2 * self.frame and s.rate is None:
+            s.long_frames.append(np.frombuffer(data, dtype="<i2").astype(np.float32) / np.float32(32767.0))
+
+    def _replay_held(self, s: PooledSession) -> None:
+        """The frames that arrived while the session moved, in order, onto the pool it landed on (``_lock`` held; called by
+        ``ShardedStreamPool.migrate`` right before it clears ``moving``)."""
+        while s._held:
+            f = s._held.popleft()
+            try:
+                if isinstance(f, (bytes, bytearray)):
+                    self._ingest_pcm16(s, bytes(f))
+                else:
+                    self._ingest_f32(s, f)
+            except Exception as e:
+                s.lost += 1
+                self._report(s, e if isinstance(e, AudioProcessingError) else AudioProcessingError(f"Model prediction failed: {e}"))
 
     def _flush_inbox(self) -> None:
         """The collected wire frames -> the engine's tick staging, one call per gate value (``_lock`` held).  A frame the engine
@@ -394,6 +455,7 @@ class SharedStreamPool:
     def _refused(self, slot: int, status: int) -> None:
         s = self._by_slot[slot] if 0 <= slot < len(self._by_slot) else None
         if s is not None and not s.closed:
+            s.lost += 1                        # sent, never to be stepped: the app's back-pressure count must not wait for it
             why = "256 frames are waiting for this stream" if status == _ffi.VAD_ERR_BUSY else f"engine status {status}"
             self._report(s, AudioProcessingError(f"Model prediction failed: frame not queued: {why}"))
 
@@ -429,7 +491,9 @@ class SharedStreamPool:
                             s.long_frames.popleft()          # the whole over-long frame kept for voice_continue went with it
                         victims.append(s)
                 for s in victims:
+                    s.lost += 1
                     self._report(s, err)
+                self.backlog = 0                   # a failing engine is not hammered back to back: the next tick waits its interval
                 return 0
             n = int(slots.size)
             self.backlog = int(getattr(self.engine, "last_tick_staged_next", 0))    # > 0: someone is ahead of the ticker

@@ -852,27 +852,43 @@ def v4_step_t16(W, sect, x, hc, gate=0.01, k8=False):
             t = 2 * grp + cp
             y = xp[:, 64 * t:64 * t + 256] * wtab[None, :]
             y1, y2, y3, y4 = y[:, n], y[:, 128 - n], y[:, 128 + n], y[:, (256 - n) % 256]
-            for k, arr in enumerate((y1 + y4 + y2 + y3, y1 + y4 - y2 - y3, y1 - y4 - y2 + y3, y1 - y4 + y2 - y3)):
-                arr = arr.copy()
+            pe, po, qe, qo = y1 + y4 + y2 + y3, y1 + y4 - y2 - y3, y1 - y4 - y2 + y3, y1 - y4 + y2 - y3
+            for arr in (pe, po, qe, qo):
                 arr[:, 0] = 0.0
-                UV[64 * cp + 16 * k:64 * cp + 16 * k + 16] = arr.reshape(16, 16, 4).transpose(1, 0, 2)
+            # the even bins' operands fold once more about n = 32; the unpaired n = 32 rides in slot 0 (pe[32]: k / 2 even, qe[32]: odd)
+            m = np.arange(32)
+            pee, peo = pe[:, m] + pe[:, (64 - m) % 64], pe[:, m] - pe[:, (64 - m) % 64]
+            qee, qeo = qe[:, m] - qe[:, (64 - m) % 64], qe[:, m] + qe[:, (64 - m) % 64]
+            pee[:, 0], peo[:, 0], qee[:, 0], qeo[:, 0] = pe[:, 32], 0.0, 0.0, qe[:, 32]
+            base = 64 * cp                                                  # rows: po 0..15 | qo 16..31 | pee | peo | qee | qeo (8 each)
+            UV[base:base + 16] = po.reshape(16, 16, 4).transpose(1, 0, 2)
+            UV[base + 16:base + 32] = qo.reshape(16, 16, 4).transpose(1, 0, 2)
+            for k, arr in enumerate((pee, peo, qee, qeo)):
+                UV[base + 32 + 8 * k:base + 40 + 8 * k] = arr.reshape(16, 8, 4).transpose(1, 0, 2)
             fcor[cp] = y[:, 128], y[:, 64] + y[:, 192], y[:, 64] - y[:, 192]
             e, o = y[:, 0::2].sum(1), y[:, 1::2].sum(1)                      # the two real bins straight from the samples (float64)
             RX[33 * t + 32, :, 0] = np.abs(e - o)
             dc = e + o
             for w in range(4):
                 ws = sect[w][S["S_STFT"]]
-                rR, rI = (0, 32) if w < 2 else (16, 48)
-                for rt in range(2):
-                    are, aim = np.zeros((16, 16)), np.zeros((16, 16))
-                    for j in range(4):
-                        are += _mfma16(W[ws + 4 * j + rt], _rows16(UV, 64 * cp + rR + 4 * j))
-                        aim += _mfma16(W[ws + 4 * j + 2 + rt], _rows16(UV, 64 * cp + rI + 4 * j))
-                    y128, a64, b64 = fcor[cp, 0][None, :], fcor[cp, 1][None, :], fcor[cp, 2][None, :]
-                    re, im = (are + y128 + sgn * a64, aim) if w < 2 else (are - y128, aim - sgn * b64)
-                    if w == 0 and rt == 0:
-                        re[0] = dc
-                    _store16(RX, 33 * t + 8 * w + 4 * rt, np.sqrt(re ** 2 + im ** 2), relu=False)
+                y128, a64, b64 = fcor[cp, 0][None, :], fcor[cp, 1][None, :], fcor[cp, 2][None, :]
+                # row tile 0: the wave's 16 odd bins, K = 64
+                are, aim = np.zeros((16, 16)), np.zeros((16, 16))
+                for j in range(4):
+                    are += _mfma16(W[ws + 2 * j], _rows16(UV, base + 4 * j))
+                    aim += _mfma16(W[ws + 2 * j + 1], _rows16(UV, base + 16 + 4 * j))
+                re, im = are - y128, aim - sgn * b64
+                _store16(RX, 33 * t + 8 * w, np.sqrt(re ** 2 + im ** 2), relu=False)
+                # row tile 1: 16 even bins, K = 32; waves 0, 1: k / 2 odd (peo | qeo), waves 2, 3: k / 2 even (pee | qee)
+                eR, eI = (40, 56) if w < 2 else (32, 48)
+                are, aim = np.zeros((16, 16)), np.zeros((16, 16))
+                for j in range(2):
+                    are += _mfma16(W[ws + 8 + 2 * j], _rows16(UV, base + eR + 4 * j))
+                    aim += _mfma16(W[ws + 8 + 2 * j + 1], _rows16(UV, base + eI + 4 * j))
+                re, im = are + (y128 - a64 if w < 2 else y128 + a64), aim
+                if w == 2:
+                    re[0] = dc
+                _store16(RX, 33 * t + 8 * w + 4, np.sqrt(re ** 2 + im ** 2), relu=False)
     lg = lambda mg: np.log(1.0 + mg * 1048576.0)
     o_dw0 = sect[0][S["S_DW0"]]
     colmean = np.zeros((8, 16))

@@ -94,3 +94,17 @@ def resample_generic_inputs():
         ("list_input_64_32000_16000", [float(v) for v in rn(18, 64, np.float64)], 32000, 16000),
     ]
     return cases
+
+
+def one_ulp_conditioning(step_f64, frames, trials=256, seed=0):
+    """How far the float64 ORACLE's own answer moves when every input sample is perturbed by at most one float32 ulp (relative
+    2^-23): max over `trials` seeded perturbations and over the frames of |p(x (1 + d)) - p(x)|, d uniform in +-2^-23.
+    `step_f64(frames[n, T, L]) -> probs[n, T]` runs n independent streams from zero state.  This is a property of the function
+    and the input - its conditioning at float32 input precision - not of any float32 evaluation: an evaluation that is backward
+    stable to one ulp of the input cannot be expected closer to float64 than this, and the tests that feed ill-conditioned inputs
+    (exact spectral nulls under Silero V4's log(1 + |X| 2^20)) hold the kernels to exactly this bound."""
+    x = np.asarray(frames, np.float32)
+    base = step_f64(x[None])[0]
+    d = np.random.default_rng(seed).uniform(-2.0 ** -23, 2.0 ** -23, (trials,) + x.shape)
+    pert = (x[None].astype(np.float64) * (1.0 + d)).astype(np.float32)
+    return float(np.abs(step_f64(pert) - base[None]).max())

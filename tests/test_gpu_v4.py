@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from cutter_vad_amd import weights_io
-from tests.signals import make_streams
+from tests.signals import make_streams, one_ulp_conditioning
 
 pytestmark = pytest.mark.gpu
 TOL_P = 2e-5      # bar: 1e-4 (1 M-frame sweep: max 5.1e-6, profiles/r02_parity_sweep.json)
@@ -14,8 +14,11 @@ TOL_S = 5e-4
 # happens to the two REAL bins (k = 0, 128) about once in 10^4 columns and practically never to a complex bin
 # (tools/v4_real_bins.py), so silero_v4.hip sums exactly those two in float64 and the fixed bar below holds; the sweep
 # in profiles/r02_parity_sweep.json (1 M frames) has the kernel closer to the f64 oracle than the oracle's own float32 build.
-# The one constructed input with exact nulls in COMPLEX bins (period-64 full-scale square wave) is held to the float32
-# yardstick on that input instead of a flat number: test_edge_inputs, profiles/r03_f32_yardsticks.json.
+# The one constructed input with exact nulls in COMPLEX bins (period-64 full-scale square wave) is ill-conditioned for every
+# evaluation: ONE float32 ulp on the input samples moves the float64 oracle's own probabilities by 3.1e-3 (16 kHz) / 1.0e-2 (8 kHz
+# sub-model).  There the kernels are held to that conditioning bound (tests/signals.py::one_ulp_conditioning) - a property of the
+# function and the input, independent of any float32 build or kernel: test_edge_inputs, test_8k_golden...,
+# profiles/r04_v4_square_conditioning.json.
 
 
 @pytest.fixture(scope="module")
@@ -120,16 +123,14 @@ def test_edge_inputs(engine, om, blob):
         got = np.stack([engine.step(slots, frames[:, t]) for t in range(T)], axis=1)
         assert np.abs(got[:3] - ref_p[:3]).max() <= TOL_P
         # The period-64 full-scale square wave has EXACT nulls in complex spectral bins, which V4 multiplies by 2^20 inside a
-        # log: every float32 evaluation is order dependent there.  The bar is therefore the float32 yardstick on this very
-        # input, computed here: the oracle's own float32 build against its float64 build (recorded with PyTorch's float32
-        # operators next to it in profiles/r03_f32_yardsticks.json: oracle-f32 1.08e-3, torch-f32 8.8e-5, kernels 6.5e-4 /
-        # 7.7e-4 over these 8 frames).  The kernel may be at most twice as far from float64 as that build.
-        from oracle import oracle
-        o32 = oracle.OracleModel(blob, "f32")
-        ref32, _ = _oracle_run(o32, frames[3:], 0.01)
-        yard = float(np.abs(ref32[0] - ref_p[3]).max())
-        assert 1e-4 < yard < 5e-3                                   # the input does what the comment says
-        assert np.abs(got[3] - ref_p[3]).max() <= 2 * yard
+        # log: the answer is ill-conditioned for ANY evaluation - one float32 ulp on the input samples moves the float64 oracle's
+        # own probabilities by 3.1e-3 over these 8 frames.  The bar is that conditioning bound: the kernel may be no farther from
+        # the float64 oracle than the oracle itself moves under a one-ulp perturbation of its input (backward stable to one ulp).
+        # Recorded next to the float32 evaluations in profiles/r04_v4_square_conditioning.json (oracle-f32 1.08e-3, torch-f32
+        # 8.8e-5, kernels 6.5e-4 .. 7.7e-4).
+        cond = one_ulp_conditioning(lambda fr: _oracle_run(om, fr, 0.01)[0], frames[3])
+        assert 1e-3 < cond < 1e-2                                   # the input does what the comment says
+        assert np.abs(got[3] - ref_p[3]).max() <= cond
     finally:
         for s in slots:
             engine.close_stream(s)
@@ -233,17 +234,15 @@ def test_8k_golden_and_wrapper_rate_selection(setup8k):
     try:
         got = np.array([eng.step([slot], sp[t:t + 1])[0] for t in range(240)])
         assert np.abs(got - g["speech_gate.probs"]).max() <= TOL_P
-        # exact complex-bin nulls, 8 kHz sub-model: bar = twice the float32 yardstick on the same input, as in test_edge_inputs
-        # (profiles/r03_f32_yardsticks.json: oracle-f32 4.2e-3, torch-f32 2.4e-3, kernels 3.6e-3 / 5.3e-3 over 8 frames)
-        from oracle import oracle
-        with open(weights_io.packaged_blob_path(4, 8000), "rb") as f:
-            o32 = oracle.OracleModel(f.read(), "f32")
+        # exact complex-bin nulls, 8 kHz sub-model: the same conditioning bar as in test_edge_inputs - one float32 ulp on the input
+        # moves the float64 oracle by 1.0e-2 here (two LSTM steps per frame); profiles/r04_v4_square_conditioning.json
         sq = np.where(np.arange(512 * 8) % 64 < 32, 1.0, -1.0).astype(np.float32).reshape(1, 8, 512)
         r64, _ = _oracle_run(setup8k[1], sq, 0.01)
-        r32, _ = _oracle_run(o32, sq, 0.01)
+        cond = one_ulp_conditioning(lambda fr: _oracle_run(setup8k[1], fr, 0.01)[0], sq[0])
+        assert 3e-3 < cond < 3e-2
         eng.reset([slot])
         k = np.array([eng.step([slot], sq[:, t])[0] for t in range(8)])
-        assert np.abs(k - r64[0]).max() <= 2 * float(np.abs(r32 - r64).max())
+        assert np.abs(k - r64[0]).max() <= cond
     finally:
         eng.close_stream(slot)
     for rate in (8000, 48000):

@@ -587,3 +587,186 @@ def test_loop_relay_delivers_in_order_with_one_wakeup_per_batch():
             await asyncio.sleep(0.001)
         assert got == list(range(1000)) and 1 <= len(wakeups) <= 50
     asyncio.run(main())
+
+
+# ---------------------------------------------------------------------------------------------- ADVICE round 3
+def test_a_close_that_raced_a_migration_closes_the_session_where_it_landed():
+    """A caller that read ``s.pool`` before a migration finished used to resume on the SOURCE pool with ``s.slot`` already the
+    destination's slot number: it popped another client's session there and cancelled / closed that client's stream, and the
+    migrated stream was never closed.  Emulated as in the finding: a = (shard 0, slot 0), b = (shard 0, slot 1); a moves to shard 1
+    and gets slot number 1 there; the stale ``src.close_session(a)`` must close a on shard 1 and leave b alone."""
+    cfg = VADConfig(voice_start_frame_count=1, buffer_size=512)
+    pool, engines = _sharded(2)
+    filler = pool.open_session(cfg, shard=1)                 # so that a's slot on shard 1 gets b's slot NUMBER on shard 0
+    a, b = pool.open_session(cfg, shard=0), pool.open_session(cfg, shard=0)
+    src = a.pool
+    assert (a.slot, b.slot, filler.slot) == (0, 1, 0)
+    pool.migrate(a, 1)
+    assert a.pool is pool.shards[1] and a.slot == 1 and a._home == (pool.shards[1], 1)
+    src.close_session(a)                                     # the stale call
+    assert a.closed and not b.closed
+    assert pool.shards[0]._by_slot[1] is b and pool.shards[0]._sessions == {1: b}
+    assert pool.shards[1]._sessions == {0: filler} and 1 in engines[1].closed and engines[0].closed == [0]
+    b.submit(LOUD)
+    pool.tick()
+    assert b.frames_done == 1
+    pool.close()
+
+
+def test_close_and_reconfigure_wait_for_a_running_migration():
+    """Threaded: a migration is held between the drain and the state transfer; close_session (through the sharded front and
+    directly on the session) and reconfigure started meanwhile act on the pool the session ends up on."""
+    import threading
+    import time
+    cfg = VADConfig(voice_start_frame_count=1, buffer_size=512)
+    for how in ("front", "direct", "reconfigure"):
+        pool, engines = _sharded(2)
+        a, b = pool.open_session(cfg, shard=0), pool.open_session(cfg, shard=0)
+        pool.open_session(cfg, shard=1)
+        entered, release = threading.Event(), threading.Event()
+        orig = engines[0].save_stream
+
+        def slow_save(slot, orig=orig):
+            entered.set()
+            release.wait(5)
+            return orig(slot)
+        engines[0].save_stream = slow_save
+        mover = threading.Thread(target=lambda: pool.migrate(a, 1))
+        mover.start()
+        assert entered.wait(5)
+        new_cfg = VADConfig(voice_start_frame_count=3, buffer_size=512)
+        act = {"front": lambda: pool.close_session(a), "direct": a.close, "reconfigure": lambda: pool.reconfigure(a, new_cfg)}[how]
+        other = threading.Thread(target=act)
+        other.start()
+        time.sleep(0.05)
+        assert other.is_alive() and not a.closed                 # it waits: the session is between two shards
+        release.set()
+        mover.join(5)
+        other.join(5)
+        assert not mover.is_alive() and not other.is_alive()
+        assert a.pool is pool.shards[1] and not b.closed and pool.shards[0]._sessions == {b.slot: b}
+        if how == "reconfigure":
+            assert not a.closed and a.config is new_cfg and engines[1].thr[a.slot][4] == 3
+        else:
+            assert a.closed and a.slot in engines[1].closed and a.slot not in pool.shards[1]._sessions
+        pool.close()
+
+
+def test_frames_that_arrive_while_a_session_moves_are_held_not_waited_for():
+    """``submit`` on a moving session used to spin with time.sleep - on the ASGI app that is the event loop's thread, so one
+    migration froze every socket of the loop.  Now the frame is held on the session and replayed, in order, on the pool it lands on."""
+    import threading
+    import time
+    cfg = VADConfig(voice_start_frame_count=1, buffer_size=512)
+    pool, engines = _sharded(2)
+    s = pool.open_session(cfg, shard=0)
+    got = []
+    s.set_callbacks(voice_start_callback=lambda: got.append("S"), voice_continue_callback=lambda pcm: got.append(len(pcm)))
+    entered, release = threading.Event(), threading.Event()
+    orig = engines[0].save_stream
+
+    def slow_save(slot):
+        entered.set()
+        release.wait(5)
+        return orig(slot)
+    engines[0].save_stream = slow_save
+    mover = threading.Thread(target=lambda: pool.migrate(s, 1))
+    mover.start()
+    assert entered.wait(5) and s.moving
+    t0 = time.perf_counter()
+    s.submit(LOUD)                                           # float32 frame, 480 samples
+    s.submit_pcm16((np.full(512, 0.5) * 32767).astype("<i2").tobytes())
+    s.submit(LOUD)
+    assert time.perf_counter() - t0 < 0.05 and len(s._held) == 3 and s.moving       # returned at once, nothing reached an engine
+    release.set()
+    mover.join(5)
+    assert not s.moving and len(s._held) == 0 and pool.shard_of(s) == 1
+    pool.drain()
+    assert s.frames_done == 3 and got == ["S", 4 * 512, 4 * 480]      # START on the first, CONTINUE payloads of the next two, in order
+    pool.close()
+
+
+class _FailingTicks:
+    """tick_run raises for the first `n` calls, dropping one queued frame per stream like the engine does, and says whose"""
+
+    def __init__(self, eng, n):
+        self.eng, self.left, self.orig = eng, n, eng.tick_run
+
+    def __call__(self, denoise=0.01):
+        if self.left > 0:
+            self.left -= 1
+            q = self.eng.__dict__.setdefault("_tickq", {})
+            slots = [s for s in list(q) if q[s]]
+            lens = [int(q[s].pop(0)[1].size) for s in slots]
+            for s in slots:
+                if not q[s]:
+                    del q[s]
+            self.eng.last_tick_lost = (np.array(slots, np.int64), np.array(lens, np.int32))
+            self.eng.last_tick_staged_next = sum(len(v) for v in q.values())
+            raise RuntimeError("device fault (scripted)")
+        return self.orig(denoise)
+
+
+def test_backlog_counts_lost_frames_and_a_failed_tick_waits_its_interval():
+    pool, eng, _ = make_pool()
+    s = pool.open_session(VADConfig(voice_start_frame_count=1, buffer_size=480))
+    errors = []
+    s.set_callbacks(error_callback=errors.append)
+    eng.tick_run = _FailingTicks(eng, 100)
+    for _ in range(120):
+        s.submit(LOUD)
+    pool.backlog = 7                                         # left over by an earlier successful tick
+    for k in range(100):
+        assert pool.tick() == 0
+        assert pool.backlog == 0                             # the ticker does not hammer a failing engine back to back
+    assert s.lost == 100 and len(errors) == 100 and s.frames_done == 0
+    pool.drain()
+    assert s.frames_done == 20 and s.lost == 100             # sent 120 = stepped 20 + lost 100: the app's backlog is 0 again
+    pool.close()
+
+
+def test_a_paused_socket_is_read_again_after_a_failing_engine():
+    """`sent - frames_done` stayed high for ever after ~97 lost frames and the receive loop never read the socket again."""
+    import asyncio
+    from cutter_vad_amd.server import app as appmod
+    pool, eng, _ = make_pool()
+    s = pool.open_session(VADConfig(voice_start_frame_count=1, buffer_size=480))
+
+    class Client:
+        backlog = appmod.ClientSession.backlog
+        wait_for_pool = appmod.ClientSession.wait_for_pool
+        session, session_error, sent = s, None, 0
+    c = Client()
+    eng.tick_run = _FailingTicks(eng, 150)
+    for _ in range(150):
+        s.submit(LOUD)
+        c.sent += 1
+    for _ in range(150):
+        pool.tick()
+    assert s.lost == 150 and c.backlog() == 0                # accounted for: nothing to wait for
+    asyncio.run(asyncio.wait_for(c.wait_for_pool(0.001), 2))
+    # frames lost WITHOUT the engine saying whose (an old count, a bug): the wait is bounded by the pool's progress
+    c.sent += 200
+    t0 = __import__("time").time()
+    asyncio.run(asyncio.wait_for(c.wait_for_pool(0.001), 5))
+    assert c.backlog() == 0 and __import__("time").time() - t0 < 3
+    # a closed session ends the wait at once
+    c.sent += 200
+    s.close()
+    asyncio.run(asyncio.wait_for(c.wait_for_pool(0.001), 1))
+    pool.close()
+
+
+def test_loop_relay_does_not_keep_its_event_loop_alive():
+    import asyncio
+    import gc
+    import weakref
+    from cutter_vad_amd.server.app import _RELAYS, relay_of
+    loop = asyncio.new_event_loop()
+    r = relay_of(loop)
+    assert r.loop is loop and relay_of(loop) is r
+    wl, wr = weakref.ref(loop), weakref.ref(r)
+    loop.close()
+    del loop, r
+    gc.collect()
+    assert wl() is None and wr() is None and all(k is not None for k in _RELAYS.keys())

@@ -149,6 +149,38 @@ def test_frames_pushed_while_a_flush_is_in_the_engine_are_kept_for_the_next_one(
     assert counted == [1000, 300] and len(box) == 0
 
 
+def test_a_frame_pushed_during_a_flush_never_overtakes_its_sessions_earlier_frame():
+    """flush used to walk the live boxes with the GIL released per box, so a frame pushed in that window (the epoch
+    guard lets it through: its session's last frame carries the previous epoch) could leave in the SAME flush from a box not yet
+    visited, ahead of the session's earlier frame waiting in a box visited later.  Three boxes in creation order 512 B, 640 B,
+    1024 B; slot 2 has 1024 B queued and pushes 640 B from inside the first group's engine call."""
+    box = _wirebox.Inbox(2048)
+    other1, other2, two = box.pusher(1, True), box.pusher(3, True), box.pusher(2, True)
+    assert other1(bytes(512)) and other2(bytes(640))            # boxes 0 (512 B) and 1 (640 B)
+    assert two(b"\x01\x00" * 512)                                # box 2 (1024 B): slot 2's EARLIER frame
+    seen = []
+    pushed_inside = []
+
+    def entry(eng, slots, n, ptrs, nsamples, fmt, gate, status):
+        if not pushed_inside:                                    # first group in the engine: slot 2's LATER frame arrives now
+            pushed_inside.append(two(b"\x02\x00" * 320))
+        seen.extend((int(slots[i]), int(nsamples)) for i in range(n))
+        return 0
+
+    cb = GATHER(entry)
+    addr = C.cast(cb, C.c_void_p).value
+    assert box.flush(addr, 1) == []
+    # whether the push was taken or refused, slot 2's frames reach the engine in the order they were sent
+    if pushed_inside == [True]:
+        assert len(box) == 1
+        assert box.flush(addr, 1) == []
+    else:
+        assert len(box) == 0
+    mine = [ns for slot, ns in seen if slot == 2]
+    assert mine == ([512, 320] if pushed_inside == [True] else [512]), (seen, pushed_inside)
+    assert sorted(seen[:3]) == [(1, 256), (2, 512), (3, 320)]    # the first flush carried exactly the three frames queued before it
+
+
 def test_many_producers_and_a_flusher_lose_nothing():
     box = _wirebox.Inbox(64)
     total = []
