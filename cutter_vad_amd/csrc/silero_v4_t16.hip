@@ -40,14 +40,12 @@ namespace {
 constexpr int MT16 = 16;
 constexpr int QSL = 17;
 constexpr int QSD = 16;
-// STFT part: reflect-padded frame [16][176 quads] | folded operands of two columns [128 rows][QSL] | window [64] | small
+// STFT part: reflect-padded frame [16][176 quads] | folded operands of two columns [128 rows][QSL] | small
 constexpr int XPQ = 176;
 constexpr int U_XS = MT16 * XPQ;
 constexpr int U_UV = 128 * QSL;
-constexpr int U_WT = 64;
 constexpr int U_SMALL = 40;                       // nyqv [2][16], dcv [2][16], fcor [2][3][16] floats
-constexpr int K1_F4 = U_XS + U_UV + U_WT + U_SMALL;
-static_assert((U_XS + U_UV) % 16 == 0, "window table must start on a 16-quad boundary (XOR-swizzled reads)");
+constexpr int K1_F4 = U_XS + U_UV + U_SMALL;
 // tail: rows as in vad_layout.h v4 (33 t + q magnitudes, R_A16, R_Y*, R_H*), dense stride
 constexpr int T_ROWS = vadk::v4::MAG_ROWS + 16;
 constexpr int T_MISC_FLOATS = 16 + 8 * 16 + 2 * 4 * 16;      // mm [16], colmean [8][16], head partials [2 steps][4 waves][16]
@@ -133,8 +131,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
     __shared__ f32x4 lds[T16_LDS_F4];
     f32x4 *const XP = lds;
     f32x4 *const UV = lds + U_XS;
-    f32x4 *const WT = UV + U_UV;
-    float *const nyqv = reinterpret_cast<float *>(WT + U_WT);    // [2][16] |X128| of the two columns in flight
+    float *const nyqv = reinterpret_cast<float *>(UV + U_UV);    // [2][16] |X128| of the two columns in flight
     float *const dcv = nyqv + 32;                                 // [2][16] X0 (signed)
     float *const fcor = dcv + 32;                                 // [2 columns][y128, a64, b64][16 streams]
 
@@ -163,13 +160,16 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
     const int slot = live ? (P.slots ? P.slots[gf] : gf) : 0;
 
     STAMP(0);
-    // window of the stored basis for this thread's fold position n = 4 fq .. 4 fq + 3, and the window table for the float64 sums:
-    // requested BEFORE the frame (a wave's loads return in order - behind the frame they would arrive with its last byte)
+    // window of the stored basis for this thread's fold position n = 4 fq .. 4 fq + 3 (W1 = w[n] = w[256 - n], W3 = w[128 + n] =
+    // w[128 - n]: the packer checked the symmetry bit for bit): requested BEFORE the frame (a wave's loads return in order - behind the frame they would arrive with its last byte)
     const int fq = tid & 15, fms = tid >> 4;
     const int o_win = (int)P.sect[w][S_NYQ];
     const f32x4 W1 = ldw(wrs, fq * 16, o_win), W3 = ldw(wrs, (32 + fq) * 16, o_win);
     const float w64 = ldw(wrs, 16 * 16, o_win).x;                 // w[64] = w[192]
-    const f32x4 wtq = ldw(wrs, (tid & 63) * 16, o_win);
+    // ... and as doubles for the float64 sums of the two real bins: converted once per frame, not once per column they serve
+    const double W1d[4] = {(double)W1.x, (double)W1.y, (double)W1.z, (double)W1.w};
+    const double W3d[4] = {(double)W3.x, (double)W3.y, (double)W3.z, (double)W3.w};
+    const double w64d = (double)w64;
     f32x4 S0w[12];                                   // ... and so are the DFT blocks of the first column pair (6 k-iterations x {cos, -sin})
 #pragma unroll
     for (int k = 0; k < 12; ++k) S0w[k] = WL(o_stft + k);
@@ -206,7 +206,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
         }                                                                                                   \
         XP[fms * XPQ + 24 + 16 * (it) + fq] = gate4(v_, thr);                                               \
     }
-    if (tid < U_WT) WT[tid] = wtq;
     X_PUT(0) X_PUT(1) X_PUT(2) X_PUT(3)
     SB();
     X_ISSUE(4, 8)          // asked for only now: HBM serves every workgroup's first half first
@@ -241,6 +240,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
         asm volatile("" : "+s"(ws));
         if (grp == 2) X_MIRROR(true)      // pieces 6, 7 were stored before the barrier that ended column pair 1; read by pair 3's fold
         // ---- window + 4-way fold: stream fms, n = 4 fq + i, one column per pass (silero_v4.hip has the algebra)
+        double ed[2], od[2];                         // this lane's share of E = sum over even n of w[n] x[n], O = the odd n, per column
 #pragma unroll
         for (int cp = 0; cp < 2; ++cp) {
             const int Q0 = 16 * (2 * grp + cp);
@@ -260,12 +260,26 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
             f32x4 po = f32x4{s14.x - s23.x, s14.y - s23.y, s14.z - s23.z, s14.w - s23.w};
             f32x4 qe = f32x4{d14.x - d23.x, d14.y - d23.y, d14.z - d23.z, d14.w - d23.w};
             f32x4 qo = f32x4{d14.x + d23.x, d14.y + d23.y, d14.z + d23.z, d14.w + d23.w};
+            // ---- the two REAL bins, k = 0 and k = 128, in float64 straight from the samples (DESIGN.md §3 "Numerics"): X0 = E + O,
+            //      X128 = E - O.  The fold's own loads are the operands: this lane holds x[n], x[256 - n] (window w[n]) and x[128 - n],
+            //      x[128 + n] (window w[128 + n]) for n = 4 fq + i - the window is symmetric, so each PAIR is added in float64 (exact)
+            //      and multiplied once; parity of n = parity of i.  n = 0 has w = 0; n = 128 is its own partner (counted once).
+            {
+                const double a0 = (double)xA.x + (double)r2a.x, a1 = (double)xA.y + (double)r2b.w;
+                const double a2 = (double)xA.z + (double)r2b.z, a3 = (double)xA.w + (double)r2b.y;
+                const double b0 = (double)(fq == 0 ? 0.f : r1a.x) + (double)xC.x, b1 = (double)r1b.w + (double)xC.y;
+                const double b2 = (double)r1b.z + (double)xC.z, b3 = (double)r1b.y + (double)xC.w;
+                ed[cp] = __builtin_fma(W1d[0], a0, W3d[0] * b0) + __builtin_fma(W1d[2], a2, W3d[2] * b2);
+                od[cp] = __builtin_fma(W1d[1], a1, W3d[1] * b1) + __builtin_fma(W1d[3], a3, W3d[3] * b3);
+            }
             if (fq == 0) {
                 pe.x = po.x = qe.x = qo.x = 0.f;
-                const float y64 = xs[16].x * w64, y192 = xs[48].x * w64;
+                const float x64 = xs[16].x, x192 = xs[48].x;
+                const float y64 = x64 * w64, y192 = x192 * w64;
                 fcor[(cp * 3 + 0) * 16 + fms] = y3.x;           // y[128]
                 fcor[(cp * 3 + 1) * 16 + fms] = y64 + y192;     // a64
                 fcor[(cp * 3 + 2) * 16 + fms] = y64 - y192;     // b64
+                ed[cp] = __builtin_fma(w64d, (double)x64 + (double)x192, ed[cp]);      // n = 64, 192: even, unpaired by the fold
             }
             // the even bins k = 2 m fold once more, about n = 32 (vad_layout.h, bin_of_channel_t16): m even pairs pe[n] + pe[64 - n]
             // and qe[n] - qe[64 - n], m odd the opposite signs, n = 1..31; the unpaired n = 32 (lane 8, component 0) rides in the
@@ -284,34 +298,22 @@ __global__ void __launch_bounds__(NTHREADS, 2) silero_v4_step16(const StepParams
                 st2(&UV[(64 * cp + 56 + fq) * QSL + fms], qeo);
             }
         }
-        // ---- the two REAL bins, k = 0 and k = 128, in float64 straight from the samples (DESIGN.md §3 "Numerics"): X0 = E + O,
-        //      X128 = E - O with E / O = sum over even / odd n of w[n] xp[n].  32 (column, stream) pairs, 8 lanes each; lane (blk,
-        //      half) sums quads 16 blk + 8 half .. + 7, order XOR-swizzled so that 16 neighbouring lanes read 16 different banks
+        // ---- E, O of both columns summed over the stream's 16 lanes.  Four doubles per lane; instead of four butterflies of four
+        //      values each, every step HALVES what a lane carries: step 1 (lane ^ 8) leaves lanes 0..7 with column 0 and lanes 8..15
+        //      with column 1, step 2 (7 - lane within a half row) leaves the lower four lanes of a half with E and the upper four
+        //      with O, steps 3 and 4 finish inside a quad; then E and O meet once more.  27 instead of 48 float64-rate instructions.
         {
-            const int pair = tid >> 3, p8 = tid & 7;
-            const int cp = pair >> 4, ms = pair & 15;
-            const int blk = p8 >> 1, half = p8 & 1;
-            const unsigned sw = (unsigned)(4 * (ms & 1) + blk);
-            const unsigned bx = (((unsigned)(ms * XPQ + 16 * (2 * grp + cp) + 16 * blk + 8 * half)) ^ sw) << 4;   // byte offsets; bases are multiples of 8 quads
-            const unsigned bw = (((unsigned)(U_XS + U_UV + 16 * blk + 8 * half)) ^ sw) << 4;
-            const char *const lb = reinterpret_cast<const char *>(lds);
-            double e0 = 0., e1 = 0., o0 = 0., o1 = 0.;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x4 xv = *reinterpret_cast<const f32x4 *>(lb + (bx ^ (unsigned)(i << 4)));
-                const f32x4 wv = *reinterpret_cast<const f32x4 *>(lb + (bw ^ (unsigned)(i << 4)));
-                e0 = __builtin_fma((double)wv.x, (double)xv.x, e0);
-                o0 = __builtin_fma((double)wv.y, (double)xv.y, o0);
-                e1 = __builtin_fma((double)wv.z, (double)xv.z, e1);
-                o1 = __builtin_fma((double)wv.w, (double)xv.w, o1);
-            }
-            double e = e0 + e1, o = o0 + o1;
-            e += dpp_f64<0xB1>(e); o += dpp_f64<0xB1>(o);      // quad_perm [1,0,3,2]
-            e += dpp_f64<0x4E>(e); o += dpp_f64<0x4E>(o);      // quad_perm [2,3,0,1]
-            e += dpp_f64<0x141>(e); o += dpp_f64<0x141>(o);    // row_half_mirror: the other quad of the group of 8
-            if (p8 == 0) {
-                dcv[cp * 16 + ms] = (float)(e + o);
-                nyqv[cp * 16 + ms] = fabsf((float)(e - o));
+            const bool up8 = (fq & 8) != 0, up4 = (fq & 4) != 0;
+            const double se = up8 ? ed[0] : ed[1], so = up8 ? od[0] : od[1];       // what the lane gives away
+            double ke = up8 ? ed[1] : ed[0], ko = up8 ? od[1] : od[0];             // what it keeps
+            ke += dpp_f64<0x128>(se); ko += dpp_f64<0x128>(so);                     // row_ror:8
+            double v = (up4 ? ko : ke) + dpp_f64<0x141>(up4 ? ke : ko);             // row_half_mirror
+            v += dpp_f64<0xB1>(v);                                                  // quad_perm [1,0,3,2]
+            v += dpp_f64<0x4E>(v);                                                  // quad_perm [2,3,0,1]
+            const double other = dpp_f64<0x141>(v);                                 // lanes 0..3 of a half: E here, O there
+            if ((fq & 7) == 0) {
+                dcv[(fq >> 3) * 16 + fms] = (float)(v + other);
+                nyqv[(fq >> 3) * 16 + fms] = fabsf((float)(v - other));
             }
         }
         f32x4 Aw[2], Bw[2];
