@@ -228,20 +228,38 @@ def main() -> int:
     # identity = what this rank asked for (device ordinal under its visibility masks), not a property the runtime reports:
     # a runtime that reported one uuid for all GPUs must not be able to stop a legitimate run
     masks = "|".join(os.environ.get(k, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    pci = None                                         # "dddd:bb:dd" of the device this rank steps, when the runtime tells
     if not fake:
         pr = torch.cuda.get_device_properties(local_rank)
         ident = (socket.gethostname(), masks, local_rank)
-        shown = f"cuda:{local_rank} pci {getattr(pr, 'pci_bus_id', '?'):02x}" if isinstance(getattr(pr, "pci_bus_id", None), int) else f"cuda:{local_rank}"
+        bus = getattr(pr, "pci_bus_id", None)
+        if isinstance(bus, int):
+            pci = f"{int(getattr(pr, 'pci_domain_id', 0) or 0):04x}:{bus:02x}:{int(getattr(pr, 'pci_device_id', 0) or 0):02x}"
+        shown = f"cuda:{local_rank} pci {bus:02x}" if isinstance(bus, int) else f"cuda:{local_rank}"
     else:
         ident = (socket.gethostname(), masks, int(os.environ.get("VAD_BENCH_FAKE_DEVICE", local_rank)))
         shown = f"fake:{ident[2]}"
+        if os.environ.get("VAD_BENCH_FAKE_PCI"):       # "a,b,..." per rank (tests: two ranks that report one PCI id)
+            pci = os.environ["VAD_BENCH_FAKE_PCI"].split(",")[rank]
+    single = os.environ.get("VAD_BENCH_SINGLE_DEVICE") == "1"
     dup = sharding.duplicate_devices(cp.gather(ident))
-    if dup and os.environ.get("VAD_BENCH_SINGLE_DEVICE") != "1":
+    if dup and not single:
         if rank == 0:
             sys.stderr.write(f"bench.py: ranks {dup[0][0]} and {dup[0][1]} map to the same GPU {dup[0][2]}; refusing to report "
                              f"n_gpus = {world} for fewer devices (LOCAL_RANK -> device map)\n")
         cp.close()
         return 2
+    # ... and the hardware's own word for it: with more than one rank the PCI addresses must be pairwise distinct (the identity
+    # above is what the ranks ASKED for; two ordinals that resolve to one physical device would pass it)
+    pcis = cp.gather((socket.gethostname(), pci))
+    if world > 1 and not single and all(p[1] is not None for p in pcis):
+        dup = sharding.duplicate_devices(pcis)
+        if dup:
+            if rank == 0:
+                sys.stderr.write(f"bench.py: ranks {dup[0][0]} and {dup[0][1]} step the same physical GPU (PCI {dup[0][2][1]}); refusing "
+                                 f"to report n_gpus = {world} for fewer devices\n")
+            cp.close()
+            return 2
 
     B = args.streams
     first_stream, _ = sharding.stream_shard(world * B, world, rank)   # weak scaling: B streams per rank
@@ -255,7 +273,7 @@ def main() -> int:
             for i in range(args.steps):
                 stepper.step(i)
         elapsed, own = sharding.timed_region_detail(cp, run, sync)
-        preamble, ring_h, gpu_probs, versions = 0, None, None, [5]
+        preamble, ring_h, gpu_probs, versions = 0, None, None, ([5] if args.mix == "v5" else [5, 4])
     else:
         from cutter_vad_amd import weights_io
         from cutter_vad_amd.engine import Engine
@@ -322,7 +340,7 @@ def main() -> int:
             assert bool(torch.isfinite(p).all()) and float(p.min()) >= 0.0 and float(p.max()) <= 1.0
 
     # every rank's own figures, so that a straggler is visible behind the MAX
-    per_rank = cp.gather({"rank": rank, "device": shown,
+    per_rank = cp.gather({"rank": rank, "device": shown, "pci": pci,
                           "kernel_us": None if kernel_s[0] is None else kernel_s[0] * 1e6,
                           "ms_per_step": own / args.steps * 1e3, "frames_per_s": B * args.steps / own})
     if rank == 0:
@@ -330,8 +348,18 @@ def main() -> int:
         mixed = len(versions) > 1
         workload = ("configs[2]: batch=8192 concurrent streams per GPU, Silero V5, 16 kHz, one 512-sample frame per stream "
                     "per step, denoise gate 0.01, state machine on") if not mixed else (
-                    "configs[4] per-GPU share: 4096 Silero V4 + 4096 Silero V5 streams per GPU (two engines, two HIP streams), "
-                    "16 kHz, one 512-sample frame per stream per step, denoise gate 0.01, state machines on")
+                    f"configs[4]: batch={world * B} streams sharded {B}/GPU across {world} x MI355X, Silero V4 + V5 mixed - per GPU "
+                    f"{B // 2} Silero V4 + {B // 2} Silero V5 streams (two engines, two HIP streams), 16 kHz, one 512-sample frame per "
+                    "stream per step, denoise gate 0.01, state machines on" + ("" if world == 8 and B == B_PER_GPU else
+                    f" [configs[4] as stated is 8 GPUs x {B_PER_GPU}: this run is its {world}-GPU share]"))
+        # how evenly the ranks ran: behind the MAX the slowest rank sets the line's time
+        kus = [r["kernel_us"] for r in per_rank if r["kernel_us"] is not None]
+        best = max(r["frames_per_s"] for r in per_rank)
+        ranks = {"kernel_us": ({"min": min(kus), "max": max(kus), "mean": sum(kus) / len(kus)} if kus else None),
+                 "best_rank_frames_per_s": best,
+                 # value / (N x the best single rank's own rate): 1.0 = every rank as fast as the fastest and no time lost at the
+                 # barrier.  NOT the scaling efficiency across N - the driver computes that from the per-N lines.
+                 "scaling_efficiency": value / (world * best)}
         out = {
             "metric": "512-sample frames/sec, Silero V5 16kHz, batch=8192 streams per GPU" if not mixed else
                       "512-sample frames/sec, Silero V4 + V5 mixed, 8192 streams per GPU",
@@ -349,6 +377,7 @@ def main() -> int:
             "config": {
                 "workload": workload,
                 "streams_per_gpu": B,
+                "streams_total": world * B,
                 "frames_per_step_per_gpu": B,
                 "ring_frames": RING,
                 "sharding": f"{world} independent per-GPU stream pools, no collective",
@@ -356,6 +385,7 @@ def main() -> int:
             "preamble_steps": preamble,
             "control_plane": cp.backend or "none (single process)",
             "per_rank": per_rank,
+            "ranks": ranks,
         }
         if cp.fallback_reason:
             out["control_plane_fallback"] = cp.fallback_reason

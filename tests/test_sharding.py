@@ -144,6 +144,33 @@ def test_bench_survives_a_failing_rccl_and_refuses_two_ranks_on_one_device():
     assert r.returncode != 0 and "map to the same GPU" in r.stderr and not [x for x in r.stdout.splitlines() if x.startswith("{")]
 
 
+def test_bench_line_checks_itself_before_the_first_8_gpu_run():
+    """pairwise distinct PCI addresses when world > 1, min / max / mean kernel time and the within-run
+    efficiency over the ranks, and `--mix v4v5 --gpus N` naming configs[4] with its total stream count."""
+    import json
+    # two ranks whose ordinals differ but whose devices answer with ONE PCI address: refused
+    r = _bench("--gpus", "2", "--steps", "5", "--warmup", "1", VAD_BENCH_FAKE="1", VAD_BENCH_FAKE_PCI="0000:05:00,0000:05:00")
+    assert r.returncode != 0 and "same physical GPU (PCI 0000:05:00)" in r.stderr and not [x for x in r.stdout.splitlines() if x.startswith("{")]
+    # distinct addresses: the line carries them, the spread over the ranks and the efficiency against the best rank
+    r = _bench("--gpus", "2", "--steps", "10", "--warmup", "1", "--mix", "v4v5", VAD_BENCH_FAKE="1", VAD_BENCH_FAKE_PCI="0000:05:00,0000:15:00")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")][0]
+    assert [x["pci"] for x in out["per_rank"]] == ["0000:05:00", "0000:15:00"]
+    best = max(x["frames_per_s"] for x in out["per_rank"])
+    assert out["ranks"]["best_rank_frames_per_s"] == pytest.approx(best)
+    assert out["ranks"]["scaling_efficiency"] == pytest.approx(out["value"] / (2 * best)) and 0.5 < out["ranks"]["scaling_efficiency"] <= 1.0
+    assert out["ranks"]["kernel_us"] is None                                     # the fake step has no kernel
+    assert out["config"]["streams_total"] == 2 * 8192 and out["config"]["streams_per_gpu"] == 8192
+    assert out["config"]["workload"].startswith("configs[4]: batch=16384 streams sharded 8192/GPU across 2 x MI355X, Silero V4 + V5 mixed")
+    assert "its 2-GPU share" in out["config"]["workload"] and "V4 + V5 mixed" in out["metric"]
+    # at the north-star size the workload IS configs[4] (string only: eight fake ranks are eight processes of one core each)
+    r = _bench("--gpus", "8", "--steps", "3", "--warmup", "0", "--mix", "v4v5", VAD_BENCH_FAKE="1")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")][0]
+    assert out["n_gpus"] == 8 and out["config"]["streams_total"] == 65536 and len(out["per_rank"]) == 8
+    assert out["config"]["workload"].startswith("configs[4]: batch=65536 streams sharded 8192/GPU across 8 x MI355X") and "share]" not in out["config"]["workload"]
+
+
 def test_bench_refuses_to_run_fewer_gpus_than_asked():
     r = _bench("--gpus", "8")                                 # no GPU in the CPU suite's container; 1 on a gpurun box
     assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()
