@@ -13,7 +13,6 @@ import ctypes
 import os
 import re
 import shutil
-import subprocess
 import sys
 import types
 
@@ -28,12 +27,8 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "real
 
 def _standin_library(tmp) -> str:
     """csrc/engine.cpp as a shared library over the HIP stand-in (tools/san_tick): every C-ABI entry point, no device."""
-    out = os.path.join(str(tmp), "libvad_engine.so")
-    src = ["tools/san_tick/fake_kernels.cpp", "cutter_vad_amd/csrc/engine.cpp", "cutter_vad_amd/csrc/pack_weights.cpp",
-           "cutter_vad_amd/csrc/resample_tables.cpp"]
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Itools/san_tick", "-Icutter_vad_amd/csrc", "-o", out,
-                           *src, "-lpthread"], cwd=ROOT)
-    return out
+    from tests import standin
+    return standin.build(tmp, "-O1")
 
 
 def _doc_stub_source() -> str:

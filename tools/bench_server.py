@@ -153,6 +153,91 @@ def run_rates(n, ticks=40):
             "real_time_factor": (n * ticks / (t_sub + t_tick)) / (n * 1000 / 32), "events": counts}
 
 
+def run_fake_shards(n_shards, sessions, ticks=60, talking=0.5):
+    """Host-side rehearsal of the north-star size (65 536 sessions = 8 GPUs x 8 192) WITHOUT GPUs: `n_shards` engines of the REAL
+    host code (csrc/engine.cpp: tick assembler, segment arena, the C ABI) over the HIP stand-in of tools/san_tick/ (tests/standin.py:
+    host stand-ins for the kernel launches, p = |first sample|), behind ShardedStreamPool - one pool, one ticker thread per shard -
+    with the C inbox and the reference server's callbacks (voice_continue as a notification).  What it measures is everything the
+    serving process does on the host per 30 ms of audio of every client: `submit_pcm16` per session on ONE thread (the event loop's
+    role), then every shard's tick on its own thread, side by side under one GIL.  Half the sessions talk (their frames open and close
+    segments: START / CONTINUE per frame / END with a WAV payload), half are silent."""
+    import threading
+    from cutter_vad_amd import _ffi, weights_io
+    from cutter_vad_amd.pool import EnginePool
+    from tests import standin
+    _ffi.LIB_PATH = standin.build(os.path.join(os.path.dirname(os.path.abspath(__file__)), "san_tick", "_build"))
+    per = sessions // n_shards
+    pool = ShardedStreamPool(shards=[SharedStreamPool(max_streams=per, pool=EnginePool(), device_id=0) for _ in range(n_shards)])
+    assert all(p._wire is not None and p._wire_entry is not None for p in pool.shards), "the C inbox is part of what is measured"
+    cfg = VADConfig(vad_start_probability=0.4, vad_end_probability=0.3, voice_start_frame_count=6, voice_end_frame_count=12, buffer_size=480)
+    counts = {"start": 0, "end": 0, "continue": 0, "wav_bytes": 0}
+    lock = threading.Lock()                     # callbacks run on eight ticker threads
+
+    def on_start():
+        with lock:
+            counts["start"] += 1
+
+    def on_end(wav):
+        with lock:
+            counts["end"] += 1
+            counts["wav_bytes"] += len(wav)
+
+    def on_cont(pcm):
+        counts["continue"] += 1                 # (unlocked on purpose: the reference's handler only formats a message)
+    t0 = time.perf_counter()
+    sess = []
+    for k in range(sessions):
+        s = pool.open_session(cfg, shard=k % n_shards)
+        s.set_callbacks(on_start, on_end, on_cont, continue_payload=False)
+        sess.append(s)
+    t_open = time.perf_counter() - t0
+    # the stand-in model's probability is |first sample|
+    loud = np.zeros(480, "<i2"); loud[0] = int(0.9 * 32767); loud[1:] = (np.random.default_rng(1).standard_normal(479) * 3000).astype("<i2")
+    quiet = np.zeros(480, "<i2")
+    loud_b, quiet_b = loud.tobytes(), quiet.tobytes()
+    n_talk = int(sessions * talking)
+    tick_wall = [[] for _ in range(n_shards)]
+    for k, p in enumerate(pool.shards):         # per-shard tick wall time, measured inside its own thread
+        orig = p.tick
+
+        def timed(orig=orig, k=k):
+            a = time.perf_counter()
+            n = orig()
+            tick_wall[k].append(time.perf_counter() - a)
+            return n
+        p.tick = timed
+    t_sub = t_tick = 0.0
+    warm = 5
+    # a talker's 40-tick cycle (20 loud, 20 quiet) starts at its own phase, so STARTs and ENDs (a WAV payload each) are spread
+    # over the ticks as they are among real clients, instead of 32 768 segments ending in one tick
+    rows = [[(loud_b if ((t + k) % 40) < 20 else quiet_b) if k < n_talk else quiet_b for k in range(sessions)] for t in range(40)]
+    for t in range(ticks + warm):
+        row = rows[t % 40]
+        a = time.perf_counter()
+        for s, f in zip(sess, row):
+            s.submit_pcm16(f)
+        b = time.perf_counter()
+        n = pool.tick()
+        c = time.perf_counter()
+        assert n == sessions, n
+        if t >= warm:
+            t_sub += b - a
+            t_tick += c - b
+        else:
+            for w in tick_wall:
+                w.clear()
+    per_shard = [{"mean_ms": float(np.mean(w)) * 1e3, "max_ms": float(np.max(w)) * 1e3} for w in tick_wall]
+    stats = pool.stats()
+    pool.close()
+    per_round = (t_sub + t_tick) / ticks
+    return {"mode": "fake shards (real engine.cpp + _wirebox + pools; kernels = host stand-ins, tools/san_tick)", "shards": n_shards,
+            "sessions": sessions, "sessions_per_shard": per, "talking_fraction": talking, "ticks": ticks, "host_cores": os.cpu_count(),
+            "open_all_sessions_s": t_open, "submit_ms_per_round": t_sub / ticks * 1e3, "tick_all_shards_ms_per_round": t_tick / ticks * 1e3,
+            "per_shard_tick_wall": per_shard, "round_ms": per_round * 1e3, "audio_ms_per_round": 30.0,
+            "real_time_factor": 0.030 / per_round, "frames_per_s_host_inclusive": sessions / per_round,
+            "frames_per_launch": stats["frames_per_launch"], "events": counts}
+
+
 def warm_arena():
     """The engine's segment arena grows by 8 MB chunks and first-touches them inside the tick (≈ 0.15 ms of page faults per tick at
     8 192 talking sessions while it grows); closed sessions hand their blocks back, so a server that has been up for a minute runs
@@ -162,10 +247,18 @@ def warm_arena():
 
 
 if __name__ == "__main__":
+    if "--fake-shards" in sys.argv:
+        sys.argv.append("--cold")                  # no GPU in this mode
     if "--cold" not in sys.argv:
         warm_arena()
     else:
         sys.argv.remove("--cold")
+    if "--fake-shards" in sys.argv:
+        i = sys.argv.index("--fake-shards")
+        shards = int(sys.argv[i + 1])
+        n = int(sys.argv[sys.argv.index("--sessions") + 1]) if "--sessions" in sys.argv else 8192 * shards
+        print(json.dumps(run_fake_shards(shards, n)), flush=True)
+        sys.exit(0)
     if "--devices" in sys.argv:
         i = sys.argv.index("--devices")
         DEVICES = [int(d) for d in sys.argv[i + 1].split(",")]
