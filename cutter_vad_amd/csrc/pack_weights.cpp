@@ -186,6 +186,31 @@ void pack_dft4_wave_128_t16(StreamBuilder &sb, int w) {
     }
 }
 
+// STFT blocks of the once-more-folded DFT (vad_layout.h, v5::bin_of_channel_fold3), 16-row tiles for v_mfma_f32_16x16x4_f32.
+// Row tile 0 = 16 odd bins against the 4-way folded operands po | qo, K = 64: k-iterations j = 0..3 (n = 16 j .. 16 j + 15; n = 0 is
+// an unused slot), {cos, -sin} each.  Row tile 1 = 16 even bins k = 2 m against the operands folded once more about n = 32
+// (cos(2 pi m (64 - n) / 128) = (-1)^m cos(2 pi m n / 128), the sine with the opposite sign), K = 32: k-iterations j = 0, 1
+// (n = 16 j .. 16 j + 15), {cos, -sin} each.  Slot n = 0 of those operands carries the sample the second fold cannot pair,
+// n = 32: pe[32] for m even (weight cos(pi m / 2)), qe[32] for m odd (weight -sin(pi m / 2)); the other two are zero.
+void pack_dft_fold3_wave(StreamBuilder &sb, int w) {
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int j = 0; j < 4; ++j)
+        for (int part = 0; part < 2; ++part)
+            sb.weight_block16([&](int r, int n) {
+                const int k = v5::bin_of_channel_fold3(32 * w + r);
+                const double ph = two_pi * (double)((k * n) & 255) / 256.0;
+                return n == 0 ? 0.f : (float)(part == 0 ? std::cos(ph) : -std::sin(ph));
+            }, j);
+    for (int j = 0; j < 2; ++j)
+        for (int part = 0; part < 2; ++part)
+            sb.weight_block16([&](int r, int n) {
+                const int k = v5::bin_of_channel_fold3(32 * w + 16 + r), m = k / 2;
+                const double ph = two_pi * (double)((k * (n == 0 ? 32 : n)) & 255) / 256.0;
+                if (n == 0 && (part == 0) != (m % 2 == 0)) return 0.f;       // pe[32] enters the even m, qe[32] the odd m
+                return (float)(part == 0 ? std::cos(ph) : -std::sin(ph));
+            }, j);
+}
+
 void pack_dft4_wave(StreamBuilder &sb, int w) {
     const double two_pi = 6.283185307179586476925286766559;
     for (int j = 0; j < 8; ++j) {
@@ -230,6 +255,7 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
     if (!err.empty()) return false;
     if (!check_stft_symmetry(stft, err, N)) return false;
     if (!check_windowed_dft(stft, err, N)) return false;
+    if (!k8 && !check_even_bin_fold(err)) return false;
 
     StreamBuilder sb;
     auto convw = [&](int layer, int o, int c, int tap) -> float {
@@ -239,7 +265,7 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
         // STFT on the folded input (vad_layout.h): bins 32w..32w+31, {re, im} per k-iteration;
         // k-iteration j contracts n = 8j+1 .. 8j+8 (quad 2j on the lower half-wave, 2j+1 on the upper)
         out.sect[w][S_STFT] = sb.blocks();
-        if (!k8) pack_dft4_wave(sb, w);
+        if (!k8) pack_dft_fold3_wave(sb, w);              // 128 bins: an odd and an even 16-row tile per wave, even bins folded once more
         else pack_dft4_wave_128_t16(sb, w);               // 64 bins = four 16-row tiles, one per wave
         // enc0 as a Toom-3 product (vad_layout.h): out channels 32w.., per k-iteration the five point-wise weight blocks
         // V(0) = w2, V(1)/2, V(-1)/2, V(2), V(inf) = w0 of V(z) = w2 + w1 z + w0 z^2 (evaluated in double); then the
@@ -259,7 +285,7 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
         };
         for (int j = 0; j < (k8 ? 8 : 16); ++j)
             for (int p = 0; p < 5; ++p)
-                sb.weight_block([&](int np, int c) { return toom(32 * w + np, k8 ? bin_of_channel_8k(c) : bin_of_channel(c), p); }, j);
+                sb.weight_block([&](int np, int c) { return toom(32 * w + np, k8 ? bin_of_channel_8k(c) : bin_of_channel_fold3(c), p); }, j);
         {
             float *a = sb.new_block();
             for (int l = 0; l < 32; ++l)
@@ -369,16 +395,10 @@ bool pack_silero_v5_t16(const void *blob, size_t len, PackedWeights &out, std::s
         }
     };
     for (int w = 0; w < NWAVES; ++w) {
-        // STFT: per k-iteration (n = 16 j .. 16 j + 15): cos rt0, cos rt1, -sin rt0, -sin rt1
+        // STFT: the once-more-folded DFT (pack_dft_fold3_wave): row tile 0 = odd bins (4 k-iterations x {cos, -sin}), row tile 1 =
+        // even bins on the operands folded again about n = 32 (2 k-iterations x {cos, -sin})
         out.sect[w][S_STFT] = sb.blocks();
-        for (int j = 0; j < 4; ++j)
-            for (int part = 0; part < 2; ++part)
-                for (int rt = 0; rt < 2; ++rt)
-                    sb.weight_block16([&](int r, int n) {
-                        const int k = bin_of_channel(32 * w + 16 * rt + r);
-                        const double ph = two_pi * (double)((k * n) & 255) / 256.0;
-                        return n == 0 ? 0.f : (float)(part == 0 ? std::cos(ph) : -std::sin(ph));
-                    }, j);
+        pack_dft_fold3_wave(sb, w);
         // enc0 (Toom-3): bias rt0, rt1; per k-iteration the five points x two row tiles; Nyquist channel: points 0,1,-1,2 in the
         // components of lanes kq = 0 (the other channel groups carry zeros), rt0, rt1; then the point at infinity, rt0, rt1
         out.sect[w][S_ENC0] = sb.blocks();
@@ -386,7 +406,7 @@ bool pack_silero_v5_t16(const void *blob, size_t len, PackedWeights &out, std::s
         for (int j = 0; j < 8; ++j)
             for (int p = 0; p < 5; ++p)
                 for (int rt = 0; rt < 2; ++rt)
-                    sb.weight_block16([&](int r, int c) { return toom(32 * w + 16 * rt + r, bin_of_channel(c), p); }, j);
+                    sb.weight_block16([&](int r, int c) { return toom(32 * w + 16 * rt + r, bin_of_channel_fold3(c), p); }, j);
         for (int part = 0; part < 2; ++part)
             for (int rt = 0; rt < 2; ++rt) {
                 float *a = sb.new_block();
@@ -954,28 +974,8 @@ bool pack_silero_v4_t16(const void *blob, size_t len, PackedWeights &out, std::s
         for (int k = 0; k < S_COUNT; ++k) out.sect[w][k] = sec[k];
         out.sect[w][S_LSTM0] = lstm_sec[0][w];
         out.sect[w][S_LSTM1] = lstm_sec[1][w];
-        // STFT (vad_layout.h, v4::bin_of_channel_t16).  Row tile 0 = 16 odd bins against the 4-way folded operands po | qo, K = 64:
-        // k-iterations j = 0..3 (n = 16 j .. 16 j + 15; n = 0 is an unused slot), {cos, -sin} each.  Row tile 1 = 16 even bins
-        // k = 2 m against the operands folded once more about n = 32 (cos(2 pi m (64 - n) / 128) = (-1)^m cos(2 pi m n / 128), the sine
-        // with the opposite sign), K = 32: k-iterations j = 0, 1 (n = 16 j .. 16 j + 15), {cos, -sin} each.  Slot n = 0 of those
-        // operands carries the sample the second fold cannot pair, n = 32: pe[32] for m even (weight cos(pi m / 2)), qe[32] for m
-        // odd (weight -sin(pi m / 2)); the other two are zero.
         out.sect[w][S_STFT] = sb.blocks();
-        for (int j = 0; j < 4; ++j)
-            for (int part = 0; part < 2; ++part)
-                sb.weight_block16([&](int r, int n) {
-                    const int k = bin_of_channel_t16(32 * w + r);
-                    const double ph = two_pi * (double)((k * n) & 255) / 256.0;
-                    return n == 0 ? 0.f : (float)(part == 0 ? std::cos(ph) : -std::sin(ph));
-                }, j);
-        for (int j = 0; j < 2; ++j)
-            for (int part = 0; part < 2; ++part)
-                sb.weight_block16([&](int r, int n) {
-                    const int k = bin_of_channel_t16(32 * w + 16 + r), m = k / 2;
-                    const double ph = two_pi * (double)((k * (n == 0 ? 32 : n)) & 255) / 256.0;
-                    if (n == 0 && (part == 0) != (m % 2 == 0)) return 0.f;       // pe[32] enters the even m, qe[32] the odd m
-                    return (float)(part == 0 ? std::cos(ph) : -std::sin(ph));
-                }, j);
+        pack_dft_fold3_wave(sb, w);
     }
     out.data = std::move(sb.data);
     return true;

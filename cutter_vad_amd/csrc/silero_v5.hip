@@ -204,6 +204,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
             auto mirror = [](float v) -> float {      // every lane of a row has a source: no `old` value to materialise
                 return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K8 ? 0x141 : 0x140, 0xf, 0xf, true));
             };
+            auto shl8 = [](float v) -> float {        // row_shl:8: lane q gets lane q + 8 (lanes 8..15: zero)
+                return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x108, 0xf, 0xf, true));
+            };
             auto shr1 = [&](float edge, float v) -> float {
                 const float r = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
                 return (K8 && q0) ? edge : r;
@@ -242,10 +245,33 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
         }                                                                                                       \
         /* stored as two 8-byte halves each: the sums come out of the packed adds as register PAIRS, a 16-byte store      \
            would first copy them into four consecutive registers */                                            \
-        st2(&RX[(CS * (c) + q) * QS + ms], pe);                                                                 \
-        st2(&RX[(CS * (c) + QL + q) * QS + ms], po);                                                            \
-        st2(&RX[(CS * (c) + 2 * QL + q) * QS + ms], qe);                                                        \
-        st2(&RX[(CS * (c) + 3 * QL + q) * QS + ms], qo);                                                        \
+        if constexpr (K8) {                                                                                     \
+            st2(&RX[(CS * (c) + q) * QS + ms], pe);                                                             \
+            st2(&RX[(CS * (c) + QL + q) * QS + ms], po);                                                        \
+            st2(&RX[(CS * (c) + 2 * QL + q) * QS + ms], qe);                                                    \
+            st2(&RX[(CS * (c) + 3 * QL + q) * QS + ms], qo);                                                    \
+        } else {                                                                                                \
+            /* 16 kHz: the odd bins contract po | qo as they are; the even bins' operands fold once more, about n = 32      \
+               (vad_layout.h, bin_of_channel_fold3): partner of n = 4q + i is 64 - n = lane 16 - q component 0 (i = 0: row_mirror \
+               then row_shr:1) or lane 15 - q components 3, 2, 1 (row_mirror).  Lanes q < 8 hold n = 0..31 and store; lanes      \
+               q >= 8 hold the same values again and drop them into sink rows (a select on the address, no branch: the fold   \
+               stays in the MFMAs' basic block).  Slot n = 0 carries the unpaired n = 32 (lane 8, component 0): pe[32] | qe[32] */ \
+            const f32x4 pm = f32x4{shr1(0.f, mirror(pe.x)), mirror(pe.w), mirror(pe.z), mirror(pe.y)};           \
+            const f32x4 qm = f32x4{shr1(0.f, mirror(qe.x)), mirror(qe.w), mirror(qe.z), mirror(qe.y)};           \
+            f32x4 pep = f32x4{pe.x + pm.x, pe.y + pm.y, pe.z + pm.z, pe.w + pm.w};                              \
+            f32x4 pen = f32x4{pe.x - pm.x, pe.y - pm.y, pe.z - pm.z, pe.w - pm.w};                              \
+            f32x4 qen = f32x4{qe.x - qm.x, qe.y - qm.y, qe.z - qm.z, qe.w - qm.w};                              \
+            f32x4 qep = f32x4{qe.x + qm.x, qe.y + qm.y, qe.z + qm.z, qe.w + qm.w};                              \
+            const float pe32 = shl8(pe.x), qe32 = shl8(qe.x);                                                   \
+            pep.x = q0 ? pe32 : pep.x; pen.x = q0 ? 0.f : pen.x; qen.x = q0 ? 0.f : qen.x; qep.x = q0 ? qe32 : qep.x; \
+            st2(&RX[(CS * (c) + q) * QS + ms], po);                                                             \
+            st2(&RX[(CS * (c) + 16 + q) * QS + ms], qo);                                                        \
+            const int er = (q < 8 ? CS * (c) + 32 + q : ROW_FOLD_SINK - 8 + q) * QS + ms;                       \
+            st2(&RX[er], pep);                                                                                  \
+            st2(&RX[er + 8 * QS], pen);                                                                         \
+            st2(&RX[er + 16 * QS], qen);                                                                        \
+            st2(&RX[er + 24 * QS], qep);                                                                        \
+        }                                                                                                       \
     }
 #define H_LDW(WS, g) _Pragma("unroll") for (int k = 0; k < 8; ++k) WS[k] = WL(wh + 8 * (g) + k);
 #define H_MMA(WS, g)                                                                                            \
@@ -319,9 +345,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
             const int c = pair >> 5, ms = pair & 31;
             float a = 0.f;
             if (pr < 24) {
+                // 16 kHz: sum_n pe[n] (-1)^n over n = 1..63 = the same alternating sum over pe[n] + pe[64 - n], n = 1..31, plus
+                // pe[32] - which is what the pe+ rows hold (slot 0 = pe[32], sign +)
+                constexpr int NQ = K8 ? QL / 2 : 4, R0 = K8 ? 0 : 32;
 #pragma unroll
-                for (int i = 0; i < QL / 2; ++i) {
-                    const f32x4 pp = RX[(CS * c + half * (QL / 2) + i) * QS + ms];
+                for (int i = 0; i < NQ; ++i) {
+                    const f32x4 pp = RX[(CS * c + R0 + half * NQ + i) * QS + ms];
                     a += (pp.x - pp.y) + (pp.z - pp.w);
                 }
             }
@@ -414,44 +443,72 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
             }
         } else
         {
-            // The accumulators START from the rank-1 terms of n = 0, 64, 128 (the samples the fold cannot pair), so the
-            // epilogue only takes magnitudes.  Register 4g+i holds tile row r = 8g+4h+i: (-1)^r = (-1)^i.
-            //   even bins: re += y128 + a64 (-1)^r ; odd bins: re -= y128, im -= b64 (-1)^r
-            const bool even = K8 ? w == 0 : w < 2;          // this wave's bins: even | odd
-            const bool stft_wave = !K8 || w < 2;             // 8 kHz: 64 complex bins = two tiles, waves 2 / 3 have none
-            f32x16 are[3], aim[3];
+            // 16 kHz: wave w owns the channels 32 w .. 32 w + 31 as TWO 16-row tiles on v_mfma_f32_16x16x4_f32 (lane = (stream
+            // n16 + 16 sh, channel group kq); vad_layout.h, bin_of_channel_fold3): row tile 0 = 16 odd bins, cos on po, -sin on qo,
+            // K = 64 (k-iterations 0..3); row tile 1 = 16 even bins on the once-more-folded operands pe+- | qe-+ (waves 2, 3 | waves
+            // 0, 1), K = 32 (k-iterations 4, 5).  288 half-length MFMAs per wave instead of 192 full ones: three quarters.
+            // The accumulators START from the rank-1 terms of n = 0, 64, 128 (the samples the fold cannot pair), so the epilogue
+            // only takes magnitudes; tile row r = 4 kq + i, (-1)^r = (-1)^i:
+            //   odd k: re = -y128, im = -+ b64 (sin(pi k / 2) alternates along the rows); even k = 2 m: re = y128 + (-1)^m a64, im = 0
+            const int n16 = lane & 15, kq = lane >> 4;
+            const bool mo = w < 2;                           // this wave's even tile: m odd | m even
+            f32x4 sre[3][2][2], sim[3][2][2];                // [column][stream half][row tile]
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float y128 = fcor[(c * 3 + 0) * 32 + m], a64 = fcor[(c * 3 + 1) * 32 + m], b64 = fcor[(c * 3 + 2) * 32 + m];
-                const float rp = even ? y128 + a64 : -y128, rm = even ? y128 - a64 : -y128;
-                const float ip = even ? 0.f : -b64, im_ = even ? 0.f : b64;
-                const f32x4 qr = f32x4{rp, rm, rp, rm}, qi = f32x4{ip, im_, ip, im_};
-                are[c] = acc_of(qr, qr, qr, qr);
-                aim[c] = acc_of(qi, qi, qi, qi);
-            }
-            const int rR = even ? 0 : QL, rI = even ? 2 * QL : 3 * QL;     // even bins read pe / qe, odd bins po / qo
-            const f32x4 *const XR = RX + rR * QS + hq, *const XI = RX + rI * QS + hq;
-            if (stft_wave) {
-            f32x4 Au0 = XR[0], Au1 = XR[CS * QS], Au2 = XR[2 * CS * QS];
-            f32x4 Av0 = XI[0], Av1 = XI[CS * QS], Av2 = XI[2 * CS * QS];
-            f32x4 Bre, Bim, Bu0, Bu1, Bu2, Bv0, Bv1, Bv2;
-#define STFT_LD(S, jj)                                                                     \
-    S##re = WL(ws_stft + 2 * (jj)); S##im = WL(ws_stft + 2 * (jj) + 1);                    \
-    S##u0 = XR[(2 * (jj)) * QS]; S##u1 = XR[(CS + 2 * (jj)) * QS]; S##u2 = XR[(2 * CS + 2 * (jj)) * QS]; \
-    S##v0 = XI[(2 * (jj)) * QS]; S##v1 = XI[(CS + 2 * (jj)) * QS]; S##v2 = XI[(2 * CS + 2 * (jj)) * QS];
-#define STFT_MMA(S)                                                                        \
-    are[0] = mfma4(S##re, S##u0, are[0]); are[1] = mfma4(S##re, S##u1, are[1]); are[2] = mfma4(S##re, S##u2, are[2]); \
-    aim[0] = mfma4(S##im, S##v0, aim[0]); aim[1] = mfma4(S##im, S##v1, aim[1]); aim[2] = mfma4(S##im, S##v2, aim[2]);
-            for (int j = 0; j < NJ; j += 2) {
-                STFT_LD(B, j + 1) SB();
-                STFT_MMA(A) SB();
-                const int jn = j + 2 < NJ ? j + 2 : NJ - 2;
-                STFT_LD(A, jn) SB();
-                STFT_MMA(B) SB();
-            }
-#undef STFT_LD
-#undef STFT_MMA
-            }
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int sh = 0; sh < 2; ++sh) {
+                    const int ms = n16 + 16 * sh;
+                    const float y128 = fcor[(c * 3 + 0) * 32 + ms], a64 = fcor[(c * 3 + 1) * 32 + ms], b64 = fcor[(c * 3 + 2) * 32 + ms];
+                    const float re1 = mo ? y128 - a64 : y128 + a64;
+                    sre[c][sh][0] = f32x4{-y128, -y128, -y128, -y128};
+                    sim[c][sh][0] = f32x4{-b64, b64, -b64, b64};
+                    sre[c][sh][1] = f32x4{re1, re1, re1, re1};
+                    sim[c][sh][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            auto mma16 = [](f32x4 wv, f32x4 a, f32x4 acc) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, a.w, acc, 0, 0, 0);
+                return acc;
+            };
+            const int eR = mo ? 40 : 32, eI = mo ? 56 : 48;
+            const f32x4 *const XB = RX + kq * QS + n16;
+            // operand rows of k-iteration t: odd tile t = 0..3: po rows 4 t + kq, qo rows 16 + 4 t + kq; even tile t = 4, 5
+#define S_ROW_R(t) ((t) < 4 ? 4 * (t) : eR + 4 * ((t) - 4))
+#define S_ROW_I(t) ((t) < 4 ? 16 + 4 * (t) : eI + 4 * ((t) - 4))
+            f32x4 Awr = Are, Awi = Aim, Bwr, Bwi;            // Are / Aim: the first k-iteration's blocks, requested before barrier (1)
+            f32x4 Au[3][2], Av[3][2], Bu[3][2], Bv[3][2];
+#define S_LDX(S, tt)                                                                       \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c)                                          \
+        _Pragma("unroll") for (int sh = 0; sh < 2; ++sh) {                                 \
+            S##u[c][sh] = XB[(CS * c + S_ROW_R(tt)) * QS + 16 * sh];                       \
+            S##v[c][sh] = XB[(CS * c + S_ROW_I(tt)) * QS + 16 * sh];                       \
+        }
+#define S_LD(S, tt) S##wr = WL(ws_stft + 2 * (tt)); S##wi = WL(ws_stft + 2 * (tt) + 1); S_LDX(S, tt)
+#define S_MMA(S, rt)                                                                       \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c)                                          \
+        _Pragma("unroll") for (int sh = 0; sh < 2; ++sh) {                                 \
+            sre[c][sh][rt] = mma16(S##wr, S##u[c][sh], sre[c][sh][rt]);                    \
+            sim[c][sh][rt] = mma16(S##wi, S##v[c][sh], sim[c][sh][rt]);                    \
+        }
+            S_LDX(A, 0)
+            S_LD(B, 1) SB();
+            S_MMA(A, 0) SB();
+            S_LD(A, 2) SB();
+            S_MMA(B, 0) SB();
+            S_LD(B, 3) SB();
+            S_MMA(A, 0) SB();
+            S_LD(A, 4) SB();
+            S_MMA(B, 0) SB();
+            S_LD(B, 5) SB();
+            S_MMA(A, 1) SB();
+            S_MMA(B, 1) SB();
+#undef S_LDX
+#undef S_LD
+#undef S_MMA
+#undef S_ROW_R
+#undef S_ROW_I
             // request enc0's bias + first weights now: they land while the magnitudes are written
             e0b0 = WL(ws_e0); e0b1 = WL(ws_e0 + 1); e0b2 = WL(ws_e0 + 2); e0b3 = WL(ws_e0 + 3);
 #pragma unroll
@@ -459,28 +516,27 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
             SB();
             STAMP(16);
             __syncthreads();   // (1b) every wave is done reading u/v: the magnitudes may overwrite them
-            // magnitudes.  The three columns
-            // m0, m1, m2 of a bin go to enc0 as the Toom-3 evaluations of m0 + m1 z + m2 z^2 (vad_layout.h):
-            // rows 32p + 8w + 2g + h, p = 0..4 for z = 0, 1, -1, 2, inf  (8 kHz: 16p + 8w + 2g + h on waves 0 / 1)
-            if (stft_wave) {
+            // magnitudes.  The three columns m0, m1, m2 of a bin go to enc0 as the Toom-3 evaluations of m0 + m1 z + m2 z^2
+            // (vad_layout.h): rows 32 p + channel / 4 = 32 p + 8 w + 4 rt + kq, p = 0..4 for z = 0, 1, -1, 2, inf
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 mg[3];
+            for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const f32x4 r = quad_of(are[c], g), i = quad_of(aim[c], g);
-                    mg[c] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
+                for (int sh = 0; sh < 2; ++sh) {
+                    f32x4 mg[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const f32x4 r = sre[c][sh][rt], i = sim[c][sh][rt];
+                        mg[c] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
+                    }
+                    const f32x4 s02 = mg[0] + mg[2];
+                    f32x4 *o = RX + (8 * w + 4 * rt + kq) * QS + n16 + 16 * sh;
+                    st2(o, mg[0]);
+                    st2(o + PS * QS, s02 + mg[1]);
+                    st2(o + 2 * PS * QS, s02 - mg[1]);
+                    st2(o + 3 * PS * QS, f32x4{fmaf(4.f, mg[2].x, fmaf(2.f, mg[1].x, mg[0].x)), fmaf(4.f, mg[2].y, fmaf(2.f, mg[1].y, mg[0].y)),
+                                               fmaf(4.f, mg[2].z, fmaf(2.f, mg[1].z, mg[0].z)), fmaf(4.f, mg[2].w, fmaf(2.f, mg[1].w, mg[0].w))});
+                    st2(o + 4 * PS * QS, mg[2]);
                 }
-                const f32x4 s02 = f32x4{mg[0].x + mg[2].x, mg[0].y + mg[2].y, mg[0].z + mg[2].z, mg[0].w + mg[2].w};
-                f32x4 *o = RX + (8 * w + 2 * g) * QS + hq;
-                st2(o, mg[0]);
-                st2(o + PS * QS, f32x4{s02.x + mg[1].x, s02.y + mg[1].y, s02.z + mg[1].z, s02.w + mg[1].w});
-                st2(o + 2 * PS * QS, f32x4{s02.x - mg[1].x, s02.y - mg[1].y, s02.z - mg[1].z, s02.w - mg[1].w});
-                st2(o + 3 * PS * QS, f32x4{fmaf(4.f, mg[2].x, fmaf(2.f, mg[1].x, mg[0].x)), fmaf(4.f, mg[2].y, fmaf(2.f, mg[1].y, mg[0].y)),
-                                           fmaf(4.f, mg[2].z, fmaf(2.f, mg[1].z, mg[0].z)), fmaf(4.f, mg[2].w, fmaf(2.f, mg[1].w, mg[0].w))});
-                st2(o + 4 * PS * QS, mg[2]);
-            }
-            }
             // |X128|: rows 160 / 161 = (points 0, 1, -1, 2) / zeros, rows 162 / 163 = (inf, 0, 0, 0) / zeros
             if (tid < 64) {
                 const float n0 = nyqv[m], n1 = nyqv[32 + m], n2 = nyqv[64 + m];

@@ -35,7 +35,7 @@ using namespace vadk::dev;
 namespace {
 
 constexpr int MT16 = 16;
-constexpr int QSL = 17;                   // loader view: rows 64 c + {0, 16, 32, 48} + q of the folded operands, 192 rows
+constexpr int QSL = 17;                   // loader view: rows 64 c + .. of the folded operands (po 0.. | qo 16.. | pe+ 32.. | pe- 40.. | qe- 48.. | qe+ 56..), 192 rows
 constexpr int QSD = 16;                   // dense view of the same memory, used by everything else:
 //   rows 0..159 Toom-3 planes (32 p + ch/4); the Nyquist channel takes 8 rows (values on the kq = 0 row of a group of four, zeros
 //   on the other three): 160..163 = points 0, 1, -1, 2; 164..167 = infinity; rows 0..31 later enc1 output, then the LSTM input;
@@ -44,7 +44,8 @@ constexpr int T_ROW_NYQ = 160;
 constexpr int T_ROW_E = 168;
 constexpr int T_ROWS_X = 264;
 constexpr int T_ROWS_H = 32;
-static_assert(T_ROWS_X * QSD >= 192 * QSL, "the loader view must end before h");
+constexpr int T_FOLD_SINK = 192;          // loader view: 32 rows behind the three columns, where the loader lanes q >= 8 drop their duplicate quads
+static_assert(T_ROWS_X * QSD >= (T_FOLD_SINK + 32) * QSL, "the loader view (and its sink rows) must end before h");
 constexpr int T_LDS_F4 = (T_ROWS_X + T_ROWS_H) * QSD + 16 + 12 + 36 + 16 + 96;   // + head partials [4][16], |X128| [3][16], fold corrections [3][3][16], sink [64], state machines [16] x 96 B
 static_assert(T_LDS_F4 * 16 <= 80 * 1024, "stays under half a CU's LDS");
 // RS instantiation (fused resample -> step).  The resampler's folded input chunks (2 buffers x {ue, ve, uo, vo} x 16 quad rows,
@@ -605,6 +606,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             auto shr1 = [](float edge, float v) -> float {
                 return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
             };
+            auto shl8 = [](float v) -> float {        // row_shl:8: lane q gets lane q + 8 (lanes 8..15: zero)
+                return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x108, 0xf, 0xf, true));
+            };
             // the fold of silero_v5.hip, one call per column: stream ms = tid >> 4, n = 4 q + j
 #define X_FOLD(c, XR)                                                                                           \
     {                                                                                                           \
@@ -632,10 +636,25 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             fcor[fo + (q0 ? 16 : 0)] = y64 + y192;                                                              \
             fcor[fo + (q0 ? 32 : 0)] = y64 - y192;                                                              \
         }                                                                                                       \
-        st2(&RX[(64 * (c) + q) * QSL + ms], pe);                                                               \
-        st2(&RX[(64 * (c) + 16 + q) * QSL + ms], po);                                                          \
-        st2(&RX[(64 * (c) + 32 + q) * QSL + ms], qe);                                                          \
-        st2(&RX[(64 * (c) + 48 + q) * QSL + ms], qo);                                                          \
+        /* the odd bins contract po | qo as they are; the even bins' operands fold once more, about n = 32 (vad_layout.h,            \
+           bin_of_channel_fold3; silero_v5.hip has the lane algebra).  Lanes q < 8 hold n = 0..31 and store; lanes q >= 8 hold the \
+           same values again and drop them into sink rows (a select on the address, no branch: the fold stays in the MFMAs' basic \
+           block).  Slot n = 0 carries the unpaired n = 32 (lane 8, component 0): pe[32] | qe[32] */                  \
+        const f32x4 pm = f32x4{shr1(0.f, mirror(pe.x)), mirror(pe.w), mirror(pe.z), mirror(pe.y)};               \
+        const f32x4 qm = f32x4{shr1(0.f, mirror(qe.x)), mirror(qe.w), mirror(qe.z), mirror(qe.y)};               \
+        f32x4 pep = f32x4{pe.x + pm.x, pe.y + pm.y, pe.z + pm.z, pe.w + pm.w};                                  \
+        f32x4 pen = f32x4{pe.x - pm.x, pe.y - pm.y, pe.z - pm.z, pe.w - pm.w};                                  \
+        f32x4 qen = f32x4{qe.x - qm.x, qe.y - qm.y, qe.z - qm.z, qe.w - qm.w};                                  \
+        f32x4 qep = f32x4{qe.x + qm.x, qe.y + qm.y, qe.z + qm.z, qe.w + qm.w};                                  \
+        const float pe32 = shl8(pe.x), qe32 = shl8(qe.x);                                                       \
+        pep.x = q0 ? pe32 : pep.x; pen.x = q0 ? 0.f : pen.x; qen.x = q0 ? 0.f : qen.x; qep.x = q0 ? qe32 : qep.x;   \
+        st2(&RX[(64 * (c) + q) * QSL + ms], po);                                                               \
+        st2(&RX[(64 * (c) + 16 + q) * QSL + ms], qo);                                                          \
+        const int er = (q < 8 ? 64 * (c) + 32 + q : T_FOLD_SINK - 8 + q) * QSL + ms;                            \
+        st2(&RX[er], pep);                                                                                      \
+        st2(&RX[er + 8 * QSL], pen);                                                                            \
+        st2(&RX[er + 16 * QSL], qen);                                                                           \
+        st2(&RX[er + 24 * QSL], qep);                                                                           \
     }
 #define H_LDW(WS, g) _Pragma("unroll") for (int k = 0; k < 8; ++k) WS[k] = WL(wh + 8 * (g) + k);
 #define H_MMA(WS, g)                                                                                            \
@@ -671,9 +690,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 #undef H_LDW
 #undef X_FOLD
         }
-        f32x4 Sw[4];                              // STFT blocks of k-iteration 0: cos rt0, cos rt1, -sin rt0, -sin rt1
+        f32x4 Sw[2];                              // STFT blocks of k-iteration 0: cos, -sin of the odd tile
 #pragma unroll
-        for (int k = 0; k < 4; ++k) Sw[k] = WL(ws_stft + k);
+        for (int k = 0; k < 2; ++k) Sw[k] = WL(ws_stft + k);
         SB();
         __syncthreads();   // (1) folded x visible
 
@@ -684,8 +703,8 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             float a = 0.f;
             if (pair < 48) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 pp = RX[(64 * c + pt * 4 + i) * QSL + ms];
+                for (int i = 0; i < 2; ++i) {     // sum_n pe[n] (-1)^n = the same sum over the pe+ rows (slot 0 = pe[32], sign +)
+                    const f32x4 pp = RX[(64 * c + 32 + pt * 2 + i) * QSL + ms];
                     a += (pp.x - pp.y) + (pp.z - pp.w);
                 }
             }
@@ -694,43 +713,55 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             if (pair < 48 && pt == 0) nyqv[c * 16 + ms] = fabsf(a + fcor[(c * 3 + 0) * 16 + ms] + fcor[(c * 3 + 1) * 16 + ms]);
         }
 
-        // ---- STFT: wave w owns bins bin_of_channel(32 w + 16 rt + r): cos on pe | po, -sin on qe | qo, 3 columns, K = 64 ----
+        // ---- STFT: wave w owns bins bin_of_channel_fold3(32 w + 16 rt + r): row tile 0 = 16 odd bins, cos on po, -sin on qo, K = 64
+        //      (k-iterations 0..3); row tile 1 = 16 even bins on the once-more-folded operands pe+- | qe-+ (waves 2, 3 | 0, 1), K = 32
+        //      (k-iterations 4, 5); 3 columns.  144 MFMAs per wave instead of 192 ----
         f32x4 e0b[2], E0w[10];
         {
             f32x4 are[3][2], aim[3][2];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float y128 = fcor[(c * 3 + 0) * 16 + n], a64 = fcor[(c * 3 + 1) * 16 + n], b64 = fcor[(c * 3 + 2) * 16 + n];
-                const float rp = w < 2 ? y128 + a64 : -y128, rm = w < 2 ? y128 - a64 : -y128;
-                const float ip = w < 2 ? 0.f : -b64, im_ = w < 2 ? 0.f : b64;
-                // register i of a D quad is tile row 4 rq + i (+ 16 rt): (-1)^row = (-1)^i
-                are[c][0] = are[c][1] = f32x4{rp, rm, rp, rm};
-                aim[c][0] = aim[c][1] = f32x4{ip, im_, ip, im_};
+                const float re1 = w < 2 ? y128 - a64 : y128 + a64;
+                // register i of a D quad is tile row 4 rq + i: odd k: re = -y128, im = -+ b64 along the rows; even k = 2 m:
+                // re = y128 + (-1)^m a64, im = 0
+                are[c][0] = f32x4{-y128, -y128, -y128, -y128};
+                aim[c][0] = f32x4{-b64, b64, -b64, b64};
+                are[c][1] = f32x4{re1, re1, re1, re1};
+                aim[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            const int rR = w < 2 ? 0 : 16, rI = w < 2 ? 32 : 48;
-            const f32x4 *const XR = RX + rR * QSL + nqL, *const XI = RX + rI * QSL + nqL;      // loader view
-            f32x4 Aw[4], Bw[4], Au[3], Av[3], Bu[3], Bv[3];
+            const int eR = w < 2 ? 40 : 32, eI = w < 2 ? 56 : 48;
+            const f32x4 *const XB = RX + nqL;                                                   // loader view
+#define S_ROW_R(t) ((t) < 4 ? 4 * (t) : eR + 4 * ((t) - 4))
+#define S_ROW_I(t) ((t) < 4 ? 16 + 4 * (t) : eI + 4 * ((t) - 4))
+            f32x4 Aw[2], Bw[2], Au[3], Av[3], Bu[3], Bv[3];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) Aw[k] = Sw[k];
+            for (int k = 0; k < 2; ++k) Aw[k] = Sw[k];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { Au[c] = XR[(64 * c) * QSL]; Av[c] = XI[(64 * c) * QSL]; }
-#define S_LD(S, jj)                                                                        \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) S##w[k] = WL(ws_stft + 4 * (jj) + k);    \
-    _Pragma("unroll") for (int c = 0; c < 3; ++c) { S##u[c] = XR[(64 * c + 4 * (jj)) * QSL]; S##v[c] = XI[(64 * c + 4 * (jj)) * QSL]; }
-#define S_MMA(S)                                                                           \
+            for (int c = 0; c < 3; ++c) { Au[c] = XB[(64 * c + S_ROW_R(0)) * QSL]; Av[c] = XB[(64 * c + S_ROW_I(0)) * QSL]; }
+#define S_LD(S, tt)                                                                        \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) S##w[k] = WL(ws_stft + 2 * (tt) + k);    \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) { S##u[c] = XB[(64 * c + S_ROW_R(tt)) * QSL]; S##v[c] = XB[(64 * c + S_ROW_I(tt)) * QSL]; }
+#define S_MMA(S, rt)                                                                       \
     _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                        \
-        are[c][0] = mfma16(S##w[0], S##u[c], are[c][0]); are[c][1] = mfma16(S##w[1], S##u[c], are[c][1]);   \
-        aim[c][0] = mfma16(S##w[2], S##v[c], aim[c][0]); aim[c][1] = mfma16(S##w[3], S##v[c], aim[c][1]);   \
+        are[c][rt] = mfma16(S##w[0], S##u[c], are[c][rt]);                                 \
+        aim[c][rt] = mfma16(S##w[1], S##v[c], aim[c][rt]);                                 \
     }
-            for (int j = 0; j < 4; j += 2) {
-                S_LD(B, j + 1) SB();
-                S_MMA(A) SB();
-                const int jn = j + 2 < 4 ? j + 2 : 2;
-                S_LD(A, jn) SB();
-                S_MMA(B) SB();
-            }
+            S_LD(B, 1) SB();
+            S_MMA(A, 0) SB();
+            S_LD(A, 2) SB();
+            S_MMA(B, 0) SB();
+            S_LD(B, 3) SB();
+            S_MMA(A, 0) SB();
+            S_LD(A, 4) SB();
+            S_MMA(B, 0) SB();
+            S_LD(B, 5) SB();
+            S_MMA(A, 1) SB();
+            S_MMA(B, 1) SB();
 #undef S_LD
 #undef S_MMA
+#undef S_ROW_R
+#undef S_ROW_I
             e0b[0] = WL(ws_e0); e0b[1] = WL(ws_e0 + 1);
 #pragma unroll
             for (int k = 0; k < 10; ++k) E0w[k] = WL(ws_e0 + 2 + k);

@@ -55,6 +55,21 @@ enum Section { S_STFT = 0, S_NYQ, S_ENC0, S_ENC1, S_ENC2, S_ENC3, S_LSTM, S_HEAD
 __host__ __device__ constexpr int bin_of_channel(int ch) {
     return (ch >> 5) < 2 ? 64 * (ch >> 5) + 2 * (ch & 31) : 64 * ((ch >> 5) - 2) + 2 * (ch & 31) + 1;
 }
+// Channel order of the kernels whose STFT folds the EVEN bins once more (silero_v5.hip's 16 kHz instantiation, silero_v4_t16.hip):
+// wave w owns the channels 32 w .. 32 w + 31 as two 16-row tiles of v_mfma_f32_16x16x4_f32.  Row tile 0: the odd bins
+// 2 (16 w + r) + 1 against the 4-way folded operands po | qo (K = 64).  Row tile 1: even bins k = 2 m, whose operands fold again
+// about n = 32 - cos(2 pi m (64 - n) / 128) = (-1)^m cos(2 pi m n / 128), the sine with the opposite sign - into K = 32, in two
+// classes by the parity of m: waves 0, 1: k = 4 (16 w + r) + 2 (m odd: pe[n] - pe[64 - n] | qe[n] + qe[64 - n]), waves 2, 3:
+// k = 4 (16 (w - 2) + r) (m even: pe[n] + pe[64 - n] | qe[n] - qe[64 - n]; bin 0 = wave 2, tile 1, row 0).  Per column a wave
+// contracts 16 x (64 + 64) + 16 x (32 + 32) instead of 32 x (64 + 64): three quarters of the 4-way fold's MFMAs, the same on
+// every wave.
+//   loader (v5, 16 kHz): column c: po -> rows 64c + q, qo -> 64c + 16 + q (q = 0..15, n = 4q..4q+3), then n = 4q'..4q'+3, q' = 0..7:
+//   pe+ -> 64c + 32 + q', pe- -> 64c + 40 + q', qe- -> 64c + 48 + q', qe+ -> 64c + 56 + q'; slot n = 0 of pe+ holds pe[32], of qe+ qe[32]
+__host__ __device__ constexpr int bin_of_channel_fold3(int ch) {
+    return (ch & 16) == 0 ? 2 * (16 * (ch >> 5) + (ch & 15)) + 1
+                          : ((ch >> 5) < 2 ? 4 * (16 * (ch >> 5) + (ch & 15)) + 2 : 4 * (16 * ((ch >> 5) - 2) + (ch & 15)));
+}
+constexpr int ROW_FOLD_SINK = 192;         // 32 rows past the three columns: where the loader lanes q >= 8 drop their duplicate quads
 // The graph's 8 kHz sub-model (If_0 else-branch) is the same dataflow at half the front-end size: 256-sample
 // frames, window N = 128, hop 64 -> three columns at 0, 64, 128; 65 bins; 4-way fold with n = 1..31 (K = 32), unpaired samples
 // n = 0, 32, 64; the 64 complex bins are two 32-row tiles - wave 0: even bins 2 r, wave 1: odd bins 2 r + 1 - and bin 64
@@ -97,14 +112,9 @@ enum Section {
     S_L0,                         // first layer: pw(relu(dw(x1))) + proj(x1), 16 outputs (rows 16..31 of the tile are zero)
     S_S0, S_L1, S_S1, S_L2, S_S2, S_L3, S_S3, S_LSTM0, S_LSTM1, S_HEADB, S_COUNT
 };
-// Channel order of the 16-STREAM kernel's STFT (silero_v4_t16.hip; the 32-stream kernel keeps v5::bin_of_channel): wave w owns the
-// channels 32 w .. 32 w + 31 as two 16-row tiles.  Row tile 0: the odd bins 2 (16 w + r) + 1 (4-way folded operands, K = 64).
-// Row tile 1: even bins, whose operands fold once more about n = 32 (K = 32) into two classes by k / 2's parity - waves 0, 1:
-// k = 4 (16 w + r) + 2 (k / 2 odd), waves 2, 3: k = 4 (16 (w - 2) + r) (k / 2 even; bin 0 = wave 2, tile 1, row 0).
-__host__ __device__ constexpr int bin_of_channel_t16(int ch) {
-    return (ch & 16) == 0 ? 2 * (16 * (ch >> 5) + (ch & 15)) + 1
-                          : ((ch >> 5) < 2 ? 4 * (16 * (ch >> 5) + (ch & 15)) + 2 : 4 * (16 * ((ch >> 5) - 2) + (ch & 15)));
-}
+// Channel order of the 16-STREAM kernel's STFT (silero_v4_t16.hip; the 32-stream kernel keeps v5::bin_of_channel): the order of
+// the once-more-folded DFT, v5::bin_of_channel_fold3
+__host__ __device__ constexpr int bin_of_channel_t16(int ch) { return v5::bin_of_channel_fold3(ch); }
 constexpr int MAG_Q = 33;                      // quads per STFT column: 128 bins + Nyquist (+3 pad channels)
 constexpr int MAG_ROWS = 8 * MAG_Q;            // 264 rows per tile, row = 33 t + q
 // STFT part, LDS: reflect-padded frame [32][704] f32 + the 4-way fold of two columns (2 x 64 quad rows: pe, po, qe, qo as in

@@ -86,17 +86,29 @@ def v5_step(W, sect, x, hc, gate=0.01, k8=False):
         y1, y2, y3, y4 = y[:, n], y[:, H - n], y[:, H + n], y[:, (N - n) % N]
         pe, po = y1 + y4 + y2 + y3, y1 + y4 - y2 - y3
         qe, qo = y1 - y4 - y2 + y3, y1 - y4 + y2 - y3
-        for k, arr in enumerate((pe, po, qe, qo)):
-            arr = arr.copy()
+        for arr in (pe, po, qe, qo):
             arr[:, 0] = 0.0                                                   # n = 0 is not part of the folded sums
-            RX[CS * c + QL * k:CS * c + QL * k + QL] = arr.reshape(32, QL, 4).transpose(1, 0, 2)
+        if k8:
+            for k, arr in enumerate((pe, po, qe, qo)):
+                RX[CS * c + QL * k:CS * c + QL * k + QL] = arr.reshape(32, QL, 4).transpose(1, 0, 2)
+        else:
+            # 16 kHz: po | qo as they are (rows 0..15 | 16..31); the even bins' operands fold once more about n = 32 (8 rows each):
+            # pe+ 32.., pe- 40.., qe- 48.., qe+ 56..; slot 0 carries the unpaired n = 32 (pe[32] in pe+, qe[32] in qe+)
+            mm = np.arange(32)
+            pep, pen = pe[:, mm] + pe[:, (64 - mm) % 64], pe[:, mm] - pe[:, (64 - mm) % 64]
+            qen, qep = qe[:, mm] - qe[:, (64 - mm) % 64], qe[:, mm] + qe[:, (64 - mm) % 64]
+            pep[:, 0], pen[:, 0], qen[:, 0], qep[:, 0] = pe[:, 32], 0.0, 0.0, qe[:, 32]
+            RX[CS * c:CS * c + 16] = po.reshape(32, 16, 4).transpose(1, 0, 2)
+            RX[CS * c + 16:CS * c + 32] = qo.reshape(32, 16, 4).transpose(1, 0, 2)
+            for k, arr in enumerate((pep, pen, qen, qep)):
+                RX[CS * c + 32 + 8 * k:CS * c + 40 + 8 * k] = arr.reshape(32, 8, 4).transpose(1, 0, 2)
         fcor[c, 0], fcor[c, 1], fcor[c, 2] = y[:, H], y[:, Q4] + y[:, H + Q4], y[:, Q4] - y[:, H + Q4]
     RH[:] = hc[:, :128].astype(np.float64).reshape(32, 32, 4).transpose(1, 0, 2)
     c_prev = hc[:, 128:].astype(np.float64)
-    # bin 128: alternating sum of pe + rank-1 terms
+    # bin 128: alternating sum of pe (16 kHz: of the pe+ rows, whose slot 0 is pe[32]) + rank-1 terms
     nyq = np.zeros((3, 32))
     for c in range(3):
-        pe = RX[CS * c:CS * c + QL]                                           # [16, 32, 4]
+        pe = RX[CS * c:CS * c + QL] if k8 else RX[CS * c + 32:CS * c + 40]
         alt = (pe[:, :, 0] - pe[:, :, 1] + pe[:, :, 2] - pe[:, :, 3]).sum(0)
         nyq[c] = np.abs(alt + fcor[c, 0] + fcor[c, 1])
     # STFT: wave w owns bins bin_of_channel(32w + r); even bins contract pe / qe, odd bins po / qo
@@ -132,31 +144,35 @@ def v5_step(W, sect, x, hc, gate=0.01, k8=False):
             m0, m1, m2 = mg8[w]
             for p, val in enumerate((m0, (m0 + m2) + m1, (m0 + m2) - m1, m0 + 2 * m1 + 4 * m2, m2)):
                 RX[PS * p + 4 * w:PS * p + 4 * w + 4] = val.reshape(4, 4, 32).transpose(0, 2, 1)   # quad row = channel / 4
-    stft_waves = () if k8 else (0, 1, 2, 3)
-    for w in stft_waves:
-        ws = sect[w][S_STFT]
-        even = (w == 0) if k8 else (w < 2)
-        rR, rI = (0, 2 * QL) if even else (QL, 3 * QL)
-        are = [np.zeros((32, 32)) for _ in range(3)]
-        aim = [np.zeros((32, 32)) for _ in range(3)]
-        for j in range(NJ):
-            wre, wim = W[ws + 2 * j], W[ws + 2 * j + 1]
-            for c in range(3):
-                are[c] += _mfma4(wre, _rows(RX, CS * c + rR + 2 * j, CS * c + rR + 2 * j + 1))
-                aim[c] += _mfma4(wim, _rows(RX, CS * c + rI + 2 * j, CS * c + rI + 2 * j + 1))
-        mags[w] = []
-        for c in range(3):
-            y128, a64, b64 = fcor[c, 0][None, :], fcor[c, 1][None, :], fcor[c, 2][None, :]
-            if even:
-                re, im = are[c] + y128 + sgn * a64, aim[c]
-            else:
-                re, im = are[c] - y128, aim[c] - sgn * b64
-            mags[w].append(np.sqrt(re ** 2 + im ** 2))
-    # enc0 input: Toom-3 evaluations of m0 + m1 z + m2 z^2 at z = 0, 1, -1, 2, inf -> rows 32 p + ch/4
-    for w in stft_waves:
-        m0, m1, m2 = mags[w]
-        for p, v in enumerate((m0, (m0 + m2) + m1, (m0 + m2) - m1, m0 + 2 * m1 + 4 * m2, m2)):
-            _store_tile(RX, PS * p + 8 * w, v, relu=False)
+    if not k8:
+        # 16 kHz: two 16-row tiles per wave on v_mfma_f32_16x16x4_f32 (pack_dft_fold3_wave): tile 0 = 16 odd bins on po | qo (K = 64,
+        # blocks ws + 2 j, + 1, j = 0..3), tile 1 = 16 even bins on pe-+ | qe+- (waves 0, 1: m odd) or pe+ | qe- (waves 2, 3), K = 32
+        sgn16 = np.where(np.arange(16) % 2 == 0, 1.0, -1.0)[:, None]
+        blk = lambda b: W[b].astype(np.float64).reshape(4, 16, 4)                   # [kq][row][i]
+        mg16 = {}
+        for w in range(4):
+            ws = sect[w][S_STFT]
+            eR, eI = (40, 56) if w < 2 else (32, 48)
+            for rt in range(2):
+                mg = []
+                for c in range(3):
+                    are, aim = np.zeros((16, 32)), np.zeros((16, 32))
+                    for j in range(4 if rt == 0 else 2):
+                        b0 = ws + (2 * j if rt == 0 else 8 + 2 * j)
+                        rR, rI = (4 * j, 16 + 4 * j) if rt == 0 else (eR + 4 * j, eI + 4 * j)
+                        are += np.einsum("kri,kmi->rm", blk(b0), RX[CS * c + rR:CS * c + rR + 4])
+                        aim += np.einsum("kri,kmi->rm", blk(b0 + 1), RX[CS * c + rI:CS * c + rI + 4])
+                    y128, a64, b64 = fcor[c, 0][None, :], fcor[c, 1][None, :], fcor[c, 2][None, :]
+                    if rt == 0:
+                        re, im = are - y128, aim - sgn16 * b64
+                    else:
+                        re, im = are + (y128 - a64 if w < 2 else y128 + a64), aim
+                    mg.append(np.sqrt(re ** 2 + im ** 2))                           # [16 channels, 32 streams]
+                mg16[w, rt] = mg
+        for (w, rt), (m0, m1, m2) in mg16.items():                                  # (behind the kernel's barrier 1b)
+            for p, val in enumerate((m0, (m0 + m2) + m1, (m0 + m2) - m1, m0 + 2 * m1 + 4 * m2, m2)):
+                r0 = PS * p + 8 * w + 4 * rt
+                RX[r0:r0 + 4] = val.reshape(4, 4, 32).transpose(0, 2, 1)            # quad row = channel / 4
     n0, n1, n2 = nyq
     RX[ROWN] = np.stack([n0, (n0 + n2) + n1, (n0 + n2) - n1, n0 + 2 * n1 + 4 * n2], axis=1)
     RX[ROWN + 2] = np.stack([n2, np.zeros(32), np.zeros(32), np.zeros(32)], axis=1)
@@ -613,34 +629,39 @@ def v5_step_t16(W, sect, x, hc, gate=0.01):
         y = x[:, 128 * c:128 * c + 256] * wtab[None, :]
         n = np.arange(64)
         y1, y2, y3, y4 = y[:, n], y[:, 128 - n], y[:, 128 + n], y[:, (256 - n) % 256]
-        for k, arr in enumerate((y1 + y4 + y2 + y3, y1 + y4 - y2 - y3, y1 - y4 - y2 + y3, y1 - y4 + y2 - y3)):
-            arr = arr.copy()
+        pe, po, qe, qo = y1 + y4 + y2 + y3, y1 + y4 - y2 - y3, y1 - y4 - y2 + y3, y1 - y4 + y2 - y3
+        for arr in (pe, po, qe, qo):
             arr[:, 0] = 0.0
-            RX[64 * c + 16 * k:64 * c + 16 * k + 16] = arr.reshape(16, 16, 4).transpose(1, 0, 2)
+        mm = np.arange(32)                                  # the even bins' operands fold once more about n = 32 (silero_v5.hip)
+        pep, pen = pe[:, mm] + pe[:, (64 - mm) % 64], pe[:, mm] - pe[:, (64 - mm) % 64]
+        qen, qep = qe[:, mm] - qe[:, (64 - mm) % 64], qe[:, mm] + qe[:, (64 - mm) % 64]
+        pep[:, 0], pen[:, 0], qen[:, 0], qep[:, 0] = pe[:, 32], 0.0, 0.0, qe[:, 32]
+        RX[64 * c:64 * c + 16] = po.reshape(16, 16, 4).transpose(1, 0, 2)
+        RX[64 * c + 16:64 * c + 32] = qo.reshape(16, 16, 4).transpose(1, 0, 2)
+        for k, arr in enumerate((pep, pen, qen, qep)):
+            RX[64 * c + 32 + 8 * k:64 * c + 40 + 8 * k] = arr.reshape(16, 8, 4).transpose(1, 0, 2)
         fcor[c] = y[:, 128], y[:, 64] + y[:, 192], y[:, 64] - y[:, 192]
     nyq = np.zeros((3, 16))
     for c in range(3):
-        pe = RX[64 * c:64 * c + 16]
+        pe = RX[64 * c + 32:64 * c + 40]                    # the pe+ rows: slot 0 = pe[32]
         nyq[c] = np.abs((pe[:, :, 0] - pe[:, :, 1] + pe[:, :, 2] - pe[:, :, 3]).sum(0) + fcor[c, 0] + fcor[c, 1])
     sgn = np.where(np.arange(16) % 2 == 0, 1.0, -1.0)[:, None]
     mags = {}
     for w in range(4):
         ws = sect[w][S_STFT]
-        rR, rI = (0, 32) if w < 2 else (16, 48)
-        are = [[np.zeros((16, 16)) for _ in range(2)] for _ in range(3)]
-        aim = [[np.zeros((16, 16)) for _ in range(2)] for _ in range(3)]
-        for j in range(4):
-            blk = W[ws + 4 * j:ws + 4 * j + 4]
-            for c in range(3):
-                u, v = _rows16(RX, 64 * c + rR + 4 * j), _rows16(RX, 64 * c + rI + 4 * j)
-                for rt in range(2):
-                    are[c][rt] += _mfma16(blk[rt], u)
-                    aim[c][rt] += _mfma16(blk[2 + rt], v)
+        eR, eI = (40, 56) if w < 2 else (32, 48)
         for c in range(3):
             y128, a64, b64 = fcor[c, 0][None, :], fcor[c, 1][None, :], fcor[c, 2][None, :]
-            for rt in range(2):
-                re, im = (are[c][rt] + y128 + sgn * a64, aim[c][rt]) if w < 2 else (are[c][rt] - y128, aim[c][rt] - sgn * b64)
-                mags[w, c, rt] = np.sqrt(re ** 2 + im ** 2)
+            are, aim = np.zeros((16, 16)), np.zeros((16, 16))
+            for j in range(4):                              # row tile 0: 16 odd bins on po | qo, K = 64
+                are += _mfma16(W[ws + 2 * j], _rows16(RX, 64 * c + 4 * j))
+                aim += _mfma16(W[ws + 2 * j + 1], _rows16(RX, 64 * c + 16 + 4 * j))
+            mags[w, c, 0] = np.sqrt((are - y128) ** 2 + (aim - sgn * b64) ** 2)
+            are, aim = np.zeros((16, 16)), np.zeros((16, 16))
+            for j in range(2):                              # row tile 1: 16 even bins, K = 32
+                are += _mfma16(W[ws + 8 + 2 * j], _rows16(RX, 64 * c + eR + 4 * j))
+                aim += _mfma16(W[ws + 8 + 2 * j + 1], _rows16(RX, 64 * c + eI + 4 * j))
+            mags[w, c, 1] = np.sqrt((are + (y128 - a64 if w < 2 else y128 + a64)) ** 2 + aim ** 2)
     for w in range(4):
         for rt in range(2):
             m0, m1, m2 = (mags[w, c, rt] for c in range(3))
