@@ -106,7 +106,7 @@ def build_wirebox(force: bool = False) -> str:
         raise RuntimeError("a C compiler and Python.h are needed to build _wirebox")
     tmp = out + ".tmp"
     subprocess.check_call([cc, "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-missing-field-initializers", "-Wno-cast-function-type",
-                           f"-I{inc}", src, "-o", tmp])
+                           f"-I{inc}", f"-I{os.path.join(os.path.dirname(HERE), 'include')}", src, "-o", tmp, "-lpthread"])
     os.replace(tmp, out)
     return out
 

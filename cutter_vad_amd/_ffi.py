@@ -93,6 +93,24 @@ class TickResult(C.Structure):
     ]
 
 
+class TickWork(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("n_slots", C.c_int64),
+        ("last_prob", C.POINTER(C.c_float)),
+        ("frames_done", C.POINTER(C.c_int64)),
+        ("active", C.POINTER(C.c_uint8)),
+        ("continue_cb", C.POINTER(C.c_uint8)),
+        ("continue_payload", C.POINTER(C.c_uint8)),
+        ("n_work", C.c_int64),
+        ("work_index", C.POINTER(C.c_int32)),
+        ("work_kind", C.POINTER(C.c_uint8)),
+        ("work_samples", C.POINTER(C.c_int64)),
+    ]
+
+
+VAD_WORK_START, VAD_WORK_END, VAD_WORK_CONTINUE, VAD_WORK_PAYLOAD, VAD_WORK_LONG = 1, 2, 4, 8, 16
+
 # name -> (restype, argtypes); mirrors include/vad_engine.h one-to-one
 _vp, _i64p, _f32p, _u8p, _i32p = C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
 SIGNATURES = {
@@ -126,6 +144,8 @@ SIGNATURES = {
     "vad_tick_enable_segments": (C.c_int, [_vp, C.c_int]),
     "vad_tick_take_segment": (C.c_int, [_vp, C.c_int64, _f32p, C.c_int64, _i64p]),
     "vad_tick_run": (C.c_int, [_vp, C.c_float, C.POINTER(TickResult)]),
+    "vad_tick_run_work": (C.c_int, [_vp, C.c_float, C.POINTER(TickResult), C.POINTER(TickWork)]),
+    "vad_tick_take_segment_wav16": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int64, _i64p]),
     "vad_step_rates_device": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_void_p), _i64p, C.POINTER(C.c_int32), _vp, C.c_float,
                                         _vp, _vp, _vp, _vp]),
     "vad_step_rates": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_void_p), _i64p, C.POINTER(C.c_int32), _i64p, C.c_float,

@@ -94,6 +94,9 @@ struct vad_engine {
     bool shared_gpu = false;                 // VAD_ENGINE_SHARED_GPU: keep to 32-stream tiles (n / 32 CUs), leave the rest to the co-tenant
     int sample_rate = 16000;
     int frame_samples = VAD_FRAME_SAMPLES;   // samples per model step (512; Silero V5's 8 kHz sub-model: 256)
+    std::vector<int32_t> work_index;         // vad_tick_run_work: the tick's entries the caller has work for
+    std::vector<uint8_t> work_kind;
+    std::vector<int64_t> work_samples;
     // batched slot control (open / reset / thresholds): one pinned block up, one kernel
     uint8_t *h_ctl = nullptr, *d_ctl = nullptr; size_t ctl_cap = 0;
     // pipelined host ingest (vad_step_submit / vad_step_collect): H2D of ticket t+1 on `copy_in` while the kernel of
@@ -2206,6 +2209,95 @@ int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out) {
         e->copy_crew.run(plan.data(), plan.size());
         out->host_us[2] = us(t2, now());
     }
+    return VAD_OK;
+}
+
+int vad_tick_run_work(vad_engine *e, float denoise_thresh, vad_tick_result *out, vad_tick_work *work) {
+    if (!e || !work || work->struct_size < sizeof(vad_tick_work)) return VAD_ERR_INVALID_ARG;
+    work->n_work = 0;
+    work->work_index = nullptr;
+    work->work_kind = nullptr;
+    if (work->n_slots < 0 || (work->n_slots > 0 && (!work->last_prob || !work->frames_done || !work->active || !work->continue_cb ||
+                                                    !work->continue_payload)))
+        return e->fail(VAD_ERR_INVALID_ARG, "vad_tick_run_work: the per-slot arrays are missing");
+    if (const int rc = vad_tick_run(e, denoise_thresh, out)) return rc;
+    const int64_t n = out->n;
+    // one tick at a time per engine (the caller's rule for vad_tick_run): the two vectors belong to this call until the next one
+    e->work_index.clear();
+    e->work_kind.clear();
+    e->work_samples.clear();
+    const int64_t first_rate_entry = out->group_start[6];       // chunks at another rate always have their exact length
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t sl = out->slots[k];
+        if (sl < 0 || sl >= work->n_slots) return e->fail(VAD_ERR_INVALID_ARG, "vad_tick_run_work: slot %lld beyond the caller's arrays (%lld)", (long long)sl, (long long)work->n_slots);
+        const uint8_t ev = out->events[k];
+        const bool was = work->active[sl] != 0, started = (ev & VAD_EV_START) != 0, ended = (ev & VAD_EV_END) != 0;
+        work->last_prob[sl] = out->probs[k];
+        work->frames_done[sl] += 1;
+        work->active[sl] = (uint8_t)((was || started) && !ended);
+        uint8_t kind = (uint8_t)((started ? VAD_WORK_START : 0) | (ended ? VAD_WORK_END : 0));
+        if (was && work->continue_cb[sl]) kind |= (uint8_t)(VAD_WORK_CONTINUE | (work->continue_payload[sl] ? VAD_WORK_PAYLOAD : 0));
+        if (k < first_rate_entry && out->nsamples[k] > e->frame_samples) kind |= VAD_WORK_LONG;
+        if (kind) {
+            e->work_index.push_back((int32_t)k);
+            e->work_kind.push_back(kind);
+            e->work_samples.push_back(0);
+        }
+    }
+    {   // the finished segments' lengths (segment assembly on): the caller sizes its payload buffers without a second call
+        std::lock_guard<std::mutex> tl(e->tick_mu);
+        for (size_t j = 0; j < e->work_kind.size(); ++j)
+            if (e->work_kind[j] & VAD_WORK_END) {
+                const size_t sl = (size_t)out->slots[e->work_index[j]];
+                e->work_samples[j] = sl < e->seg_state.size() ? e->seg_state[sl].done.samples : 0;
+            }
+    }
+    work->n_work = (int64_t)e->work_index.size();
+    work->work_index = e->work_index.data();
+    work->work_kind = e->work_kind.data();
+    work->work_samples = e->work_samples.data();
+    return VAD_OK;
+}
+
+int vad_tick_take_segment_wav16(vad_engine *e, int64_t slot, int32_t sample_rate, void *out, int64_t cap, int64_t *nbytes) {
+    if (!e || !nbytes || sample_rate < 1) return VAD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->tick_mu);
+    if (slot < 0 || (size_t)slot >= e->seg_state.size()) return e->fail(VAD_ERR_BAD_SLOT, "slot %lld has no segment state", (long long)slot);
+    vad_engine::SegAudio &d = e->seg_state[(size_t)slot].done;
+    const int64_t ns = d.samples, total = 44 + 2 * ns;
+    *nbytes = total;
+    if (!out) return VAD_OK;                       // size query
+    if (cap < total) return e->fail(VAD_ERR_INVALID_ARG, "WAV buffer too small (%lld < %lld bytes)", (long long)cap, (long long)total);
+    uint8_t *o = static_cast<uint8_t *>(out);
+    auto put32 = [&](size_t at, uint32_t v) { std::memcpy(o + at, &v, 4); };       // (little-endian host, as everywhere in this file)
+    auto put16 = [&](size_t at, uint16_t v) { std::memcpy(o + at, &v, 2); };
+    std::memcpy(o, "RIFF", 4); put32(4, (uint32_t)(36 + 2 * ns)); std::memcpy(o + 8, "WAVEfmt ", 8);
+    put32(16, 16); put16(20, 1); put16(22, 1); put32(24, (uint32_t)sample_rate); put32(28, (uint32_t)sample_rate * 2u); put16(32, 2); put16(34, 16);
+    std::memcpy(o + 36, "data", 4); put32(40, (uint32_t)(2 * ns));
+    // every stored run as vad_tick_take_segment hands it over (int16 / its scale as a float32 division, the run's gate), then
+    // WAVWriter's conversion - float32 product, clip, truncation toward zero - in ONE pass, no float copy of the segment in between
+    int16_t *q = reinterpret_cast<int16_t *>(o + 44);
+    auto wav = [](float x) -> int16_t {
+        float y = x * 32767.0f;
+        y = y < -32768.0f ? -32768.0f : (y > 32767.0f ? 32767.0f : y);
+        return (int16_t)y;
+    };
+    d.for_each_piece([&](const vad_engine::SegAudio::Run &r, const uint8_t *src, size_t cnt) {
+        const bool g = vad_engine::SegAudio::gated(r.group);
+        const float thr = r.thr;
+        if (!vad_engine::SegAudio::is_i16(r.group)) {
+            const float *x = reinterpret_cast<const float *>(src);
+            if (g) for (size_t k = 0; k < cnt; ++k) q[k] = wav(std::fabs(x[k]) > thr ? x[k] : 0.f);
+            else for (size_t k = 0; k < cnt; ++k) q[k] = wav(x[k]);
+        } else {
+            const float sc = r.group < 4 ? 32767.0f : 32768.0f;
+            const int16_t *p16 = reinterpret_cast<const int16_t *>(src);
+            if (g) for (size_t k = 0; k < cnt; ++k) { const float x = (float)p16[k] / sc; q[k] = wav(std::fabs(x) > thr ? x : 0.f); }
+            else for (size_t k = 0; k < cnt; ++k) q[k] = wav((float)p16[k] / sc);
+        }
+        q += cnt;
+    });
+    d.clear(e->seg_arena);
     return VAD_OK;
 }
 

@@ -376,6 +376,9 @@ class Engine:
         r = _ffi.TickResult()
         r.struct_size = C.sizeof(_ffi.TickResult)
         rc = self._lib.vad_tick_run(self._h, float(denoise), C.byref(r))
+        return self._tick_arrays(r, rc)
+
+    def _tick_arrays(self, r, rc):
         self.last_tick_dropped = int(r.dropped)   # frames left out because their stream was closed after the push
         self.last_tick_staged_next = int(r.staged_next)   # frames that were waiting and are already staged for the next tick
         # a failed tick has consumed its frames: which streams lost one, and how long those frames were (TickFailure below)
@@ -404,6 +407,62 @@ class Engine:
             flen = self.frame_samples if g < 6 else TICK_RATE_CHUNK[(g - 6) % 3]
             frames.append(as_arr(C.cast(r.group_frames[g], C.POINTER(ct)), (cnt, flen)))
         return slots, probs, events, seg, gs, frames, as_arr(r.nsamples, (n,))
+
+    def tick_run_work(self, denoise: float, last_prob: np.ndarray, frames_done: np.ndarray, active: np.ndarray,
+                      continue_cb: np.ndarray, continue_payload: np.ndarray):
+        """``tick_run`` + the per-session bookkeeping of a serving front end in the same C call (``vad_tick_run_work``): the five
+        per-slot arrays (float32, int64, bool, bool, bool; the caller's, updated in place) and ->
+        ``(slots, group_start, frames, nsamples, work_index, work_kind, work_samples)``: ``work_index[j]`` = the entry of the tick's
+        arrays the caller has something to do for, ``work_kind[j]`` = VAD_WORK_* bits (START, END, CONTINUE, PAYLOAD, LONG),
+        ``work_samples[j]`` = the finished segment's length for END entries."""
+        r, w = self.tick_work_begin(last_prob, frames_done, active, continue_cb, continue_payload)
+        return self.tick_work_end(r, w, self._lib.vad_tick_run_work(self._h, float(denoise), C.byref(r), C.byref(w)))
+
+    def tick_work_begin(self, last_prob: np.ndarray, frames_done: np.ndarray, active: np.ndarray, continue_cb: np.ndarray,
+                        continue_payload: np.ndarray):
+        """The two structs of a ``vad_tick_run_work`` call, inputs filled in - for callers that make the call themselves
+        (``_wirebox.tick_shards``: several engines' ticks side by side); ``tick_work_end`` turns them into arrays afterwards."""
+        r = _ffi.TickResult()
+        r.struct_size = C.sizeof(_ffi.TickResult)
+        w = _ffi.TickWork()
+        w.struct_size = C.sizeof(_ffi.TickWork)
+        w.n_slots = int(last_prob.size)
+        assert frames_done.size == w.n_slots and active.size == w.n_slots and continue_cb.size == w.n_slots and continue_payload.size == w.n_slots
+        w.last_prob = _ptr(last_prob, C.c_float)
+        w.frames_done = _ptr(frames_done, C.c_int64)
+        w.active = active.ctypes.data_as(C.POINTER(C.c_uint8))
+        w.continue_cb = continue_cb.ctypes.data_as(C.POINTER(C.c_uint8))
+        w.continue_payload = continue_payload.ctypes.data_as(C.POINTER(C.c_uint8))
+        return r, w
+
+    def tick_work_end(self, r, w, rc: int):
+        slots, _p, _ev, _seg, gs, frames, nsamp = self._tick_arrays(r, rc)
+        nw = int(w.n_work)
+        if nw == 0:
+            return slots, gs, frames, nsamp, np.empty(0, np.int32), np.empty(0, np.uint8), np.empty(0, np.int64)
+        as_arr = np.ctypeslib.as_array
+        return slots, gs, frames, nsamp, as_arr(w.work_index, (nw,)), as_arr(w.work_kind, (nw,)), as_arr(w.work_samples, (nw,))
+
+    def tick_work_entry(self) -> int:
+        """address of ``vad_tick_run_work``"""
+        return C.cast(self._lib.vad_tick_run_work, C.c_void_p).value
+
+    def tick_wav_entry(self):
+        """(address of ``vad_tick_take_segment_wav16``, address of this engine) for callers that take segments from C
+        (``_wirebox.take_wav16``: the payload is written straight into the bytes object)."""
+        if not self._h:
+            raise VADError("engine is closed")
+        return C.cast(self._lib.vad_tick_take_segment_wav16, C.c_void_p).value, int(self._h.value)
+
+    def tick_take_segment_wav16(self, slot: int, sample_rate: int) -> bytes:
+        """The finished segment of ``slot`` as the ``voice_end_callback`` payload: RIFF/WAVE header + int16 PCM, built in the
+        engine (``vad_tick_take_segment_wav16``), byte for byte ``WAVWriter(sample_rate, 16, 1).write_wav_data`` of it."""
+        n = C.c_int64()
+        self._check(self._lib.vad_tick_take_segment_wav16(self._h, int(slot), int(sample_rate), None, 0, C.byref(n)), VADError)
+        buf = bytearray(int(n.value))
+        self._check(self._lib.vad_tick_take_segment_wav16(self._h, int(slot), int(sample_rate),
+                                                          (C.c_char * len(buf)).from_buffer(buf), len(buf), C.byref(n)), VADError)
+        return bytes(buf)
 
     # ------------------------------------------------------------------ pipelined host ingest
     def submit(self, slots, frames, denoise: Optional[float] = 0.01, i16_scale: int = 32767) -> int:

@@ -359,7 +359,7 @@ def create_app(pool: Optional[SharedStreamPool] = None, tick_interval: float = 0
 
     def ensure_ticker() -> None:
         p = get_pool()
-        if hasattr(p, "shards"):                 # one free-running ticker thread per GPU: a slow device holds nobody else back
+        if hasattr(p, "shards"):                 # one ticker thread conducts every GPU's tick (ShardedStreamPool.start)
             p.tick_interval = tick_interval
             p.start()
         elif state["ticker"] is None or state["ticker"].done():

@@ -17,12 +17,13 @@ that never moved (tests/test_gpu_server.py).  ``rebalance()`` uses it to even th
 from __future__ import annotations
 
 import threading
+import time
 from typing import List, Optional, Sequence
 
 from ..core.config import SileroModelVersion, VADConfig
 from ..core.exceptions import AudioProcessingError
 from ..pool import EnginePool
-from .shared_pool import PooledSession, SharedStreamPool
+from .shared_pool import PooledSession, SharedStreamPool, conduct_ticks
 
 
 class ShardedStreamPool:
@@ -47,6 +48,8 @@ class ShardedStreamPool:
         self.convert_rates = self.shards[0].convert_rates
         self.tick_interval = tick_interval
         self._place = threading.Lock()             # placement and migration: one at a time
+        self._thread: Optional[threading.Thread] = None
+        self._stop = threading.Event()
         self.migrations = 0
 
     # ------------------------------------------------------------------ sessions (the SharedStreamPool surface)
@@ -116,6 +119,8 @@ class ShardedStreamPool:
                         dst._grow(new_slot + 1)
                         for name in ("_thr", "_active", "_cont", "_contp", "_gate", "_lastp", "_done"):
                             getattr(dst, name)[new_slot] = getattr(src, name)[old_slot]
+                        dst._cont_cb[new_slot], src._cont_cb[old_slot] = src._cont_cb[old_slot], None
+                        dst._wav_rate[new_slot], src._wav_rate[old_slot] = src._wav_rate[old_slot], 0
                         src._sessions.pop(old_slot, None)
                         src._by_slot[old_slot] = None
                         s._home = (dst, new_slot)      # readers of the pair (frames_done, active) never see a mixed one
@@ -147,21 +152,10 @@ class ShardedStreamPool:
 
     # ------------------------------------------------------------------ ticking
     def tick(self) -> int:
-        """One tick on every shard, the devices side by side (each shard's tick on its own thread); -> frames processed.
-        The serving path uses ``start()`` instead: one free-running ticker per shard."""
-        if len(self.shards) == 1:
-            return self.shards[0].tick()
-        out = [0] * len(self.shards)
-
-        def one(i: int) -> None:
-            out[i] = self.shards[i].tick()
-        ths = [threading.Thread(target=one, args=(i,)) for i in range(1, len(self.shards))]
-        for t in ths:
-            t.start()
-        one(0)
-        for t in ths:
-            t.join()
-        return sum(out)
+        """One tick on every shard, the devices side by side, conducted by this thread (``shared_pool.conduct_ticks``: the
+        engines' work on one C thread per shard behind a single release of the interpreter lock, then the events pool by pool);
+        -> frames processed."""
+        return conduct_ticks(self.shards)
 
     def drain(self, max_ticks: int = 1 << 30) -> int:
         total = 0
@@ -173,15 +167,34 @@ class ShardedStreamPool:
         return total
 
     def start(self) -> None:
-        for p in self.shards:
-            p.tick_interval = self.tick_interval
-            p.start()
+        """ONE ticker thread for all shards: every ``tick_interval`` it conducts a tick of every pool (``tick``).  (A ticker
+        thread per pool, as round 3 had it, made the threads queue for the interpreter lock: DESIGN.md §4.4.)"""
+        if self._thread is not None:
+            return
+        self._stop.clear()
+
+        def loop():
+            while not self._stop.is_set():
+                t0 = time.perf_counter()
+                try:
+                    self.tick()
+                except Exception:                   # the ticker outlives any single bad tick
+                    pass
+                if self.backlog:                    # a client is ahead of real time: catch up, do not sleep
+                    continue
+                self._stop.wait(max(0.0, self.tick_interval - (time.perf_counter() - t0)))
+
+        self._thread = threading.Thread(target=loop, name="vad-shards-ticker", daemon=True)
+        self._thread.start()
 
     def stop(self) -> None:
-        for p in self.shards:
-            p.stop()
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+            self._thread = None
 
     def close(self) -> None:
+        self.stop()
         for p in self.shards:
             p.close()
 

@@ -42,7 +42,7 @@ extern "C" {
 #define VAD_API
 #endif
 
-#define VAD_ABI_VERSION 3
+#define VAD_ABI_VERSION 4
 #define VAD_FRAME_SAMPLES 512   /* core/silero_model.py:464-468: frames are padded/truncated to 512 (Silero V5 8 kHz engines: 256, see vad_info) */
 #define VAD_STATE_FLOATS 256    /* V5: state[2][1][128]; V4: h[2][1][64] then c[2][1][64]  (silero_model.py:391-401) */
 
@@ -344,6 +344,48 @@ VAD_API int vad_tick_take_segment(vad_engine *e, int64_t slot, float *out, int64
 VAD_API int vad_tick_segment_save(vad_engine *e, int64_t slot, void *buf, int64_t cap, int64_t *nbytes);
 VAD_API int vad_tick_segment_restore(vad_engine *e, int64_t slot, const void *buf, int64_t nbytes);
 VAD_API int vad_tick_run(vad_engine *e, float denoise_thresh, vad_tick_result *out);
+
+/*
+ * ABI 4: vad_tick_run + the per-session bookkeeping a serving front end does with its result, in the same call - so that a
+ * front end whose callbacks live in an interpreter touches only the sessions that HAVE something to hear (the reference does all
+ * of this per frame and client in Python: VADProcessor.process_frame / VADWrapper._handle_callbacks,
+ * core/silero_model.py:723-762, core/vad_wrapper.py:478-522).
+ *   in  (caller-owned, one entry per slot, n_slots entries; updated for every stepped slot i = slots[k]):
+ *         last_prob[i] = probs[k];  frames_done[i] += 1;  active[i] = (active[i] | START) & !END   ("inside a segment")
+ *       continue_cb[i] / continue_payload[i]: the session registered a voice_continue callback / wants the frame's bytes with it
+ *   out (engine-owned, valid until the next tick): the entries k of the tick's arrays the caller has work for, in order, with
+ *       work_kind[j] = VAD_WORK_START | VAD_WORK_END (the tick's event bits) | VAD_WORK_CONTINUE (the session was inside a segment
+ *       before this frame and has a voice_continue callback: vad_wrapper.py:513-519) | VAD_WORK_PAYLOAD (... which wants the bytes)
+ *       | VAD_WORK_LONG (the pushed frame was longer than the model's frame: the caller kept the whole frame, vad_tick_push)
+ * Entries without any of these (idle sessions, sessions talking without a continue callback) are not listed.
+ */
+#define VAD_WORK_START 1
+#define VAD_WORK_END 2
+#define VAD_WORK_CONTINUE 4
+#define VAD_WORK_PAYLOAD 8
+#define VAD_WORK_LONG 16
+typedef struct vad_tick_work {
+    uint32_t struct_size;          /* sizeof(vad_tick_work) */
+    int64_t n_slots;               /* length of the five arrays below */
+    float *last_prob;
+    int64_t *frames_done;
+    uint8_t *active;
+    const uint8_t *continue_cb;
+    const uint8_t *continue_payload;
+    int64_t n_work;                /* out */
+    const int32_t *work_index;     /* out: k into vad_tick_result's arrays */
+    const uint8_t *work_kind;      /* out */
+    const int64_t *work_samples;   /* out: VAD_WORK_END entries: samples of the finished segment (vad_tick_take_segment*), else 0 */
+} vad_tick_work;
+VAD_API int vad_tick_run_work(vad_engine *e, float denoise_thresh, vad_tick_result *out, vad_tick_work *work);
+
+/*
+ * ABI 4: vad_tick_take_segment as the finished payload of voice_end_callback: 44-byte RIFF/WAVE header + int16 PCM, byte for
+ * byte what WAVWriter.write_wav_data makes of the segment (utils/wav_writer.py:40-136: clip(x * 32767, -32768, 32767) truncated
+ * to int16, mono).  out == NULL: size query (*nbytes = 44 + 2 * samples; vad_tick_work.work_samples has the count already).
+ * The segment is released when it has been written.
+ */
+VAD_API int vad_tick_take_segment_wav16(vad_engine *e, int64_t slot, int32_t sample_rate, void *out, int64_t cap, int64_t *nbytes);
 
 /*
  * One tick for streams whose audio arrives at another rate: VADConfig.auto_convert_sample_rate.  The reference's hook for it

@@ -178,6 +178,35 @@ class FakeEngine:
         out, st["done"] = st["done"], None
         return out
 
+    def tick_take_segment_wav16(self, slot, sample_rate):
+        """vad_tick_take_segment_wav16: the finished segment as WAVWriter(sample_rate, 16, 1) writes it"""
+        from cutter_vad_amd.utils.wav_writer import WAVWriter
+        return WAVWriter(sample_rate=int(sample_rate), bit_depth=16, channels=1).write_wav_data(self.tick_take_segment(slot))
+
+    def tick_run_work(self, denoise, last_prob, frames_done, active, continue_cb, continue_payload):
+        """vad_tick_run_work (include/vad_engine.h, ABI 4), statement for statement: the tick, the bookkeeping on the caller's
+        per-slot arrays, and the entries the caller has work for with their VAD_WORK_* bits"""
+        slots, p, ev, _seg, gs, frames, nsamp = self.tick_run(denoise)
+        widx, wkind, wsamp = [], [], []
+        first_rate_entry = int(gs[6])
+        for k in range(int(slots.size)):
+            sl, e = int(slots[k]), int(ev[k])
+            was, started, ended = bool(active[sl]), bool(e & 1), bool(e & 2)
+            last_prob[sl] = p[k]
+            frames_done[sl] += 1
+            active[sl] = (was or started) and not ended
+            kind = (1 if started else 0) | (2 if ended else 0)
+            if was and continue_cb[sl]:
+                kind |= 4 | (8 if continue_payload[sl] else 0)
+            if k < first_rate_entry and int(nsamp[k]) > self.frame_samples:
+                kind |= 16
+            if kind:
+                widx.append(k)
+                wkind.append(kind)
+                st = self.__dict__.get("_seg", {}).get(sl)
+                wsamp.append(int(st["done"].size) if (kind & 2) and st and st["done"] is not None else 0)
+        return slots, gs, frames, nsamp, np.array(widx, np.int32), np.array(wkind, np.uint8), np.array(wsamp, np.int64)
+
     def _assemble(self, slot, g, x, p, ev, denoise):
         """the host half of _process_voice_state on the frame as pushed (vad_tick_enable_segments)"""
         st = self.__dict__.setdefault("_seg", {}).setdefault(int(slot), dict(active=False, pre=[], seg=[], done=None))

@@ -181,6 +181,39 @@ def test_a_frame_pushed_during_a_flush_never_overtakes_its_sessions_earlier_fram
     assert sorted(seen[:3]) == [(1, 256), (2, 512), (3, 320)]    # the first flush carried exactly the three frames queued before it
 
 
+def test_a_pusher_with_a_fallback_is_a_complete_submit_method():
+    """What PooledSession.submit_pcm16 is while a session is live: one C call per wire frame; a frame the inbox does not take is
+    handed to the fallback from inside that call, and its result (or exception) is the call's."""
+    import gc
+    import weakref
+    box = _wirebox.Inbox(1024)
+    got = []
+
+    class Owner:
+        def general(self, data):
+            got.append(data)
+            if data == b"boom":
+                raise ValueError("general path failed")
+            return "general"
+    o = Owner()
+    push = box.pusher(5, True, 0, 0, o.general)
+    o.push = push                                   # owner <-> pusher <-> bound method: a cycle through a C object
+    assert push(bytes(512)) is True and len(box) == 1 and got == []
+    assert push(bytes(3)) == "general" and push(bytearray(8)) == "general" and len(box) == 1      # odd length / not bytes
+    assert push(bytes(480)) == "general"            # another length within one flush: the general path flushes first
+    with pytest.raises(ValueError, match="general path failed"):
+        push(b"boom")
+    push.invalidate()
+    assert push(bytes(512)) == "general" and len(box) == 1 and len(got) == 5
+    with pytest.raises(TypeError):
+        box.pusher(5, True, 0, 0, 42)
+    assert box.pusher(5, True, 0, 0, None)(bytes(3)) is False          # no fallback: the old contract
+    w = weakref.ref(o)
+    del o, push
+    gc.collect()
+    assert w() is None                              # the pusher takes part in garbage collection: the cycle does not leak
+
+
 def test_many_producers_and_a_flusher_lose_nothing():
     box = _wirebox.Inbox(64)
     total = []
@@ -274,7 +307,9 @@ def test_closing_or_moving_a_session_takes_its_pusher_away_first(monkeypatch):
     assert len(pool._wire) == 1
     s.close()
     assert not push.valid and s._push is None and len(pool._wire) == 0
-    assert not push(bytes(960)) and len(pool._wire) == 0            # a stale reference to the pusher cannot reach a recycled slot
+    with pytest.raises(AudioProcessingError, match="closed"):       # a stale reference to the pusher cannot reach a recycled slot:
+        push(bytes(960))                                            # not taken -> its fallback, the general path, which says why
+    assert len(pool._wire) == 0 and s.submit_pcm16 == s._submit_pcm16_general
     t = pool.open_session(VADConfig(buffer_size=480, sample_rate=16000))
     assert t._push is not push and t._push.valid
     pool.close()

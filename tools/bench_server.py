@@ -159,7 +159,8 @@ def run_fake_shards(n_shards, sessions, ticks=60, talking=0.5):
     host stand-ins for the kernel launches, p = |first sample|), behind ShardedStreamPool - one pool, one ticker thread per shard -
     with the C inbox and the reference server's callbacks (voice_continue as a notification).  What it measures is everything the
     serving process does on the host per 30 ms of audio of every client: `submit_pcm16` per session on ONE thread (the event loop's
-    role), then every shard's tick on its own thread, side by side under one GIL.  Half the sessions talk (their frames open and close
+    role), then one conducted tick of all shards (`ShardedStreamPool.tick`): the engines' share side by side on C threads behind one
+    release of the interpreter lock, then the events fanned out shard by shard on the conducting thread.  Half the sessions talk (their frames open and close
     segments: START / CONTINUE per frame / END with a WAV payload), half are silent."""
     import threading
     from cutter_vad_amd import _ffi, weights_io
@@ -196,16 +197,16 @@ def run_fake_shards(n_shards, sessions, ticks=60, talking=0.5):
     quiet = np.zeros(480, "<i2")
     loud_b, quiet_b = loud.tobytes(), quiet.tobytes()
     n_talk = int(sessions * talking)
-    tick_wall = [[] for _ in range(n_shards)]
-    for k, p in enumerate(pool.shards):         # per-shard tick wall time, measured inside its own thread
-        orig = p.tick
+    tick_wall = [[] for _ in range(n_shards)]   # per shard: the fan-out of its events on the conducting thread
+    for k, p in enumerate(pool.shards):
+        orig = p._fan_out
 
-        def timed(orig=orig, k=k):
+        def timed(res, wavs, orig=orig, k=k):
             a = time.perf_counter()
-            n = orig()
+            n = orig(res, wavs)
             tick_wall[k].append(time.perf_counter() - a)
             return n
-        p.tick = timed
+        p._fan_out = timed
     t_sub = t_tick = 0.0
     warm = 5
     # a talker's 40-tick cycle (20 loud, 20 quiet) starts at its own phase, so STARTs and ENDs (a WAV payload each) are spread
@@ -227,13 +228,15 @@ def run_fake_shards(n_shards, sessions, ticks=60, talking=0.5):
             for w in tick_wall:
                 w.clear()
     per_shard = [{"mean_ms": float(np.mean(w)) * 1e3, "max_ms": float(np.max(w)) * 1e3} for w in tick_wall]
+    fan = sum(x["mean_ms"] for x in per_shard)
     stats = pool.stats()
     pool.close()
     per_round = (t_sub + t_tick) / ticks
     return {"mode": "fake shards (real engine.cpp + _wirebox + pools; kernels = host stand-ins, tools/san_tick)", "shards": n_shards,
             "sessions": sessions, "sessions_per_shard": per, "talking_fraction": talking, "ticks": ticks, "host_cores": os.cpu_count(),
             "open_all_sessions_s": t_open, "submit_ms_per_round": t_sub / ticks * 1e3, "tick_all_shards_ms_per_round": t_tick / ticks * 1e3,
-            "per_shard_tick_wall": per_shard, "round_ms": per_round * 1e3, "audio_ms_per_round": 30.0,
+            "engines_side_by_side_ms_per_round": t_tick / ticks * 1e3 - fan, "fan_out_all_shards_ms_per_round": fan,
+            "per_shard_fan_out_wall": per_shard, "round_ms": per_round * 1e3, "audio_ms_per_round": 30.0,
             "real_time_factor": 0.030 / per_round, "frames_per_s_host_inclusive": sessions / per_round,
             "frames_per_launch": stats["frames_per_launch"], "events": counts}
 
