@@ -47,10 +47,12 @@ B_PER_GPU = 8192
 RING = 32
 FLOP_PER_FRAME = {5: 988160, 4: 1380000}   # SURVEY §8 d: V5 494 080 valid-tap MAC; V4 ~0.69 M MAC
 BYTES_PER_FRAME = 4100                     # SURVEY §8 d: 2048 in + 1024 state R + 1024 state W + 4 prob
-# What the V5 kernel EXECUTES per frame: 1 221 v_mfma_f32_32x32x2_f32 per wave (recurrent half 256, 4-way folded
-# DFT 192, Toom-3 enc0 325, enc1 128, enc2 32, enc3 32, LSTM input half 256) x 4 waves x 2048 MAC / 32 streams.  Fewer than
-# the algorithmic count because the folds and the Toom-3 product are exact algebraic reductions of the graph's sums.
-EXECUTED_FLOP_PER_FRAME = 1221 * 4 * 2048 * 2 // 32
+# What the V5 kernel EXECUTES per frame, in units of one v_mfma_f32_32x32x2_f32 (2 048 MAC) per wave: recurrent
+# half 256, folded DFT 144 (288 v_mfma_f32_16x16x4_f32 of half the size: the even bins fold a third time since round 4; 192 before),
+# Toom-3 enc0 325, enc1 128, enc2 32, enc3 32, LSTM input half 256 = 1 173 (1 221 through round 3) x 4 waves x 2048 MAC / 32
+# streams.  Fewer than the algorithmic count because the folds and the Toom-3 product are exact algebraic reductions of the sums.
+EXECUTED_MFMA_UNITS_PER_WAVE = 1173
+EXECUTED_FLOP_PER_FRAME = EXECUTED_MFMA_UNITS_PER_WAVE * 4 * 2048 * 2 // 32
 PEAK_FP32_MFMA = 157.3e12        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM = 8.0e12                # same guide, HBM3E spec
 PARITY_STEPS = 4
@@ -419,7 +421,7 @@ def main() -> int:
                 "host_enqueue_us_per_launch": host_enqueue[0] / args.steps / len(versions) * 1e6,
                 "algorithmic_flop_per_launch": flop,
                 "note": "frac = ALGORITHMIC FLOPs (the graph's dense sums, SURVEY 8d) / launch time / peak, as the bench "
-                        "contract prescribes; the V5 kernel executes 63 % of them (folded DFT, Toom-3 enc0), so frac can "
+                        "contract prescribes; the V5 kernel executes 61 % of them (folded DFT, Toom-3 enc0), so frac can "
                         "exceed 1 while the MFMA pipe is busy executed_frac_of_peak of the time: read executed_frac_of_peak "
                         "as the utilisation",
                 "hbm_algorithmic_GBps": BYTES_PER_FRAME * B / ks / 1e9,

@@ -222,18 +222,11 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
         const f32x4 xA = decode(XR[(XO) + 0]), xB = decode(XR[(XO) + 1]);                                       \
         const f32x4 xC = decode(XR[(XO) + 2]), xD = decode(XR[(XO) + 3]);                                       \
         const float mBx = mirror(xB.x), mDx = mirror(xD.x);                                                     \
-        const f32x4 y1 = f32x4{xA.x * W1.x, xA.y * W1.y, xA.z * W1.z, xA.w * W1.w};                             \
-        const f32x4 y3 = f32x4{xC.x * W3.x, xC.y * W3.y, xC.z * W3.z, xC.w * W3.w};                             \
-        const f32x4 y2 = f32x4{shr1(xC.x, mBx) * W3.x, mirror(xB.w) * W3.y, mirror(xB.z) * W3.z, mirror(xB.y) * W3.w}; \
-        const f32x4 y4 = f32x4{shr1(0.f, mDx) * W1.x, mirror(xD.w) * W1.y, mirror(xD.z) * W1.z, mirror(xD.y) * W1.w};  \
-        const f32x4 s14 = f32x4{y1.x + y4.x, y1.y + y4.y, y1.z + y4.z, y1.w + y4.w};                            \
-        const f32x4 d14 = f32x4{y1.x - y4.x, y1.y - y4.y, y1.z - y4.z, y1.w - y4.w};                            \
-        const f32x4 s23 = f32x4{y2.x + y3.x, y2.y + y3.y, y2.z + y3.z, y2.w + y3.w};                            \
-        const f32x4 d23 = f32x4{y2.x - y3.x, y2.y - y3.y, y2.z - y3.z, y2.w - y3.w};                            \
-        f32x4 pe = f32x4{s14.x + s23.x, s14.y + s23.y, s14.z + s23.z, s14.w + s23.w};                           \
-        f32x4 po = f32x4{s14.x - s23.x, s14.y - s23.y, s14.z - s23.z, s14.w - s23.w};                           \
-        f32x4 qe = f32x4{d14.x - d23.x, d14.y - d23.y, d14.z - d23.z, d14.w - d23.w};                           \
-        f32x4 qo = f32x4{d14.x + d23.x, d14.y + d23.y, d14.z + d23.z, d14.w + d23.w};                           \
+        const f32x4 y1 = pk::mul(xA, W1), y3 = pk::mul(xC, W3);                                                 \
+        const f32x4 y2 = pk::mul(f32x4{shr1(xC.x, mBx), mirror(xB.w), mirror(xB.z), mirror(xB.y)}, W3);         \
+        const f32x4 y4 = pk::mul(f32x4{shr1(0.f, mDx), mirror(xD.w), mirror(xD.z), mirror(xD.y)}, W1);          \
+        const f32x4 s14 = pk::add(y1, y4), d14 = pk::sub(y1, y4), s23 = pk::add(y2, y3), d23 = pk::sub(y2, y3); \
+        f32x4 pe = pk::add(s14, s23), po = pk::sub(s14, s23), qe = pk::sub(d14, d23), qo = pk::add(d14, d23);   \
         {                             /* n = 0 is not part of the folded sums; rank-1 terms of n = 0 / 64 / 128 (branch-free): */ \
             /* lane q = 0 holds sample 64 (B.x), 128 (C.x) and 192 (D.x) of the column */                       \
             pe.x = q0 ? 0.f : pe.x; po.x = q0 ? 0.f : po.x; qe.x = q0 ? 0.f : qe.x; qo.x = q0 ? 0.f : qo.x;        \
@@ -258,10 +251,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
                stays in the MFMAs' basic block).  Slot n = 0 carries the unpaired n = 32 (lane 8, component 0): pe[32] | qe[32] */ \
             const f32x4 pm = f32x4{shr1(0.f, mirror(pe.x)), mirror(pe.w), mirror(pe.z), mirror(pe.y)};           \
             const f32x4 qm = f32x4{shr1(0.f, mirror(qe.x)), mirror(qe.w), mirror(qe.z), mirror(qe.y)};           \
-            f32x4 pep = f32x4{pe.x + pm.x, pe.y + pm.y, pe.z + pm.z, pe.w + pm.w};                              \
-            f32x4 pen = f32x4{pe.x - pm.x, pe.y - pm.y, pe.z - pm.z, pe.w - pm.w};                              \
-            f32x4 qen = f32x4{qe.x - qm.x, qe.y - qm.y, qe.z - qm.z, qe.w - qm.w};                              \
-            f32x4 qep = f32x4{qe.x + qm.x, qe.y + qm.y, qe.z + qm.z, qe.w + qm.w};                              \
+            f32x4 pep = pk::add(pe, pm), pen = pk::sub(pe, pm), qen = pk::sub(qe, qm), qep = pk::add(qe, qm);   \
             const float pe32 = shl8(pe.x), qe32 = shl8(qe.x);                                                   \
             pep.x = q0 ? pe32 : pep.x; pen.x = q0 ? 0.f : pen.x; qen.x = q0 ? 0.f : qen.x; qep.x = q0 ? qe32 : qep.x; \
             st2(&RX[(CS * (c) + q) * QS + ms], po);                                                             \
@@ -524,17 +514,13 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
                 for (int sh = 0; sh < 2; ++sh) {
                     f32x4 mg[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const f32x4 r = sre[c][sh][rt], i = sim[c][sh][rt];
-                        mg[c] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
-                    }
-                    const f32x4 s02 = mg[0] + mg[2];
+                    for (int c = 0; c < 3; ++c) mg[c] = pk::mag(sre[c][sh][rt], sim[c][sh][rt]);
+                    const f32x4 s02 = pk::add(mg[0], mg[2]);
                     f32x4 *o = RX + (8 * w + 4 * rt + kq) * QS + n16 + 16 * sh;
                     st2(o, mg[0]);
-                    st2(o + PS * QS, s02 + mg[1]);
-                    st2(o + 2 * PS * QS, s02 - mg[1]);
-                    st2(o + 3 * PS * QS, f32x4{fmaf(4.f, mg[2].x, fmaf(2.f, mg[1].x, mg[0].x)), fmaf(4.f, mg[2].y, fmaf(2.f, mg[1].y, mg[0].y)),
-                                               fmaf(4.f, mg[2].z, fmaf(2.f, mg[1].z, mg[0].z)), fmaf(4.f, mg[2].w, fmaf(2.f, mg[1].w, mg[0].w))});
+                    st2(o + PS * QS, pk::add(s02, mg[1]));
+                    st2(o + 2 * PS * QS, pk::sub(s02, mg[1]));
+                    st2(o + 3 * PS * QS, pk::fma(pk::splat(4.f), mg[2], pk::fma(pk::splat(2.f), mg[1], mg[0])));
                     st2(o + 4 * PS * QS, mg[2]);
                 }
             // |X128|: rows 160 / 161 = (points 0, 1, -1, 2) / zeros, rows 162 / 163 = (inf, 0, 0, 0) / zeros
@@ -591,15 +577,17 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
             }
             // interpolation (P(1), P(-1) arrive halved: the 1/2 sits in the weights) + bias
             {
+                // (packed: sixteen registers per tile and step - written with the scalar operators every subtraction here became
+                // sixteen v_sub_f32)
                 const f32x16 bias = acc_of(e0b0, e0b1, e0b2, e0b3);
                 const f32x16 y0 = acc[0], y4 = acc[4];
-                const f32x16 bb = acc[1] - acc[2];
-                const f32x16 y2 = (acc[1] + acc[2]) - y0 - y4;
-                const f32x16 t2 = (acc[3] - y0) - 4.0f * y2 - 16.0f * y4;          // = 2 (y1 + 4 y3)
-                const f32x16 y3 = t2 * (1.0f / 6.0f) - bb * (1.0f / 3.0f);
-                acc[0] = (bb - y3) + bias;
-                acc[1] = y2 + bias;
-                acc[2] = y3 + bias;
+                const f32x16 bb = pk::sub16(acc[1], acc[2]);
+                const f32x16 y2 = pk::sub16(pk::sub16(pk::add16(acc[1], acc[2]), y0), y4);
+                const f32x16 t2 = pk::fma16(y4, -16.0f, pk::fma16(y2, -4.0f, pk::sub16(acc[3], y0)));          // = 2 (y1 + 4 y3)
+                const f32x16 y3 = pk::fma16(bb, -1.0f / 3.0f, pk::mul16(t2, 1.0f / 6.0f));
+                acc[0] = pk::add16(pk::sub16(bb, y3), bias);
+                acc[1] = pk::add16(y2, bias);
+                acc[2] = pk::add16(y3, bias);
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) store_tile_relu(RE, c * 32 + 8 * w, m, h, acc[c]);

@@ -616,18 +616,11 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
         const int ms = tid >> 4;                                                                                \
         const f32x4 xA = decode(XR[0]), xB = decode(XR[1]), xC = decode(XR[2]), xD = decode(XR[3]);             \
         const float mBx = mirror(xB.x), mDx = mirror(xD.x);                                                     \
-        const f32x4 y1 = f32x4{xA.x * W1.x, xA.y * W1.y, xA.z * W1.z, xA.w * W1.w};                             \
-        const f32x4 y3 = f32x4{xC.x * W3.x, xC.y * W3.y, xC.z * W3.z, xC.w * W3.w};                             \
-        const f32x4 y2 = f32x4{shr1(xC.x, mBx) * W3.x, mirror(xB.w) * W3.y, mirror(xB.z) * W3.z, mirror(xB.y) * W3.w}; \
-        const f32x4 y4 = f32x4{shr1(0.f, mDx) * W1.x, mirror(xD.w) * W1.y, mirror(xD.z) * W1.z, mirror(xD.y) * W1.w};  \
-        const f32x4 s14 = f32x4{y1.x + y4.x, y1.y + y4.y, y1.z + y4.z, y1.w + y4.w};                            \
-        const f32x4 d14 = f32x4{y1.x - y4.x, y1.y - y4.y, y1.z - y4.z, y1.w - y4.w};                            \
-        const f32x4 s23 = f32x4{y2.x + y3.x, y2.y + y3.y, y2.z + y3.z, y2.w + y3.w};                            \
-        const f32x4 d23 = f32x4{y2.x - y3.x, y2.y - y3.y, y2.z - y3.z, y2.w - y3.w};                            \
-        f32x4 pe = f32x4{s14.x + s23.x, s14.y + s23.y, s14.z + s23.z, s14.w + s23.w};                           \
-        f32x4 po = f32x4{s14.x - s23.x, s14.y - s23.y, s14.z - s23.z, s14.w - s23.w};                           \
-        f32x4 qe = f32x4{d14.x - d23.x, d14.y - d23.y, d14.z - d23.z, d14.w - d23.w};                           \
-        f32x4 qo = f32x4{d14.x + d23.x, d14.y + d23.y, d14.z + d23.z, d14.w + d23.w};                           \
+        const f32x4 y1 = pk::mul(xA, W1), y3 = pk::mul(xC, W3);                                                 \
+        const f32x4 y2 = pk::mul(f32x4{shr1(xC.x, mBx), mirror(xB.w), mirror(xB.z), mirror(xB.y)}, W3);         \
+        const f32x4 y4 = pk::mul(f32x4{shr1(0.f, mDx), mirror(xD.w), mirror(xD.z), mirror(xD.y)}, W1);          \
+        const f32x4 s14 = pk::add(y1, y4), d14 = pk::sub(y1, y4), s23 = pk::add(y2, y3), d23 = pk::sub(y2, y3); \
+        f32x4 pe = pk::add(s14, s23), po = pk::sub(s14, s23), qe = pk::sub(d14, d23), qo = pk::add(d14, d23);   \
         {                                                                                                       \
             pe.x = q0 ? 0.f : pe.x; po.x = q0 ? 0.f : po.x; qe.x = q0 ? 0.f : qe.x; qo.x = q0 ? 0.f : qo.x;        \
             const float y64 = xB.x * w64, y192 = xD.x * w64;                                                    \
@@ -642,10 +635,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
            block).  Slot n = 0 carries the unpaired n = 32 (lane 8, component 0): pe[32] | qe[32] */                  \
         const f32x4 pm = f32x4{shr1(0.f, mirror(pe.x)), mirror(pe.w), mirror(pe.z), mirror(pe.y)};               \
         const f32x4 qm = f32x4{shr1(0.f, mirror(qe.x)), mirror(qe.w), mirror(qe.z), mirror(qe.y)};               \
-        f32x4 pep = f32x4{pe.x + pm.x, pe.y + pm.y, pe.z + pm.z, pe.w + pm.w};                                  \
-        f32x4 pen = f32x4{pe.x - pm.x, pe.y - pm.y, pe.z - pm.z, pe.w - pm.w};                                  \
-        f32x4 qen = f32x4{qe.x - qm.x, qe.y - qm.y, qe.z - qm.z, qe.w - qm.w};                                  \
-        f32x4 qep = f32x4{qe.x + qm.x, qe.y + qm.y, qe.z + qm.z, qe.w + qm.w};                                  \
+        f32x4 pep = pk::add(pe, pm), pen = pk::sub(pe, pm), qen = pk::sub(qe, qm), qep = pk::add(qe, qm);       \
         const float pe32 = shl8(pe.x), qe32 = shl8(qe.x);                                                       \
         pep.x = q0 ? pe32 : pep.x; pen.x = q0 ? 0.f : pen.x; qen.x = q0 ? 0.f : qen.x; qep.x = q0 ? qe32 : qep.x;   \
         st2(&RX[(64 * (c) + q) * QSL + ms], po);                                                               \
@@ -772,17 +762,13 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             for (int rt = 0; rt < 2; ++rt) {
                 f32x4 mg[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const f32x4 r = are[c][rt], i = aim[c][rt];
-                    mg[c] = f32x4{mag_(r.x, i.x), mag_(r.y, i.y), mag_(r.z, i.z), mag_(r.w, i.w)};
-                }
-                const f32x4 s02 = f32x4{mg[0].x + mg[2].x, mg[0].y + mg[2].y, mg[0].z + mg[2].z, mg[0].w + mg[2].w};
+                for (int c = 0; c < 3; ++c) mg[c] = pk::mag(are[c][rt], aim[c][rt]);
+                const f32x4 s02 = pk::add(mg[0], mg[2]);
                 f32x4 *o = RX + (8 * w + 4 * rt) * QSD + nq;
                 st2(o, mg[0]);
-                st2(o + 32 * QSD, f32x4{s02.x + mg[1].x, s02.y + mg[1].y, s02.z + mg[1].z, s02.w + mg[1].w});
-                st2(o + 64 * QSD, f32x4{s02.x - mg[1].x, s02.y - mg[1].y, s02.z - mg[1].z, s02.w - mg[1].w});
-                st2(o + 96 * QSD, f32x4{fmaf(4.f, mg[2].x, fmaf(2.f, mg[1].x, mg[0].x)), fmaf(4.f, mg[2].y, fmaf(2.f, mg[1].y, mg[0].y)),
-                                         fmaf(4.f, mg[2].z, fmaf(2.f, mg[1].z, mg[0].z)), fmaf(4.f, mg[2].w, fmaf(2.f, mg[1].w, mg[0].w))});
+                st2(o + 32 * QSD, pk::add(s02, mg[1]));
+                st2(o + 64 * QSD, pk::sub(s02, mg[1]));
+                st2(o + 96 * QSD, pk::fma(pk::splat(4.f), mg[2], pk::fma(pk::splat(2.f), mg[1], mg[0])));
                 st2(o + 128 * QSD, mg[2]);
             }
             if (tid < 64) {      // |X128|: values on the kq = 0 rows (160, 164), zeros on the other three of each group
@@ -843,14 +829,14 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             for (int rt = 0; rt < 2; ++rt) {      // interpolation (P(1), P(-1) arrive halved) + bias + ReLU -> rows 168 + 32 c + 8 w + 4 rt + kq
                 const f32x4 bias = e0b[rt];
                 const f32x4 y0 = acc[0][rt], y4 = acc[4][rt];
-                const f32x4 bb = acc[1][rt] - acc[2][rt];
-                const f32x4 y2 = (acc[1][rt] + acc[2][rt]) - y0 - y4;
-                const f32x4 t2 = (acc[3][rt] - y0) - 4.0f * y2 - 16.0f * y4;
-                const f32x4 y3 = t2 * (1.0f / 6.0f) - bb * (1.0f / 3.0f);
+                const f32x4 bb = pk::sub(acc[1][rt], acc[2][rt]);
+                const f32x4 y2 = pk::sub(pk::sub(pk::add(acc[1][rt], acc[2][rt]), y0), y4);
+                const f32x4 t2 = pk::fma(y4, pk::splat(-16.0f), pk::fma(y2, pk::splat(-4.0f), pk::sub(acc[3][rt], y0)));
+                const f32x4 y3 = pk::fma(bb, pk::splat(-1.0f / 3.0f), pk::mul(t2, pk::splat(1.0f / 6.0f)));
                 f32x4 *o = RE + (8 * w + 4 * rt) * QSD + nq;
-                o[0] = relu4((bb - y3) + bias);
-                o[32 * QSD] = relu4(y2 + bias);
-                o[64 * QSD] = relu4(y3 + bias);
+                o[0] = relu4(pk::add(pk::sub(bb, y3), bias));
+                o[32 * QSD] = relu4(pk::add(y2, bias));
+                o[64 * QSD] = relu4(pk::add(y3, bias));
             }
         }
         __syncthreads();   // (3) enc0 out

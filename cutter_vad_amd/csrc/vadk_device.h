@@ -78,6 +78,60 @@ __device__ __forceinline__ f32x16 acc_of(f32x4 b0, f32x4 b1, f32x4 b2, f32x4 b3)
     return a;
 }
 
+// ---- quad / tile arithmetic as PACKED fp32 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two lanes of a register pair per
+// instruction, the scalar forms' rounding).  fp32 MFMAs and VALU instructions share the vector pipe on this chip, so every VALU
+// instruction not issued is time; left to itself the compiler packs about a fifth of such code and scalarises every subtraction
+// (the backend has no packed subtract: the packed add with its negate modifier is written out).  The add / mul helpers are
+// compiled WITHOUT contraction: where a caller keeps a product and a sum apart (the loaders' folds: the int16 and float32
+// instantiations must round alike) they stay apart after inlining.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma clang fp contract(off)
+namespace pk {
+__device__ __forceinline__ f32x4 cat(f32x2 lo, f32x2 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3); }
+__device__ __forceinline__ f32x2 sub2(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x4 add(f32x4 a, f32x4 b) { return cat(a.lo + b.lo, a.hi + b.hi); }
+__device__ __forceinline__ f32x4 sub(f32x4 a, f32x4 b) { return cat(sub2(a.lo, b.lo), sub2(a.hi, b.hi)); }
+__device__ __forceinline__ f32x4 mul(f32x4 a, f32x4 b) { return cat(a.lo * b.lo, a.hi * b.hi); }
+__device__ __forceinline__ f32x4 fma(f32x4 a, f32x4 b, f32x4 c) {
+    return cat(__builtin_elementwise_fma(a.lo, b.lo, c.lo), __builtin_elementwise_fma(a.hi, b.hi, c.hi));
+}
+__device__ __forceinline__ f32x4 splat(float v) { return f32x4{v, v, v, v}; }
+// |re + i im| of a quad: fma(re, re, im * im) as in mag_(), packed, then the four square roots
+__device__ __forceinline__ f32x4 mag(f32x4 re, f32x4 im) {
+    const f32x4 q = fma(re, re, mul(im, im));
+    return f32x4{__builtin_amdgcn_sqrtf(q.x), __builtin_amdgcn_sqrtf(q.y), __builtin_amdgcn_sqrtf(q.z), __builtin_amdgcn_sqrtf(q.w)};
+}
+// the same on a 32 x 32 tile's 16 accumulator registers, quad by quad
+#define VADK_PK16(expr)                                                                                            \
+    {                                                                                                              \
+        f32x16 r_;                                                                                                 \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                         \
+            const f32x4 q_ = (expr);                                                                               \
+            switch (g_) {                                                                                          \
+                case 0: r_.s0 = q_.x; r_.s1 = q_.y; r_.s2 = q_.z; r_.s3 = q_.w; break;                             \
+                case 1: r_.s4 = q_.x; r_.s5 = q_.y; r_.s6 = q_.z; r_.s7 = q_.w; break;                             \
+                case 2: r_.s8 = q_.x; r_.s9 = q_.y; r_.sa = q_.z; r_.sb = q_.w; break;                             \
+                default: r_.sc = q_.x; r_.sd = q_.y; r_.se = q_.z; r_.sf = q_.w; break;                            \
+            }                                                                                                      \
+        }                                                                                                          \
+        return r_;                                                                                                 \
+    }
+__device__ __forceinline__ f32x4 q16(const f32x16 &a, int g) {
+    return g == 0 ? f32x4{a.s0, a.s1, a.s2, a.s3} : g == 1 ? f32x4{a.s4, a.s5, a.s6, a.s7}
+         : g == 2 ? f32x4{a.s8, a.s9, a.sa, a.sb} : f32x4{a.sc, a.sd, a.se, a.sf};
+}
+__device__ __forceinline__ f32x16 add16(const f32x16 &a, const f32x16 &b) VADK_PK16(add(q16(a, g_), q16(b, g_)))
+__device__ __forceinline__ f32x16 sub16(const f32x16 &a, const f32x16 &b) VADK_PK16(sub(q16(a, g_), q16(b, g_)))
+__device__ __forceinline__ f32x16 fma16(const f32x16 &a, float k, const f32x16 &c) VADK_PK16(fma(q16(a, g_), splat(k), q16(c, g_)))
+__device__ __forceinline__ f32x16 mul16(const f32x16 &a, float k) VADK_PK16(mul(q16(a, g_), splat(k)))
+#undef VADK_PK16
+}  // namespace pk
+#pragma clang fp contract(fast)
+
 // No instruction may be moved across this point by the compiler's scheduler.  The kernel's
 // software pipelining (weights for iteration i+1 are requested before the MFMAs of iteration i
 // are issued) only survives hipcc's machine scheduler when it is fenced like this.

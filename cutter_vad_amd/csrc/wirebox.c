@@ -557,24 +557,89 @@ static void *shard_thread(void *a) {
     return NULL;
 }
 
-/* f(job) for every job, the first on this thread, the others on a thread each (created per call: two dozen microseconds each,
- * twice per 10 ms round); a thread that cannot be created runs here instead */
-static void shards_parallel(void (*f)(ShardJob *), ShardJob *jobs, Py_ssize_t n) {
+/* f(job) for every job, side by side: the first on this thread, job k on worker k - a small crew of threads that is started
+ * once and sleeps between rounds (a thread created per job and round cost ~25 us each and started on a cold core every time).
+ * The crew serves one caller at a time; a second conductor in the process, or a thread that cannot be started, falls back to
+ * threads of its own / to running the job here. */
+typedef struct CrewWorker {
+    pthread_t th;
+    int started;
+    void (*f)(ShardJob *);
+    ShardJob *job;
+    uint64_t posted, taken;      /* rounds handed over / picked up */
+} CrewWorker;
+static CrewWorker g_crew[64];
+static pthread_mutex_t g_crew_m = PTHREAD_MUTEX_INITIALIZER;       /* guards every field of the workers */
+static pthread_cond_t g_crew_go = PTHREAD_COND_INITIALIZER, g_crew_done = PTHREAD_COND_INITIALIZER;
+static pthread_mutex_t g_crew_busy = PTHREAD_MUTEX_INITIALIZER;    /* one conductor at a time */
+static int g_crew_pending = 0;
+
+static void *crew_thread(void *a) {
+    CrewWorker *w = (CrewWorker *)a;
+    pthread_mutex_lock(&g_crew_m);
+    for (;;) {
+        while (w->taken == w->posted) pthread_cond_wait(&g_crew_go, &g_crew_m);
+        w->taken = w->posted;
+        void (*f)(ShardJob *) = w->f;
+        ShardJob *job = w->job;
+        pthread_mutex_unlock(&g_crew_m);
+        f(job);
+        pthread_mutex_lock(&g_crew_m);
+        if (--g_crew_pending == 0) pthread_cond_signal(&g_crew_done);
+    }
+    return NULL;
+}
+
+static void shards_parallel_own_threads(void (*f)(ShardJob *), ShardJob *jobs, Py_ssize_t n) {
     pthread_t th[64];
     ShardCall call[64];
     int started[64];
     for (Py_ssize_t k = 1; k < n; ++k) {
         call[k].f = f;
         call[k].job = &jobs[k];
-        const int perr = pthread_create(&th[k], NULL, shard_thread, &call[k]);
-        started[k] = perr == 0;
-        if (perr && getenv("VAD_WIREBOX_TIMING")) fprintf(stderr, "tick_shards: pthread_create failed (%d)\n", perr);
+        started[k] = pthread_create(&th[k], NULL, shard_thread, &call[k]) == 0;
     }
     if (n > 0) f(&jobs[0]);
     for (Py_ssize_t k = 1; k < n; ++k) {
         if (started[k]) pthread_join(th[k], NULL);
         else f(&jobs[k]);
     }
+}
+
+static void shards_parallel(void (*f)(ShardJob *), ShardJob *jobs, Py_ssize_t n) {
+    if (n <= 1) {
+        if (n == 1) f(&jobs[0]);
+        return;
+    }
+    if (pthread_mutex_trylock(&g_crew_busy) != 0) {
+        shards_parallel_own_threads(f, jobs, n);
+        return;
+    }
+    int inline_from = (int)n;                  /* jobs from here on have no worker: run on this thread */
+    pthread_mutex_lock(&g_crew_m);
+    for (Py_ssize_t k = 1; k < n; ++k) {
+        CrewWorker *w = &g_crew[k];
+        if (!w->started) {
+            pthread_attr_t at;
+            pthread_attr_init(&at);
+            pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+            w->started = pthread_create(&w->th, &at, crew_thread, w) == 0;
+            pthread_attr_destroy(&at);
+            if (!w->started) { inline_from = (int)k; break; }
+        }
+        w->f = f;
+        w->job = &jobs[k];
+        w->posted += 1;
+        g_crew_pending += 1;
+    }
+    pthread_cond_broadcast(&g_crew_go);
+    pthread_mutex_unlock(&g_crew_m);
+    f(&jobs[0]);
+    for (Py_ssize_t k = inline_from; k < n; ++k) f(&jobs[k]);
+    pthread_mutex_lock(&g_crew_m);
+    while (g_crew_pending > 0) pthread_cond_wait(&g_crew_done, &g_crew_m);
+    pthread_mutex_unlock(&g_crew_m);
+    pthread_mutex_unlock(&g_crew_busy);
 }
 
 static void shard_job_free(ShardJob *j) {
