@@ -23,6 +23,7 @@ from typing import List, Optional, Sequence
 from ..core.config import SileroModelVersion, VADConfig
 from ..core.exceptions import AudioProcessingError
 from ..pool import EnginePool
+from . import shared_pool
 from .shared_pool import PooledSession, SharedStreamPool, conduct_ticks
 
 
@@ -47,6 +48,10 @@ class ShardedStreamPool:
         self.frame = self.shards[0].frame
         self.convert_rates = self.shards[0].convert_rates
         self.tick_interval = tick_interval
+        # a process that serves several GPUs builds tens of MB of voice_end payloads per tick: the allocator keeps what a tick frees
+        # (csrc/wirebox.c, keep_heap - otherwise every tick's payloads are fresh pages, faulted in by all shards' threads at once)
+        if shared_pool._wirebox is not None and len(self.shards) > 1:
+            shared_pool._wirebox.keep_heap(1 << 30, 256 << 20)
         self._place = threading.Lock()             # placement and migration: one at a time
         self._thread: Optional[threading.Thread] = None
         self._stop = threading.Event()
