@@ -542,11 +542,18 @@ static void shard_push_and_run(ShardJob *j) {
 }
 
 static void shard_write_wavs(ShardJob *j) {
+    struct timespec a_, b_;
+    const int timing = getenv("VAD_WIREBOX_TIMING") != NULL;
+    if (timing) clock_gettime(CLOCK_MONOTONIC, &a_);
     for (Py_ssize_t k = 0; k < j->n_wav; ++k) {
         int64_t got = 0;
         const int64_t nb = 44 + 2 * j->wav_ns[k];
         const int rc = j->wav(j->eng, j->wav_slot[k], j->wav_sr[k], j->wav_buf[k], nb, &got);
         if ((rc != 0 || got != nb) && !j->wav_bad) j->wav_bad = rc ? rc : -1;
+    }
+    if (timing) {
+        clock_gettime(CLOCK_MONOTONIC, &b_);
+        fprintf(stderr, "  wavs of one shard: %zd payloads in %.2f ms\n", j->n_wav, (b_.tv_sec - a_.tv_sec) * 1e3 + (b_.tv_nsec - a_.tv_nsec) * 1e-6);
     }
 }
 
@@ -783,6 +790,7 @@ static PyObject *wirebox_tick_shards(PyObject *Py_UNUSED(mod), PyObject *args) {
             const Py_ssize_t k = j->n_wav++;
             j->wav_slot[k] = slot; j->wav_ns[k] = w->work_samples[q]; j->wav_sr[k] = rate_of[slot];
             j->wav_buf[k] = PyBytes_AS_STRING(b); j->wav_entry[k] = (Py_ssize_t)q;
+            if (getenv("VAD_WIREBOX_TOUCH")) memset(j->wav_buf[k], 0, (size_t)(44 + 2 * w->work_samples[q]));
         }
     }
     if (!ok) goto done;

@@ -211,7 +211,9 @@ def run_fake_shards(n_shards, sessions, ticks=60, talking=0.5):
     warm = 5
     # a talker's 40-tick cycle (20 loud, 20 quiet) starts at its own phase, so STARTs and ENDs (a WAV payload each) are spread
     # over the ticks as they are among real clients, instead of 32 768 segments ending in one tick
-    rows = [[(loud_b if ((t + k) % 40) < 20 else quiet_b) if k < n_talk else quiet_b for k in range(sessions)] for t in range(40)]
+    # (the phase is the session's index WITHIN its shard - sessions are dealt to the shards round robin - so that every shard sees
+    # the same share of STARTs and ENDs in every tick; a phase of (t + k) % 40 puts all of a tick's ENDs on one shard)
+    rows = [[(loud_b if ((t + k // n_shards) % 40) < 20 else quiet_b) if k < n_talk else quiet_b for k in range(sessions)] for t in range(40)]
     for t in range(ticks + warm):
         row = rows[t % 40]
         a = time.perf_counter()
