@@ -652,7 +652,7 @@ int vad_engine_create(const vad_engine_desc *desc, vad_engine **out) {
     if ((r = hipMalloc((void **)&e->d_wstream, e->wbytes)) != hipSuccess) return bail(r, "hipMalloc(weights)");
     if ((r = hipMemcpy(e->d_wstream, pw.data.data(), e->wbytes, hipMemcpyHostToDevice)) != hipSuccess)
         return bail(r, "hipMemcpy(weights)");
-    if (desc->model_version == 4 || !want_8k) {          // every model but V5's 8 kHz sub-model has a 16-stream tile kernel
+    {                                                    // every model has a 16-stream tile kernel for small calls
         vadk::PackedWeights pw16;
         const bool ok16 = desc->model_version == 4 ? vadk::pack_silero_v4_t16(desc->weights, desc->weights_len, pw16, perr)
                                                    : vadk::pack_silero_v5_t16(desc->weights, desc->weights_len, pw16, perr);

@@ -358,14 +358,18 @@ bool pack_silero_v5_t16(const void *blob, size_t len, PackedWeights &out, std::s
         err = "Failed to load model: weight blob is not Silero V5";
         return false;
     }
+    // the graph's 8 kHz sub-model (else-branch): window 128, 65 bins, encoder.0 65 -> 128, 256-sample frames
+    bool k8 = false;
     for (uint32_t i = 0; i < B.n; ++i)
         if (std::strncmp(B.tab[i].name, "meta.variant", sizeof B.tab[i].name) == 0) {
-            err = "Failed to load model: the 16-stream tile kernel is built for Silero V5's 16 kHz sub-model";
-            return false;
+            const float *v = B.get("meta.variant", 1);
+            k8 = v && v[0] == 8000.0f;
         }
-    const float *stft = B.get("stft.basis", 258 * 256);
+    const int N = k8 ? 128 : 256, NB = N / 2 + 1;
+    const float *stft = B.get("stft.basis", (uint64_t)2 * NB * N);
     const float *ew[4], *eb[4];
-    static const int co[4] = {128, 64, 64, 128}, ci[4] = {129, 128, 64, 64};
+    static const int co[4] = {128, 64, 64, 128};
+    const int ci[4] = {NB, 128, 64, 64};
     for (int i = 0; i < 4; ++i) {
         char nm[32];
         std::snprintf(nm, sizeof nm, "enc%d.w", i);
@@ -377,15 +381,15 @@ bool pack_silero_v5_t16(const void *blob, size_t len, PackedWeights &out, std::s
     const float *b_ih = B.get("lstm.b_ih", 512), *b_hh = B.get("lstm.b_hh", 512);
     const float *head_w = B.get("head.w", 128), *head_b = B.get("head.b", 1);
     if (!err.empty()) return false;
-    if (!check_stft_symmetry(stft, err)) return false;
-    if (!check_windowed_dft(stft, err)) return false;
-    const double two_pi = 6.283185307179586476925286766559;
-    out.variant = 0;
+    if (!check_stft_symmetry(stft, err, N)) return false;
+    if (!check_windowed_dft(stft, err, N)) return false;
+    if (!k8 && !check_even_bin_fold(err)) return false;
+    out.variant = k8 ? 1 : 0;
     StreamBuilder sb;
     auto convw = [&](int layer, int o, int c, int tap) -> float { return ew[layer][((size_t)o * ci[layer] + c) * 3 + tap]; };
-    auto toom = [&](int o, int c129, int p) -> float {
-        const double v0 = ew[0][((size_t)o * 129 + c129) * 3 + 2], v1 = ew[0][((size_t)o * 129 + c129) * 3 + 1],
-                     v2 = ew[0][((size_t)o * 129 + c129) * 3 + 0];
+    auto toom = [&](int o, int cin, int p) -> float {
+        const double v0 = ew[0][((size_t)o * NB + cin) * 3 + 2], v1 = ew[0][((size_t)o * NB + cin) * 3 + 1],
+                     v2 = ew[0][((size_t)o * NB + cin) * 3 + 0];
         switch (p) {
             case 0: return (float)v0;
             case 1: return (float)(0.5 * (v0 + v1 + v2));
@@ -398,20 +402,21 @@ bool pack_silero_v5_t16(const void *blob, size_t len, PackedWeights &out, std::s
         // STFT: the once-more-folded DFT (pack_dft_fold3_wave): row tile 0 = odd bins (4 k-iterations x {cos, -sin}), row tile 1 =
         // even bins on the operands folded again about n = 32 (2 k-iterations x {cos, -sin})
         out.sect[w][S_STFT] = sb.blocks();
-        pack_dft_fold3_wave(sb, w);
+        if (!k8) pack_dft_fold3_wave(sb, w);
+        else pack_dft4_wave_128_t16(sb, w);               // 8 kHz: 64 bins = four 16-row tiles, one per wave (as the 32-stream kernel)
         // enc0 (Toom-3): bias rt0, rt1; per k-iteration the five points x two row tiles; Nyquist channel: points 0,1,-1,2 in the
         // components of lanes kq = 0 (the other channel groups carry zeros), rt0, rt1; then the point at infinity, rt0, rt1
         out.sect[w][S_ENC0] = sb.blocks();
         for (int rt = 0; rt < 2; ++rt) sb.vector_block16([&](int c) { return eb[0][32 * w + 16 * rt + c]; });
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < (k8 ? 4 : 8); ++j)
             for (int p = 0; p < 5; ++p)
                 for (int rt = 0; rt < 2; ++rt)
-                    sb.weight_block16([&](int r, int c) { return toom(32 * w + 16 * rt + r, bin_of_channel_fold3(c), p); }, j);
+                    sb.weight_block16([&](int r, int c) { return toom(32 * w + 16 * rt + r, k8 ? bin_of_channel_8k(c) : bin_of_channel_fold3(c), p); }, j);
         for (int part = 0; part < 2; ++part)
             for (int rt = 0; rt < 2; ++rt) {
                 float *a = sb.new_block();
                 for (int r = 0; r < 16; ++r)
-                    for (int p = 0; p < (part == 0 ? 4 : 1); ++p) a[r * 4 + p] = toom(32 * w + 16 * rt + r, 128, part == 0 ? p : 4);
+                    for (int p = 0; p < (part == 0 ? 4 : 1); ++p) a[r * 4 + p] = toom(32 * w + 16 * rt + r, NB - 1, part == 0 ? p : 4);
             }
         // enc1: n-tile w&1, output column w>>1; taps (1,2) for column 0, (0,1) for column 1; iteration it = 8 ti + j
         out.sect[w][S_ENC1] = sb.blocks();
@@ -455,7 +460,7 @@ bool pack_silero_v5_t16(const void *blob, size_t len, PackedWeights &out, std::s
     const uint32_t hb = sb.blocks();
     sb.new_block()[0] = head_b[0];
     const uint32_t nb = sb.blocks();
-    std::memcpy(sb.new_block(), stft, 256 * sizeof(float));
+    std::memcpy(sb.new_block(), stft, (size_t)N * sizeof(float));
     for (int w = 0; w < NWAVES; ++w) {
         out.sect[w][S_HEADB] = hb;
         out.sect[w][S_NYQ] = nb;

@@ -73,7 +73,12 @@ __device__ __forceinline__ f32x4 mfma16(f32x4 w, f32x4 a, f32x4 acc) {
 // RS: one tick for streams at other input rates (vad_step_rates): the tile first resamples its 16 chunks to 16 kHz into LDS -
 // AudioUtils.resample_audio's Fourier method as the folded operator of resample.hip, on 16 x 16 x 4 tiles - and the frame loop
 // ingests them from there: no second launch, no HBM round trip of the 16 kHz frames.  T = 1, float32 input.
-template <bool F32IN, bool RS>
+// K8: the graph's 8 kHz sub-model on native 8 kHz audio in 256-sample frames (silero_v5.hip has the algebra: window 128, hop 64, three
+// columns, 4-way fold with n = 1..31, 64 complex bins as four 16-row tiles - one per wave - bin 64 on the VALU, encoder.0 with 65
+// input channels; from enc1 on the instantiations are the same): pools of at most 4 096 native-8 kHz sessions get one tile per CU
+// like the 16 kHz model's (the 32-stream K8 kernel runs n / 32 CUs: 37 us whatever the size).  Loader: 8 lanes per stream, so a
+// fold call covers TWO columns of the tile's 16 streams (threads 0..127 / 128..255).
+template <bool F32IN, bool RS, bool K8 = false>
 // One workgroup per CU also here.  Built for two (a tick's segments are padded to whole tiles, so it can have a few more tiles
 // than CUs), the dispatcher packs consecutive workgroups onto the same CU: 258 tiles ran on ~130 CUs, 69.9 us per tick against
 // 55.6 for the two-launch form - so the engine uses this launch only when the tick has at most one tile per CU.
@@ -84,6 +89,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 #define KP(f) k_##f
     using namespace vadk::v5;
     static_assert(!RS || F32IN, "resampled frames are float32");
+    static_assert(!(RS && K8), "the fused resampler feeds the 16 kHz model");
+    constexpr int QL = K8 ? 8 : 16;               // loader lanes per stream = quads per quarter column
+    constexpr int CS = 4 * QL;                    // folded-operand rows per column
+    constexpr int PS = K8 ? 16 : 32;              // quad rows per Toom-3 plane
+    constexpr int ROWN = K8 ? 80 : T_ROW_NYQ;     // the Nyquist channel's rows (8: values on the kq = 0 row of each group of four)
+    constexpr int NJ0 = K8 ? 4 : 8;               // k-iterations of enc0
     __shared__ f32x4 lds[T_LDS_F4 + (RS ? MT16 * FQ : 0)];     // RS: + the tile's 16 kHz frames F (one workgroup per CU either way)
     f32x4 *const RX = lds;
     f32x4 *const RE = lds + T_ROW_E * QSD;
@@ -126,13 +137,15 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 
     // ---- frame ingest set-up: 16 lanes per stream, 16 streams per fold call (ms = tid >> 4) ----
     const float thr = P.thresh;
-    const int q = tid & 15;
+    const int q = tid & (QL - 1);
     const bool q0 = q == 0;
+    const int lms = K8 ? (tid >> 3) & 15 : tid >> 4;      // the loader's stream of this thread
+    const int lcol = tid >> 7;                            // K8: which of a fold call's two columns
     constexpr bool f32in = F32IN;
     constexpr int qsh = f32in ? 4 : 3;
     const float sc = P.fmt == 1 ? 32767.0f : 32768.0f, rsc = 1.0f / sc;
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void *>(KP(frames)), 0, (int)((unsigned)KP(n) * (unsigned)T * (f32in ? 2048u : 1024u)), 0x00020000);
+        const_cast<void *>(KP(frames)), 0, (int)((unsigned)KP(n) * (unsigned)T * ((f32in ? 2048u : 1024u) >> (K8 ? 1 : 0))), 0x00020000);
     u32x4 xa_[4], xb_[4], xc_[4];                  // raw quads of the three columns
     f32x4 *const F4 = lds + T_LDS_F4;              // RS: the tile's resampled frames
 #define X_ISSUE(c, XR, tt)                                                                                      \
@@ -143,6 +156,16 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
         const int fq = ((tile0 + (tid >> 4)) * T + (tt)) * 128 + 32 * (c) + q;                                  \
         _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                           \
             XR[k] = __builtin_amdgcn_raw_buffer_load_b128(frs, (fq + 16 * k) << qsh, 0, 0);                     \
+    }
+
+    // 8 kHz: a frame is 64 quads, column c = quads 16 c .. 16 c + 31; lane q of a stream's 8 loads quads q, 8 + q, 16 + q, 24 + q
+    // of column min(c0 + lcol, 2) (the second call's upper half repeats column 2: same values to the same places)
+#define X_ISSUE8(c0, XR, tt)                                                                                    \
+    {                                                                                                           \
+        const int cc_ = (c0) + lcol < 2 ? (c0) + lcol : 2;                                                      \
+        const int fq = ((tile0 + lms) * T + (tt)) * 64 + 16 * cc_ + q;                                          \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                           \
+            XR[k] = __builtin_amdgcn_raw_buffer_load_b128(frs, (fq + 8 * k) << qsh, 0, 0);                      \
     }
 
     // ---- RS: the tile's parts.  A part = the columns c0 .. c1 - 1 of this tile that belong to one segment (one input rate); a tile
@@ -221,8 +244,8 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
         const f32x4 v = reinterpret_cast<const f32x4 *>(KP(state) + (size_t)slot * 256)[part * 2 + qq];
         hv[qq] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const f32x4 W1 = ldw(wrs, q * 16, o_nyq), W3 = ldw(wrs, (32 + q) * 16, o_nyq);
-    const float w64 = ldw(wrs, 16 * 16, o_nyq).x;
+    const f32x4 W1 = ldw(wrs, q * 16, o_nyq), W3 = ldw(wrs, (2 * QL + q) * 16, o_nyq);   // w[n], w[128 + n]  (8 kHz: w[64 + n])
+    const float w64 = ldw(wrs, QL * 16, o_nyq).x;                                          // w[64]             (8 kHz: w[32])
     f32x4 cst[2];                                  // c of units 32 w + 16 rt + 4 kq + i
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -600,11 +623,14 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
                 }
                 return gate4(v, thr);
             };
+            // (8 kHz: 8 lanes per stream - row_half_mirror, and lane 8 of a row, which row_shr:1 would feed from the neighbouring
+            // stream's lane 7, takes `edge` by a select)
             auto mirror = [](float v) -> float {
-                return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+                return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K8 ? 0x141 : 0x140, 0xf, 0xf, true));
             };
-            auto shr1 = [](float edge, float v) -> float {
-                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+            auto shr1 = [&](float edge, float v) -> float {
+                const float r = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+                return (K8 && q0) ? edge : r;
             };
             auto shl8 = [](float v) -> float {        // row_shl:8: lane q gets lane q + 8 (lanes 8..15: zero)
                 return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x108, 0xf, 0xf, true));
@@ -613,7 +639,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 #define X_FOLD(c, XR)                                                                                           \
     {                                                                                                           \
         _Pragma("clang fp contract(off)")                                                                       \
-        const int ms = tid >> 4;                                                                                \
+        const int ms = lms;                                                                                     \
         const f32x4 xA = decode(XR[0]), xB = decode(XR[1]), xC = decode(XR[2]), xD = decode(XR[3]);             \
         const float mBx = mirror(xB.x), mDx = mirror(xD.x);                                                     \
         const f32x4 y1 = pk::mul(xA, W1), y3 = pk::mul(xC, W3);                                                 \
@@ -629,6 +655,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             fcor[fo + (q0 ? 16 : 0)] = y64 + y192;                                                              \
             fcor[fo + (q0 ? 32 : 0)] = y64 - y192;                                                              \
         }                                                                                                       \
+        if constexpr (K8) {                                                                                     \
+            st2(&RX[(CS * (c) + q) * QSL + ms], pe);                                                            \
+            st2(&RX[(CS * (c) + QL + q) * QSL + ms], po);                                                       \
+            st2(&RX[(CS * (c) + 2 * QL + q) * QSL + ms], qe);                                                   \
+            st2(&RX[(CS * (c) + 3 * QL + q) * QSL + ms], qo);                                                   \
+        } else {                                                                                                \
         /* the odd bins contract po | qo as they are; the even bins' operands fold once more, about n = 32 (vad_layout.h,            \
            bin_of_channel_fold3; silero_v5.hip has the lane algebra).  Lanes q < 8 hold n = 0..31 and store; lanes q >= 8 hold the \
            same values again and drop them into sink rows (a select on the address, no branch: the fold stays in the MFMAs' basic \
@@ -645,6 +677,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
         st2(&RX[er + 8 * QSL], pen);                                                                            \
         st2(&RX[er + 16 * QSL], qen);                                                                           \
         st2(&RX[er + 24 * QSL], qep);                                                                           \
+        }                                                                                                       \
     }
 #define H_LDW(WS, g) _Pragma("unroll") for (int k = 0; k < 8; ++k) WS[k] = WL(wh + 8 * (g) + k);
 #define H_MMA(WS, g)                                                                                            \
@@ -662,12 +695,22 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             for (int k = 0; k < 8; ++k) nb[k] = WL(ws_l + k);
             H_LDW(wA, 0)
             SB();
-            H_LDW(wB, 1) X_ISSUE(0, xa_, t) X_ISSUE(1, xb_, t) SB();
+            if constexpr (K8) { H_LDW(wB, 1) X_ISSUE8(0, xa_, t) X_ISSUE8(2, xb_, t) SB(); }
+            else { H_LDW(wB, 1) X_ISSUE(0, xa_, t) X_ISSUE(1, xb_, t) SB(); }
             if constexpr (RS) { X_ISSUE(2, xc_, t) SB(); }     // F is dead once every wave has passed the barrier below
             __syncthreads();   // (0) h_{t-1} visible (t > 0: follows barrier (8))
 #pragma unroll
             for (int k = 0; k < 8; ++k) G[k] = nb[k];
             H_MMA(wA, 0) SB();
+            if constexpr (K8) {             // two fold calls: columns (0 | 1) by half of the workgroup, then column 2
+            H_LDW(wA, 2) SB(); H_MMA(wB, 1) SB();
+            H_LDW(wB, 3) SB(); H_MMA(wA, 2) X_FOLD(lcol, xa_) H_MIX SB();
+            H_LDW(wA, 4) SB(); H_MMA(wB, 3) SB();
+            H_LDW(wB, 5) SB(); H_MMA(wA, 4) X_FOLD(2, xb_) H_MIX SB();
+            H_LDW(wA, 6) SB(); H_MMA(wB, 5) SB();
+            H_LDW(wB, 7) SB(); H_MMA(wA, 6) SB();
+            H_MMA(wB, 7) SB();
+            } else {
             H_LDW(wA, 2) if constexpr (!RS) { X_ISSUE(2, xc_, t) } SB(); H_MMA(wB, 1) SB();
             H_LDW(wB, 3) SB(); H_MMA(wA, 2) X_FOLD(0, xa_) H_MIX SB();
             H_LDW(wA, 4) SB(); H_MMA(wB, 3) SB();
@@ -675,6 +718,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             H_LDW(wA, 6) SB(); H_MMA(wB, 5) SB();
             H_LDW(wB, 7) SB(); H_MMA(wA, 6) X_FOLD(2, xc_) H_MIX SB();
             H_MMA(wB, 7) SB();
+            }
 #undef H_MIX
 #undef H_MMA
 #undef H_LDW
@@ -693,8 +737,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             float a = 0.f;
             if (pair < 48) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {     // sum_n pe[n] (-1)^n = the same sum over the pe+ rows (slot 0 = pe[32], sign +)
-                    const f32x4 pp = RX[(64 * c + 32 + pt * 2 + i) * QSL + ms];
+                // 16 kHz: sum_n pe[n] (-1)^n = the same sum over the pe+ rows (slot 0 = pe[32], sign +); 8 kHz: over its 8 pe rows
+                for (int i = 0; i < 2; ++i) {
+                    const f32x4 pp = RX[(CS * c + (K8 ? 0 : 32) + pt * 2 + i) * QSL + ms];
                     a += (pp.x - pp.y) + (pp.z - pp.w);
                 }
             }
@@ -703,10 +748,67 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             if (pair < 48 && pt == 0) nyqv[c * 16 + ms] = fabsf(a + fcor[(c * 3 + 0) * 16 + ms] + fcor[(c * 3 + 1) * 16 + ms]);
         }
 
+        f32x4 e0b[2], E0w[10];
+        if constexpr (K8) {
+            // ---- STFT, 8 kHz sub-model: 64 complex bins = four 16-row tiles, ONE per wave (pack_dft4_wave_128_t16): wave w owns the
+            //      bins 2 (16 (w & 1) + r) + (w >> 1), r = 0..15 - waves 0 / 1 the even bins (pe | qe), 2 / 3 the odd ones (po | qo);
+            //      K = 32 = two k-iterations; the accumulators start from the rank-1 terms of n = 0, 32, 64 as in the 16 kHz model ----
+            const bool even = w < 2;
+            f32x4 sre[3], sim[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float y128 = fcor[(c * 3 + 0) * 16 + n], a64 = fcor[(c * 3 + 1) * 16 + n], b64 = fcor[(c * 3 + 2) * 16 + n];
+                const float rp = even ? y128 + a64 : -y128, rm = even ? y128 - a64 : -y128;
+                const float ip = even ? 0.f : -b64, im_ = even ? 0.f : b64;
+                sre[c] = f32x4{rp, rm, rp, rm};
+                sim[c] = f32x4{ip, im_, ip, im_};
+            }
+            const int rR = even ? 0 : QL, rI = even ? 2 * QL : 3 * QL;
+            const f32x4 wr0 = Sw[0], wi0 = Sw[1], wr1 = WL(ws_stft + 2), wi1 = WL(ws_stft + 3);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 wr = j ? wr1 : wr0, wi = j ? wi1 : wi0;
+                f32x4 u[3], v[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    u[c] = RX[(CS * c + rR + 4 * j) * QSL + nqL];
+                    v[c] = RX[(CS * c + rI + 4 * j) * QSL + nqL];
+                }
+                SB();
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    sre[c] = mfma16(wr, u[c], sre[c]);
+                    sim[c] = mfma16(wi, v[c], sim[c]);
+                }
+                SB();
+            }
+            e0b[0] = WL(ws_e0); e0b[1] = WL(ws_e0 + 1);
+#pragma unroll
+            for (int k = 0; k < 10; ++k) E0w[k] = WL(ws_e0 + 2 + k);
+            SB();
+            __syncthreads();   // (1b) every wave is done reading the folded operands: the magnitudes may overwrite them
+            {   // |.| -> Toom-3 evaluation planes, rows 16 p + channel / 4 = 16 p + 4 w + kq
+                f32x4 mg[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) mg[c] = pk::mag(sre[c], sim[c]);
+                const f32x4 s02 = pk::add(mg[0], mg[2]);
+                f32x4 *o = RX + (4 * w) * QSD + nq;
+                st2(o, mg[0]);
+                st2(o + PS * QSD, pk::add(s02, mg[1]));
+                st2(o + 2 * PS * QSD, pk::sub(s02, mg[1]));
+                st2(o + 3 * PS * QSD, pk::fma(pk::splat(4.f), mg[2], pk::fma(pk::splat(2.f), mg[1], mg[0])));
+                st2(o + 4 * PS * QSD, mg[2]);
+            }
+            if (tid < 64) {      // |X64|: values on the kq = 0 rows (80, 84), zeros on the other three of each group
+                const float n0 = nyqv[n], n1 = nyqv[16 + n], n2 = nyqv[32 + n];
+                const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                RX[ROWN * QSD + nq] = kq == 0 ? f32x4{n0, (n0 + n2) + n1, (n0 + n2) - n1, fmaf(4.f, n2, fmaf(2.f, n1, n0))} : z4;
+                RX[(ROWN + 4) * QSD + nq] = kq == 0 ? f32x4{n2, 0.f, 0.f, 0.f} : z4;
+            }
+        } else
         // ---- STFT: wave w owns bins bin_of_channel_fold3(32 w + 16 rt + r): row tile 0 = 16 odd bins, cos on po, -sin on qo, K = 64
         //      (k-iterations 0..3); row tile 1 = 16 even bins on the once-more-folded operands pe+- | qe-+ (waves 2, 3 | 0, 1), K = 32
         //      (k-iterations 4, 5); 3 columns.  144 MFMAs per wave instead of 192 ----
-        f32x4 e0b[2], E0w[10];
         {
             f32x4 are[3][2], aim[3][2];
 #pragma unroll
@@ -791,26 +893,26 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 #pragma unroll
             for (int k = 0; k < 10; ++k) Aw[k] = E0w[k];
 #pragma unroll
-            for (int p = 0; p < 5; ++p) Aa[p] = RX[(32 * p) * QSD + nq];
+            for (int p = 0; p < 5; ++p) Aa[p] = RX[(PS * p) * QSD + nq];
 #define E0_LD(S, jj)                                                                       \
     _Pragma("unroll") for (int k = 0; k < 10; ++k) S##w[k] = WL(ws + 10 * (jj) + k);       \
-    _Pragma("unroll") for (int p = 0; p < 5; ++p) S##a[p] = RX[(32 * p + 4 * (jj)) * QSD + nq];
+    _Pragma("unroll") for (int p = 0; p < 5; ++p) S##a[p] = RX[(PS * p + 4 * (jj)) * QSD + nq];
 #define E0_MMA(S)                                                                          \
     _Pragma("unroll") for (int p = 0; p < 5; ++p) {                                        \
         acc[p][0] = mfma16(S##w[2 * p], S##a[p], acc[p][0]); acc[p][1] = mfma16(S##w[2 * p + 1], S##a[p], acc[p][1]); \
     }
-            for (int j = 0; j < 8; j += 2) {
+            for (int j = 0; j < NJ0; j += 2) {
                 E0_LD(B, j + 1) SB();
                 E0_MMA(A) SB();
-                const int jn = j + 2 < 8 ? j + 2 : 6;
+                const int jn = j + 2 < NJ0 ? j + 2 : NJ0 - 2;
                 E0_LD(A, jn) SB();
                 E0_MMA(B) SB();
             }
 #undef E0_LD
 #undef E0_MMA
             {   // input channel 128 (Nyquist bin): K = 4 MFMAs whose k = 1..3 slots are zero on both operands
-                const f32x4 an = RX[T_ROW_NYQ * QSD + nq], bn = RX[(T_ROW_NYQ + 4) * QSD + nq];
-                const f32x4 wa0 = WL(ws + 80), wa1 = WL(ws + 81), wb0 = WL(ws + 82), wb1 = WL(ws + 83);
+                const f32x4 an = RX[ROWN * QSD + nq], bn = RX[(ROWN + 4) * QSD + nq];
+                const f32x4 wa0 = WL(ws + 10 * NJ0), wa1 = WL(ws + 10 * NJ0 + 1), wb0 = WL(ws + 10 * NJ0 + 2), wb1 = WL(ws + 10 * NJ0 + 3);
                 e1b[0] = WL(ws_e1); e1b[1] = WL(ws_e1 + 1);
                 E1w[0] = WL(ws_e1 + 2); E1w[1] = WL(ws_e1 + 3);
                 SB();
@@ -986,7 +1088,12 @@ extern "C" hipError_t vadk_launch_silero_v5_t16(const vadk::StepParams *p, hipSt
     const int tiles = (p->n + MT16 - 1) / MT16;
     if (tiles <= 0) return hipSuccess;
     const vadk::RateParams none{};
-    if (p->fmt == 0)
+    if (p->variant) {                  // the 8 kHz sub-model's blob (256-sample frames)
+        if (p->fmt == 0)
+            hipLaunchKernelGGL((silero_v5_step16<true, false, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS, none);
+        else
+            hipLaunchKernelGGL((silero_v5_step16<false, false, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS, none);
+    } else if (p->fmt == 0)
         hipLaunchKernelGGL((silero_v5_step16<true, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS, none);
     else
         hipLaunchKernelGGL((silero_v5_step16<false, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS, none);

@@ -613,9 +613,14 @@ def _store16(region, row0, acc, relu=True):
         region[row0 + rq] = v[4 * rq:4 * rq + 4].T                             # [16 m, 4]
 
 
-def v5_step_t16(W, sect, x, hc, gate=0.01):
-    """x [16,512] f32, hc [16,256] -> (prob [16], new hc [16,256]); float64 contractions; mirrors silero_v5_t16.hip."""
-    ROW_NYQ, ROW_E = 160, 168
+def v5_step_t16(W, sect, x, hc, gate=0.01, k8=False):
+    """x [16,512] f32, hc [16,256] -> (prob [16], new hc [16,256]); float64 contractions; mirrors silero_v5_t16.hip.
+    k8: the 8 kHz sub-model instantiation (x [16,256]; window 128, hop 64, four 16-row STFT tiles, planes of 16 rows)."""
+    ROW_NYQ, ROW_E = (80 if k8 else 160), 168
+    N = 128 if k8 else 256
+    H, Q4 = N // 2, N // 4
+    QL = Q4 // 4
+    CS, PS, NJ0 = 4 * QL, (16 if k8 else 32), (4 if k8 else 8)
     x = x.astype(np.float64)
     if gate is not None and gate >= 0:
         x = np.where(np.abs(x) > gate, x, 0.0)
@@ -623,35 +628,49 @@ def v5_step_t16(W, sect, x, hc, gate=0.01):
     RE = RX[ROW_E:]
     RH = hc[:, :128].astype(np.float64).reshape(16, 32, 4).transpose(1, 0, 2).copy()
     c_prev = hc[:, 128:].astype(np.float64)
-    wtab = W[sect[0][S_NYQ]].reshape(-1)[:256].astype(np.float64)
+    wtab = W[sect[0][S_NYQ]].reshape(-1)[:N].astype(np.float64)
     fcor = np.zeros((3, 3, 16))
     for c in range(3):
-        y = x[:, 128 * c:128 * c + 256] * wtab[None, :]
-        n = np.arange(64)
-        y1, y2, y3, y4 = y[:, n], y[:, 128 - n], y[:, 128 + n], y[:, (256 - n) % 256]
+        y = x[:, H * c:H * c + N] * wtab[None, :]
+        n = np.arange(Q4)
+        y1, y2, y3, y4 = y[:, n], y[:, H - n], y[:, H + n], y[:, (N - n) % N]
         pe, po, qe, qo = y1 + y4 + y2 + y3, y1 + y4 - y2 - y3, y1 - y4 - y2 + y3, y1 - y4 + y2 - y3
         for arr in (pe, po, qe, qo):
             arr[:, 0] = 0.0
-        mm = np.arange(32)                                  # the even bins' operands fold once more about n = 32 (silero_v5.hip)
-        pep, pen = pe[:, mm] + pe[:, (64 - mm) % 64], pe[:, mm] - pe[:, (64 - mm) % 64]
-        qen, qep = qe[:, mm] - qe[:, (64 - mm) % 64], qe[:, mm] + qe[:, (64 - mm) % 64]
-        pep[:, 0], pen[:, 0], qen[:, 0], qep[:, 0] = pe[:, 32], 0.0, 0.0, qe[:, 32]
-        RX[64 * c:64 * c + 16] = po.reshape(16, 16, 4).transpose(1, 0, 2)
-        RX[64 * c + 16:64 * c + 32] = qo.reshape(16, 16, 4).transpose(1, 0, 2)
-        for k, arr in enumerate((pep, pen, qen, qep)):
-            RX[64 * c + 32 + 8 * k:64 * c + 40 + 8 * k] = arr.reshape(16, 8, 4).transpose(1, 0, 2)
-        fcor[c] = y[:, 128], y[:, 64] + y[:, 192], y[:, 64] - y[:, 192]
+        if k8:
+            for k, arr in enumerate((pe, po, qe, qo)):
+                RX[CS * c + QL * k:CS * c + QL * k + QL] = arr.reshape(16, QL, 4).transpose(1, 0, 2)
+        else:
+            mm = np.arange(32)                              # the even bins' operands fold once more about n = 32 (silero_v5.hip)
+            pep, pen = pe[:, mm] + pe[:, (64 - mm) % 64], pe[:, mm] - pe[:, (64 - mm) % 64]
+            qen, qep = qe[:, mm] - qe[:, (64 - mm) % 64], qe[:, mm] + qe[:, (64 - mm) % 64]
+            pep[:, 0], pen[:, 0], qen[:, 0], qep[:, 0] = pe[:, 32], 0.0, 0.0, qe[:, 32]
+            RX[64 * c:64 * c + 16] = po.reshape(16, 16, 4).transpose(1, 0, 2)
+            RX[64 * c + 16:64 * c + 32] = qo.reshape(16, 16, 4).transpose(1, 0, 2)
+            for k, arr in enumerate((pep, pen, qen, qep)):
+                RX[64 * c + 32 + 8 * k:64 * c + 40 + 8 * k] = arr.reshape(16, 8, 4).transpose(1, 0, 2)
+        fcor[c] = y[:, H], y[:, Q4] + y[:, H + Q4], y[:, Q4] - y[:, H + Q4]
     nyq = np.zeros((3, 16))
     for c in range(3):
-        pe = RX[64 * c + 32:64 * c + 40]                    # the pe+ rows: slot 0 = pe[32]
+        pe = RX[CS * c:CS * c + QL] if k8 else RX[64 * c + 32:64 * c + 40]      # 16 kHz: the pe+ rows, slot 0 = pe[32]
         nyq[c] = np.abs((pe[:, :, 0] - pe[:, :, 1] + pe[:, :, 2] - pe[:, :, 3]).sum(0) + fcor[c, 0] + fcor[c, 1])
     sgn = np.where(np.arange(16) % 2 == 0, 1.0, -1.0)[:, None]
     mags = {}
     for w in range(4):
         ws = sect[w][S_STFT]
-        eR, eI = (40, 56) if w < 2 else (32, 48)
         for c in range(3):
             y128, a64, b64 = fcor[c, 0][None, :], fcor[c, 1][None, :], fcor[c, 2][None, :]
+            if k8:          # one 16-row tile per wave: waves 0 / 1 even bins (pe | qe), 2 / 3 odd bins (po | qo); K = 32
+                even = w < 2
+                rR, rI = (0, 2 * QL) if even else (QL, 3 * QL)
+                are, aim = np.zeros((16, 16)), np.zeros((16, 16))
+                for j in range(2):
+                    are += _mfma16(W[ws + 2 * j], _rows16(RX, CS * c + rR + 4 * j))
+                    aim += _mfma16(W[ws + 2 * j + 1], _rows16(RX, CS * c + rI + 4 * j))
+                re, im = (are + y128 + sgn * a64, aim) if even else (are - y128, aim - sgn * b64)
+                mags[w, c, 0] = np.sqrt(re ** 2 + im ** 2)
+                continue
+            eR, eI = (40, 56) if w < 2 else (32, 48)
             are, aim = np.zeros((16, 16)), np.zeros((16, 16))
             for j in range(4):                              # row tile 0: 16 odd bins on po | qo, K = 64
                 are += _mfma16(W[ws + 2 * j], _rows16(RX, 64 * c + 4 * j))
@@ -663,10 +682,10 @@ def v5_step_t16(W, sect, x, hc, gate=0.01):
                 aim += _mfma16(W[ws + 8 + 2 * j + 1], _rows16(RX, 64 * c + eI + 4 * j))
             mags[w, c, 1] = np.sqrt((are + (y128 - a64 if w < 2 else y128 + a64)) ** 2 + aim ** 2)
     for w in range(4):
-        for rt in range(2):
+        for rt in range(1 if k8 else 2):
             m0, m1, m2 = (mags[w, c, rt] for c in range(3))
             for p, v in enumerate((m0, (m0 + m2) + m1, (m0 + m2) - m1, m0 + 2 * m1 + 4 * m2, m2)):
-                _store16(RX, 32 * p + 8 * w + 4 * rt, v, relu=False)
+                _store16(RX, PS * p + (4 * w if k8 else 8 * w + 4 * rt), v, relu=False)
     n0, n1, n2 = nyq
     RX[ROW_NYQ:ROW_NYQ + 8] = 0
     RX[ROW_NYQ] = np.stack([n0, (n0 + n2) + n1, (n0 + n2) - n1, n0 + 2 * n1 + 4 * n2], axis=1)
@@ -675,15 +694,15 @@ def v5_step_t16(W, sect, x, hc, gate=0.01):
     for w in range(4):
         ws = sect[w][S_ENC0]
         P = [[np.zeros((16, 16)) for _ in range(2)] for _ in range(5)]
-        for j in range(8):
+        for j in range(NJ0):
             for p in range(5):
-                a = _rows16(RX, 32 * p + 4 * j)
+                a = _rows16(RX, PS * p + 4 * j)
                 for rt in range(2):
                     P[p][rt] += _mfma16(W[ws + 2 + 10 * j + 2 * p + rt], a)
         an, bn = _rows16(RX, ROW_NYQ), _rows16(RX, ROW_NYQ + 4)
         for rt in range(2):
-            wa = W[ws + 82 + rt].astype(np.float64).reshape(4, 16, 4)
-            wb = W[ws + 84 + rt].astype(np.float64).reshape(4, 16, 4)
+            wa = W[ws + 2 + 10 * NJ0 + rt].astype(np.float64).reshape(4, 16, 4)
+            wb = W[ws + 2 + 10 * NJ0 + 2 + rt].astype(np.float64).reshape(4, 16, 4)
             for p in range(4):
                 P[p][rt] += np.einsum("kr,km->rm", wa[:, :, p], an.reshape(4, 16, 4)[:, :, p])
             P[4][rt] += np.einsum("kr,km->rm", wb[:, :, 0], bn.reshape(4, 16, 4)[:, :, 0])

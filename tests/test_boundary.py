@@ -132,6 +132,26 @@ def test_packed_layout_for_the_16_stream_tile_kernel_reproduces_the_oracle():
             assert np.abs(hc - hc_o).max() <= 1e-4
 
 
+def test_packed_layout_for_the_16_stream_tile_kernel_8k_sub_model_reproduces_the_oracle():
+    """pack_silero_v5_t16 on the 8 kHz blob through the K8 instantiation's dataflow (silero_v5_step16<., ., K8 = true>) == oracle."""
+    from oracle import oracle
+    from tests import kernel_model as KM
+    from tests.signals import make_streams
+    with open(weights_io.packaged_blob_path(5, 8000), "rb") as f:
+        blob = f.read()
+    W, sect = KM.packed_streams(516, blob)
+    om = oracle.OracleModel(blob, "f64")
+    x = make_streams(16, 2, seed=16).reshape(16, 4, 256)
+    hc = np.zeros((16, 256), np.float32)
+    hc_o = hc.copy()
+    with np.errstate(over="ignore"):
+        for t in range(4):
+            p, hc = KM.v5_step_t16(W, sect, x[:, t], hc, gate=0.01, k8=True)
+            po = om.step_batch(oracle.denoise(x[:, t]).reshape(16, 256), hc_o)
+            assert np.abs(p - po).max() <= 5e-6
+            assert np.abs(hc - hc_o).max() <= 1e-4
+
+
 @pytest.mark.parametrize("n_in", [256, 768, 1536])
 def test_fused_resampler_operator_packing_reproduces_scipy(n_in):
     """pack_resample_operator_t16 through the model of the fused kernel's resample prologue == scipy.signal.resample."""
