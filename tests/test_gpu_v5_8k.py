@@ -22,10 +22,13 @@ def blob():
         return f.read()
 
 
-@pytest.fixture(scope="module")
-def engine(blob):
+@pytest.fixture(scope="module", params=[16, 32], ids=["tile16", "tile32"])
+def engine(blob, request):
+    """both kernel shapes: silero_v5_step16<., ., K8> (16-stream tiles: what the engine picks for calls of at most 4 096 streams) and
+    silero_v5_step<., K8> (32-stream tiles), pinned with vad_debug_set_tile"""
     from cutter_vad_amd.engine import Engine
     e = Engine(blob, model_version=5, max_streams=2048, sample_rate=8000)
+    e.set_tile(request.param)
     yield e
     e.close()
 
@@ -131,6 +134,29 @@ def test_interpreter_goldens_gate_int16_and_edges(engine, om, blob):
     finally:
         for k in slots:
             engine.close_stream(int(k))
+
+
+def test_the_two_tile_shapes_agree_and_the_engine_picks_by_call_size(blob):
+    from cutter_vad_amd.engine import Engine
+    x = _frames(300, 6, 77)
+    got = {}
+    with Engine(blob, model_version=5, max_streams=8192, sample_rate=8000) as e:
+        slots = e.open_streams(300)
+        for tile in (16, 32, 0):
+            e.set_tile(tile)
+            e.reset(slots)
+            got[tile] = np.stack([e.step(slots, x[:, t]) for t in range(6)], axis=1)
+        assert np.abs(got[16] - got[32]).max() <= 2e-6           # the same algebra on the two MFMA shapes: equal to rounding
+        assert np.array_equal(got[0], got[16])                  # 300 streams: the engine's own choice is the 16-stream tiles
+        big = e.open_streams(8192 - 300)
+        allslots = np.concatenate([slots, big])
+        xb = _frames(8192, 1, 5)
+        e.set_tile(0)
+        e.reset(allslots)
+        a = e.step(allslots, xb[:, 0])
+        e.set_tile(32)
+        e.reset(allslots)
+        assert np.array_equal(a, e.step(allslots, xb[:, 0]))    # 8 192 streams: 32-stream tiles
 
 
 def test_wrong_frame_length_and_wrong_blob_are_refused(engine, blob):

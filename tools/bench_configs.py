@@ -265,6 +265,26 @@ def v5_8k():
     return {"config": "batch=8192, V5 8 kHz sub-model (256-sample frames)", "us_per_step": dt * 1e6, "frames_per_s": B / dt}
 
 
+def v5_8k_tile_shapes():
+    """Silero V5's 8 kHz sub-model on 16- against 32-stream tiles, 256 ... 8 192 streams (the engine picks 16-stream tiles up to 4 096)."""
+    out = []
+    eng = Engine(open(weights_io.packaged_blob_path(5, 8000), "rb").read(), model_version=5, max_streams=8192, sample_rate=8000)
+    eng.open_streams(8192)
+    ring = (0.1 * torch.randn(16, 8192, 256, device="cuda")).contiguous()
+    probs = torch.empty(8192, device="cuda")
+    ts = torch.cuda.Stream()
+    for B in (256, 1024, 4096, 8192):
+        row = {"config": f"batch={B}, V5 8 kHz sub-model, device-resident", "streams": B}
+        for tile in (32, 16):
+            eng.set_tile(tile)
+            dt = timed(lambda i: eng.step_device(B, ring[i % 16].data_ptr(), probs.data_ptr(), stream=ts.cuda_stream), [ts])
+            row[f"us_per_step_tile{tile}"] = dt * 1e6
+            row[f"frames_per_s_tile{tile}"] = B / dt
+        out.append(row)
+    eng.close()
+    return out
+
+
 def int16_ingest():
     """Device-resident int16 frames (the wire format of the serving path) against float32 ones, V5 and V4, 8 192 streams."""
     from cutter_vad_amd import _ffi
