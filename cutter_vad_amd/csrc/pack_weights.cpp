@@ -328,6 +328,14 @@ bool pack_silero_v5(const void *blob, size_t len, PackedWeights &out, std::strin
             for (int q = 0; q < 4; ++q)
                 sb.weight_block([&](int np, int c) { return w_hh[(size_t)(q * 128 + 32 * w + np) * 128 + c]; }, j);
         sb.vector_blocks([&](int c) { return head_w[32 * w + c]; });
+        // block 148 of the section: the same gate biases once more, compact - floats [gate q][unit c] - for the kernel that keeps
+        // them in LDS and initialises its accumulators from there (silero_v5.hip: 512 B per wave instead of 16 KB at the head
+        // of the launch's first requests)
+        {
+            float *cb = sb.new_block();
+            for (int q = 0; q < 4; ++q)
+                for (int c = 0; c < 32; ++c) cb[q * 32 + c] = b_ih[q * 128 + 32 * w + c] + b_hh[q * 128 + 32 * w + c];
+        }
     }
     out.sect[2][S_ENC2] = out.sect[0][S_ENC2];
     out.sect[3][S_ENC2] = out.sect[1][S_ENC2];

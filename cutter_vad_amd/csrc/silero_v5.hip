@@ -63,6 +63,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
     float *const nyqv = headp + 128;             // [3][32] |X128| per column
     float *const fcor = nyqv + 96;               // [3 columns][y128, a64, b64][32 streams]
     SmSlot *const smL = reinterpret_cast<SmSlot *>(fcor + 288 + 64);   // the tile's 32 state machines, resident for the call
+    f32x4 *const biasL = reinterpret_cast<f32x4 *>(smL + MT);          // gate biases, compact: [4 waves][4 gates][8 quads of units]
     constexpr int FCOR_SINK = 288;               // [64] floats after fcor: where lanes q != 0 drop their (unused) correction terms
 
     const int tid = threadIdx.x;
@@ -118,40 +119,60 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
     }
 
     // ---- prologue: h_{t-1} -> LDS quads, c_{t-1} -> registers (this lane's 16 units) -------
+    // Request order = the order in which the frame loop needs things (vmcnt retires in issue order): h and the tile's state
+    // machines (stored to LDS before barrier (0)), then the frame loop's first requests - the gate biases, the W_hh blocks of
+    // its first two groups, the frame's first column(s): they depend on kernel arguments only, and W_hh is the coldest part of
+    // the weight stream (last touched at the start of the previous launch, behind a launch's worth of frames and state in L2),
+    // so its round trip now overlaps the state's instead of following it - then the window and c, which nothing needs before
+    // the fold of group 2 and the cell.  Only h and the state machines are waited for before the first MFMA.
+    // Streams past n (the last tile's tail) read slot 0's state - valid memory - and compute on it: a stream is a column of
+    // every MFMA, nothing crosses columns, and every store of the kernel is guarded by `live`.
     f32x4 hv[4];
     const int fm = tid & 31, part = tid >> 5;
-    {
-        // fm == m (a wave is 64 lanes): the stream this thread loads h for is the stream of its MFMA column -> ONE slot lookup
+    // fm == m (a wave is 64 lanes): the stream this thread loads h for is the stream of its MFMA column -> ONE slot lookup
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const f32x4 v = reinterpret_cast<const f32x4 *>(KP(state) + (size_t)slot * 256)[part * 4 + qq];
-            hv[qq] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+    for (int qq = 0; qq < 4; ++qq) hv[qq] = reinterpret_cast<const f32x4 *>(KP(state) + (size_t)slot * 256)[part * 4 + qq];
+    SB();                                          // h is on its way before anything waits for a section offset (a scalar load)
+    // the wave's gate biases - the accumulators' initial values - compact: 128 floats [gate][unit], two per lane, kept in LDS
+    // for the call and broadcast from there (lane-expanded blocks in the stream were 16 KB per wave at the head of the queue)
+    auto bias2 = __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8, (o_l + LSTM_BIAS_BLOCK) * 1024, 0);
+    // the slot's state machine (96 B in HBM between calls) lives in LDS for the call and goes back with the last frame: its HBM
+    // latency is off the tail of the kernel
+    const bool sm_thread = (tid < MT) && live;
+    const int sm_slot = slot;
+    f32x4 smq[6];
+    if (tid < MT) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) smq[k] = reinterpret_cast<const f32x4 *>(KP(sm) + slot)[k];
     }
+    SB();
+    f32x4 wA[8], wB[8];                            // W_hh blocks of a group of 2 k-iterations, ping-pong
+#define H_LDW(WS, g, WH) _Pragma("unroll") for (int k = 0; k < 8; ++k) WS[k] = WL((WH) + 8 * (g) + k);
+#define H_FIRST(L, tt)                                                                                          \
+    {                                                                                                           \
+        H_LDW(wA, 0, (L) + 16 + 64)                                                                             \
+        SB();                                                                                                   \
+        H_LDW(wB, 1, (L) + 16 + 64)                                                                             \
+        if constexpr (K8) { X_ISSUE8(0, xa_, 0, tt) X_ISSUE8(1, xa_, 4, tt) }                                   \
+        else { X_ISSUE(0, xa_, tt) }                                                                            \
+        SB();                                                                                                   \
+    }
+    H_FIRST(o_l, 0)                                // frames t > 0 request theirs at the end of frame t - 1
     const f32x4 W1 = ldw(wrs, q * 16, o_nyq), W3 = ldw(wrs, (2 * QL + q) * 16, o_nyq);   // window w[n], w[128+n] = w[128-n]  (8 kHz: w[64+n])
     const float w64 = ldw(wrs, QL * 16, o_nyq).x;                                           // w[64] = w[192]                     (8 kHz: w[32] = w[96])
     f32x16 cst;   // c state of units 32w + 8g + 4h + i  (reg 4g+i)
     {
         f32x4 c4[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(KP(state) + (size_t)slot * 256 + 128 + 32 * w + 8 * g + 4 * h);
-            c4[g] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int g = 0; g < 4; ++g) c4[g] = *reinterpret_cast<const f32x4 *>(KP(state) + (size_t)slot * 256 + 128 + 32 * w + 8 * g + 4 * h);
         cst = acc_of(c4[0], c4[1], c4[2], c4[3]);
     }
-    // the slot's state machine (96 B in HBM between calls) is fetched now, lives in LDS for the call and goes back with
-    // the last frame: its HBM latency is off the tail of the kernel.  It is REQUESTED with h and c (every thread asks for
-    // the slot of stream tid & 31 - the same lookup again - threads < 32 keep it) and stored to LDS after h: asked for
-    // behind the h store it was a second memory round trip before the frame loop.
-    const bool sm_thread = (tid < MT) && live;
-    const int sm_slot = slot;
-    f32x4 smq[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) smq[k] = reinterpret_cast<const f32x4 *>(KP(sm) + slot)[k];
     SB();
+    STAMP(29);
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) RH[(part * 4 + qq) * QS + fm] = hv[qq];
+    reinterpret_cast<decltype(bias2) *>(biasL + 32 * w)[lane] = bias2;
+    STAMP(30);
     int seg_last = 0;
     if (tid < MT) {
 #pragma unroll
@@ -167,7 +188,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
         asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6));
     }
     STAMP(0);
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0;;) {                          // T >= 1 (the launcher never passes less); the back edge is at the bottom, behind the next frame's first requests
         // section offsets, made opaque per frame: otherwise every block offset of the kernel (~300 SGPR
         // values) is hoisted out of this loop as loop-invariant and spilled
         int ws_stft = o_stft, ws_nyq = o_nyq, ws_e0 = o_e0, ws_e1 = o_e1, ws_e2 = o_e2, ws_e3 = o_e3, ws_l = o_l;
@@ -263,7 +284,6 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
             st2(&RX[er + 24 * QS], qep);                                                                        \
         }                                                                                                       \
     }
-#define H_LDW(WS, g) _Pragma("unroll") for (int k = 0; k < 8; ++k) WS[k] = WL(wh + 8 * (g) + k);
 #define H_MMA(WS, g)                                                                                            \
     {                                                                                                           \
         const f32x4 av0 = RH[(4 * (g)) * QS + hq], av1 = RH[(4 * (g) + 2) * QS + hq];                           \
@@ -279,44 +299,39 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                      \
         __builtin_amdgcn_sched_group_barrier(0x002, 40, 0);                                                     \
     }
-            f32x4 wA[8], wB[8];                            // W_hh blocks of a group of 2 k-iterations, ping-pong
-            f32x4 nb[16];                                  // gate biases = the accumulators' initial values
-#pragma unroll
-            for (int k = 0; k < 16; ++k) nb[k] = WL(ws_l + k);
-            H_LDW(wA, 0)
-            SB();
-            if constexpr (K8) { H_LDW(wB, 1) X_ISSUE8(0, xa_, 0, t) X_ISSUE8(1, xa_, 4, t) SB(); }
-            else { H_LDW(wB, 1) X_ISSUE(0, xa_, t) SB(); }
-            // (0) h_{t-1} visible.  The barrier sits INSIDE the loop, behind the first requests: the loop-invariant
-            // address arithmetic the compiler hoists into the preheader and the weight / frame requests above then run
-            // while the state loads of the prologue are still in flight.  For t > 0 it follows barrier (8) and costs nothing.
+            {   // the accumulators start at the gate biases: register 4 g + i of a lane = unit 8 g + 4 h + i (every lane of a half
+                // wave reads the same 16 bytes: a broadcast).  The wave reads what the wave itself wrote: ahead of the barrier.
+                const f32x4 *const bq = biasL + 32 * w + h;
+                gi = acc_of(bq[0], bq[2], bq[4], bq[6]);
+                gfo = acc_of(bq[8], bq[10], bq[12], bq[14]);
+                gg = acc_of(bq[16], bq[18], bq[20], bq[22]);
+                go = acc_of(bq[24], bq[26], bq[28], bq[30]);
+            }
+            // (0) h_{t-1} visible (wA, wB and the first column were requested in the prologue / at the end of the previous
+            // frame).  For t > 0 it follows barrier (8) and costs nothing.
             __syncthreads();
-            gi = acc_of(nb[0], nb[1], nb[2], nb[3]);
-            gfo = acc_of(nb[4], nb[5], nb[6], nb[7]);
-            gg = acc_of(nb[8], nb[9], nb[10], nb[11]);
-            go = acc_of(nb[12], nb[13], nb[14], nb[15]);
+            STAMP(31);
             if constexpr (!K8) {
             H_MMA(wA, 0) SB(); STAMP(20);
-            H_LDW(wA, 2) X_ISSUE(1, xb_, t) SB(); H_MMA(wB, 1) SB(); STAMP(21);
-            H_LDW(wB, 3) SB(); H_MMA(wA, 2) X_FOLD1(0, 0, xa_) H_MIX(6) SB(); STAMP(22);
-            H_LDW(wA, 4) SB(); H_MMA(wB, 3) X_FOLD1(0, 1, xa_) H_MIX(6) SB(); STAMP(23);
-            H_LDW(wB, 5) X_ISSUE(2, xa_, t) SB(); H_MMA(wA, 4) X_FOLD1(1, 0, xb_) H_MIX(6) SB(); STAMP(24);
-            H_LDW(wA, 6) SB(); H_MMA(wB, 5) X_FOLD1(1, 1, xb_) H_MIX(6) SB(); STAMP(25);
-            H_LDW(wB, 7) SB(); H_MMA(wA, 6) X_FOLD1(2, 0, xa_) H_MIX(6) SB(); STAMP(26);
+            H_LDW(wA, 2, wh) X_ISSUE(1, xb_, t) SB(); H_MMA(wB, 1) SB(); STAMP(21);
+            H_LDW(wB, 3, wh) SB(); H_MMA(wA, 2) X_FOLD1(0, 0, xa_) H_MIX(6) SB(); STAMP(22);
+            H_LDW(wA, 4, wh) SB(); H_MMA(wB, 3) X_FOLD1(0, 1, xa_) H_MIX(6) SB(); STAMP(23);
+            H_LDW(wB, 5, wh) X_ISSUE(2, xa_, t) SB(); H_MMA(wA, 4) X_FOLD1(1, 0, xb_) H_MIX(6) SB(); STAMP(24);
+            H_LDW(wA, 6, wh) SB(); H_MMA(wB, 5) X_FOLD1(1, 1, xb_) H_MIX(6) SB(); STAMP(25);
+            H_LDW(wB, 7, wh) SB(); H_MMA(wA, 6) X_FOLD1(2, 0, xa_) H_MIX(6) SB(); STAMP(26);
             H_MMA(wB, 7) X_FOLD1(2, 1, xa_) H_MIX(6) SB(); STAMP(27);
             } else {           // 8 kHz: three columns of 32 quads, one fold call each (8 lanes per stream)
             H_MMA(wA, 0) SB();
-            H_LDW(wA, 2) X_ISSUE8(2, xb_, 0, t) SB(); H_MMA(wB, 1) SB();
-            H_LDW(wB, 3) SB(); H_MMA(wA, 2) X_FOLD8(0, xa_, 0) H_MIX(6) SB();
-            H_LDW(wA, 4) SB(); H_MMA(wB, 3) X_FOLD8(1, xa_, 4) H_MIX(6) SB();
-            H_LDW(wB, 5) SB(); H_MMA(wA, 4) X_FOLD8(2, xb_, 0) H_MIX(6) SB();
-            H_LDW(wA, 6) SB(); H_MMA(wB, 5) SB();
-            H_LDW(wB, 7) SB(); H_MMA(wA, 6) SB();
+            H_LDW(wA, 2, wh) X_ISSUE8(2, xb_, 0, t) SB(); H_MMA(wB, 1) SB();
+            H_LDW(wB, 3, wh) SB(); H_MMA(wA, 2) X_FOLD8(0, xa_, 0) H_MIX(6) SB();
+            H_LDW(wA, 4, wh) SB(); H_MMA(wB, 3) X_FOLD8(1, xa_, 4) H_MIX(6) SB();
+            H_LDW(wB, 5, wh) SB(); H_MMA(wA, 4) X_FOLD8(2, xb_, 0) H_MIX(6) SB();
+            H_LDW(wA, 6, wh) SB(); H_MMA(wB, 5) SB();
+            H_LDW(wB, 7, wh) SB(); H_MMA(wA, 6) SB();
             H_MMA(wB, 7) SB();
             }
 #undef H_MIX
 #undef H_MMA
-#undef H_LDW
 #undef X_FOLD1
 #undef X_FOLD8
 #undef X_FOLDG
@@ -775,8 +790,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
         }
         // no barrier needed here: the next frame's loader only writes region A (free since (7)),
         // headp is rewritten only after barriers (1)..(7) of the next frame.
+        if (++t >= T) break;
+        H_FIRST(o_l, t)                            // the next frame's first requests
     }
 
+#undef H_FIRST
+#undef H_LDW
 #undef X_ISSUE
 #undef X_ISSUE8
     // ---- epilogue ----

@@ -96,7 +96,8 @@ constexpr int ROWS_X = 260;
 constexpr int ROW_E = 164;                 // first row of the upper part (enc0 / enc2 outputs)
 constexpr int ROW_NYQ = 160;
 constexpr int ROWS_H = 32;                 // h_{t-1}
-constexpr int LDS_F4 = (ROWS_X + ROWS_H) * QS + 32 + 24 + 72 + 16 + 192;  // + head partials [4][32], |X128| [3][32], fold corrections [3][3][32], write sink [64], state machines [32] x 96 B
+constexpr int LDS_F4 = (ROWS_X + ROWS_H) * QS + 32 + 24 + 72 + 16 + 192 + 128;  // + head partials [4][32], |X128| [3][32], fold corrections [3][3][32], write sink [64], state machines [32] x 96 B, gate biases [4 waves][4 gates][32 units]
+constexpr int LSTM_BIAS_BLOCK = 16 + 64 + 64 + 4;   // block of a wave's LSTM section that holds its gate biases compact: floats [gate][unit]
 constexpr int LDS_BYTES = LDS_F4 * 16;
 }  // namespace v5
 

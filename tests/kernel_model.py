@@ -250,7 +250,12 @@ def v5_step(W, sect, x, hc, gate=0.01, k8=False):
     z = np.zeros(32)
     for w in range(4):
         ws = sect[w][S_LSTM]
-        g = [np.repeat(_vec(W[ws + 4 * q:ws + 4 * q + 4])[:, None], 32, 1) for q in range(4)]
+        # the accumulators start from the section's COMPACT bias block (floats [gate][unit]; LSTM_BIAS_BLOCK in vad_layout.h);
+        # the lane-expanded copies at the head of the section must say the same
+        cb = W[ws + 16 + 64 + 64 + 4].reshape(-1)[:128].reshape(4, 32)
+        for q in range(4):
+            assert np.array_equal(cb[q], _vec(W[ws + 4 * q:ws + 4 * q + 4]).astype(cb.dtype))
+        g = [np.repeat(cb[q].astype(np.float64)[:, None], 32, 1) for q in range(4)]
         ws += 16
         for src in (RX, RH):
             for j in range(16):

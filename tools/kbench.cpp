@@ -140,6 +140,12 @@ int main(int argc, char **argv) {
         double pro = 0;
         for (int b = 0; b < tiles; ++b) pro += (double)(S(b, w, 0) - S(b, w, 19));
         printf("   prologue (kernel entry -> frame loop) = %.0f\n", pro / tiles);
+        // (s_memtime is a per-CU counter: stamps of different tiles cannot be set against each other)
+        double a29 = 0, a30 = 0, a31 = 0;
+        for (int b = 0; b < tiles; ++b) {
+            a29 += (double)(S(b, w, 29) - S(b, w, 19)); a30 += (double)(S(b, w, 30) - S(b, w, 19)); a31 += (double)(S(b, w, 31) - S(b, w, 19));
+        }
+        if (S(0, w, 29)) printf("        since kernel entry: all first requests issued %.0f, h in LDS %.0f, past barrier (0) %.0f\n", a29 / tiles, a30 / tiles, a31 / tiles);
     }
 #endif
     return 0;
