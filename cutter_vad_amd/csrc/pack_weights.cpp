@@ -462,6 +462,12 @@ bool pack_silero_v5_t16(const void *blob, size_t len, PackedWeights &out, std::s
                     for (int rt = 0; rt < 2; ++rt)
                         sb.weight_block16([&](int r, int c) { return W[(size_t)(q * 128 + 32 * w + 16 * rt + r) * 128 + c]; }, j);
         for (int rt = 0; rt < 2; ++rt) sb.vector_block16([&](int c) { return head_w[32 * w + 16 * rt + c]; });
+        // block 138 of the section: the gate biases once more, compact - floats [gate q][unit] (silero_v5_t16.hip keeps them in LDS)
+        {
+            float *cb = sb.new_block();
+            for (int q = 0; q < 4; ++q)
+                for (int c = 0; c < 32; ++c) cb[q * 32 + c] = b_ih[q * 128 + 32 * w + c] + b_hh[q * 128 + 32 * w + c];
+        }
     }
     out.sect[2][S_ENC2] = out.sect[0][S_ENC2];
     out.sect[3][S_ENC2] = out.sect[1][S_ENC2];

@@ -788,6 +788,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
                 if (P.events) P.events[(size_t)(tile0 + tid) * T + t] = (uint8_t)ev;
             }
         }
+        STAMP(28);
         // no barrier needed here: the next frame's loader only writes region A (free since (7)),
         // headp is rewritten only after barriers (1)..(7) of the next frame.
         if (++t >= T) break;

@@ -46,7 +46,8 @@ constexpr int T_ROWS_X = 264;
 constexpr int T_ROWS_H = 32;
 constexpr int T_FOLD_SINK = 192;          // loader view: 32 rows behind the three columns, where the loader lanes q >= 8 drop their duplicate quads
 static_assert(T_ROWS_X * QSD >= (T_FOLD_SINK + 32) * QSL, "the loader view (and its sink rows) must end before h");
-constexpr int T_LDS_F4 = (T_ROWS_X + T_ROWS_H) * QSD + 16 + 12 + 36 + 16 + 96;   // + head partials [4][16], |X128| [3][16], fold corrections [3][3][16], sink [64], state machines [16] x 96 B
+constexpr int T_LDS_F4 = (T_ROWS_X + T_ROWS_H) * QSD + 16 + 12 + 36 + 16 + 96 + 128;   // + head partials [4][16], |X128| [3][16], fold corrections [3][3][16], sink [64], state machines [16] x 96 B, gate biases [4 waves][4 gates][32 units]
+constexpr int T_LSTM_BIAS_BLOCK = 8 + 64 + 64 + 2;   // block of a wave's LSTM section that holds its gate biases compact: floats [gate][unit]
 static_assert(T_LDS_F4 * 16 <= 80 * 1024, "stays under half a CU's LDS");
 // RS instantiation (fused resample -> step).  The resampler's folded input chunks (2 buffers x {ue, ve, uo, vo} x 16 quad rows,
 // loader stride) are staged in the activation region, which is idle until the frame loop starts; the tile's 16 kHz frames
@@ -104,6 +105,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
     float *const fcor = nyqv + 48;               // [3 columns][y128, a64, b64][16 streams]
     constexpr int FCOR_SINK = 144;               // [64] floats after fcor
     SmSlot *const smL = reinterpret_cast<SmSlot *>(fcor + 144 + 64);
+    f32x4 *const biasL = reinterpret_cast<f32x4 *>(smL + MT16);          // gate biases, compact: [4 waves][4 gates][8 quads of units]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -237,26 +239,44 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
     //  47.9 - 48.2 for 4 096 streams at 48 kHz on one box - it delays the state loads queued behind it.  Behind them: below.)
 
     // ---- prologue: h_{t-1} -> LDS quads (32 rows x 16 streams), c_{t-1} -> registers, state machines -> LDS ----
+    // Request order = the order in which the frame loop needs things (vmcnt retires in issue order): h, the wave's gate biases
+    // (compact: 128 floats, kept in LDS for the call) and the tile's state machines (their 16 threads only), then - not RS, where
+    // a whole resampling phase sits in front of the frame loop - the frame loop's first requests: the W_hh blocks of its first two
+    // groups and the frame's first two columns depend on kernel arguments only, and W_hh is the coldest part of the weight
+    // stream; then the window and c.  Streams past n (the last tile's tail) read slot 0's state and compute on it: a stream is
+    // a column of every MFMA, nothing crosses columns, and every store of the kernel is guarded by `live`.
     f32x4 hv[2];
     const int fm = tid & 15, part = tid >> 4;      // fm == n: ONE slot lookup serves h, c and the state machine
 #pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-        const f32x4 v = reinterpret_cast<const f32x4 *>(KP(state) + (size_t)slot * 256)[part * 2 + qq];
-        hv[qq] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qq = 0; qq < 2; ++qq) hv[qq] = reinterpret_cast<const f32x4 *>(KP(state) + (size_t)slot * 256)[part * 2 + qq];
+    SB();
+    auto bias2 = __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8, (o_l + T_LSTM_BIAS_BLOCK) * 1024, 0);
+    const bool sm_thread = (tid < MT16) && live;
+    const int sm_slot = slot;
+    f32x4 smq[6];
+    if (tid < MT16) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) smq[k] = reinterpret_cast<const f32x4 *>(KP(sm) + slot)[k];
     }
+    SB();
+    f32x4 wA[8], wB[8];                            // W_hh blocks of a group, ping-pong
+#define H_LDW(WS, g, WH) _Pragma("unroll") for (int k = 0; k < 8; ++k) WS[k] = WL((WH) + 8 * (g) + k);
+#define H_FIRST(L, tt)                                                                                          \
+    {                                                                                                           \
+        H_LDW(wA, 0, (L) + 8 + 64)                                                                              \
+        SB();                                                                                                   \
+        H_LDW(wB, 1, (L) + 8 + 64)                                                                              \
+        if constexpr (K8) { X_ISSUE8(0, xa_, tt) X_ISSUE8(2, xb_, tt) }                                         \
+        else { X_ISSUE(0, xa_, tt) X_ISSUE(1, xb_, tt) }                                                        \
+        SB();                                                                                                   \
+        if constexpr (RS) { X_ISSUE(2, xc_, tt) SB(); }                                                         \
+    }
+    if constexpr (!RS) H_FIRST(o_l, 0)             // frames t > 0 request theirs at the end of frame t - 1; RS: at the top of the frame
     const f32x4 W1 = ldw(wrs, q * 16, o_nyq), W3 = ldw(wrs, (2 * QL + q) * 16, o_nyq);   // w[n], w[128 + n]  (8 kHz: w[64 + n])
     const float w64 = ldw(wrs, QL * 16, o_nyq).x;                                          // w[64]             (8 kHz: w[32])
     f32x4 cst[2];                                  // c of units 32 w + 16 rt + 4 kq + i
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(KP(state) + (size_t)slot * 256 + 128 + 32 * w + 16 * rt + 4 * kq);
-        cst[rt] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const bool sm_thread = (tid < MT16) && live;
-    const int sm_slot = slot;
-    f32x4 smq[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) smq[k] = reinterpret_cast<const f32x4 *>(KP(sm) + slot)[k];
+    for (int rt = 0; rt < 2; ++rt) cst[rt] = *reinterpret_cast<const f32x4 *>(KP(state) + (size_t)slot * 256 + 128 + 32 * w + 16 * rt + 4 * kq);
     // RS, first part at 48 kHz (the tiles that set a mixed tick's time): its first chunk is requested right BEHIND the state loads -
     // loads return in order, so the state is not delayed - and has its HBM round trip under the state's waits, the LDS writes and
     // the operator prefetch.  Same box: 43.3 -> 42.9 us (4 096 streams at 48 kHz), configs[3] 46.0 -> 45.5; for 8 / 24 kHz first
@@ -272,6 +292,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
     SB();
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) RH[(part * 2 + qq) * QSD + fm] = hv[qq];
+    reinterpret_cast<decltype(bias2) *>(biasL + 32 * w)[lane] = bias2;
     int seg_last = 0;
     if (tid < MT16) {
 #pragma unroll
@@ -607,7 +628,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
         }                                                             // next part
     }
 
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0;;) {                          // T >= 1; the back edge is at the bottom, behind the next frame's first requests
         int ws_stft = o_stft, ws_e0 = o_e0, ws_e1 = o_e1, ws_e2 = o_e2, ws_e3 = o_e3, ws_l = o_l;
         asm volatile("" : "+s"(ws_stft), "+s"(ws_e0), "+s"(ws_e1), "+s"(ws_e2), "+s"(ws_e3), "+s"(ws_l));
         // ---- recurrent gate half W_hh . h_{t-1} (8 k-iterations x {4 gates x 2 row tiles}) with the frame ingested under it ----
@@ -679,7 +700,6 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
         st2(&RX[er + 24 * QSL], qep);                                                                           \
         }                                                                                                       \
     }
-#define H_LDW(WS, g) _Pragma("unroll") for (int k = 0; k < 8; ++k) WS[k] = WL(wh + 8 * (g) + k);
 #define H_MMA(WS, g)                                                                                            \
     {                                                                                                           \
         const f32x4 av = RH[(4 * (g)) * QSD + nq];                                                             \
@@ -690,38 +710,34 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                      \
         __builtin_amdgcn_sched_group_barrier(0x002, 40, 0);                                                     \
     }
-            f32x4 wA[8], wB[8], nb[8];
+            if constexpr (RS) H_FIRST(ws_l, t)                 // F is dead once every wave has passed the barrier below
+            {   // the accumulators start at the gate biases: G[2 q + rt] register i of a lane = unit 16 rt + 4 kq + i of gate q (the
+                // 16 lanes of a row group read the same 16 bytes: a broadcast).  The wave reads what the wave itself wrote.
+                const f32x4 *const bq = biasL + 32 * w + kq;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) nb[k] = WL(ws_l + k);
-            H_LDW(wA, 0)
-            SB();
-            if constexpr (K8) { H_LDW(wB, 1) X_ISSUE8(0, xa_, t) X_ISSUE8(2, xb_, t) SB(); }
-            else { H_LDW(wB, 1) X_ISSUE(0, xa_, t) X_ISSUE(1, xb_, t) SB(); }
-            if constexpr (RS) { X_ISSUE(2, xc_, t) SB(); }     // F is dead once every wave has passed the barrier below
+                for (int k = 0; k < 8; ++k) G[k] = bq[(k >> 1) * 8 + (k & 1) * 4];
+            }
             __syncthreads();   // (0) h_{t-1} visible (t > 0: follows barrier (8))
-#pragma unroll
-            for (int k = 0; k < 8; ++k) G[k] = nb[k];
             H_MMA(wA, 0) SB();
             if constexpr (K8) {             // two fold calls: columns (0 | 1) by half of the workgroup, then column 2
-            H_LDW(wA, 2) SB(); H_MMA(wB, 1) SB();
-            H_LDW(wB, 3) SB(); H_MMA(wA, 2) X_FOLD(lcol, xa_) H_MIX SB();
-            H_LDW(wA, 4) SB(); H_MMA(wB, 3) SB();
-            H_LDW(wB, 5) SB(); H_MMA(wA, 4) X_FOLD(2, xb_) H_MIX SB();
-            H_LDW(wA, 6) SB(); H_MMA(wB, 5) SB();
-            H_LDW(wB, 7) SB(); H_MMA(wA, 6) SB();
+            H_LDW(wA, 2, wh) SB(); H_MMA(wB, 1) SB();
+            H_LDW(wB, 3, wh) SB(); H_MMA(wA, 2) X_FOLD(lcol, xa_) H_MIX SB();
+            H_LDW(wA, 4, wh) SB(); H_MMA(wB, 3) SB();
+            H_LDW(wB, 5, wh) SB(); H_MMA(wA, 4) X_FOLD(2, xb_) H_MIX SB();
+            H_LDW(wA, 6, wh) SB(); H_MMA(wB, 5) SB();
+            H_LDW(wB, 7, wh) SB(); H_MMA(wA, 6) SB();
             H_MMA(wB, 7) SB();
             } else {
-            H_LDW(wA, 2) if constexpr (!RS) { X_ISSUE(2, xc_, t) } SB(); H_MMA(wB, 1) SB();
-            H_LDW(wB, 3) SB(); H_MMA(wA, 2) X_FOLD(0, xa_) H_MIX SB();
-            H_LDW(wA, 4) SB(); H_MMA(wB, 3) SB();
-            H_LDW(wB, 5) SB(); H_MMA(wA, 4) X_FOLD(1, xb_) H_MIX SB();
-            H_LDW(wA, 6) SB(); H_MMA(wB, 5) SB();
-            H_LDW(wB, 7) SB(); H_MMA(wA, 6) X_FOLD(2, xc_) H_MIX SB();
+            H_LDW(wA, 2, wh) if constexpr (!RS) { X_ISSUE(2, xc_, t) } SB(); H_MMA(wB, 1) SB();
+            H_LDW(wB, 3, wh) SB(); H_MMA(wA, 2) X_FOLD(0, xa_) H_MIX SB();
+            H_LDW(wA, 4, wh) SB(); H_MMA(wB, 3) SB();
+            H_LDW(wB, 5, wh) SB(); H_MMA(wA, 4) X_FOLD(1, xb_) H_MIX SB();
+            H_LDW(wA, 6, wh) SB(); H_MMA(wB, 5) SB();
+            H_LDW(wB, 7, wh) SB(); H_MMA(wA, 6) X_FOLD(2, xc_) H_MIX SB();
             H_MMA(wB, 7) SB();
             }
 #undef H_MIX
 #undef H_MMA
-#undef H_LDW
 #undef X_FOLD
         }
         f32x4 Sw[2];                              // STFT blocks of k-iteration 0: cos, -sin of the odd tile
@@ -1074,7 +1090,11 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
                 if (P.events) P.events[(size_t)gf * T + t] = (uint8_t)ev;
             }
         }
+        if (++t >= T) break;
+        if constexpr (!RS) H_FIRST(o_l, t)         // the next frame's first requests
     }
+#undef H_FIRST
+#undef H_LDW
 #undef X_ISSUE
 #undef WL
     if (sm_thread && P.seg_frames) P.seg_frames[gf] = seg_last;

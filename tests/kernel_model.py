@@ -757,8 +757,13 @@ def v5_step_t16(W, sect, x, hc, gate=0.01, k8=False):
     h_new, c_new, z = np.zeros((16, 128)), np.zeros((16, 128)), np.zeros(16)
     for w in range(4):
         ws = sect[w][S_LSTM]
+        # the accumulators start from the section's COMPACT bias block (floats [gate][unit]; T_LSTM_BIAS_BLOCK in silero_v5_t16.hip);
+        # the lane-expanded copies at the head of the section must say the same
+        cb = W[ws + 8 + 64 + 64 + 2].reshape(-1)[:128].reshape(4, 32)
         for rt in range(2):
-            g = [np.repeat(_vec16(W[ws + 2 * q + rt])[:, None], 16, 1) for q in range(4)]
+            for q in range(4):
+                assert np.array_equal(cb[q, 16 * rt:16 * rt + 16], _vec16(W[ws + 2 * q + rt]).astype(cb.dtype))
+            g = [np.repeat(cb[q, 16 * rt:16 * rt + 16].astype(np.float64)[:, None], 16, 1) for q in range(4)]
             for half, src in enumerate((RX, RH)):
                 for j in range(8):
                     a = _rows16(src, 4 * j)

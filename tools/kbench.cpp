@@ -145,6 +145,11 @@ int main(int argc, char **argv) {
         for (int b = 0; b < tiles; ++b) {
             a29 += (double)(S(b, w, 29) - S(b, w, 19)); a30 += (double)(S(b, w, 30) - S(b, w, 19)); a31 += (double)(S(b, w, 31) - S(b, w, 19));
         }
+        if (w == 0 && S(0, 0, 28)) {
+            double tl = 0;
+            for (int b = 0; b < tiles; ++b) tl += (double)(S(b, 0, 28) - S(b, 0, 15));
+            printf("        head + state machine (32 lanes of wave 0, behind barrier (8)) = %.0f\n", tl / tiles);
+        }
         if (S(0, w, 29)) printf("        since kernel entry: all first requests issued %.0f, h in LDS %.0f, past barrier (0) %.0f\n", a29 / tiles, a30 / tiles, a31 / tiles);
     }
 #endif
