@@ -76,13 +76,9 @@ __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) {
 }
 __device__ __forceinline__ f32x4 mul4(f32x4 a, f32x4 b) { return cat2(a.lo * b.lo, a.hi * b.hi); }
 __device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 b) { return cat2(a.lo + b.lo, a.hi + b.hi); }
-// a - b: the backend scalarises a two-lane subtract (and folds fma(b, -1, a) back into one), so the packed add with its
-// negate modifier on the second source is written out
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
-    f32x2 d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
+// a - b as one packed instruction: vadk_device.h, pk::sub2 (v_pk_fma_f32 with an opaque -1; no inline-asm instruction, which the
+// hazard recogniser could not see)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { return pk::sub2(a, b); }
 __device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) { return cat2(pk_sub(a.lo, b.lo), pk_sub(a.hi, b.hi)); }
 __device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
 // |re + i im| of a quad: fma(re, re, im * im) as in mag_(), packed, then the four square roots

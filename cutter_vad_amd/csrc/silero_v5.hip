@@ -742,19 +742,17 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
             STAMP(13);
             __syncthreads();   // (7) every wave is done reading h_{t-1}; region A free for the next frame
             STAMP(14);
-            float part = 0.f;
+            f32x4 part4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 i4 = quad_of(gi, g), f4 = quad_of(gfo, g), g4 = quad_of(gg, g), o4 = quad_of(go, g);
                 const f32x4 c4 = quad_of(cst, g);
                 const f32x4 hw = g == 0 ? hw0 : (g == 1 ? hw1 : (g == 2 ? hw2 : hw3));
-                f32x4 cn, hn;
-#define CELL(k)                                                             \
-    cn.k = sigmoidf_(f4.k) * c4.k + sigmoidf_(i4.k) * tanhf_(g4.k);       \
-    hn.k = sigmoidf_(o4.k) * tanhf_(cn.k);                                \
-    part += hw.k * fmaxf(hn.k, 0.f);
-                CELL(x) CELL(y) CELL(z) CELL(w)
-#undef CELL
+                // c' = sigma(f) c + sigma(i) tanh(g); h' = sigma(o) tanh(c'); head partial += w relu(h') - a quad at a time, the
+                // full-rate arithmetic packed (pk::), the transcendentals per component
+                const f32x4 cn = pk::fma(pk::sigmoid4(f4), c4, pk::mul(pk::sigmoid4(i4), pk::tanh4(g4)));
+                const f32x4 hn = pk::mul(pk::sigmoid4(o4), pk::tanh4(cn));
+                part4 = pk::fma(hw, relu4(hn), part4);
                 RH[(8 * w + 2 * g) * QS + hq] = hn;
                 if (t == T - 1 && live) {   // last frame of the call: h' and c' go back to HBM under barrier (8), head and state machine
                     *reinterpret_cast<f32x4 *>(KP(state) + (size_t)slot * 256 + 32 * w + 8 * g + 4 * h) = hn;
@@ -767,6 +765,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
                     default: cst.sc = cn.x; cst.sd = cn.y; cst.se = cn.z; cst.sf = cn.w; break;
                 }
             }
+            float part = (part4.x + part4.y) + (part4.z + part4.w);
             part += __shfl_xor(part, 32);
             if (h == 0) headp[w * 32 + m] = part;
         }

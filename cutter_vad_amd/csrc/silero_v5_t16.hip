@@ -1052,17 +1052,15 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 #undef L_LD
 #undef L_MMA
             __syncthreads();   // (7) every wave is done reading h_{t-1}
-            float part_ = 0.f;
+            f32x4 part4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const f32x4 i4 = G[0 + rt], f4 = G[2 + rt], g4 = G[4 + rt], o4 = G[6 + rt], c4 = cst[rt], hwv = hw[rt];
-                f32x4 cn, hn;
-#define CELL(k)                                                             \
-    cn.k = sigmoidf_(f4.k) * c4.k + sigmoidf_(i4.k) * tanhf_(g4.k);       \
-    hn.k = sigmoidf_(o4.k) * tanhf_(cn.k);                                \
-    part_ += hwv.k * fmaxf(hn.k, 0.f);
-                CELL(x) CELL(y) CELL(z) CELL(w)
-#undef CELL
+                // c' = sigma(f) c + sigma(i) tanh(g); h' = sigma(o) tanh(c'); head partial += w relu(h') - a quad at a time, the
+                // full-rate arithmetic packed (pk::), the transcendentals per component
+                const f32x4 cn = pk::fma(pk::sigmoid4(f4), c4, pk::mul(pk::sigmoid4(i4), pk::tanh4(g4)));
+                const f32x4 hn = pk::mul(pk::sigmoid4(o4), pk::tanh4(cn));
+                part4 = pk::fma(hwv, relu4(hn), part4);
                 RH[(8 * w + 4 * rt) * QSD + nq] = hn;
                 if (t == T - 1 && live) {
                     *reinterpret_cast<f32x4 *>(KP(state) + (size_t)slot * 256 + 32 * w + 16 * rt + 4 * kq) = hn;
@@ -1070,6 +1068,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
                 }
                 cst[rt] = cn;
             }
+            float part_ = (part4.x + part4.y) + (part4.z + part4.w);
             part_ += __shfl_xor(part_, 16);
             part_ += __shfl_xor(part_, 32);
             if (kq == 0) headp[w * 16 + n] = part_;

@@ -38,7 +38,9 @@ __device__ __forceinline__ void st2(f32x4 *dst, f32x4 v) {
     d[1] = f32x2{v.z, v.w};
 }
 
-// ReLU as ONE v_med3_f32 (median of v, 0, +inf): fmaxf() costs two v_max_f32 each, the first only to quiet signalling NaNs
+// ReLU: median of (v, 0, +inf).  (Written as inline asm `v_max_f32 %0, 0, %1` it would save the compiler's NaN-quieting
+// v_max (v, v) in front - and lose the wait states the hazard recogniser inserts between an MFMA and a VALU read of its result:
+// inline asm is opaque to it.  Tried, measured: Silero V4's probabilities came out wrong by 0.5.)
 __device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)}; }
 
@@ -88,10 +90,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma clang fp contract(off)
 namespace pk {
 __device__ __forceinline__ f32x4 cat(f32x2 lo, f32x2 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3); }
+// a - b as ONE packed instruction.  The backend has no packed subtract (an fsub of a <2 x float> is split into two v_sub_f32, and
+// fma(b, -1, a) is folded back into that fsub), so the -1 is made opaque: v_pk_fma_f32(b, k, a) with k = -1 from an empty asm - the
+// product is exact, the one rounding is that of a - b.  NOT written as inline asm (`v_pk_add_f32 ... neg_lo:[0,1] neg_hi:[0,1]`, as
+// it was): inline asm is opaque to the hazard recogniser, which then does not insert the wait states an MFMA result needs before a
+// VALU instruction reads it - and this helper is applied to accumulators (enc0's Toom-3 interpolation).
 __device__ __forceinline__ f32x2 sub2(f32x2 a, f32x2 b) {
-    f32x2 d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
+    float k = -1.0f;
+    asm("" : "+v"(k));
+    return __builtin_elementwise_fma(b, f32x2{k, k}, a);
 }
 __device__ __forceinline__ f32x4 add(f32x4 a, f32x4 b) { return cat(a.lo + b.lo, a.hi + b.hi); }
 __device__ __forceinline__ f32x4 sub(f32x4 a, f32x4 b) { return cat(sub2(a.lo, b.lo), sub2(a.hi, b.hi)); }
@@ -120,6 +127,18 @@ __device__ __forceinline__ f32x4 mag(f32x4 re, f32x4 im) {
         }                                                                                                          \
         return r_;                                                                                                 \
     }
+// sigmoidf_ / tanhf_ on a quad: the same operations per component (scale, v_exp_f32, 1 +, v_rcp_f32, and tanh's 1 - 2 r as one fma),
+// the full-rate ones as packed instructions: half the issue slots of the LSTM cell's non-transcendental part
+__device__ __forceinline__ f32x4 exp2_4(f32x4 v) {
+    return f32x4{__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y), __builtin_amdgcn_exp2f(v.z), __builtin_amdgcn_exp2f(v.w)};
+}
+__device__ __forceinline__ f32x4 rcp4(f32x4 v) {
+    return f32x4{__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y), __builtin_amdgcn_rcpf(v.z), __builtin_amdgcn_rcpf(v.w)};
+}
+__device__ __forceinline__ f32x4 sigmoid4(f32x4 v) { return rcp4(add(exp2_4(mul(v, splat(-1.44269504088896341f))), splat(1.0f))); }
+__device__ __forceinline__ f32x4 tanh4(f32x4 v) {
+    return fma(rcp4(add(exp2_4(mul(v, splat(2.88539008177792681f))), splat(1.0f))), splat(-2.0f), splat(1.0f));
+}
 __device__ __forceinline__ f32x4 q16(const f32x16 &a, int g) {
     return g == 0 ? f32x4{a.s0, a.s1, a.s2, a.s3} : g == 1 ? f32x4{a.s4, a.s5, a.s6, a.s7}
          : g == 2 ? f32x4{a.s8, a.s9, a.sa, a.sb} : f32x4{a.sc, a.sd, a.se, a.sf};
