@@ -38,10 +38,16 @@ __device__ __forceinline__ void st2(f32x4 *dst, f32x4 v) {
     d[1] = f32x2{v.z, v.w};
 }
 
-// ReLU: median of (v, 0, +inf).  (Written as inline asm `v_max_f32 %0, 0, %1` it would save the compiler's NaN-quieting
-// v_max (v, v) in front - and lose the wait states the hazard recogniser inserts between an MFMA and a VALU read of its result:
-// inline asm is opaque to it.  Tried, measured: Silero V4's probabilities came out wrong by 0.5.)
-__device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
+// ReLU as ONE instruction: max of the BIT PATTERN, as a signed integer, with 0 - a float with its sign bit clear is a non-negative
+// integer and is kept, one with the sign bit set (negative values, -0) is a negative integer and becomes +0.  fmaxf(v, 0) and
+// v_med3_f32(v, 0, +inf) - which the compiler folds back into fmaxf - cost two v_max_f32 each, the first (v, v) only to quiet a
+// signalling NaN the hardware would quiet anyway.  (Inline asm `v_max_f32 %0, 0, %1` is NOT an option: inline asm is opaque to the
+// hazard recogniser, which then leaves out the wait states between an MFMA and a VALU read of its result - tried, Silero V4's
+// probabilities came out wrong by 0.5.)
+__device__ __forceinline__ float relu1(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)}; }
 
 __device__ __forceinline__ f32x4 quad_of(const f32x16 &a, int g) {
