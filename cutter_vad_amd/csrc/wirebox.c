@@ -581,6 +581,17 @@ static pthread_cond_t g_crew_go = PTHREAD_COND_INITIALIZER, g_crew_done = PTHREA
 static pthread_mutex_t g_crew_busy = PTHREAD_MUTEX_INITIALIZER;    /* one conductor at a time */
 static int g_crew_pending = 0;
 
+/* A forked child has none of the crew's threads (fork copies the calling thread only) but would inherit their bookkeeping, post
+ * rounds to workers that do not exist and wait for them for ever: the child starts with an empty crew and fresh locks. */
+static void crew_atfork_child(void) {
+    memset(g_crew, 0, sizeof g_crew);
+    g_crew_pending = 0;
+    pthread_mutex_init(&g_crew_m, NULL);
+    pthread_mutex_init(&g_crew_busy, NULL);
+    pthread_cond_init(&g_crew_go, NULL);
+    pthread_cond_init(&g_crew_done, NULL);
+}
+
 static void *crew_thread(void *a) {
     CrewWorker *w = (CrewWorker *)a;
     pthread_mutex_lock(&g_crew_m);
@@ -888,6 +899,7 @@ PyMODINIT_FUNC PyInit__wirebox(void) {
     if (PyType_Ready(&InboxType) < 0 || PyType_Ready(&PusherType) < 0) return NULL;
     PyObject *m = PyModule_Create(&moduledef);
     if (!m) return NULL;
+    pthread_atfork(NULL, NULL, crew_atfork_child);
     Py_INCREF(&InboxType);
     Py_INCREF(&PusherType);
     if (PyModule_AddObject(m, "Inbox", (PyObject *)&InboxType) < 0 || PyModule_AddObject(m, "Pusher", (PyObject *)&PusherType) < 0) {

@@ -75,6 +75,30 @@ x = np.concatenate([np.frombuffer(f, "<i2").astype(np.float32) / np.float32(3276
 x = np.where(np.abs(x) > 0.01, x, 0).astype(np.float32)
 want = WAVWriter(16000, 16, 1).write_wav_data(x)
 eng_pool.close()
-print(json.dumps({"same_events": a_log == b_log, "events": len(a_log), "ends": sum(1 for e in a_log if e[1] == "E"),
+
+# a forked child conducts by itself: it has none of the parent's crew threads (fork copies the calling thread only) and must not wait
+# for them (wirebox.c: crew_atfork_child).  The child gets 60 s; a hang is a failure, not a timeout of the whole test.
+def forked_child_conducts() -> bool:
+    import signal
+    pid = os.fork()
+    if pid == 0:
+        try:
+            signal.alarm(60)
+            shards = [SharedStreamPool(max_streams=16, pool=EnginePool(), device_id=0) for _ in range(3)]
+            pool = ShardedStreamPool(shards=shards)
+            ss = [pool.open_session(VADConfig(buffer_size=480), shard=k % 3) for k in range(6)]
+            for t in range(3):
+                for k, s_ in enumerate(ss):
+                    s_.submit_pcm16(frame(0.5, seed=t * 10 + k))
+                assert pool.tick() == 6
+            os._exit(0)
+        except BaseException:
+            os._exit(1)
+    _, status = os.waitpid(pid, 0)
+    return os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+
+
+child_ok = forked_child_conducts()
+print(json.dumps({"forked_child_conducts": child_ok, "same_events": a_log == b_log, "events": len(a_log), "ends": sum(1 for e in a_log if e[1] == "E"),
                   "same_done": a_done == b_done, "done": a_done[:4], "wav_matches_wavwriter": bool(got and got[0] == want),
                   "wav_len": len(got[0]) if got else 0, "want_len": len(want)}))

@@ -16,3 +16,4 @@ def test_conducted_tick_equals_the_per_pool_tick_and_builds_wavwriters_bytes():
     assert r["same_events"] and r["same_done"], r            # three pools conducted from C == each pool ticked by itself
     assert r["events"] > 300 and r["ends"] >= 30, r          # START / CONTINUE (notifications and payloads) / END all occurred
     assert r["wav_matches_wavwriter"] and r["wav_len"] == r["want_len"] > 44, r
+    assert r["forked_child_conducts"], r                     # a forked child starts with an empty crew (no wait for threads it has not got)
