@@ -43,7 +43,12 @@ using namespace vadk::dev;
 // blocks, first frame column): scalar arguments at the head of the list are PRELOADED into SGPRs by the command processor on
 // gfx950 (`-mllvm -amdgpu-kernarg-preload-count=8` in _build.py: 13 dwords), struct fields are fetched with s_load after the wave
 // has started.  Same box: 49.98 - 50.13 -> 49.84 - 49.87 us per step of 8 192 streams (KP(f) = that field's preloaded copy).
-template <bool F32IN, bool K8>
+// ONE: the call steps one frame per stream (k_T == 1: the serving tick, vad_step, the bench) - instantiated WITHOUT the frame loop.
+// With the loop the compiler hoists every loop-invariant address computation of the frame (~250 instructions, 94 of them only
+// to park the result in an AGPR that the frame reads back once) in front of it, and keeps 100 more registers live; as straight-line
+// code the addresses are formed where they are used: 2 137 -> 1 930 VALU instructions per wave, 369 -> 290 registers, and
+// 46.35 -> 45.5 us per 8 192 streams on one box (profiles/r04_v5_single_frame_ab_same_box.log).  Same results, bit for bit.
+template <bool F32IN, bool K8, bool ONE>
 __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wstream, float *k_state, SmSlot *k_sm, const int32_t *k_slots,
                                                               const void *k_frames, const int k_n, const uint32_t k_wstream_bytes, const int k_T,
                                                               const StepParams P) {
@@ -86,7 +91,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
     const int o_stft = (int)P.sect[w][S_STFT], o_nyq = (int)P.sect[w][S_NYQ], o_e0 = (int)P.sect[w][S_ENC0];
     const int o_e1 = (int)P.sect[w][S_ENC1], o_e2 = (int)P.sect[w][S_ENC2], o_e3 = (int)P.sect[w][S_ENC3];
     const int o_l = (int)P.sect[w][S_LSTM];
-    const int T = KP(T);
+    const int T = ONE ? 1 : KP(T);
     const int hq = h * QS + m;                    // lane's offset inside a quad-row pair
 
     // ---- frame ingest set-up (loop-invariant) ----
@@ -809,15 +814,18 @@ extern "C" hipError_t vadk_launch_silero_v5(const vadk::StepParams *p, hipStream
     const int tiles = (p->n + vadk::MT - 1) / vadk::MT;
     if (tiles <= 0) return hipSuccess;
 #define V5_ARGS p->wstream, p->state, p->sm, p->slots, p->frames, (int)p->n, p->wstream_bytes, (int)p->T, *p
-    if (p->variant == 1) {       // the 8 kHz sub-model, 256-sample frames
-        if (p->fmt == 0)
-            hipLaunchKernelGGL((silero_v5_step<true, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS);
-        else
-            hipLaunchKernelGGL((silero_v5_step<false, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS);
-    } else if (p->fmt == 0)
-        hipLaunchKernelGGL((silero_v5_step<true, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS);
-    else
-        hipLaunchKernelGGL((silero_v5_step<false, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS);
+#define V5_LAUNCH(F, K, O) hipLaunchKernelGGL((silero_v5_step<F, K, O>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS)
+    if (p->T < 1) return hipErrorInvalidValue;     // the frame loop tests its count at the bottom
+    const bool k8 = p->variant == 1;               // the 8 kHz sub-model, 256-sample frames
+    const bool f32 = p->fmt == 0, one = p->T == 1;
+    if (k8) {
+        if (f32) { if (one) V5_LAUNCH(true, true, true); else V5_LAUNCH(true, true, false); }
+        else { if (one) V5_LAUNCH(false, true, true); else V5_LAUNCH(false, true, false); }
+    } else {
+        if (f32) { if (one) V5_LAUNCH(true, false, true); else V5_LAUNCH(true, false, false); }
+        else { if (one) V5_LAUNCH(false, false, true); else V5_LAUNCH(false, false, false); }
+    }
+#undef V5_LAUNCH
 #undef V5_ARGS
     return hipGetLastError();
 }

@@ -79,7 +79,9 @@ __device__ __forceinline__ f32x4 mfma16(f32x4 w, f32x4 a, f32x4 acc) {
 // input channels; from enc1 on the instantiations are the same): pools of at most 4 096 native-8 kHz sessions get one tile per CU
 // like the 16 kHz model's (the 32-stream K8 kernel runs n / 32 CUs: 37 us whatever the size).  Loader: 8 lanes per stream, so a
 // fold call covers TWO columns of the tile's 16 streams (threads 0..127 / 128..255).
-template <bool F32IN, bool RS, bool K8 = false>
+// ONE: one frame per stream in the call (k_T == 1), instantiated without the frame loop (silero_v5.hip has the reasons); the fused
+// resample -> step launch is always one frame.
+template <bool F32IN, bool RS, bool K8 = false, bool ONE = false>
 // One workgroup per CU also here.  Built for two (a tick's segments are padded to whole tiles, so it can have a few more tiles
 // than CUs), the dispatcher packs consecutive workgroups onto the same CU: 258 tiles ran on ~130 CUs, 69.9 us per tick against
 // 55.6 for the two-launch form - so the engine uses this launch only when the tick has at most one tile per CU.
@@ -135,7 +137,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
     const int o_stft = (int)P.sect[w][S_STFT], o_nyq = (int)P.sect[w][S_NYQ], o_e0 = (int)P.sect[w][S_ENC0];
     const int o_e1 = (int)P.sect[w][S_ENC1], o_e2 = (int)P.sect[w][S_ENC2], o_e3 = (int)P.sect[w][S_ENC3];
     const int o_l = (int)P.sect[w][S_LSTM];
-    const int T = KP(T);
+    const int T = (ONE || RS) ? 1 : KP(T);
 
     // ---- frame ingest set-up: 16 lanes per stream, 16 streams per fold call (ms = tid >> 4) ----
     const float thr = P.thresh;
@@ -1107,15 +1109,18 @@ extern "C" hipError_t vadk_launch_silero_v5_t16(const vadk::StepParams *p, hipSt
     const int tiles = (p->n + MT16 - 1) / MT16;
     if (tiles <= 0) return hipSuccess;
     const vadk::RateParams none{};
-    if (p->variant) {                  // the 8 kHz sub-model's blob (256-sample frames)
-        if (p->fmt == 0)
-            hipLaunchKernelGGL((silero_v5_step16<true, false, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS, none);
-        else
-            hipLaunchKernelGGL((silero_v5_step16<false, false, true>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS, none);
-    } else if (p->fmt == 0)
-        hipLaunchKernelGGL((silero_v5_step16<true, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS, none);
-    else
-        hipLaunchKernelGGL((silero_v5_step16<false, false>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS, none);
+#define T16_LAUNCH(F, K, O) hipLaunchKernelGGL((silero_v5_step16<F, false, K, O>), dim3(tiles), dim3(vadk::NTHREADS), 0, stream, V5_ARGS, none)
+    if (p->T < 1) return hipErrorInvalidValue;     // the frame loop tests its count at the bottom
+    const bool k8 = p->variant != 0;               // the 8 kHz sub-model's blob (256-sample frames)
+    const bool f32 = p->fmt == 0, one = p->T == 1;
+    if (k8) {
+        if (f32) { if (one) T16_LAUNCH(true, true, true); else T16_LAUNCH(true, true, false); }
+        else { if (one) T16_LAUNCH(false, true, true); else T16_LAUNCH(false, true, false); }
+    } else {
+        if (f32) { if (one) T16_LAUNCH(true, false, true); else T16_LAUNCH(true, false, false); }
+        else { if (one) T16_LAUNCH(false, false, true); else T16_LAUNCH(false, false, false); }
+    }
+#undef T16_LAUNCH
     return hipGetLastError();
 }
 
