@@ -47,12 +47,14 @@ B_PER_GPU = 8192
 RING = 32
 FLOP_PER_FRAME = {5: 988160, 4: 1380000}   # SURVEY §8 d: V5 494 080 valid-tap MAC; V4 ~0.69 M MAC
 BYTES_PER_FRAME = 4100                     # SURVEY §8 d: 2048 in + 1024 state R + 1024 state W + 4 prob
-# What the V5 kernel EXECUTES per frame, in units of one v_mfma_f32_32x32x2_f32 (2 048 MAC) per wave: recurrent
-# half 256, folded DFT 144 (288 v_mfma_f32_16x16x4_f32 of half the size: the even bins fold a third time since round 4; 192 before),
-# Toom-3 enc0 325, enc1 128, enc2 32, enc3 32, LSTM input half 256 = 1 173 (1 221 through round 3) x 4 waves x 2048 MAC / 32
-# streams.  Fewer than the algorithmic count because the folds and the Toom-3 product are exact algebraic reductions of the sums.
-EXECUTED_MFMA_UNITS_PER_WAVE = 1173
-EXECUTED_FLOP_PER_FRAME = EXECUTED_MFMA_UNITS_PER_WAVE * 4 * 2048 * 2 // 32
+# What the V5 kernel EXECUTES per frame.  One-frame calls run on 16-stream tiles (silero_v5_step16, two workgroups per CU; engine.cpp
+# launch()): 1 178 v_mfma_f32_16x16x4_f32 (1 024 MAC each) per wave - recurrent half 256, folded DFT 144 (the even bins fold three
+# times), Toom-3 enc0 330, enc1 128, enc2 32, enc3 32, LSTM input half 256 - x 4 waves / 16 streams (the SQ counter
+# SQ_INSTS_VALU_MFMA_F32 says the same: profiles/).  The 32-stream kernel (multi-frame calls of more than 4 096 streams, the mix)
+# executes 1 173 units of 2 048 MAC per wave and 32 streams: the same count to 0.4 %.  Fewer than the algorithmic count because
+# the folds and the Toom-3 product are exact algebraic reductions of the sums.
+EXECUTED_MFMA_16X16X4_PER_WAVE = 1178
+EXECUTED_FLOP_PER_FRAME = EXECUTED_MFMA_16X16X4_PER_WAVE * 4 * 1024 * 2 // 16
 PEAK_FP32_MFMA = 157.3e12        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM = 8.0e12                # same guide, HBM3E spec
 PARITY_STEPS = 4
@@ -410,7 +412,8 @@ def main() -> int:
                     traffic = None
             out["roofline"] = {
                 "bound": "mfma",
-                "kernel": "silero_v5_step" if not mixed else "silero_v5_step + silero_v4_step16 (concurrent)",
+                "kernel": ("silero_v5_step16 (16-stream tiles, two workgroups per CU)" if not mixed
+                           else "silero_v5_step + silero_v4_step16 (concurrent)"),
                 "achieved": achieved / 1e12,
                 "peak": PEAK_FP32_MFMA / 1e12,
                 "unit": "TFLOP/s",

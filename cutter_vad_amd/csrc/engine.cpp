@@ -82,9 +82,12 @@ struct vad_engine {
     std::vector<void *> host_blocks;                         // vad_host_alloc: freed with the engine
     uint8_t *d_small_in = nullptr, *d_small_out = nullptr;
     vadk::StepParams base{};
-    // Silero V5 16 kHz: the same weights packed for the 16-stream tile kernel (csrc/silero_v5_t16.hip), used when a call has at
-    // most T16_MAX_STREAMS streams: half-size tiles put a small batch on twice as many CUs (a 32-stream tile takes ~47 us
-    // however few tiles a launch has)
+    // Silero V5: the same weights packed for the 16-stream tile kernel (csrc/silero_v5_t16.hip).  It serves
+    //   - every ONE-frame call (T == 1: the serving tick, vad_step, the bench): its single-frame instantiation needs 220 registers
+    //     and 80.6 KB of LDS, so TWO workgroups share a CU and fill each other's waits - 8 192 streams 44.1 us against 45.4 on
+    //     32-stream tiles, 12 288 streams 65.9 against 87.9 (three tiles on a CU instead of two rounds of one);
+    //   - multi-frame calls of at most T16_MAX_STREAMS streams: half-size tiles put a small batch on twice as many CUs (its
+    //     multi-frame instantiation has 256 - 265 registers: one workgroup per CU, so a larger batch would run in two rounds).
     static constexpr int T16_MAX_STREAMS = 4096;
     float *d_wstream16 = nullptr;
     size_t wbytes16 = 0;
@@ -463,7 +466,7 @@ int check_slots(vad_engine *e, const int64_t *slots, int64_t n) {
 
 int launch(vad_engine *e, const vadk::StepParams &p, hipStream_t s) {
     hipError_t r = hipErrorInvalidValue;
-    const bool t16 = e->d_wstream16 && (e->tile_policy == 16 || (e->tile_policy == 0 && !e->shared_gpu && p.n <= vad_engine::T16_MAX_STREAMS));
+    const bool t16 = e->d_wstream16 && (e->tile_policy == 16 || (e->tile_policy == 0 && !e->shared_gpu && (p.T == 1 || p.n <= vad_engine::T16_MAX_STREAMS)));
     if (e->version == 4 && e->d_wstream16 && e->tile_policy != 32) {
         // Silero V4: 16-stream tiles, two workgroups per CU (each fills the other's waits) - one per CU while the call has no
         // more tiles than the GPU has CUs, so that a small batch spreads out instead of pairing up

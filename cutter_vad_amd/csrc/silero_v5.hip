@@ -496,24 +496,33 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step(const float *k_wst
             S##v[c][sh] = XB[(CS * c + S_ROW_I(tt)) * QS + 16 * sh];                       \
         }
 #define S_LD(S, tt) S##wr = WL(ws_stft + 2 * (tt)); S##wi = WL(ws_stft + 2 * (tt) + 1); S_LDX(S, tt)
+    // (program order: the twelve accumulators in turn for each of a quad's four components - consecutive MFMAs are independent)
 #define S_MMA(S, rt)                                                                       \
-    _Pragma("unroll") for (int c = 0; c < 3; ++c)                                          \
-        _Pragma("unroll") for (int sh = 0; sh < 2; ++sh) {                                 \
-            sre[c][sh][rt] = mma16(S##wr, S##u[c][sh], sre[c][sh][rt]);                    \
-            sim[c][sh][rt] = mma16(S##wi, S##v[c][sh], sim[c][sh][rt]);                    \
-        }
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c)                                      \
+            _Pragma("unroll") for (int sh = 0; sh < 2; ++sh) {                             \
+                sre[c][sh][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(S##wr[j], S##u[c][sh][j], sre[c][sh][rt], 0, 0, 0); \
+                sim[c][sh][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(S##wi[j], S##v[c][sh][j], sim[c][sh][rt], 0, 0, 0); \
+            }
+            // a k-iteration's 48 MFMAs (32 cycles each) with the NEXT iteration's requests - 2 weight blocks, 12 LDS reads - issued in
+            // their shadow, one LDS read behind every four MFMAs: issued as a burst between the groups (as the other phases, whose
+            // MFMAs are twice as long and whose requests are half as many, still do) they cost ~430 cycles per group, 2.6 k of this
+            // phase's 11.8 k
+#define S_IL                                                                               \
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                 \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
+    }
             S_LDX(A, 0)
-            S_LD(B, 1) SB();
-            S_MMA(A, 0) SB();
-            S_LD(A, 2) SB();
-            S_MMA(B, 0) SB();
-            S_LD(B, 3) SB();
-            S_MMA(A, 0) SB();
-            S_LD(A, 4) SB();
-            S_MMA(B, 0) SB();
-            S_LD(B, 5) SB();
-            S_MMA(A, 1) SB();
+            SB();
+            S_LD(B, 1) S_MMA(A, 0) S_IL SB();
+            S_LD(A, 2) S_MMA(B, 0) S_IL SB();
+            S_LD(B, 3) S_MMA(A, 0) S_IL SB();
+            S_LD(A, 4) S_MMA(B, 0) S_IL SB();
+            S_LD(B, 5) S_MMA(A, 1) S_IL SB();
             S_MMA(B, 1) SB();
+#undef S_IL
 #undef S_LDX
 #undef S_LD
 #undef S_MMA

@@ -71,6 +71,21 @@ __device__ __forceinline__ f32x4 mfma16(f32x4 w, f32x4 a, f32x4 acc) {
 
 }  // namespace
 
+// A k-iteration's MFMAs with the NEXT iteration's requests issued in their shadow: ND LDS reads first, then one weight-block
+// request behind every four MFMAs, NV times.  On this kernel's 32-cycle MFMAs a burst of 8 - 10 requests between two groups of 32
+// costs ~10 % of the group (the 32-stream kernel's MFMAs are twice as long and were left alone, but for its STFT).
+#define T16_IL(NV, ND)                                                                                          \
+    __builtin_amdgcn_sched_group_barrier(0x100, (ND), 0);                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < (NV); ++i_) {                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                      \
+    }
+// eight accumulators, the four components of a quad in turn: consecutive MFMAs are independent
+#define T16_MMA8(G, WS, AV)                                                                                     \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                            \
+        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_)                                                        \
+            G[k_] = __builtin_amdgcn_mfma_f32_16x16x4f32(WS[k_][j_], (AV)[j_], G[k_], 0, 0, 0);
+
 // RS: one tick for streams at other input rates (vad_step_rates): the tile first resamples its 16 chunks to 16 kHz into LDS -
 // AudioUtils.resample_audio's Fourier method as the folded operator of resample.hip, on 16 x 16 x 4 tiles - and the frame loop
 // ingests them from there: no second launch, no HBM round trip of the 16 kHz frames.  T = 1, float32 input.
@@ -705,7 +720,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 #define H_MMA(WS, g)                                                                                            \
     {                                                                                                           \
         const f32x4 av = RH[(4 * (g)) * QSD + nq];                                                             \
-        _Pragma("unroll") for (int k = 0; k < 8; ++k) G[k] = mfma16(WS[k], av, G[k]);                           \
+        T16_MMA8(G, WS, av)                                                                                     \
     }
 #define H_MIX                                                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                          \
@@ -722,19 +737,19 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             __syncthreads();   // (0) h_{t-1} visible (t > 0: follows barrier (8))
             H_MMA(wA, 0) SB();
             if constexpr (K8) {             // two fold calls: columns (0 | 1) by half of the workgroup, then column 2
-            H_LDW(wA, 2, wh) SB(); H_MMA(wB, 1) SB();
+            H_LDW(wA, 2, wh) H_MMA(wB, 1) T16_IL(8, 1) SB();
             H_LDW(wB, 3, wh) SB(); H_MMA(wA, 2) X_FOLD(lcol, xa_) H_MIX SB();
-            H_LDW(wA, 4, wh) SB(); H_MMA(wB, 3) SB();
+            H_LDW(wA, 4, wh) H_MMA(wB, 3) T16_IL(8, 1) SB();
             H_LDW(wB, 5, wh) SB(); H_MMA(wA, 4) X_FOLD(2, xb_) H_MIX SB();
-            H_LDW(wA, 6, wh) SB(); H_MMA(wB, 5) SB();
-            H_LDW(wB, 7, wh) SB(); H_MMA(wA, 6) SB();
+            H_LDW(wA, 6, wh) H_MMA(wB, 5) T16_IL(8, 1) SB();
+            H_LDW(wB, 7, wh) H_MMA(wA, 6) T16_IL(8, 1) SB();
             H_MMA(wB, 7) SB();
             } else {
             H_LDW(wA, 2, wh) if constexpr (!RS) { X_ISSUE(2, xc_, t) } SB(); H_MMA(wB, 1) SB();
             H_LDW(wB, 3, wh) SB(); H_MMA(wA, 2) X_FOLD(0, xa_) H_MIX SB();
-            H_LDW(wA, 4, wh) SB(); H_MMA(wB, 3) SB();
+            H_LDW(wA, 4, wh) H_MMA(wB, 3) T16_IL(8, 1) SB();
             H_LDW(wB, 5, wh) SB(); H_MMA(wA, 4) X_FOLD(1, xb_) H_MIX SB();
-            H_LDW(wA, 6, wh) SB(); H_MMA(wB, 5) SB();
+            H_LDW(wA, 6, wh) H_MMA(wB, 5) T16_IL(8, 1) SB();
             H_LDW(wB, 7, wh) SB(); H_MMA(wA, 6) X_FOLD(2, xc_) H_MIX SB();
             H_MMA(wB, 7) SB();
             }
@@ -853,21 +868,24 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
     _Pragma("unroll") for (int k = 0; k < 2; ++k) S##w[k] = WL(ws_stft + 2 * (tt) + k);    \
     _Pragma("unroll") for (int c = 0; c < 3; ++c) { S##u[c] = XB[(64 * c + S_ROW_R(tt)) * QSL]; S##v[c] = XB[(64 * c + S_ROW_I(tt)) * QSL]; }
 #define S_MMA(S, rt)                                                                       \
-    _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                        \
-        are[c][rt] = mfma16(S##w[0], S##u[c], are[c][rt]);                                 \
-        aim[c][rt] = mfma16(S##w[1], S##v[c], aim[c][rt]);                                 \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                       \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                    \
+            are[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(S##w[0][j_], S##u[c][j_], are[c][rt], 0, 0, 0); \
+            aim[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(S##w[1][j_], S##v[c][j_], aim[c][rt], 0, 0, 0); \
+        }
+#define S_IL                                                                               \
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                 \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
     }
-            S_LD(B, 1) SB();
-            S_MMA(A, 0) SB();
-            S_LD(A, 2) SB();
-            S_MMA(B, 0) SB();
-            S_LD(B, 3) SB();
-            S_MMA(A, 0) SB();
-            S_LD(A, 4) SB();
-            S_MMA(B, 0) SB();
-            S_LD(B, 5) SB();
-            S_MMA(A, 1) SB();
+            S_LD(B, 1) S_MMA(A, 0) S_IL SB();
+            S_LD(A, 2) S_MMA(B, 0) S_IL SB();
+            S_LD(B, 3) S_MMA(A, 0) S_IL SB();
+            S_LD(A, 4) S_MMA(B, 0) S_IL SB();
+            S_LD(B, 5) S_MMA(A, 1) S_IL SB();
             S_MMA(B, 1) SB();
+#undef S_IL
 #undef S_LD
 #undef S_MMA
 #undef S_ROW_R
@@ -916,15 +934,15 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
     _Pragma("unroll") for (int k = 0; k < 10; ++k) S##w[k] = WL(ws + 10 * (jj) + k);       \
     _Pragma("unroll") for (int p = 0; p < 5; ++p) S##a[p] = RX[(PS * p + 4 * (jj)) * QSD + nq];
 #define E0_MMA(S)                                                                          \
-    _Pragma("unroll") for (int p = 0; p < 5; ++p) {                                        \
-        acc[p][0] = mfma16(S##w[2 * p], S##a[p], acc[p][0]); acc[p][1] = mfma16(S##w[2 * p + 1], S##a[p], acc[p][1]); \
-    }
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                       \
+        _Pragma("unroll") for (int p = 0; p < 5; ++p) {                                    \
+            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(S##w[2 * p][j_], S##a[p][j_], acc[p][0], 0, 0, 0);         \
+            acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(S##w[2 * p + 1][j_], S##a[p][j_], acc[p][1], 0, 0, 0);     \
+        }
             for (int j = 0; j < NJ0; j += 2) {
-                E0_LD(B, j + 1) SB();
-                E0_MMA(A) SB();
+                E0_LD(B, j + 1) E0_MMA(A) T16_IL(10, 5) SB();
                 const int jn = j + 2 < NJ0 ? j + 2 : NJ0 - 2;
-                E0_LD(A, jn) SB();
-                E0_MMA(B) SB();
+                E0_LD(A, jn) E0_MMA(B) T16_IL(10, 5) SB();
             }
 #undef E0_LD
 #undef E0_MMA
@@ -1042,14 +1060,12 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 #pragma unroll
             for (int k = 0; k < 8; ++k) Aw[k] = Lw[k];
 #define L_LD(S, it) _Pragma("unroll") for (int k = 0; k < 8; ++k) S##w[k] = WL(ws + 8 * (it) + k); S##a = RX[(4 * (it)) * QSD + nq];
-#define L_MMA(S) _Pragma("unroll") for (int k = 0; k < 8; ++k) G[k] = mfma16(S##w[k], S##a, G[k]);
+#define L_MMA(S) T16_MMA8(G, S##w, S##a)
             for (int it = 0; it < 8; it += 2) {
-                L_LD(B, it + 1) SB();
-                L_MMA(A) SB();
+                L_LD(B, it + 1) L_MMA(A) T16_IL(8, 1) SB();
                 const int itn = it + 2 < 8 ? it + 2 : 6;
-                L_LD(A, itn) SB();
                 if (it == 6) { hw[0] = WL(ws + 128); hw[1] = WL(ws + 129); SB(); }
-                L_MMA(B) SB();
+                L_LD(A, itn) L_MMA(B) T16_IL(8, 1) SB();
             }
 #undef L_LD
 #undef L_MMA

@@ -107,13 +107,20 @@ def test_tile_position_independence(setup, frames):
 def test_multi_frame_launch_equals_single_frame_launches(setup, frames):
     v, eng, slots, _ = setup
     T = frames.shape[1]
-    eng.reset(slots)
-    single = np.stack([eng.step(slots, frames[:, t]) for t in range(T)], axis=1)
-    s_single = eng.get_state(int(slots[777]))
-    eng.reset(slots)
-    multi, _ = eng.step_multi(slots, frames)
-    assert np.array_equal(multi, single)
-    assert np.array_equal(eng.get_state(int(slots[777])), s_single)
+    # V5: the engine serves one-frame calls on 16-stream tiles and a multi-frame call of 8 192 streams on 32-stream tiles (equal to
+    # rounding); bit-exactness between the two launch forms is a property of ONE kernel shape, so each shape is pinned in turn
+    for tile in ((32, 16) if v == 5 else (0,)):
+        eng.set_tile(tile)
+        try:
+            eng.reset(slots)
+            single = np.stack([eng.step(slots, frames[:, t]) for t in range(T)], axis=1)
+            s_single = eng.get_state(int(slots[777]))
+            eng.reset(slots)
+            multi, _ = eng.step_multi(slots, frames)
+            assert np.array_equal(multi, single), tile
+            assert np.array_equal(eng.get_state(int(slots[777])), s_single), tile
+        finally:
+            eng.set_tile(0)
 
 
 def test_int16_ingest_equals_float_ingest_of_the_same_samples(setup, frames):

@@ -154,9 +154,16 @@ def test_the_two_tile_shapes_agree_and_the_engine_picks_by_call_size(blob):
         e.set_tile(0)
         e.reset(allslots)
         a = e.step(allslots, xb[:, 0])
+        e.set_tile(16)
+        e.reset(allslots)
+        assert np.array_equal(a, e.step(allslots, xb[:, 0]))    # 8 192 streams, ONE frame: 16-stream tiles, two workgroups per CU
+        xm = _frames(8192, 2, 6)
+        e.set_tile(0)
+        e.reset(allslots)
+        am = e.step_multi(allslots, xm)[0]
         e.set_tile(32)
         e.reset(allslots)
-        assert np.array_equal(a, e.step(allslots, xb[:, 0]))    # 8 192 streams: 32-stream tiles
+        assert np.array_equal(am, e.step_multi(allslots, xm)[0])   # 8 192 streams, two frames per launch: 32-stream tiles
 
 
 def test_wrong_frame_length_and_wrong_blob_are_refused(engine, blob):

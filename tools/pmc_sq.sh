@@ -6,7 +6,7 @@ set -e
 TAG=$1
 OUT=$PWD/gpurun_out
 REPO=$PWD
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-kernarg-preload-count=8 -o /tmp/kb tools/kbench.cpp cutter_vad_amd/csrc/silero_v5.hip cutter_vad_amd/csrc/pack_weights.cpp 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-kernarg-preload-count=8 -DKB_TILE16 -o /tmp/kb tools/kbench.cpp cutter_vad_amd/csrc/silero_v5_t16.hip cutter_vad_amd/csrc/pack_weights.cpp 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "MfmaUtil" "VALUBusy" "LdsBankConflict" "SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do

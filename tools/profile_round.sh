@@ -2,14 +2,15 @@
 # usage (repo root, GPU box): tools/profile_round.sh <tag>   -> gpurun_out/<tag>_*
 # 1. bench.py (full, with the CPU leg)            -> <tag>_bench.json
 # 2. rocprofv3 --kernel-trace --stats of bench.py -> <tag>_bench_kernel_stats.csv
-# 3. PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) over tools/kbench -> <tag>_pmc_*.csv
+# 3. PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) over tools/kbench built for the kernel bench.py runs
+#    (silero_v5_step16: one-frame calls are served on 16-stream tiles, two workgroups per CU) -> <tag>_pmc_*.csv
 set -e
 TAG=$1
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 echo "bench done" >> "$OUT/${TAG}_progress.log"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-kernarg-preload-count=8 -o /tmp/kb tools/kbench.cpp cutter_vad_amd/csrc/silero_v5.hip cutter_vad_amd/csrc/pack_weights.cpp 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-kernarg-preload-count=8 -DKB_TILE16 -o /tmp/kb tools/kbench.cpp cutter_vad_amd/csrc/silero_v5_t16.hip cutter_vad_amd/csrc/pack_weights.cpp 2>/dev/null
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_prof" -o bench -- python3 "$REPO/bench.py" --no-cpu --steps 500 --warmup 100 > "$OUT/${TAG}_prof.log" 2>&1
