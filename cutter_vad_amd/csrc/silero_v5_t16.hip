@@ -30,6 +30,15 @@
 #include "vadk_device.h"
 
 using namespace vadk;
+
+#ifdef VADK_STAMPS      // tools/kbench.sh -DKB_TILE16 -DVADK_STAMPS: the same phase indices as silero_v5.hip
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        if (lane == 0) P.stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + (k)] = clock64();          \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 using namespace vadk::dev;
 
 namespace {
@@ -645,6 +654,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
         }                                                             // next part
     }
 
+    STAMP(0);
     for (int t = 0;;) {                          // T >= 1; the back edge is at the bottom, behind the next frame's first requests
         int ws_stft = o_stft, ws_e0 = o_e0, ws_e1 = o_e1, ws_e2 = o_e2, ws_e3 = o_e3, ws_l = o_l;
         asm volatile("" : "+s"(ws_stft), "+s"(ws_e0), "+s"(ws_e1), "+s"(ws_e2), "+s"(ws_e3), "+s"(ws_l));
@@ -735,6 +745,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
                 for (int k = 0; k < 8; ++k) G[k] = bq[(k >> 1) * 8 + (k & 1) * 4];
             }
             __syncthreads();   // (0) h_{t-1} visible (t > 0: follows barrier (8))
+            STAMP(31);
             H_MMA(wA, 0) SB();
             if constexpr (K8) {             // two fold calls: columns (0 | 1) by half of the workgroup, then column 2
             H_LDW(wA, 2, wh) H_MMA(wB, 1) T16_IL(8, 1) SB();
@@ -761,7 +772,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 #pragma unroll
         for (int k = 0; k < 2; ++k) Sw[k] = WL(ws_stft + k);
         SB();
+        STAMP(1);
         __syncthreads();   // (1) folded x visible
+        STAMP(2);
 
         // ---- bin 128 on the VALU: 48 (column, stream) pairs, 4 lanes each ----
         {
@@ -916,7 +929,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
                 RX[(T_ROW_NYQ + 4) * QSD + nq] = kq == 0 ? f32x4{n2, 0.f, 0.f, 0.f} : z4;
             }
         }
+        STAMP(3);
         __syncthreads();   // (2) magnitudes complete
+        STAMP(4);
 
         // ---- enc0 (Toom-3): five point-wise contractions over 128 channels (8 k-iterations) + the Nyquist channel ----
         f32x4 e1b[2], E1w[2];
@@ -977,7 +992,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
                 o[64 * QSD] = relu4(pk::add(y3, bias));
             }
         }
+        STAMP(5);
         __syncthreads();   // (3) enc0 out
+        STAMP(6);
 
         // ---- enc1: 128 -> 64 ch, k3 s2 p1, 3 -> 2 columns; wave w: n-tile w & 1, column w >> 1; 16 k-iterations ----
         f32x4 e2b[2], E2w[2], e3b[2], E3w[2];
@@ -1006,7 +1023,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) RX[(16 * tp + 8 * nt + 4 * rt) * QSD + nq] = relu4(acc[rt]);
         }
+        STAMP(7);
         __syncthreads();   // (4) enc1 out in rows 0..31
+        STAMP(8);
 
         // ---- enc2: 64 -> 64 ch, k3 s2 p1, 2 -> 1 column; split-K: wave w = tile w & 1, K half (= input column) w >> 1 ----
         {
@@ -1027,7 +1046,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) RE[(16 * kh + 8 * (w & 1) + 4 * rt) * QSD + nq] = acc[rt];
         }
+        STAMP(9);
         __syncthreads();   // (5) enc2 partials
+        STAMP(10);
 
         // ---- enc3: 64 -> 128 ch, centre tap; input = relu(partial of K half 0 + K half 1) ----
         f32x4 Lw[8];
@@ -1051,7 +1072,9 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) RX[(8 * w + 4 * rt) * QSD + nq] = relu4(acc[rt]);
         }
+        STAMP(11);
         __syncthreads();   // (6) LSTM input x in rows 0..31
+        STAMP(12);
 
         // ---- LSTM: input half W_ih . x on top of the recurrent half, cell, head partial ----
         {
@@ -1069,7 +1092,10 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             }
 #undef L_LD
 #undef L_MMA
+            STAMP(18);
+            STAMP(13);
             __syncthreads();   // (7) every wave is done reading h_{t-1}
+            STAMP(14);
             f32x4 part4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
@@ -1092,6 +1118,7 @@ __global__ void __launch_bounds__(NTHREADS, 1) silero_v5_step16(const float *k_w
             if (kq == 0) headp[w * 16 + n] = part_;
         }
         __syncthreads();   // (8) head partials + new h visible
+        STAMP(15);
 
         if (tid < MT16) {
             const float z = hb + ((headp[tid] + headp[16 + tid]) + (headp[32 + tid] + headp[48 + tid]));

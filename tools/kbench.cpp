@@ -87,7 +87,11 @@ int main(int argc, char **argv) {
     }
     if (getenv("KB_EVENTS")) { unsigned char *d_ev; CK(hipMalloc(&d_ev, (size_t)B * T)); p.events = d_ev; }
 #ifdef VADK_STAMPS
+#ifdef KB_TILE16
+    const int tiles = (B + 15) / 16;
+#else
     const int tiles = (B + vadk::MT - 1) / vadk::MT;
+#endif
     unsigned long long *d_st;
     CK(hipMalloc(&d_st, (size_t)tiles * 4 * 32 * 8));
     CK(hipMemset(d_st, 0, (size_t)tiles * 4 * 32 * 8));
