@@ -83,8 +83,9 @@ typedef struct vad_engine_desc {
     uint32_t flags;             /* VAD_ENGINE_* bits */
 } vad_engine_desc;
 /* Another engine's kernels run on this GPU at the same time (e.g. a Silero V4 and a V5 pool side by side: BASELINE configs[4]).
- * A Silero V5 16 kHz engine normally serves calls of <= 4 096 streams on 16-stream tiles, which spreads them over up to all 256 CUs
- * (28 us instead of 47 us per step) - and leaves no CU to a co-tenant.  With this flag it keeps to 32-stream tiles: a call of n
+ * A Silero V5 engine normally serves one-frame calls (and multi-frame calls of <= 4 096 streams) on 16-stream tiles, which spreads
+ * them over up to all 256 CUs, two workgroups per CU above 4 096 streams (24.5 us per step for 1 024 streams, 44.5 for 8 192, instead
+ * of 44 - 46 us on 32-stream tiles) - and leaves no CU to a co-tenant.  With this flag it keeps to 32-stream tiles: a call of n
  * streams occupies n / 32 CUs and the other engine's workgroups run beside it.  A Silero V4 engine (16-stream tiles) then always
  * places two workgroups on a CU instead of spreading a small call over one CU per tile: n / 32 CUs as well. */
 #define VAD_ENGINE_SHARED_GPU 1u
@@ -454,10 +455,11 @@ VAD_API int vad_debug_sm_replay(vad_engine *e, int64_t slot, const float *probs,
                                 int32_t *seg_frames_out);
 
 /*
- * Diagnostic: which kernel shape serves the step calls.  0 (default) = the engine's choice - Silero V5 at 16 kHz: calls with at
- * most 4 096 streams run on 16-stream tiles (twice as many workgroups, half as long each), larger ones on 32-stream tiles; Silero
- * V4 (both sub-models): always 16-stream tiles, two workgroups per CU.  16 / 32 force one shape (the test-suite checks that both
- * give the same results to rounding; tools/bench_configs.py times them).  V5's 8 kHz sub-model has 32-stream tiles only.
+ * Diagnostic: which kernel shape serves the step calls.  0 (default) = the engine's choice - Silero V5 (both sub-models): one-frame
+ * calls run on 16-stream tiles whatever their size (the single-frame instantiation of that kernel fits two workgroups on a CU),
+ * multi-frame calls on 16-stream tiles up to 4 096 streams and on 32-stream tiles above; Silero V4 (both sub-models): always
+ * 16-stream tiles, two workgroups per CU.  16 / 32 force one shape (the test-suite checks that both give the same results to
+ * rounding; tools/bench_configs.py times them).
  * -1 / -2: vad_step_rates as two launches (resample, then model) / as the fused launch (default), for the same comparison.
  */
 VAD_API int vad_debug_set_tile(vad_engine *e, int32_t streams_per_tile);
