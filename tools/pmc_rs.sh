@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (repo root, GPU box): tools/pmc_rs.sh <tag>  -> gpurun_out/<tag>_pmc_sq_rs.json
-# SQ-side counters and HBM traffic of the FUSED resample -> step launch (silero_v5_step16<true, true>): 4 096 streams all at
+# SQ-side counters and HBM traffic of the FUSED resample -> step launch (silero_v5_step16<true, true, ...>): 4 096 streams all at
 # 48 kHz (tools/bench_configs.py rates48) and configs[3] at its stated size; one rocprofv3 --pmc pass per group, --kernel-trace
 # only, the program directly after `--`.
 set -e
@@ -23,7 +23,7 @@ import json, subprocess, sys
 out, tag = sys.argv[1], sys.argv[2]
 res = {}
 for cfg in ("rates48", "config3"):
-    res[cfg] = json.loads(subprocess.check_output([sys.executable, "tools/rocpd_export.py", "pmc", f"{out}/{tag}_rs_{cfg}", "silero_v5_step16<true, true>"]))
+    res[cfg] = json.loads(subprocess.check_output([sys.executable, "tools/rocpd_export.py", "pmc", f"{out}/{tag}_rs_{cfg}", "silero_v5_step16<true, true,"]))
 json.dump(res, open(f"{out}/{tag}_pmc_sq_rs.json", "w"), indent=1)
 print(json.dumps({k: {c: round(v["mean"], 1) for c, v in r["counters"].items()} for k, r in res.items()}, indent=1))
 PY
