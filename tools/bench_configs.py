@@ -181,6 +181,39 @@ def config4_per_gpu():
             "us_per_step": dt * 1e6, "frames_per_s": 2 * B / dt, "x8_gpus_frames_per_s": 16 * B / dt}
 
 
+def two_pools_one_gpu():
+    """configs[2]'s 8 192 streams as TWO independent pools of 4 096 on one GPU (two engines, a HIP stream each; what
+    ShardedStreamPool(devices=[0, 0]) gives a serving process): the pools' launches are not ordered against each other, so the
+    start of one pool's launch - cold L2, state and first weights on their way - runs under the other pool's tiles."""
+    B = 4096
+    ea, eb = Engine(blob(5), max_streams=B), Engine(blob(5), max_streams=B)
+    ea.open_streams(B)
+    eb.open_streams(B)
+    ring = (0.1 * torch.randn(16, 2 * B, 512, device="cuda")).contiguous()
+    pa, pb = torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+
+    fa = [ring[k, :B].data_ptr() for k in range(16)]       # pointers taken once: two tensor views per step would cost the host
+    fb = [ring[k, B:].data_ptr() for k in range(16)]       # more than the launches it has to stay ahead of
+    qa, qb, ha, hb = pa.data_ptr(), pb.data_ptr(), sa.cuda_stream, sb.cuda_stream
+
+    def step(i):
+        ea.step_device(B, fa[i % 16], qa, stream=ha)
+        eb.step_device(B, fb[i % 16], qb, stream=hb)
+
+    dt = timed(step, [sa, sb])
+    one = Engine(blob(5), max_streams=2 * B)
+    one.open_streams(2 * B)
+    p1 = torch.empty(2 * B, device="cuda")
+    q1 = p1.data_ptr()
+    dt1 = timed(lambda i: one.step_device(2 * B, fa[i % 16], q1, stream=ha), [sa])
+    for e in (ea, eb, one):
+        e.close()
+    return {"config": "8192 V5 streams as two independent pools of 4096 on one GPU (two engines, two HIP streams)",
+            "us_per_step": dt * 1e6, "frames_per_s": 2 * B / dt, "us_per_step_one_pool_of_8192": dt1 * 1e6,
+            "frames_per_s_one_pool_of_8192": 2 * B / dt1}
+
+
 def v4_alone():
     B = 8192
     eng = Engine(blob(4), model_version=4, max_streams=B)
@@ -379,5 +412,5 @@ if __name__ == "__main__":
         print(json.dumps(r), flush=True)
     for r in resampler_alone():
         print(json.dumps(r), flush=True)
-    for fn in (config1, config3, config3_255_tiles, config3_pipelined, config4_per_gpu, v4_alone, v4_8k):
+    for fn in (config1, config3, config3_255_tiles, config3_pipelined, config4_per_gpu, two_pools_one_gpu, v4_alone, v4_8k):
         print(json.dumps(fn()), flush=True)

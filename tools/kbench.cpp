@@ -104,9 +104,41 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> rounds;
+    // KB_SPLIT=n: the B streams as n independent groups, each stepped K times on a HIP stream of its own - the groups' launches are
+    // not ordered against each other, so the start of one group's launch runs under the other groups' tiles
+    const int NS = getenv("KB_SPLIT") ? atoi(getenv("KB_SPLIT")) : 1;
+    std::vector<hipStream_t> ss(NS, s);
+    std::vector<hipEvent_t> ej(NS);
+    for (int g = 1; g < NS; ++g) CK(hipStreamCreate(&ss[g]));
+    for (int g = 0; g < NS; ++g) CK(hipEventCreate(&ej[g]));
     for (int r = 0; r < 5; ++r) {
         CK(hipEventRecord(e0, s));
-        for (int i = 0; i < K; ++i) { p.frames = d_frames + (size_t)(i % RING) * B * T * 512; CK(vadk_launch_silero_v5(&p, s)); }
+        if (NS == 1) {
+            for (int i = 0; i < K; ++i) { p.frames = d_frames + (size_t)(i % RING) * B * T * 512; CK(vadk_launch_silero_v5(&p, s)); }
+        } else {
+            const int per = B / NS;
+            static std::vector<float *> wcopy;           // KB_SPLIT_OWN_WEIGHTS: a copy of the weight stream per group (two engines)
+            if (getenv("KB_SPLIT_OWN_WEIGHTS") && wcopy.empty()) {
+                wcopy.assign(NS, d_w);
+                for (int g = 1; g < NS; ++g) {
+                    CK(hipMalloc(&wcopy[g], pw.data.size() * 4));
+                    CK(hipMemcpy(wcopy[g], d_w, pw.data.size() * 4, hipMemcpyDeviceToDevice));
+                }
+            }
+            for (int g = 1; g < NS; ++g) CK(hipStreamWaitEvent(ss[g], e0, 0));
+            for (int i = 0; i < K; ++i)
+                for (int g = 0; g < NS; ++g) {
+                    vadk::StepParams q = p;
+                    q.n = per;
+                    q.state = p.state + (size_t)g * per * 256;
+                    q.sm = p.sm + (size_t)g * per;
+                    q.probs = p.probs + (size_t)g * per * T;
+                    q.frames = d_frames + ((size_t)(i % RING) * B + (size_t)g * per) * T * 512;
+                    if (!wcopy.empty()) q.wstream = wcopy[g];
+                    CK(vadk_launch_silero_v5(&q, ss[g]));
+                }
+            for (int g = 1; g < NS; ++g) { CK(hipEventRecord(ej[g], ss[g])); CK(hipStreamWaitEvent(s, ej[g], 0)); }
+        }
         CK(hipEventRecord(e1, s));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
