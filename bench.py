@@ -194,6 +194,10 @@ def main() -> int:
     ap.add_argument("--streams", type=int, default=B_PER_GPU, help="streams per GPU (headline: 8192)")
     ap.add_argument("--mix", choices=["v5", "v4v5"], default="v5", help="v4v5 = configs[4] per-GPU share (4096 V4 + 4096 V5)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--pools", type=int, default=1, choices=[1, 2],
+                    help="2 = the GPU's streams as two independent pools (an engine and a HIP stream each; what "
+                         "ShardedStreamPool(devices=[0, 0]) gives a serving process): the pools' launches are not ordered against "
+                         "each other.  NOT the headline: the default is one pool, one launch per step")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -277,16 +281,16 @@ def main() -> int:
             for i in range(args.steps):
                 stepper.step(i)
         elapsed, own = sharding.timed_region_detail(cp, run, sync)
-        preamble, ring_h, gpu_probs, versions = 0, None, None, ([5] if args.mix == "v5" else [5, 4])
+        preamble, ring_h, gpu_probs, versions = 0, None, None, ([5] * args.pools if args.mix == "v5" else [5, 4])
     else:
         from cutter_vad_amd import weights_io
         from cutter_vad_amd.engine import Engine
-        versions = [5] if args.mix == "v5" else [5, 4]
+        versions = [5] * args.pools if args.mix == "v5" else [5, 4]
         nb = B // len(versions)                       # streams per engine
         engines, streams, probs, events = [], [], [], []
         for v in versions:
             with open(weights_io.packaged_blob_path(v), "rb") as f:
-                e = Engine(f.read(), model_version=v, device_id=local_rank, max_streams=nb, shared_gpu=len(versions) > 1)
+                e = Engine(f.read(), model_version=v, device_id=local_rank, max_streams=nb, shared_gpu=args.mix != "v5")
             e.open_streams(nb)                        # slots 0..nb-1, zero state, default thresholds
             engines.append(e)
             streams.append(torch.cuda.Stream())
@@ -349,13 +353,16 @@ def main() -> int:
                           "ms_per_step": own / args.steps * 1e3, "frames_per_s": B * args.steps / own})
     if rank == 0:
         value = sharding.aggregate_rate(B, args.steps, world, elapsed)
-        mixed = len(versions) > 1
+        mixed = args.mix != "v5"
         workload = ("configs[2]: batch=8192 concurrent streams per GPU, Silero V5, 16 kHz, one 512-sample frame per stream "
                     "per step, denoise gate 0.01, state machine on") if not mixed else (
                     f"configs[4]: batch={world * B} streams sharded {B}/GPU across {world} x MI355X, Silero V4 + V5 mixed - per GPU "
                     f"{B // 2} Silero V4 + {B // 2} Silero V5 streams (two engines, two HIP streams), 16 kHz, one 512-sample frame per "
                     "stream per step, denoise gate 0.01, state machines on" + ("" if world == 8 and B == B_PER_GPU else
                     f" [configs[4] as stated is 8 GPUs x {B_PER_GPU}: this run is its {world}-GPU share]"))
+        if not mixed and args.pools > 1:
+            workload += (f" - as {args.pools} independent pools of {B // args.pools} streams per GPU (an engine and a HIP stream each; the "
+                         "pools' launches are not ordered against each other, every stream's own frames stay in order)")
         # how evenly the ranks ran: behind the MAX the slowest rank sets the line's time
         kus = [r["kernel_us"] for r in per_rank if r["kernel_us"] is not None]
         best = max(r["frames_per_s"] for r in per_rank)
@@ -412,7 +419,8 @@ def main() -> int:
                     traffic = None
             out["roofline"] = {
                 "bound": "mfma",
-                "kernel": ("silero_v5_step16 (16-stream tiles, two workgroups per CU)" if not mixed
+                "kernel": ("silero_v5_step16 (16-stream tiles, two workgroups per CU)" if not mixed and args.pools == 1
+                           else f"silero_v5_step16 x {args.pools} pools (concurrent; kernel_us = the step, not one launch)" if not mixed
                            else "silero_v5_step + silero_v4_step16 (concurrent)"),
                 "achieved": achieved / 1e12,
                 "peak": PEAK_FP32_MFMA / 1e12,

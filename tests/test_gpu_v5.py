@@ -335,3 +335,29 @@ def test_raw_c_abi_refuses_bad_arguments_and_keeps_working(engine):
     finally:
         for q in s:
             engine.close_stream(int(q))
+
+
+def test_engines_created_from_the_same_weights_share_one_device_copy_and_outlive_each_other(blob):
+    """engine.cpp keeps ONE device copy of a packed weight stream per (device, bytes), reference counted (two pools on a GPU then
+    share it in HBM and in the L2s).  Closing one engine must leave the other's weights in place."""
+    from cutter_vad_amd.engine import Engine
+    x = make_streams(40, 4, seed=91)
+    a = Engine(blob, model_version=5, max_streams=64)
+    b = Engine(blob, model_version=5, max_streams=64)
+    sa, sb = a.open_streams(40), b.open_streams(40)
+    pa = np.stack([a.step(sa, x[:, t]) for t in range(4)], axis=1)
+    pb = np.stack([b.step(sb, x[:, t]) for t in range(4)], axis=1)
+    assert np.array_equal(pa, pb)
+    a.close()                                            # the shared copy has one reference left
+    b.reset(sb)
+    again = np.stack([b.step(sb, x[:, t]) for t in range(4)], axis=1)
+    assert np.array_equal(again, pb)
+    c = Engine(blob, model_version=5, max_streams=64)    # a third engine finds (or re-creates) the copy
+    sc = c.open_streams(40)
+    assert np.array_equal(np.stack([c.step(sc, x[:, t]) for t in range(4)], axis=1), pb)
+    b.close()
+    c.close()
+    d = Engine(blob, model_version=5, max_streams=64)    # after the last reference went: uploaded afresh
+    sd = d.open_streams(40)
+    assert np.array_equal(np.stack([d.step(sd, x[:, t]) for t in range(4)], axis=1), pb)
+    d.close()

@@ -186,27 +186,27 @@ def two_pools_one_gpu():
     ShardedStreamPool(devices=[0, 0]) gives a serving process): the pools' launches are not ordered against each other, so the
     start of one pool's launch - cold L2, state and first weights on their way - runs under the other pool's tiles."""
     B = 4096
+    R = int(os.environ.get("VAD_BENCH_RING", "16"))
     ea, eb = Engine(blob(5), max_streams=B), Engine(blob(5), max_streams=B)
     ea.open_streams(B)
     eb.open_streams(B)
-    ring = (0.1 * torch.randn(16, 2 * B, 512, device="cuda")).contiguous()
+    ring = (0.1 * torch.randn(R, 2 * B, 512, device="cuda")).contiguous()
     pa, pb = torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
-
-    fa = [ring[k, :B].data_ptr() for k in range(16)]       # pointers taken once: two tensor views per step would cost the host
-    fb = [ring[k, B:].data_ptr() for k in range(16)]       # more than the launches it has to stay ahead of
+    fa = [ring[k, :B].data_ptr() for k in range(R)]        # pointers taken once: two tensor views per step would cost the host
+    fb = [ring[k, B:].data_ptr() for k in range(R)]        # more than the launches it has to stay ahead of
     qa, qb, ha, hb = pa.data_ptr(), pb.data_ptr(), sa.cuda_stream, sb.cuda_stream
 
     def step(i):
-        ea.step_device(B, fa[i % 16], qa, stream=ha)
-        eb.step_device(B, fb[i % 16], qb, stream=hb)
+        ea.step_device(B, fa[i % R], qa, stream=ha)
+        eb.step_device(B, fb[i % R], qb, stream=hb)
 
     dt = timed(step, [sa, sb])
     one = Engine(blob(5), max_streams=2 * B)
     one.open_streams(2 * B)
     p1 = torch.empty(2 * B, device="cuda")
     q1 = p1.data_ptr()
-    dt1 = timed(lambda i: one.step_device(2 * B, fa[i % 16], q1, stream=ha), [sa])
+    dt1 = timed(lambda i: one.step_device(2 * B, fa[i % R], q1, stream=ha), [sa])
     for e in (ea, eb, one):
         e.close()
     return {"config": "8192 V5 streams as two independent pools of 4096 on one GPU (two engines, two HIP streams)",
