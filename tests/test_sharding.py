@@ -171,6 +171,20 @@ def test_bench_line_checks_itself_before_the_first_8_gpu_run():
     assert out["config"]["workload"].startswith("configs[4]: batch=65536 streams sharded 8192/GPU across 8 x MI355X") and "share]" not in out["config"]["workload"]
 
 
+def test_the_two_pool_line_says_what_it_is_and_the_default_line_does_not_change():
+    """`bench.py --pools 2` (two independent pools per GPU) is an extra measurement: its workload string says so, and the default
+    line - one pool, one launch per step - is what it was."""
+    import json
+    one = _bench("--steps", "3", "--warmup", "0", "--no-cpu", VAD_BENCH_FAKE="1")
+    two = _bench("--steps", "3", "--warmup", "0", "--no-cpu", "--pools", "2", VAD_BENCH_FAKE="1")
+    assert one.returncode == 0 and two.returncode == 0, one.stderr + two.stderr
+    a = [json.loads(x) for x in one.stdout.splitlines() if x.startswith("{")][0]
+    b = [json.loads(x) for x in two.stdout.splitlines() if x.startswith("{")][0]
+    assert a["metric"] == b["metric"] and a["config"]["streams_per_gpu"] == b["config"]["streams_per_gpu"] == 8192
+    assert "independent pools" not in a["config"]["workload"]
+    assert b["config"]["workload"].startswith(a["config"]["workload"]) and "as 2 independent pools of 4096 streams per GPU" in b["config"]["workload"]
+
+
 def test_bench_refuses_to_run_fewer_gpus_than_asked():
     r = _bench("--gpus", "8")                                 # no GPU in the CPU suite's container; 1 on a gpurun box
     assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()
